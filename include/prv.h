@@ -1,0 +1,194 @@
+/*
+ * prv.h -- C ABI of the MI355X-native NeRF render + candidate-view scoring path.
+ *
+ * This is the drop-in boundary for the hot path of psc0628/NeRF-PRV.  In the
+ * reference that boundary is a process + filesystem handshake:
+ *   PRV_simulation/main.cpp:1658-1715  NBV_Net_Labeler::train_by_instantNGP writes
+ *       interact/run_with_c++.py + ready_c++.txt and polls ready_py.txt;
+ *   Instantngp_scripts/train_server.py:7-14 runs the script;
+ *   Instantngp_scripts/run.py:284-309 renders every frame of --screenshot_transforms
+ *       through pyngp.Testbed.render and writes PNGs;
+ *   PRV_simulation/main.cpp:2045-2096 / 2105-2160 reads the PNGs back and scores.
+ * Each entry point below names the reference interface it replaces.  Everything is
+ * plain C: opaque handles, pointers and sizes, int error codes; nothing throws.
+ *
+ * Memory spaces: "host" pointers are ordinary memory; "dev" pointers are HIP device
+ * memory on the context's GPU (from prv_malloc, or any other HIP allocation such as
+ * a torch tensor's data_ptr).  All work is enqueued on the context's stream
+ * (prv_set_stream) and functions that return results to host memory synchronise it.
+ *
+ * The library REQUIRES a gfx950 device: there is no CPU fallback.  prv_create fails
+ * with PRV_E_NODEVICE when no GPU is visible.
+ */
+#ifndef PRV_H
+#define PRV_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRV_ABI_VERSION 1
+
+/* error codes (0 = ok, < 0 = error; message via prv_last_error) */
+#define PRV_OK 0
+#define PRV_E_INVALID (-1)  /* bad argument */
+#define PRV_E_HIP (-2)      /* HIP runtime error */
+#define PRV_E_IO (-3)       /* file / parse error */
+#define PRV_E_NODEVICE (-4) /* no usable GPU */
+#define PRV_E_STATE (-5)    /* e.g. model slot empty */
+
+/* scoring methods; 2 and 3 are the reference's method_of_IG values (Share_Data.hpp:198-202) */
+#define PRV_SCORE_ENSEMBLE_RGB 2         /* main.cpp:2039-2097 */
+#define PRV_SCORE_ENSEMBLE_RGB_DENSITY 3 /* main.cpp:2099-2161 */
+#define PRV_SCORE_PSNR_COVERAGE 5        /* run.py:257-263 PSNR vs supplied images + mean opacity */
+
+#define PRV_MAX_MODELS 8
+#define PRV_MLP_HALFS 10240 /* 32*64 + 64*16 + 32*64 + 64*64 + 64*16, canonical [in][out] */
+
+typedef struct prv_ctx prv_ctx;
+typedef struct prv_camset prv_camset;
+
+/* The NeRF field: multiresolution hash grid (L levels x F fp16 features, L*F = 32),
+ * density MLP 32->64->16, SH-4 direction encoding, colour MLP 32->64->64->16, and an
+ * occupancy bitfield.  Stands in for the instant-ngp network the reference trains
+ * through run.py:185-208. */
+typedef struct prv_field_desc {
+  int32_t n_levels;
+  int32_t n_features;
+  int32_t log2_hashmap;
+  int32_t base_res;
+  int32_t finest_res;
+  int32_t occ_res;
+  float density_bias; /* sigma = exp(out0 + density_bias) */
+  float table_amp;    /* synthetic generator only: table ~ U(-amp, amp) */
+} prv_field_desc;
+
+/* render options == the knobs run.py sets on the Testbed before render():
+ * w,h (run.py:304), screenshot_spp (run.py:48,304), render_min_transmittance
+ * (run.py:235), background_color (run.py:94,226).  samples_per_ray is the fixed
+ * per-ray sample count of the BASELINE configs. */
+typedef struct prv_render_opts {
+  int32_t width;
+  int32_t height;
+  int32_t samples_per_ray;
+  int32_t spp;
+  float min_transmittance;
+  float background[4];
+} prv_render_opts;
+
+typedef struct prv_score_record { /* 16 bytes: the unit of the multi-GPU all-gather */
+  double score;                   /* ranking key: larger = chosen first */
+  float psnr;                     /* dB (method 5), else 0 */
+  float coverage;                 /* mean opacity of the render (method 5), else 0 */
+} prv_score_record;
+
+typedef struct prv_stats {
+  uint64_t rays;              /* primary rays generated (pixels x spp) */
+  uint64_t samples_nominal;   /* rays x samples_per_ray */
+  uint64_t samples_evaluated; /* field evaluations actually composited */
+} prv_stats;
+
+/* ---- context ------------------------------------------------------------- */
+/* replaces: starting train_server.py and importing pyngp (train_server.py:1-7, run.py:90) */
+int prv_create(prv_ctx** out, int device_id);
+void prv_destroy(prv_ctx* ctx);
+/* replaces: nothing -- the reference returns 0 unconditionally (main.cpp:1714) and hangs
+ * on failure (main.cpp:1695-1698).  ctx may be NULL for the last error of a failed create. */
+const char* prv_last_error(const prv_ctx* ctx);
+int prv_abi_version(void);
+/* enqueue all work on this hipStream_t (NULL = the context's own stream) */
+int prv_set_stream(prv_ctx* ctx, void* hip_stream);
+int prv_synchronize(prv_ctx* ctx);
+int prv_device_count(void);
+
+/* thin device-memory helpers so a C/C++ host needs no HIP headers */
+int prv_malloc(prv_ctx* ctx, void** dev_ptr, size_t bytes);
+int prv_free(prv_ctx* ctx, void* dev_ptr);
+int prv_memcpy_h2d(prv_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+int prv_memcpy_d2h(prv_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+
+/* ---- model --------------------------------------------------------------- */
+/* element counts of the three parameter arrays for a descriptor */
+int prv_model_sizes(const prv_field_desc* desc, uint64_t* table_halfs, uint64_t* mlp_halfs,
+                    uint64_t* occ_words);
+/* replaces: testbed.load_snapshot / the trained network state (run.py:123-129, 185-208).
+ * host pointers; table = fp16 bit patterns, level-major; mlp = canonical [in][out] fp16,
+ * layers density-1, density-2, rgb-1, rgb-2, rgb-3; occ = occ_res^3 bits, x fastest. */
+int prv_model_load(prv_ctx* ctx, int slot, const prv_field_desc* desc, const uint16_t* table,
+                   const uint16_t* mlp, const uint32_t* occ);
+/* deterministic synthetic field (counter-based RNG), generated on the device */
+int prv_model_synthetic(prv_ctx* ctx, int slot, const prv_field_desc* desc, uint64_t seed);
+int prv_model_export(prv_ctx* ctx, int slot, uint16_t* table, uint16_t* mlp, uint32_t* occ);
+
+/* ---- cameras ------------------------------------------------------------- */
+/* replaces: json.load(--screenshot_transforms) + set_nerf_camera_matrix + fov from
+ * camera_angle_x (run.py:132-135, 285-286, 294-296).  Reads camera_angle_x, w, h, scale,
+ * offset and frames[].transform_matrix of a transforms.json written by the planner
+ * (main.cpp:1793-1811, 1885-1924). */
+int prv_cameras_from_json(prv_ctx* ctx, const char* path, prv_camset** out);
+/* same, from memory: tm = n row-major 4x4 transform_matrix */
+int prv_cameras_from_matrices(prv_ctx* ctx, const double* tm, int n, double camera_angle_x,
+                              int width, int height, double scale, const double offset[3],
+                              prv_camset** out);
+int prv_camset_count(const prv_camset* cs);
+int prv_camset_size(const prv_camset* cs, int* width, int* height);
+/* engine-frame camera i: c2w[12] row-major 3x4, intr = {fx, fy, cx, cy} at the json w,h */
+int prv_camset_get(const prv_camset* cs, int i, float c2w[12], float intr[4]);
+void prv_camset_destroy(prv_camset* cs);
+
+/* ---- render -------------------------------------------------------------- */
+/* replaces: testbed.render(w, h, spp, linear=True) per frame (run.py:245-247, 304).
+ * out_rgba_dev: n_views * h * w * 4 float32, linear premultiplied RGBA, NO background. */
+int prv_render(prv_ctx* ctx, int model_slot, const prv_camset* cs, const int* view_ids, int n_views,
+               const prv_render_opts* opts, float* out_rgba_dev, prv_stats* stats);
+/* replaces: write_image(outname, image) PNG bytes (run.py:309) -- composited over
+ * opts->background, un-premultiplied, sRGB, 8 bit.  out: n_views*h*w*4 uint8 (dev). */
+int prv_render_rgba8(prv_ctx* ctx, int model_slot, const prv_camset* cs, const int* view_ids,
+                     int n_views, const prv_render_opts* opts, uint8_t* out_rgba8_dev,
+                     prv_stats* stats);
+int prv_quantize_rgba8(prv_ctx* ctx, const float* rgba_dev, size_t n_pixels, const float bg[4],
+                       uint8_t* out_rgba8_dev);
+
+/* ---- scores -------------------------------------------------------------- */
+/* replaces: the per-view loops main.cpp:2045-2094 (method 2) / 2105-2158 (method 3).
+ * imgs_dev[e] = n_views*pixels_per_view*4 uint8 of ensemble member e. */
+int prv_score_ensemble_images(prv_ctx* ctx, int method, const uint8_t* const* imgs_dev,
+                              int n_members, int n_views, size_t pixels_per_view,
+                              prv_score_record* records_host);
+/* replaces: run.py:257-263 per image.  score = -psnr (worst-reconstructed view first). */
+int prv_score_psnr_images(prv_ctx* ctx, const float* rgba_dev, const float* gt_rgba_dev,
+                          int n_views, size_t pixels_per_view, const float bg[4],
+                          prv_score_record* records_host);
+/* The whole scoring round of nbv_loop for one shard of views, on the device end to end:
+ * render every view with every model slot listed, reduce to one record per view.
+ *   methods 2,3: model_slots = the ensemble (main.cpp:2041-2043 + 2045-2094);
+ *   method 5   : model_slots[0] vs gt_rgba_dev (n_views*h*w*4 float, same view order).
+ * records_host and/or records_dev (n_views records) receive the result; records_dev is
+ * what a caller hands to its all-gather. */
+int prv_score_views(prv_ctx* ctx, int method, const int* model_slots, int n_models,
+                    const prv_camset* cs, const int* view_ids, int n_views,
+                    const prv_render_opts* opts, const float* gt_rgba_dev,
+                    prv_score_record* records_host, prv_score_record* records_dev,
+                    prv_stats* stats);
+/* replaces: the arg-max bookkeeping main.cpp:1971-1972, 2088-2091, 2096.
+ * order = view ids sorted by (score descending, id ascending); host only. */
+int prv_rank(const prv_score_record* records, const int* view_ids, int n, int* order);
+int prv_argmax(const prv_score_record* records, const int* view_ids, int n);
+
+/* ---- stage hooks for parity tests (host in / host out, small n) ---------- */
+/* rays of view i at (w,h): o,d = n*3, t = n*2 (AABB entry/exit; exit<=entry => miss) */
+int prv_debug_raygen(prv_ctx* ctx, const prv_camset* cs, int view, int width, int height,
+                     int spp_index, float* o, float* d, float* t);
+/* 32 fp16 features per position (bit patterns) */
+int prv_debug_encode(prv_ctx* ctx, int model_slot, const float* pos, int n, uint16_t* feat);
+/* per point: out[0]=sigma, out[1..3]=rgb, out[4..19]=density MLP outputs, out[20..35]=rgb MLP
+ * outputs; occupied[n] = occupancy bit */
+int prv_debug_field(prv_ctx* ctx, int model_slot, const float* pos, const float* dir, int n,
+                    float* out36, int32_t* occupied);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRV_H */

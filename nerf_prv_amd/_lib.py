@@ -1,0 +1,121 @@
+"""ctypes binding of include/prv.h (libprv_hip.so).
+
+The library is the product; there is NO fallback.  If the shared object is missing
+or a symbol declared in include/prv.h is not exported, importing fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprv_hip.so")
+
+PRV_OK = 0
+PRV_E_INVALID = -1
+PRV_E_HIP = -2
+PRV_E_IO = -3
+PRV_E_NODEVICE = -4
+PRV_E_STATE = -5
+
+SCORE_ENSEMBLE_RGB = 2
+SCORE_ENSEMBLE_RGB_DENSITY = 3
+SCORE_PSNR_COVERAGE = 5
+
+MAX_MODELS = 8
+MLP_HALFS = 10240
+
+
+class FieldDesc(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_int32),
+        ("n_features", C.c_int32),
+        ("log2_hashmap", C.c_int32),
+        ("base_res", C.c_int32),
+        ("finest_res", C.c_int32),
+        ("occ_res", C.c_int32),
+        ("density_bias", C.c_float),
+        ("table_amp", C.c_float),
+    ]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("samples_per_ray", C.c_int32),
+        ("spp", C.c_int32),
+        ("min_transmittance", C.c_float),
+        ("background", C.c_float * 4),
+    ]
+
+
+class ScoreRecord(C.Structure):
+    _fields_ = [("score", C.c_double), ("psnr", C.c_float), ("coverage", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("samples_nominal", C.c_uint64), ("samples_evaluated", C.c_uint64)]
+
+
+_vp = C.c_void_p
+_i = C.c_int
+_P = C.POINTER
+
+# name -> (restype, argtypes); must list every function include/prv.h declares
+SIGNATURES = {
+    "prv_create": (_i, [_P(_vp), _i]),
+    "prv_destroy": (None, [_vp]),
+    "prv_last_error": (C.c_char_p, [_vp]),
+    "prv_abi_version": (_i, []),
+    "prv_set_stream": (_i, [_vp, _vp]),
+    "prv_synchronize": (_i, [_vp]),
+    "prv_device_count": (_i, []),
+    "prv_malloc": (_i, [_vp, _P(_vp), C.c_size_t]),
+    "prv_free": (_i, [_vp, _vp]),
+    "prv_memcpy_h2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "prv_memcpy_d2h": (_i, [_vp, _vp, _vp, C.c_size_t]),
+    "prv_model_sizes": (_i, [_P(FieldDesc), _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint64)]),
+    "prv_model_load": (_i, [_vp, _i, _P(FieldDesc), _vp, _vp, _vp]),
+    "prv_model_synthetic": (_i, [_vp, _i, _P(FieldDesc), C.c_uint64]),
+    "prv_model_export": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "prv_cameras_from_json": (_i, [_vp, C.c_char_p, _P(_vp)]),
+    "prv_cameras_from_matrices": (_i, [_vp, _vp, _i, C.c_double, _i, _i, C.c_double, _vp, _P(_vp)]),
+    "prv_camset_count": (_i, [_vp]),
+    "prv_camset_size": (_i, [_vp, _P(_i), _P(_i)]),
+    "prv_camset_get": (_i, [_vp, _i, _vp, _vp]),
+    "prv_camset_destroy": (None, [_vp]),
+    "prv_render": (_i, [_vp, _i, _vp, _vp, _i, _P(RenderOpts), _vp, _P(Stats)]),
+    "prv_render_rgba8": (_i, [_vp, _i, _vp, _vp, _i, _P(RenderOpts), _vp, _P(Stats)]),
+    "prv_quantize_rgba8": (_i, [_vp, _vp, C.c_size_t, _vp, _vp]),
+    "prv_score_ensemble_images": (_i, [_vp, _i, _vp, _i, _i, C.c_size_t, _vp]),
+    "prv_score_psnr_images": (_i, [_vp, _vp, _vp, _i, C.c_size_t, _vp, _vp]),
+    "prv_score_views": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _P(RenderOpts), _vp, _vp, _vp, _P(Stats)]),
+    "prv_rank": (_i, [_vp, _vp, _i, _vp]),
+    "prv_argmax": (_i, [_vp, _vp, _i]),
+    "prv_debug_raygen": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "prv_debug_encode": (_i, [_vp, _i, _vp, _i, _vp]),
+    "prv_debug_field": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libprv_hip.so and bind every declared symbol; raise if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the render path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,357 @@
+"""Python host side of the render + view-scoring path, over the C ABI (include/prv.h).
+
+Two layers:
+  * `Context` / `CamSet`: thin object wrappers of the C entry points.  Device buffers are
+    torch tensors (torch is only plumbing here: memory, streams, torch.distributed).
+  * `Testbed`: mirrors the slice of `pyngp.Testbed` that the reference's
+    Instantngp_scripts/run.py drives on this path (run.py:90-145, 226-247, 284-309):
+    same attribute names and argument meaning, so a screenshot loop written against the
+    reference reads the same here.
+
+No CPU fallback: every call goes to libprv_hip.so; errors raise `PrvError`.
+"""
+import ctypes as C
+import json
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+RECORD_DTYPE = np.dtype([("score", "<f8"), ("psnr", "<f4"), ("coverage", "<f4")])
+
+# the two synthetic fields BASELINE.md names
+FIELD_256 = dict(n_levels=8, n_features=4, log2_hashmap=19, base_res=16, finest_res=256, occ_res=128,
+                 density_bias=3.0, table_amp=4.0)
+FIELD_512 = dict(n_levels=16, n_features=2, log2_hashmap=21, base_res=16, finest_res=512, occ_res=128,
+                 density_bias=3.0, table_amp=4.0)
+
+
+class PrvError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"prv error {code}: {msg}")
+        self.code = code
+
+
+def field_desc(**kw):
+    d = dict(FIELD_256)
+    d.update(kw)
+    return L.FieldDesc(**d)
+
+
+def render_opts(width, height, samples_per_ray=128, spp=1, min_transmittance=1e-4, background=(0.0, 0.0, 0.0, 0.0)):
+    o = L.RenderOpts()
+    o.width, o.height, o.samples_per_ray, o.spp = int(width), int(height), int(samples_per_ray), int(spp)
+    o.min_transmittance = float(min_transmittance)
+    for k in range(4):
+        o.background[k] = float(background[k])
+    return o
+
+
+def model_sizes(desc):
+    lib = L.load()
+    t, m, o = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = lib.prv_model_sizes(C.byref(desc), C.byref(t), C.byref(m), C.byref(o))
+    if rc != 0:
+        raise PrvError(rc, "invalid field descriptor")
+    return t.value, m.value, o.value
+
+
+def _ptr(a):
+    """device or host pointer of a torch tensor / numpy array / None"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a.data_ptr())
+
+
+class CamSet:
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+
+    def __len__(self):
+        return self.ctx.lib.prv_camset_count(self.handle)
+
+    @property
+    def size(self):
+        w, h = C.c_int(), C.c_int()
+        self.ctx.lib.prv_camset_size(self.handle, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def get(self, i):
+        c2w = np.zeros(12, np.float32)
+        intr = np.zeros(4, np.float32)
+        rc = self.ctx.lib.prv_camset_get(self.handle, i, _ptr(c2w), _ptr(intr))
+        if rc != 0:
+            raise PrvError(rc, "camera index out of range")
+        return c2w.reshape(3, 4), intr
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.prv_camset_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One context per process per GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        import torch
+
+        self.torch = torch
+        self.lib = L.load()
+        h = C.c_void_p()
+        rc = self.lib.prv_create(C.byref(h), int(device))
+        if rc != 0:
+            raise PrvError(rc, (self.lib.prv_last_error(None) or b"").decode())
+        self.handle = h
+        self.device = torch.device("cuda", int(device))
+        if use_torch_stream:
+            with torch.cuda.device(self.device):
+                self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # -- plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            raise PrvError(rc, (self.lib.prv_last_error(self.handle) or b"").decode())
+
+    def set_stream(self, raw_stream):
+        self._chk(self.lib.prv_set_stream(self.handle, C.c_void_p(raw_stream)))
+
+    def synchronize(self):
+        self._chk(self.lib.prv_synchronize(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.prv_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- model
+    def load_model(self, slot, desc, table, mlp, occ):
+        table = np.ascontiguousarray(table, np.uint16)
+        mlp = np.ascontiguousarray(mlp, np.uint16)
+        occ = np.ascontiguousarray(occ, np.uint32)
+        t, m, o = model_sizes(desc)
+        if table.size != t or mlp.size != m or occ.size != o:
+            raise PrvError(L.PRV_E_INVALID, f"parameter sizes {table.size},{mlp.size},{occ.size} != {t},{m},{o}")
+        self._chk(self.lib.prv_model_load(self.handle, slot, C.byref(desc), _ptr(table), _ptr(mlp), _ptr(occ)))
+
+    def synthetic_model(self, slot, desc, seed):
+        self._chk(self.lib.prv_model_synthetic(self.handle, slot, C.byref(desc), C.c_uint64(seed)))
+
+    def export_model(self, slot, desc):
+        t, m, o = model_sizes(desc)
+        table, mlp, occ = np.empty(t, np.uint16), np.empty(m, np.uint16), np.empty(o, np.uint32)
+        self._chk(self.lib.prv_model_export(self.handle, slot, _ptr(table), _ptr(mlp), _ptr(occ)))
+        return table, mlp, occ
+
+    # -- cameras
+    def cameras_from_json(self, path):
+        h = C.c_void_p()
+        self._chk(self.lib.prv_cameras_from_json(self.handle, str(path).encode(), C.byref(h)))
+        return CamSet(self, h)
+
+    def cameras_from_matrices(self, tm, camera_angle_x, width, height, scale, offset):
+        tm = np.ascontiguousarray(tm, np.float64).reshape(-1, 16)
+        off = np.ascontiguousarray(offset, np.float64)
+        h = C.c_void_p()
+        self._chk(self.lib.prv_cameras_from_matrices(self.handle, _ptr(tm), tm.shape[0], float(camera_angle_x),
+                                                     int(width), int(height), float(scale), _ptr(off), C.byref(h)))
+        return CamSet(self, h)
+
+    # -- render
+    def _ids(self, camset, view_ids):
+        if view_ids is None:
+            view_ids = np.arange(len(camset), dtype=np.int32)
+        return np.ascontiguousarray(view_ids, np.int32)
+
+    def render(self, slot, camset, view_ids, opts, out=None, want_stats=True):
+        ids = self._ids(camset, view_ids)
+        if out is None:
+            out = self.torch.empty((len(ids), opts.height, opts.width, 4), dtype=self.torch.float32, device=self.device)
+        st = L.Stats()
+        self._chk(self.lib.prv_render(self.handle, slot, camset.handle, _ptr(ids), len(ids), C.byref(opts), _ptr(out),
+                                      C.byref(st) if want_stats else None))
+        return out, st
+
+    def render_rgba8(self, slot, camset, view_ids, opts, out=None, want_stats=True):
+        ids = self._ids(camset, view_ids)
+        if out is None:
+            out = self.torch.empty((len(ids), opts.height, opts.width, 4), dtype=self.torch.uint8, device=self.device)
+        st = L.Stats()
+        self._chk(self.lib.prv_render_rgba8(self.handle, slot, camset.handle, _ptr(ids), len(ids), C.byref(opts),
+                                            _ptr(out), C.byref(st) if want_stats else None))
+        return out, st
+
+    def quantize_rgba8(self, rgba, background):
+        out = self.torch.empty(rgba.shape, dtype=self.torch.uint8, device=self.device)
+        bg = np.asarray(background, np.float32)
+        self._chk(self.lib.prv_quantize_rgba8(self.handle, _ptr(rgba), rgba.numel() // 4, _ptr(bg), _ptr(out)))
+        return out
+
+    # -- scores
+    def score_ensemble_images(self, method, images):
+        n_views = images[0].shape[0]
+        npix = images[0].numel() // 4 // max(n_views, 1)
+        arr = (C.c_void_p * len(images))(*[im.data_ptr() for im in images])
+        rec = np.zeros(n_views, RECORD_DTYPE)
+        self._chk(self.lib.prv_score_ensemble_images(self.handle, method, arr, len(images), n_views, npix, _ptr(rec)))
+        return rec
+
+    def score_psnr_images(self, rgba, gt, background=(0, 0, 0, 0)):
+        n_views = rgba.shape[0]
+        npix = rgba.numel() // 4 // max(n_views, 1)
+        bg = np.asarray(background, np.float32)
+        rec = np.zeros(n_views, RECORD_DTYPE)
+        self._chk(self.lib.prv_score_psnr_images(self.handle, _ptr(rgba), _ptr(gt), n_views, npix, _ptr(bg), _ptr(rec)))
+        return rec
+
+    def score_views(self, method, slots, camset, view_ids, opts, gt=None, records_dev=None, to_host=True,
+                    want_stats=False):
+        ids = self._ids(camset, view_ids)
+        slots = np.ascontiguousarray(slots, np.int32)
+        rec = np.zeros(len(ids), RECORD_DTYPE) if to_host else None
+        st = L.Stats()
+        self._chk(self.lib.prv_score_views(self.handle, method, _ptr(slots), len(slots), camset.handle, _ptr(ids),
+                                           len(ids), C.byref(opts), _ptr(gt), _ptr(rec), _ptr(records_dev),
+                                           C.byref(st) if want_stats else None))
+        return rec, st
+
+    def rank(self, records, view_ids):
+        records = np.ascontiguousarray(records, RECORD_DTYPE)
+        ids = np.ascontiguousarray(view_ids, np.int32)
+        order = np.zeros(len(ids), np.int32)
+        self._chk(self.lib.prv_rank(_ptr(records), _ptr(ids), len(ids), _ptr(order)))
+        return order
+
+    def argmax(self, records, view_ids):
+        records = np.ascontiguousarray(records, RECORD_DTYPE)
+        ids = np.ascontiguousarray(view_ids, np.int32)
+        return self.lib.prv_argmax(_ptr(records), _ptr(ids), len(ids))
+
+    # -- stage hooks
+    def debug_raygen(self, camset, view, width, height, spp_index=0):
+        n = width * height
+        o, d, t = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 2), np.float32)
+        self._chk(self.lib.prv_debug_raygen(self.handle, camset.handle, view, width, height, spp_index, _ptr(o), _ptr(d),
+                                            _ptr(t)))
+        return o, d, t
+
+    def debug_encode(self, slot, pos):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        feat = np.zeros((pos.shape[0], 32), np.uint16)
+        self._chk(self.lib.prv_debug_encode(self.handle, slot, _ptr(pos), pos.shape[0], _ptr(feat)))
+        return feat
+
+    def debug_field(self, slot, pos, dirs):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        out = np.zeros((pos.shape[0], 36), np.float32)
+        occ = np.zeros(pos.shape[0], np.int32)
+        self._chk(self.lib.prv_debug_field(self.handle, slot, _ptr(pos), _ptr(dirs), pos.shape[0], _ptr(out), _ptr(occ)))
+        return out, occ
+
+
+def rank_host(records, view_ids):
+    """ranking without a context (pure host entry point of the C ABI)"""
+    lib = L.load()
+    records = np.ascontiguousarray(records, RECORD_DTYPE)
+    ids = np.ascontiguousarray(view_ids, np.int32)
+    order = np.zeros(len(ids), np.int32)
+    rc = lib.prv_rank(_ptr(records), _ptr(ids), len(ids), _ptr(order))
+    if rc != 0:
+        raise PrvError(rc, "prv_rank")
+    return order
+
+
+class _NerfSettings:
+    """stands in for testbed.nerf (run.py:140,145,235)"""
+
+    def __init__(self):
+        self.render_min_transmittance = 0.01  # engine default; run.py:235 sets 1e-4 for evaluation
+        self.render_with_lens_distortion = False
+        self.sharpen = 0.0
+        self.samples_per_ray = 128
+
+
+class Testbed:
+    """The slice of pyngp.Testbed that run.py uses on the render path.
+
+    run.py:90   testbed = ngp.Testbed()
+    run.py:94   testbed.background_color = [0,0,0,1]
+    run.py:109  testbed.load_training_data(scene)       -> scale/offset/intrinsics of the json
+    run.py:127  testbed.load_snapshot(...)              -> load_model(...) / synthetic_model(...)
+    run.py:231  testbed.snap_to_pixel_centers = True
+    run.py:285  testbed.fov_axis = 0 ; testbed.fov = camera_angle_x * 180 / pi
+    run.py:296  testbed.set_nerf_camera_matrix(M[:-1,:])
+    run.py:304  image = testbed.render(w, h, spp, True)  -> float32 HxWx4, linear
+    """
+
+    def __init__(self, device=0):
+        self.ctx = Context(device)
+        self.background_color = [0.0, 0.0, 0.0, 1.0]
+        self.fov_axis = 0
+        self.fov = 50.625
+        self.snap_to_pixel_centers = False
+        self.shall_train = False
+        self.exposure = 0.0
+        self.nerf = _NerfSettings()
+        self.scale = 0.33
+        self.offset = [0.5, 0.5, 0.5]
+        self._matrix = np.eye(4)[:3]
+        self._slot = 0
+        self._have_model = False
+
+    def load_training_data(self, path):
+        with open(path) as f:
+            meta = json.load(f)
+        self.scale = float(meta.get("scale", 0.33))
+        self.offset = [float(x) for x in meta.get("offset", [0.5, 0.5, 0.5])]
+        if "camera_angle_x" in meta:
+            self.fov_axis, self.fov = 0, meta["camera_angle_x"] * 180.0 / math.pi
+        self.training_meta = meta
+
+    def load_model(self, desc, table, mlp, occ):
+        self.ctx.load_model(self._slot, desc, table, mlp, occ)
+        self._have_model = True
+
+    def synthetic_model(self, desc, seed):
+        self.ctx.synthetic_model(self._slot, desc, seed)
+        self._have_model = True
+
+    def set_nerf_camera_matrix(self, m):
+        m = np.asarray(m, np.float64)
+        if m.shape != (3, 4):
+            raise ValueError("set_nerf_camera_matrix expects a 3x4 matrix")
+        self._matrix = m
+
+    def render(self, width, height, spp=1, linear=True):
+        if not self._have_model:
+            raise PrvError(L.PRV_E_STATE, "no model loaded")
+        if not linear:
+            raise NotImplementedError("only linear=True is used on the reference path (run.py:245,247,304)")
+        if self.fov_axis != 0:
+            raise NotImplementedError("fov_axis must be 0 (run.py:285)")
+        tm = np.vstack([self._matrix, [0, 0, 0, 1]])
+        cams = self.ctx.cameras_from_matrices(tm, self.fov * math.pi / 180.0, width, height, self.scale, self.offset)
+        eff_spp = 1 if self.snap_to_pixel_centers else int(spp)
+        opts = render_opts(width, height, self.nerf.samples_per_ray, eff_spp, self.nerf.render_min_transmittance)
+        img, _ = self.ctx.render(self._slot, cams, None, opts, want_stats=False)
+        img = img[0]
+        bg = self.ctx.torch.tensor(self.background_color, dtype=img.dtype, device=img.device)
+        img = img + (1.0 - img[..., 3:4]) * bg  # composite over the background colour
+        cams.close()
+        return img.cpu().numpy()

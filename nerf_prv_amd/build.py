@@ -1,0 +1,74 @@
+"""In-tree build of the native pieces (explicit hipcc / g++ command lines, no JIT cache).
+
+  libprv_hip.so   HIP kernels + C ABI                      (hipcc --offload-arch=gfx950)
+  libprv_host.so  C++ planner shell, no GPU dependency     (g++)
+  prv_planner     the planner executable                   (g++, dlopen-free: links both)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+ROOT = os.path.dirname(HERE)
+
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (and there is no fallback)")
+
+
+def build_hip(force=False):
+    out = os.path.join(HERE, "libprv_hip.so")
+    srcs = [os.path.join(CSRC, f) for f in ("prv_kernels.hip", "prv_api.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("prv_device.hpp", "prv_kernels.hpp", "prv_json.hpp")] + [
+        os.path.join(ROOT, "include", "prv.h")]
+    if force or _newer(out, deps):
+        _run([hipcc()] + HIP_FLAGS + ["-o", out] + srcs)
+    return out
+
+
+def build_host(force=False):
+    if not os.path.isdir(HOST):
+        return None
+    out = os.path.join(HERE, "libprv_host.so")
+    srcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".cpp") and f != "main.cpp")
+    deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [
+        os.path.join(CSRC, "prv_json.hpp"), os.path.join(ROOT, "include", "prv.h"), os.path.join(ROOT, "include", "prv_host.h")]
+    deps = [d for d in deps if os.path.exists(d)]
+    if srcs and (force or _newer(out, deps)):
+        _run(["g++"] + HOST_FLAGS + ["-shared", "-o", out] + srcs)
+    exe = os.path.join(HERE, "prv_planner")
+    main = os.path.join(HOST, "main.cpp")
+    if os.path.exists(main) and (force or _newer(exe, deps + [main, os.path.join(HERE, "libprv_hip.so")])):
+        _run(["g++"] + HOST_FLAGS + ["-o", exe, main] + srcs +
+             ["-L" + HERE, "-lprv_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + HERE, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+def build_all(force=False):
+    build_hip(force)
+    build_host(force)
+
+
+if __name__ == "__main__":
+    build_all("--force" in sys.argv)

@@ -1,0 +1,851 @@
+// prv_api.cpp -- the C ABI of include/prv.h on top of the gfx950 kernels.
+// Host-side C++ compiled by hipcc; no CPU fallback anywhere: every compute entry point
+// needs a context, and a context needs a GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "prv_json.hpp"
+#include "prv_kernels.hpp"
+
+using namespace prv;
+
+// ------------------------------------------------------------------ internals
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Buffer {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct Model {
+  bool loaded = false;
+  prv_field_desc desc{};
+  FieldDev dev{};
+  uint64_t table_halfs = 0, occ_words = 0;
+  Buffer table, occ, frags, mlp; // mlp = canonical weights kept for export
+};
+
+} // namespace
+
+struct prv_camset {
+  std::vector<CamDev> cams;
+  CamDev* dev = nullptr;
+  int device = 0;
+  int width = 0, height = 0;
+};
+
+struct prv_ctx {
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  Model models[PRV_MAX_MODELS];
+  // grow-only workspaces
+  Buffer queue, counters, view_ids, img_f32, partial, records, dbg[6];
+  Buffer img_u8[PRV_MAX_MODELS];
+  int blocks_per_cu = 4;
+  int refill_min = 8;
+  size_t queue_budget = (size_t)1 << 30;
+};
+
+namespace {
+
+int fail(prv_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                           \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess) return fail((c), PRV_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
+int ensure(prv_ctx* c, Buffer& b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return PRV_OK;
+  if (b.p) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  HIPCHK(c, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return PRV_OK;
+}
+
+void release(Buffer& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+// ---- level table (same published recipe as the oracle, written independently)
+struct HostLevel {
+  float scale;
+  uint32_t res, offset, size, hashed;
+};
+
+int compute_levels(const prv_field_desc& d, HostLevel* lv, uint64_t* total) {
+  if (d.n_levels < 1 || d.n_levels > kMaxLevels) return -1;
+  if (d.n_features != 2 && d.n_features != 4) return -1;
+  if (d.n_levels * d.n_features != 32) return -1;
+  if (d.log2_hashmap < 4 || d.log2_hashmap > 28) return -1;
+  if (d.base_res < 2 || d.finest_res < d.base_res || d.finest_res > 4096) return -1;
+  if (d.occ_res < 1 || d.occ_res > 1024) return -1;
+  const double growth =
+      d.n_levels > 1 ? std::exp((std::log((double)d.finest_res) - std::log((double)d.base_res)) / (d.n_levels - 1)) : 1.0;
+  const uint64_t T = 1ull << d.log2_hashmap;
+  uint64_t off = 0;
+  for (int l = 0; l < d.n_levels; l++) {
+    double s = (double)d.base_res * std::pow(growth, (double)l) - 1.0;
+    const double nearest = std::floor(s + 0.5);
+    if (std::fabs(s - nearest) < 1e-9) s = nearest;
+    lv[l].scale = (float)s;
+    lv[l].res = (uint32_t)std::ceil(s) + 1u;
+    const uint64_t dense = (uint64_t)lv[l].res * lv[l].res * lv[l].res;
+    lv[l].hashed = dense > T;
+    lv[l].size = lv[l].hashed ? (uint32_t)T : (uint32_t)((dense + 7) & ~7ull);
+    lv[l].offset = (uint32_t)off;
+    off += lv[l].size;
+  }
+  if (off * (uint64_t)d.n_features * 2ull >= (1ull << 32)) return -1; // 32-bit byte offsets in the gather
+  *total = off;
+  return 0;
+}
+
+// ---- MFMA A-fragment prepack.  Canonical weights W[layer][in][out] (fp16 bits).
+// Fragment (layer, mt, s): lane (r,h), element j = W[kmap(s,h,j)][32*mt + r], zero past n_out.
+const int kIn[5] = {32, 64, 32, 64, 64};
+const int kOut[5] = {64, 16, 64, 64, 16};
+const int kOff[5] = {0, 2048, 3072, 5120, 9216};
+
+// hidden unit held by element j of lane half h in k-step s of a 64-wide activation
+inline int hidden_k(int s, int h, int j) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+void prepack_fragments(const uint16_t* mlp, std::vector<uint16_t>& frags) {
+  frags.assign((size_t)kNumFrags * kFragHalfs, 0);
+  int f = 0;
+  auto emit = [&](int layer, int mt, int s, int (*kmap)(int, int, int)) {
+    uint16_t* dst = frags.data() + (size_t)f * kFragHalfs;
+    for (int lane = 0; lane < 64; lane++) {
+      const int r = lane & 31, h = lane >> 5, out = 32 * mt + r;
+      for (int j = 0; j < 8; j++) {
+        const int k = kmap(s, h, j);
+        dst[lane * 8 + j] = out < kOut[layer] ? mlp[kOff[layer] + k * kOut[layer] + out] : (uint16_t)0;
+      }
+    }
+    f++;
+  };
+  auto k_feat = [](int s, int h, int j) { return 16 * h + 8 * s + j; };               // grid features
+  auto k_rgb_in = [](int s, int h, int j) { return s == 0 ? hidden_k(0, h, j) : 16 + 8 * h + j; }; // [dens | SH]
+  for (int mt = 0; mt < 2; mt++)
+    for (int s = 0; s < 2; s++) emit(0, mt, s, k_feat);
+  for (int s = 0; s < 4; s++) emit(1, 0, s, hidden_k);
+  for (int mt = 0; mt < 2; mt++)
+    for (int s = 0; s < 2; s++) emit(2, mt, s, k_rgb_in);
+  for (int mt = 0; mt < 2; mt++)
+    for (int s = 0; s < 4; s++) emit(3, mt, s, hidden_k);
+  for (int s = 0; s < 4; s++) emit(4, 0, s, hidden_k);
+}
+
+// ---- host fp16 + counter RNG for the (tiny) synthetic MLP weights and occupancy
+uint16_t f2h(float f) {
+  _Float16 h = (_Float16)f; // host clang: IEEE RNE conversion
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+float rng_sym(uint64_t seed, uint64_t stream, uint64_t i, float amp) {
+  const uint64_t hsh = mix64(seed + (stream + 1) * 0xD1B54A32D192ED03ull + i * 0x9E3779B97F4A7C15ull);
+  const uint32_t u = (uint32_t)(hsh >> 40);
+  const float v = (float)u * (1.0f / 8388608.0f) - 1.0f;
+  return v * amp;
+}
+const float kSynthSpheres[4][4] = {
+    {0.50f, 0.50f, 0.50f, 0.35f}, {0.80f, 0.50f, 0.62f, 0.13f}, {0.36f, 0.80f, 0.45f, 0.11f}, {0.40f, 0.24f, 0.78f, 0.10f}};
+
+int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t* mlp, const uint32_t* occ_host,
+                  const uint16_t* table_host /* may be null: table already on device */) {
+  Model& m = c->models[slot];
+  HostLevel lv[kMaxLevels];
+  uint64_t total = 0;
+  if (compute_levels(d, lv, &total) != 0) return fail(c, PRV_E_INVALID, "invalid field descriptor");
+  m.desc = d;
+  m.table_halfs = total * (uint64_t)d.n_features;
+  const uint64_t R = (uint64_t)d.occ_res;
+  m.occ_words = (R * R * R + 31) / 32;
+  int rc;
+  if ((rc = ensure(c, m.table, m.table_halfs * 2 + 16)) != PRV_OK) return rc;
+  if ((rc = ensure(c, m.occ, m.occ_words * 4)) != PRV_OK) return rc;
+  if ((rc = ensure(c, m.frags, (size_t)kNumFrags * kFragHalfs * 2)) != PRV_OK) return rc;
+  if ((rc = ensure(c, m.mlp, PRV_MLP_HALFS * 2)) != PRV_OK) return rc;
+  if (table_host) HIPCHK(c, hipMemcpyAsync(m.table.p, table_host, m.table_halfs * 2, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(m.occ.p, occ_host, m.occ_words * 4, hipMemcpyHostToDevice, c->stream));
+  std::vector<uint16_t> frags;
+  prepack_fragments(mlp, frags);
+  HIPCHK(c, hipMemcpyAsync(m.frags.p, frags.data(), frags.size() * 2, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(m.mlp.p, mlp, PRV_MLP_HALFS * 2, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // host staging vectors go out of scope
+  FieldDev& f = m.dev;
+  memset(&f, 0, sizeof(f));
+  f.table = (const uint16_t*)m.table.p;
+  f.occ = (const uint32_t*)m.occ.p;
+  f.frags = (const half8*)m.frags.p;
+  f.n_levels = d.n_levels;
+  f.n_features = d.n_features;
+  f.occ_res = d.occ_res;
+  f.density_bias = d.density_bias;
+  // Level order seen by the kernel: lane half h gathers canonical levels [h*L/2, (h+1)*L/2).
+  for (int l = 0; l < d.n_levels; l++) {
+    LevelDev& L = f.levels[l];
+    L.scale = lv[l].scale;
+    L.res_m1 = lv[l].res - 1;
+    L.offset = lv[l].offset;
+    L.hashed = lv[l].hashed;
+    L.mask = lv[l].hashed ? lv[l].size - 1u : 0xffffffffu;
+    L.my = lv[l].hashed ? 2654435761u : lv[l].res;
+    L.mz = lv[l].hashed ? 805459861u : lv[l].res * lv[l].res;
+    L.pad = 0;
+  }
+  m.loaded = true;
+  return PRV_OK;
+}
+
+int check_model(prv_ctx* c, int slot) {
+  if (slot < 0 || slot >= PRV_MAX_MODELS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
+  if (!c->models[slot].loaded) return fail(c, PRV_E_STATE, "model slot %d is empty", slot);
+  return PRV_OK;
+}
+
+int check_opts(prv_ctx* c, const prv_render_opts* o) {
+  if (!o) return fail(c, PRV_E_INVALID, "render options are NULL");
+  if (o->width < 1 || o->height < 1 || o->width > 16384 || o->height > 16384)
+    return fail(c, PRV_E_INVALID, "bad image size %dx%d", o->width, o->height);
+  if (o->samples_per_ray < 1 || o->samples_per_ray > kMaxSamples)
+    return fail(c, PRV_E_INVALID, "samples_per_ray must be in [1,%d], got %d", kMaxSamples, o->samples_per_ray);
+  if (o->spp < 1 || o->spp > 1024) return fail(c, PRV_E_INVALID, "spp must be in [1,1024], got %d", o->spp);
+  return PRV_OK;
+}
+
+// cameras at the render resolution: focal from camera_angle_x at the json width (run.py:285-286,
+// fov_axis = 0), rescaled to the requested width; principal point at the image centre.
+CamDev cam_at(const CamDev& c, int json_w, int w, int h) {
+  CamDev r = c;
+  const float s = (float)w / (float)json_w;
+  r.fx = c.fx * s;
+  r.fy = c.fy * s;
+  r.cx = 0.5f * (float)w;
+  r.cy = 0.5f * (float)h;
+  return r;
+}
+
+// The render of one batch of views into out_f32 (+ optional out_u8).  Views are dealt to
+// the queue in batches so the queue stays within queue_budget bytes.
+int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, int n_views,
+                 const prv_render_opts* o, float* out_f32, uint8_t* out_u8, bool zero_stats) {
+  const Model& m = c->models[slot];
+  const int W = o->width, H = o->height;
+  const size_t npix = (size_t)W * H;
+  int rc;
+  if ((rc = ensure(c, c->counters, 64)) != PRV_OK) return rc;
+  uint32_t* q_count = (uint32_t*)c->counters.p;
+  uint32_t* q_head = q_count + 1;
+  unsigned long long* stat = (unsigned long long*)((char*)c->counters.p + 16);
+  if (zero_stats) HIPCHK(c, hipMemsetAsync(stat, 0, 8, c->stream));
+  if (n_views == 0) return PRV_OK;
+
+  // cameras at this resolution, uploaded per call (tiny)
+  std::vector<CamDev> cams(n_views);
+  std::vector<int> ids(n_views);
+  for (int i = 0; i < n_views; i++) {
+    const int v = view_ids ? view_ids[i] : i;
+    if (v < 0 || v >= (int)cs->cams.size()) return fail(c, PRV_E_INVALID, "view id %d out of range", v);
+    cams[i] = cam_at(cs->cams[v], cs->width, W, H);
+    ids[i] = i;
+  }
+  if ((rc = ensure(c, c->view_ids, (size_t)n_views * (sizeof(CamDev) + sizeof(int)))) != PRV_OK) return rc;
+  CamDev* cams_dev = (CamDev*)c->view_ids.p;
+  int* ids_dev = (int*)((char*)c->view_ids.p + (size_t)n_views * sizeof(CamDev));
+  HIPCHK(c, hipMemcpyAsync(cams_dev, cams.data(), (size_t)n_views * sizeof(CamDev), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(ids_dev, ids.data(), (size_t)n_views * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // staging vectors are stack-owned
+
+  size_t batch = std::max<size_t>(1, c->queue_budget / (npix * kRecordBytes));
+  batch = std::min<size_t>(batch, (size_t)n_views);
+  if (batch * npix >= (1ull << 32)) batch = ((1ull << 32) - 1) / npix; // 32-bit pixel ids
+  if (batch == 0) return fail(c, PRV_E_INVALID, "image too large");
+  if ((rc = ensure(c, c->queue, batch * npix * kRecordBytes)) != PRV_OK) return rc;
+
+  const int n_blocks = c->n_cu * c->blocks_per_cu;
+  for (size_t b0 = 0; b0 < (size_t)n_views; b0 += batch) {
+    const int nb = (int)std::min(batch, (size_t)n_views - b0);
+    for (int k = 0; k < o->spp; k++) {
+      HIPCHK(c, hipMemsetAsync(q_count, 0, 8, c->stream));
+      MarchParams mp;
+      memset(&mp, 0, sizeof(mp));
+      mp.field = m.dev;
+      mp.cams = cams_dev;
+      mp.view_ids = ids_dev + b0;
+      mp.W = W;
+      mp.H = H;
+      mp.S = o->samples_per_ray;
+      mp.spp_k = k;
+      mp.tiles_x = (uint32_t)((W + kTile - 1) / kTile);
+      mp.tiles_y = (uint32_t)((H + kTile - 1) / kTile);
+      mp.queue = c->queue.p;
+      mp.queue_count = q_count;
+      mp.out_f32 = out_f32 + b0 * npix * 4;
+      mp.out_u8 = out_u8 ? (uint32_t*)out_u8 + b0 * npix : nullptr;
+      mp.inv_spp = 1.0f / (float)o->spp;
+      mp.last_pass = k == o->spp - 1;
+      memcpy(mp.bg, o->background, sizeof(mp.bg));
+      HIPCHK(c, launch_march(mp, nb, c->stream));
+      RenderParams rp;
+      memset(&rp, 0, sizeof(rp));
+      rp.field = m.dev;
+      rp.queue = c->queue.p;
+      rp.queue_count = q_count;
+      rp.queue_head = q_head;
+      rp.stat_evaluated = stat;
+      rp.out_f32 = mp.out_f32;
+      rp.out_u8 = mp.out_u8;
+      rp.min_T = o->min_transmittance;
+      rp.inv_spp = mp.inv_spp;
+      rp.spp_k = k;
+      rp.last_pass = mp.last_pass;
+      rp.refill_min = c->refill_min;
+      memcpy(rp.bg, o->background, sizeof(rp.bg));
+      HIPCHK(c, launch_render(rp, n_blocks, c->stream));
+    }
+  }
+  return PRV_OK;
+}
+
+int fetch_stats(prv_ctx* c, const prv_render_opts* o, int n_views, int n_models, prv_stats* st) {
+  if (!st) return PRV_OK;
+  unsigned long long ev = 0;
+  HIPCHK(c, hipMemcpyAsync(&ev, (char*)c->counters.p + 16, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  st->rays = (uint64_t)n_views * n_models * o->width * o->height * o->spp;
+  st->samples_nominal = st->rays * (uint64_t)o->samples_per_ray;
+  st->samples_evaluated = ev;
+  return PRV_OK;
+}
+
+int score_blocks(size_t npix) { return (int)std::min<size_t>(64, std::max<size_t>(1, (npix + 4095) / 4096)); }
+
+} // namespace
+
+// ------------------------------------------------------------------ context
+
+extern "C" {
+
+int prv_abi_version(void) { return PRV_ABI_VERSION; }
+
+int prv_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* prv_last_error(const prv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int prv_create(prv_ctx** out, int device_id) {
+  if (!out) return fail(nullptr, PRV_E_INVALID, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, PRV_E_NODEVICE, "no HIP device visible (%s): this library has no CPU path",
+                e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n) return fail(nullptr, PRV_E_INVALID, "device %d out of range [0,%d)", device_id, n);
+  hipDeviceProp_t prop;
+  if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess)
+    return fail(nullptr, PRV_E_HIP, "device %d: %s", device_id, hipGetErrorString(e));
+  if (!strstr(prop.gcnArchName, "gfx950"))
+    return fail(nullptr, PRV_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+  prv_ctx* c = new prv_ctx();
+  c->device = device_id;
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+    delete c;
+    return fail(nullptr, PRV_E_HIP, "stream create: %s", hipGetErrorString(e));
+  }
+  c->stream = c->own_stream;
+  if (const char* s = getenv("PRV_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(s));
+  if (const char* s = getenv("PRV_REFILL_MIN")) c->refill_min = std::min(32, std::max(1, atoi(s)));
+  if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
+  *out = c;
+  return PRV_OK;
+}
+
+void prv_destroy(prv_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& m : c->models) {
+    release(m.table);
+    release(m.occ);
+    release(m.frags);
+    release(m.mlp);
+  }
+  release(c->queue);
+  release(c->counters);
+  release(c->view_ids);
+  release(c->img_f32);
+  release(c->partial);
+  release(c->records);
+  for (auto& b : c->dbg) release(b);
+  for (auto& b : c->img_u8) release(b);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int prv_set_stream(prv_ctx* c, void* s) {
+  if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return PRV_OK;
+}
+
+int prv_synchronize(prv_ctx* c) {
+  if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PRV_OK;
+}
+
+int prv_malloc(prv_ctx* c, void** p, size_t bytes) {
+  if (!c || !p) return PRV_E_INVALID;
+  HIPCHK(c, hipMalloc(p, bytes ? bytes : 1));
+  return PRV_OK;
+}
+int prv_free(prv_ctx* c, void* p) {
+  if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipFree(p));
+  return PRV_OK;
+}
+int prv_memcpy_h2d(prv_ctx* c, void* d, const void* s, size_t bytes) {
+  if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PRV_OK;
+}
+int prv_memcpy_d2h(prv_ctx* c, void* d, const void* s, size_t bytes) {
+  if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PRV_OK;
+}
+
+// ------------------------------------------------------------------ model
+
+int prv_model_sizes(const prv_field_desc* d, uint64_t* table_halfs, uint64_t* mlp_halfs, uint64_t* occ_words) {
+  if (!d) return PRV_E_INVALID;
+  HostLevel lv[kMaxLevels];
+  uint64_t total = 0;
+  if (compute_levels(*d, lv, &total) != 0) return PRV_E_INVALID;
+  if (table_halfs) *table_halfs = total * (uint64_t)d->n_features;
+  if (mlp_halfs) *mlp_halfs = PRV_MLP_HALFS;
+  const uint64_t R = (uint64_t)d->occ_res;
+  if (occ_words) *occ_words = (R * R * R + 31) / 32;
+  return PRV_OK;
+}
+
+int prv_model_load(prv_ctx* c, int slot, const prv_field_desc* d, const uint16_t* table, const uint16_t* mlp,
+                   const uint32_t* occ) {
+  if (!c) return PRV_E_INVALID;
+  if (slot < 0 || slot >= PRV_MAX_MODELS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
+  if (!d || !table || !mlp || !occ) return fail(c, PRV_E_INVALID, "NULL argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  return install_model(c, slot, *d, mlp, occ, table);
+}
+
+int prv_model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed) {
+  if (!c) return PRV_E_INVALID;
+  if (slot < 0 || slot >= PRV_MAX_MODELS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
+  if (!d) return fail(c, PRV_E_INVALID, "NULL descriptor");
+  HIPCHK(c, hipSetDevice(c->device));
+  HostLevel lv[kMaxLevels];
+  uint64_t total = 0;
+  if (compute_levels(*d, lv, &total) != 0) return fail(c, PRV_E_INVALID, "invalid field descriptor");
+  std::vector<uint16_t> mlp(PRV_MLP_HALFS);
+  size_t o = 0;
+  for (int l = 0; l < 5; l++) {
+    const float amp = sqrtf(6.0f / (float)(kIn[l] + kOut[l]));
+    const size_t cnt = (size_t)kIn[l] * kOut[l];
+    for (size_t i = 0; i < cnt; i++) mlp[o + i] = f2h(rng_sym(seed, (uint64_t)(l + 1), i, amp));
+    o += cnt;
+  }
+  const int R = d->occ_res;
+  std::vector<uint32_t> occ(((size_t)R * R * R + 31) / 32, 0u);
+  const float invR = 1.0f / (float)R;
+  for (int z = 0; z < R; z++)
+    for (int y = 0; y < R; y++)
+      for (int x = 0; x < R; x++) {
+        const float cx = ((float)x + 0.5f) * invR, cy = ((float)y + 0.5f) * invR, cz = ((float)z + 0.5f) * invR;
+        bool in = false;
+        for (int b = 0; b < 4 && !in; b++) {
+          const float dx = cx - kSynthSpheres[b][0], dy = cy - kSynthSpheres[b][1], dz = cz - kSynthSpheres[b][2];
+          const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+          in = d2 <= kSynthSpheres[b][3] * kSynthSpheres[b][3];
+        }
+        if (in) {
+          const size_t bit = (size_t)x + (size_t)R * ((size_t)y + (size_t)R * (size_t)z);
+          occ[bit >> 5] |= 1u << (bit & 31);
+        }
+      }
+  Model& m = c->models[slot];
+  int rc = ensure(c, m.table, total * (uint64_t)d->n_features * 2 + 16);
+  if (rc != PRV_OK) return rc;
+  HIPCHK(c, launch_synth_table((uint16_t*)m.table.p, total * (uint64_t)d->n_features, seed, d->table_amp, c->stream));
+  return install_model(c, slot, *d, mlp.data(), occ.data(), nullptr);
+}
+
+int prv_model_export(prv_ctx* c, int slot, uint16_t* table, uint16_t* mlp, uint32_t* occ) {
+  if (!c) return PRV_E_INVALID;
+  int rc = check_model(c, slot);
+  if (rc != PRV_OK) return rc;
+  const Model& m = c->models[slot];
+  if (table) HIPCHK(c, hipMemcpyAsync(table, m.table.p, m.table_halfs * 2, hipMemcpyDeviceToHost, c->stream));
+  if (mlp) HIPCHK(c, hipMemcpyAsync(mlp, m.mlp.p, PRV_MLP_HALFS * 2, hipMemcpyDeviceToHost, c->stream));
+  if (occ) HIPCHK(c, hipMemcpyAsync(occ, m.occ.p, m.occ_words * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PRV_OK;
+}
+
+// ------------------------------------------------------------------ cameras
+
+// transform_matrix (NeRF convention, as written at main.cpp:1626-1641) -> engine frame:
+// negate columns 1 and 2, t*scale + offset, cycle rows (y,z,x).  ASSUMED from upstream
+// instant-ngp (not in the reference tree).
+int prv_cameras_from_matrices(prv_ctx* c, const double* tm, int n, double camera_angle_x, int width, int height,
+                              double scale, const double offset[3], prv_camset** out) {
+  if (!c) return PRV_E_INVALID;
+  if (!out) return fail(c, PRV_E_INVALID, "out is NULL");
+  *out = nullptr;
+  if (n < 0 || (n > 0 && !tm)) return fail(c, PRV_E_INVALID, "bad matrix array");
+  if (width < 1 || height < 1) return fail(c, PRV_E_INVALID, "bad size %dx%d", width, height);
+  if (!(camera_angle_x > 0.0 && camera_angle_x < M_PI)) return fail(c, PRV_E_INVALID, "bad camera_angle_x %g", camera_angle_x);
+  prv_camset* cs = new prv_camset();
+  cs->device = c->device;
+  cs->width = width;
+  cs->height = height;
+  const double off[3] = {offset ? offset[0] : 0.5, offset ? offset[1] : 0.5, offset ? offset[2] : 0.5};
+  const float focal = (float)(0.5 * (double)width / std::tan(0.5 * camera_angle_x));
+  static const int src_row[3] = {1, 2, 0};
+  cs->cams.resize(n);
+  for (int i = 0; i < n; i++) {
+    const double* m = tm + (size_t)i * 16;
+    double e[3][4];
+    for (int r = 0; r < 3; r++) {
+      e[r][0] = m[r * 4 + 0];
+      e[r][1] = -m[r * 4 + 1];
+      e[r][2] = -m[r * 4 + 2];
+      e[r][3] = m[r * 4 + 3] * scale + off[r];
+    }
+    CamDev& cam = cs->cams[i];
+    for (int r = 0; r < 3; r++)
+      for (int k = 0; k < 4; k++) cam.c2w[r * 4 + k] = (float)e[src_row[r]][k];
+    cam.fx = cam.fy = focal;
+    cam.cx = 0.5f * (float)width;
+    cam.cy = 0.5f * (float)height;
+  }
+  *out = cs;
+  return PRV_OK;
+}
+
+int prv_cameras_from_json(prv_ctx* c, const char* path, prv_camset** out) {
+  if (!c) return PRV_E_INVALID;
+  if (!out || !path) return fail(c, PRV_E_INVALID, "NULL argument");
+  *out = nullptr;
+  std::string text, err;
+  if (!prvjson::read_file(path, text)) return fail(c, PRV_E_IO, "cannot read %s", path);
+  prvjson::Value root;
+  if (!prvjson::Parser(text).parse(root, err)) return fail(c, PRV_E_IO, "%s: %s", path, err.c_str());
+  if (!root.has("camera_angle_x") || !root.has("frames") || !root.has("w") || !root.has("h"))
+    return fail(c, PRV_E_IO, "%s: missing camera_angle_x / w / h / frames", path);
+  const double scale = root.has("scale") ? root.at("scale").number() : 0.33;
+  double offset[3] = {0.5, 0.5, 0.5};
+  if (root.has("offset") && root.at("offset").arr.size() == 3)
+    for (int k = 0; k < 3; k++) offset[k] = root.at("offset").arr[k].number();
+  const auto& frames = root.at("frames").arr;
+  std::vector<double> tm(frames.size() * 16);
+  for (size_t i = 0; i < frames.size(); i++) {
+    const auto& M = frames[i].at("transform_matrix");
+    if (M.arr.size() != 4) return fail(c, PRV_E_IO, "%s: frame %zu has no 4x4 transform_matrix", path, i);
+    for (int r = 0; r < 4; r++) {
+      if (M.arr[r].arr.size() != 4) return fail(c, PRV_E_IO, "%s: frame %zu row %d is not 4 wide", path, i, r);
+      for (int k = 0; k < 4; k++) tm[i * 16 + r * 4 + k] = M.arr[r].arr[k].number();
+    }
+  }
+  return prv_cameras_from_matrices(c, tm.data(), (int)frames.size(), root.at("camera_angle_x").number(),
+                                   (int)root.at("w").number(), (int)root.at("h").number(), scale, offset, out);
+}
+
+int prv_camset_count(const prv_camset* cs) { return cs ? (int)cs->cams.size() : PRV_E_INVALID; }
+int prv_camset_size(const prv_camset* cs, int* w, int* h) {
+  if (!cs) return PRV_E_INVALID;
+  if (w) *w = cs->width;
+  if (h) *h = cs->height;
+  return PRV_OK;
+}
+int prv_camset_get(const prv_camset* cs, int i, float c2w[12], float intr[4]) {
+  if (!cs || i < 0 || i >= (int)cs->cams.size()) return PRV_E_INVALID;
+  if (c2w) memcpy(c2w, cs->cams[i].c2w, sizeof(float) * 12);
+  if (intr) {
+    intr[0] = cs->cams[i].fx;
+    intr[1] = cs->cams[i].fy;
+    intr[2] = cs->cams[i].cx;
+    intr[3] = cs->cams[i].cy;
+  }
+  return PRV_OK;
+}
+void prv_camset_destroy(prv_camset* cs) { delete cs; }
+
+// ------------------------------------------------------------------ render
+
+int prv_render(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, int n_views, const prv_render_opts* o,
+               float* out, prv_stats* st) {
+  if (!c) return PRV_E_INVALID;
+  int rc;
+  if ((rc = check_model(c, slot)) != PRV_OK || (rc = check_opts(c, o)) != PRV_OK) return rc;
+  if (!cs || n_views < 0 || (!out && n_views > 0)) return fail(c, PRV_E_INVALID, "bad camset / view count / output");
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = render_views(c, slot, cs, view_ids, n_views, o, out, nullptr, true)) != PRV_OK) return rc;
+  return fetch_stats(c, o, n_views, 1, st);
+}
+
+int prv_render_rgba8(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, int n_views,
+                     const prv_render_opts* o, uint8_t* out, prv_stats* st) {
+  if (!c) return PRV_E_INVALID;
+  int rc;
+  if ((rc = check_model(c, slot)) != PRV_OK || (rc = check_opts(c, o)) != PRV_OK) return rc;
+  if (!cs || n_views < 0 || (!out && n_views > 0)) return fail(c, PRV_E_INVALID, "bad camset / view count / output");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t npix = (size_t)o->width * o->height;
+  if ((rc = ensure(c, c->img_f32, std::max<size_t>(16, (size_t)n_views * npix * 16))) != PRV_OK) return rc;
+  if ((rc = render_views(c, slot, cs, view_ids, n_views, o, (float*)c->img_f32.p, out, true)) != PRV_OK) return rc;
+  return fetch_stats(c, o, n_views, 1, st);
+}
+
+int prv_quantize_rgba8(prv_ctx* c, const float* rgba, size_t n, const float bg[4], uint8_t* out) {
+  if (!c) return PRV_E_INVALID;
+  if (!rgba || !out || !bg) return fail(c, PRV_E_INVALID, "NULL argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (n) HIPCHK(c, launch_quantize(rgba, n, bg, out, c->stream));
+  return PRV_OK;
+}
+
+// ------------------------------------------------------------------ scores
+
+static int score_ensemble_dev(prv_ctx* c, int method, const uint8_t* const* imgs, int E, int n_views, size_t npix,
+                              prv_score_record* rec_dev) {
+  const int nblk = score_blocks(npix);
+  int rc;
+  if ((rc = ensure(c, c->partial, (size_t)n_views * nblk * 2 * sizeof(double))) != PRV_OK) return rc;
+  EnsembleParams P;
+  memset(&P, 0, sizeof(P));
+  for (int e = 0; e < E; e++) P.imgs[e] = (const uint32_t*)imgs[e];
+  P.E = E;
+  P.pixels_per_view = npix;
+  P.partial = (double*)c->partial.p;
+  HIPCHK(c, launch_score_ensemble(P, method, n_views, nblk, c->stream));
+  HIPCHK(c, launch_score_finalize(P.partial, n_views, nblk, method, npix, rec_dev, c->stream));
+  return PRV_OK;
+}
+
+static int score_psnr_dev(prv_ctx* c, const float* rgba, const float* gt, int n_views, size_t npix, const float bg[4],
+                          prv_score_record* rec_dev) {
+  const int nblk = score_blocks(npix);
+  int rc;
+  if ((rc = ensure(c, c->partial, (size_t)n_views * nblk * 2 * sizeof(double))) != PRV_OK) return rc;
+  PsnrParams P;
+  memset(&P, 0, sizeof(P));
+  P.rgba = rgba;
+  P.gt = gt;
+  P.pixels_per_view = npix;
+  memcpy(P.bg, bg, sizeof(P.bg));
+  P.partial = (double*)c->partial.p;
+  HIPCHK(c, launch_score_psnr(P, n_views, nblk, c->stream));
+  HIPCHK(c, launch_score_finalize(P.partial, n_views, nblk, PRV_SCORE_PSNR_COVERAGE, npix, rec_dev, c->stream));
+  return PRV_OK;
+}
+
+int prv_score_ensemble_images(prv_ctx* c, int method, const uint8_t* const* imgs, int E, int n_views, size_t npix,
+                              prv_score_record* rec_host) {
+  if (!c) return PRV_E_INVALID;
+  if (method != PRV_SCORE_ENSEMBLE_RGB && method != PRV_SCORE_ENSEMBLE_RGB_DENSITY)
+    return fail(c, PRV_E_INVALID, "method %d is not an ensemble score", method);
+  if (!imgs || E < 1 || E > PRV_MAX_MODELS || n_views < 0 || !rec_host) return fail(c, PRV_E_INVALID, "bad argument");
+  if (n_views == 0) return PRV_OK;
+  if (npix == 0) return fail(c, PRV_E_INVALID, "empty images");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, c->records, (size_t)n_views * sizeof(prv_score_record))) != PRV_OK) return rc;
+  if ((rc = score_ensemble_dev(c, method, imgs, E, n_views, npix, (prv_score_record*)c->records.p)) != PRV_OK) return rc;
+  return prv_memcpy_d2h(c, rec_host, c->records.p, (size_t)n_views * sizeof(prv_score_record));
+}
+
+int prv_score_psnr_images(prv_ctx* c, const float* rgba, const float* gt, int n_views, size_t npix, const float bg[4],
+                          prv_score_record* rec_host) {
+  if (!c) return PRV_E_INVALID;
+  if (!rgba || !gt || !bg || n_views < 0 || !rec_host) return fail(c, PRV_E_INVALID, "bad argument");
+  if (n_views == 0) return PRV_OK;
+  if (npix == 0) return fail(c, PRV_E_INVALID, "empty images");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, c->records, (size_t)n_views * sizeof(prv_score_record))) != PRV_OK) return rc;
+  if ((rc = score_psnr_dev(c, rgba, gt, n_views, npix, bg, (prv_score_record*)c->records.p)) != PRV_OK) return rc;
+  return prv_memcpy_d2h(c, rec_host, c->records.p, (size_t)n_views * sizeof(prv_score_record));
+}
+
+int prv_score_views(prv_ctx* c, int method, const int* model_slots, int n_models, const prv_camset* cs,
+                    const int* view_ids, int n_views, const prv_render_opts* o, const float* gt,
+                    prv_score_record* rec_host, prv_score_record* rec_dev, prv_stats* st) {
+  if (!c) return PRV_E_INVALID;
+  int rc;
+  if ((rc = check_opts(c, o)) != PRV_OK) return rc;
+  if (!cs || !model_slots || n_views < 0) return fail(c, PRV_E_INVALID, "bad argument");
+  const bool ens = method == PRV_SCORE_ENSEMBLE_RGB || method == PRV_SCORE_ENSEMBLE_RGB_DENSITY;
+  if (!ens && method != PRV_SCORE_PSNR_COVERAGE) return fail(c, PRV_E_INVALID, "unknown score method %d", method);
+  if (ens && (n_models < 1 || n_models > PRV_MAX_MODELS)) return fail(c, PRV_E_INVALID, "ensemble size %d", n_models);
+  if (!ens && (n_models != 1 || !gt)) return fail(c, PRV_E_INVALID, "method 5 needs one model and reference images");
+  for (int e = 0; e < n_models; e++)
+    if ((rc = check_model(c, model_slots[e])) != PRV_OK) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t npix = (size_t)o->width * o->height;
+  if ((rc = ensure(c, c->records, std::max<size_t>(16, (size_t)n_views * sizeof(prv_score_record)))) != PRV_OK) return rc;
+  prv_score_record* rec = (prv_score_record*)c->records.p;
+  if ((rc = ensure(c, c->img_f32, std::max<size_t>(16, (size_t)n_views * npix * 16))) != PRV_OK) return rc;
+  if (ens) {
+    const uint8_t* imgs[PRV_MAX_MODELS];
+    for (int e = 0; e < n_models; e++) {
+      if ((rc = ensure(c, c->img_u8[e], std::max<size_t>(16, (size_t)n_views * npix * 4))) != PRV_OK) return rc;
+      imgs[e] = (const uint8_t*)c->img_u8[e].p;
+      if ((rc = render_views(c, model_slots[e], cs, view_ids, n_views, o, (float*)c->img_f32.p,
+                             (uint8_t*)c->img_u8[e].p, e == 0)) != PRV_OK)
+        return rc;
+    }
+    if (n_views && (rc = score_ensemble_dev(c, method, imgs, n_models, n_views, npix, rec)) != PRV_OK) return rc;
+  } else {
+    if ((rc = render_views(c, model_slots[0], cs, view_ids, n_views, o, (float*)c->img_f32.p, nullptr, true)) != PRV_OK)
+      return rc;
+    if (n_views && (rc = score_psnr_dev(c, (const float*)c->img_f32.p, gt, n_views, npix, o->background, rec)) != PRV_OK)
+      return rc;
+  }
+  if (rec_dev && n_views)
+    HIPCHK(c, hipMemcpyAsync(rec_dev, rec, (size_t)n_views * sizeof(prv_score_record), hipMemcpyDeviceToDevice, c->stream));
+  if (rec_host && n_views) {
+    HIPCHK(c, hipMemcpyAsync(rec_host, rec, (size_t)n_views * sizeof(prv_score_record), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return fetch_stats(c, o, n_views, n_models, st);
+}
+
+// arg-max rule of main.cpp:1971-1972, 2088-2091: ascending ids, strict '>', start at -1e100
+int prv_argmax(const prv_score_record* r, const int* ids, int n) {
+  if (!r || !ids) return -1;
+  double best = -1e100;
+  int best_id = -1;
+  for (int i = 0; i < n; i++)
+    if (r[i].score > best) {
+      best = r[i].score;
+      best_id = ids[i];
+    }
+  return best_id;
+}
+
+int prv_rank(const prv_score_record* r, const int* ids, int n, int* order) {
+  if (n < 0 || (n > 0 && (!r || !ids || !order))) return PRV_E_INVALID;
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; i++) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+    if (r[a].score != r[b].score) return r[a].score > r[b].score;
+    return ids[a] < ids[b];
+  });
+  for (int i = 0; i < n; i++) order[i] = ids[idx[i]];
+  return PRV_OK;
+}
+
+// ------------------------------------------------------------------ stage hooks
+
+int prv_debug_raygen(prv_ctx* c, const prv_camset* cs, int view, int W, int H, int spp_k, float* o, float* d, float* t) {
+  if (!c) return PRV_E_INVALID;
+  if (!cs || view < 0 || view >= (int)cs->cams.size() || W < 1 || H < 1 || !o || !d || !t)
+    return fail(c, PRV_E_INVALID, "bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)W * H;
+  int rc;
+  if ((rc = ensure(c, c->dbg[0], n * 12)) != PRV_OK || (rc = ensure(c, c->dbg[1], n * 12)) != PRV_OK ||
+      (rc = ensure(c, c->dbg[2], n * 8)) != PRV_OK)
+    return rc;
+  HIPCHK(c, launch_debug_raygen(cam_at(cs->cams[view], cs->width, W, H), W, H, spp_k, (float*)c->dbg[0].p,
+                                (float*)c->dbg[1].p, (float*)c->dbg[2].p, c->stream));
+  HIPCHK(c, hipMemcpyAsync(o, c->dbg[0].p, n * 12, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d, c->dbg[1].p, n * 12, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(t, c->dbg[2].p, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PRV_OK;
+}
+
+static int debug_field_common(prv_ctx* c, int slot, const float* pos, const float* dir, int n, uint16_t* feat,
+                              float* out36, int32_t* occ) {
+  int rc;
+  if ((rc = check_model(c, slot)) != PRV_OK) return rc;
+  if (n < 0 || (n > 0 && !pos)) return fail(c, PRV_E_INVALID, "bad argument");
+  if (n == 0) return PRV_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t N = (size_t)n;
+  if ((rc = ensure(c, c->dbg[0], N * 12)) != PRV_OK || (rc = ensure(c, c->dbg[1], N * 12)) != PRV_OK ||
+      (rc = ensure(c, c->dbg[3], N * 64)) != PRV_OK || (rc = ensure(c, c->dbg[4], N * 144)) != PRV_OK ||
+      (rc = ensure(c, c->dbg[5], N * 4)) != PRV_OK)
+    return rc;
+  HIPCHK(c, hipMemcpyAsync(c->dbg[0].p, pos, N * 12, hipMemcpyHostToDevice, c->stream));
+  if (dir) HIPCHK(c, hipMemcpyAsync(c->dbg[1].p, dir, N * 12, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, launch_debug_field(c->models[slot].dev, (const float*)c->dbg[0].p, dir ? (const float*)c->dbg[1].p : nullptr,
+                               n, (uint16_t*)c->dbg[3].p, (float*)c->dbg[4].p, (int32_t*)c->dbg[5].p, c->stream));
+  if (feat) HIPCHK(c, hipMemcpyAsync(feat, c->dbg[3].p, N * 64, hipMemcpyDeviceToHost, c->stream));
+  if (out36) HIPCHK(c, hipMemcpyAsync(out36, c->dbg[4].p, N * 144, hipMemcpyDeviceToHost, c->stream));
+  if (occ) HIPCHK(c, hipMemcpyAsync(occ, c->dbg[5].p, N * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PRV_OK;
+}
+
+int prv_debug_encode(prv_ctx* c, int slot, const float* pos, int n, uint16_t* feat) {
+  if (!c) return PRV_E_INVALID;
+  if (!feat && n > 0) return fail(c, PRV_E_INVALID, "feat is NULL");
+  return debug_field_common(c, slot, pos, nullptr, n, feat, nullptr, nullptr);
+}
+
+int prv_debug_field(prv_ctx* c, int slot, const float* pos, const float* dir, int n, float* out36, int32_t* occ) {
+  if (!c) return PRV_E_INVALID;
+  if (n > 0 && (!dir || !out36)) return fail(c, PRV_E_INVALID, "NULL argument");
+  return debug_field_common(c, slot, pos, dir, n, nullptr, out36, occ);
+}
+
+} // extern "C"

@@ -1,0 +1,329 @@
+// prv_device.hpp -- device-side data layout and the per-lane building blocks of the
+// fused render kernel (gfx950 / CDNA4 only; wave = 64 lanes).
+//
+// Arithmetic contract (shared with oracle/prv_oracle.c, which is the checker, not a
+// dependency): all camera / ray / sample-position / interpolation arithmetic is IEEE
+// fp32 in a fixed order with fusion only where fmaf() is written (the file is built
+// with -ffp-contract=off), so sample positions, grid indices and fp16 features are
+// bit-identical to the oracle.  Only the MFMA accumulation order and expf differ.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace prv {
+
+constexpr int kMaxLevels = 16;
+constexpr int kNumFrags = 24;      // MFMA A-operand fragments of the two MLPs
+constexpr int kFragHalfs = 64 * 8; // one fragment: 64 lanes x 8 halfs
+constexpr int kTile = 16;          // rays are dealt in 16x16-pixel chunks
+constexpr int kChunkRays = kTile * kTile;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct LevelDev {
+  float scale;      // pos = fmaf(scale, x, 0.5)
+  uint32_t res_m1;  // vertices per axis - 1 (corner clamp)
+  uint32_t offset;  // first entry of the level
+  uint32_t mask;    // hashed: size-1 ; dense: 0xffffffff
+  uint32_t my, mz;  // dense: res, res*res ; hashed: 2654435761, 805459861
+  uint32_t hashed;  // combine with xor (1) or add (0)
+  uint32_t pad;
+};
+
+struct FieldDev {
+  const uint16_t* table;  // fp16 bit patterns, entries of F halfs, level-major
+  const uint32_t* occ;    // occ_res^3 bits, x fastest
+  const half8* frags;     // kNumFrags * 64 half8, MFMA A fragments (prepacked weights)
+  LevelDev levels[kMaxLevels];
+  int n_levels, n_features, occ_res;
+  float density_bias;
+};
+
+struct CamDev {  // engine-frame camera
+  float c2w[12]; // row-major 3x4
+  float fx, fy, cx, cy;
+};
+
+// ---------------------------------------------------------------- small helpers
+
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+// sub-pixel offset k of spp; k = 0 is the pixel centre (R2 sequence)
+__device__ __forceinline__ void spp_offset(int k, float& ox, float& oy) {
+  float fk = (float)k;
+  float a = fmaf(fk, 0.7548776662466927f, 0.5f);
+  float b = fmaf(fk, 0.5698402909980532f, 0.5f);
+  ox = a - floorf(a);
+  oy = b - floorf(b);
+}
+
+// pinhole ray through pixel (px+ox, py+oy); direction normalised
+__device__ __forceinline__ void raygen(const CamDev& cam, int px, int py, float ox, float oy,
+                                       float o[3], float d[3]) {
+  float dx = (((float)px + ox) - cam.cx) / cam.fx;
+  float dy = (((float)py + oy) - cam.cy) / cam.fy;
+  float v[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const float* m = cam.c2w + r * 4;
+    v[r] = fmaf(m[0], dx, fmaf(m[1], dy, m[2]));
+    o[r] = m[3];
+  }
+  float n2 = fmaf(v[0], v[0], fmaf(v[1], v[1], v[2] * v[2]));
+  float inv = 1.0f / sqrtf(n2);
+#pragma unroll
+  for (int r = 0; r < 3; r++) d[r] = v[r] * inv;
+}
+
+// slab test against the unit cube; returns hit
+__device__ __forceinline__ bool ray_aabb(const float o[3], const float d[3], float& t0, float& t1) {
+  float tmin = 0.0f, tmax = __builtin_inff();
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    float inv = 1.0f / d[a];
+    float ta = (0.0f - o[a]) * inv;
+    float tb = (1.0f - o[a]) * inv;
+    tmin = fmaxf(tmin, fminf(ta, tb));
+    tmax = fminf(tmax, fmaxf(ta, tb));
+  }
+  t0 = tmin;
+  t1 = tmax;
+  return tmax > tmin;
+}
+
+__device__ __forceinline__ bool occupied(const FieldDev& f, float px, float py, float pz) {
+  int R = f.occ_res;
+  float fR = (float)R;
+  int cx = min((int)(clamp01(px) * fR), R - 1);
+  int cy = min((int)(clamp01(py) * fR), R - 1);
+  int cz = min((int)(clamp01(pz) * fR), R - 1);
+  uint32_t bit = (uint32_t)cx + (uint32_t)R * ((uint32_t)cy + (uint32_t)R * (uint32_t)cz);
+  return (f.occ[bit >> 5] >> (bit & 31)) & 1u;
+}
+
+// real spherical harmonics degree 4; op order identical to the oracle
+__device__ __forceinline__ void sh4(float x, float y, float z, float o[16]) {
+  float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  o[0] = 0.28209479177387814f;
+  o[1] = -0.48860251190291987f * y;
+  o[2] = 0.48860251190291987f * z;
+  o[3] = -0.48860251190291987f * x;
+  o[4] = 1.0925484305920792f * xy;
+  o[5] = -1.0925484305920792f * yz;
+  o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+  o[7] = -1.0925484305920792f * xz;
+  o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+  o[9] = (0.59004358992664352f * y) * (-3.0f * x2 + y2);
+  o[10] = (2.8906114426405538f * xy) * z;
+  o[11] = (0.45704579946446572f * y) * (1.0f - 5.0f * z2);
+  o[12] = (0.3731763325901154f * z) * (5.0f * z2 - 3.0f);
+  o[13] = (0.45704579946446572f * x) * (1.0f - 5.0f * z2);
+  o[14] = (1.4453057213202769f * z) * (x2 - y2);
+  o[15] = (0.59004358992664352f * x) * (-x2 + 3.0f * y2);
+}
+
+// ---------------------------------------------------------------- hash-grid gather
+// One level, one sample, one lane: 8 corner loads of F halfs, trilinear blend in fp32
+// (corner order dx + 2dy + 4dz, weight = (wx*wy)*wz, acc = fmaf(w, v, acc)).
+template <int F>
+__device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table, const LevelDev& L,
+                                             float px, float py, float pz, float acc[F]) {
+  float pos[3] = {fmaf(L.scale, px, 0.5f), fmaf(L.scale, py, 0.5f), fmaf(L.scale, pz, 0.5f)};
+  uint32_t c0[3], c1[3];
+  float w1[3], w0[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    float fl = floorf(pos[a]);
+    w1[a] = pos[a] - fl;
+    w0[a] = 1.0f - w1[a];
+    uint32_t c = (uint32_t)(int)fl;
+    c0[a] = min(c, L.res_m1);
+    c1[a] = min(c + 1u, L.res_m1);
+  }
+  // per-axis index terms; dense: x + y*res + z*res^2, hashed: x ^ y*p1 ^ z*p2
+  uint32_t ty[2] = {c0[1] * L.my, c1[1] * L.my};
+  uint32_t tz[2] = {c0[2] * L.mz, c1[2] * L.mz};
+  uint32_t tx[2] = {c0[0], c1[0]};
+  float wxy[4] = {w0[0] * w0[1], w1[0] * w0[1], w0[0] * w1[1], w1[0] * w1[1]};
+  float wz[2] = {w0[2], w1[2]};
+  constexpr int BYTES = F * 2;
+  typedef uint32_t ldvec __attribute__((ext_vector_type(F / 2)));
+  ldvec v[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+    uint32_t ia = tx[dx] + ty[dy] + tz[dz];
+    uint32_t ix = tx[dx] ^ ty[dy] ^ tz[dz];
+    uint32_t idx = (L.hashed ? ix : ia) & L.mask;
+    uint32_t byte_off = (L.offset + idx) * (uint32_t)BYTES;
+    v[c] = *reinterpret_cast<const ldvec*>(reinterpret_cast<const char*>(table) + byte_off);
+  }
+#pragma unroll
+  for (int k = 0; k < F; k++) acc[k] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    float w = wxy[c & 3] * wz[c >> 2];
+#pragma unroll
+    for (int k = 0; k < F; k += 2) {
+      half2v hv = __builtin_bit_cast(half2v, v[c][k / 2]);
+      acc[k] = fmaf(w, (float)hv[0], acc[k]);
+      acc[k + 1] = fmaf(w, (float)hv[1], acc[k + 1]);
+    }
+  }
+}
+
+// The 16 canonical features [16*h, 16*h+16) of one sample, as the two MFMA B fragments
+// (k-steps 0,1) of lane half h.  Lane half h gathers levels [h*L/2, (h+1)*L/2).
+template <int F>
+__device__ __forceinline__ void encode_half(const FieldDev& fd, int h, float px, float py, float pz,
+                                            half8& b0, half8& b1) {
+  constexpr int LH = 16 / F; // levels per lane half
+  px = clamp01(px);
+  py = clamp01(py);
+  pz = clamp01(pz);
+  _Float16 out[16];
+#pragma unroll
+  for (int j = 0; j < LH; j++) {
+    // level parameters are wave-uniform per half: two scalar reads + select
+    LevelDev La = fd.levels[j], Lb = fd.levels[j + LH], L;
+    L.scale = h ? Lb.scale : La.scale;
+    L.res_m1 = h ? Lb.res_m1 : La.res_m1;
+    L.offset = h ? Lb.offset : La.offset;
+    L.mask = h ? Lb.mask : La.mask;
+    L.my = h ? Lb.my : La.my;
+    L.mz = h ? Lb.mz : La.mz;
+    L.hashed = h ? Lb.hashed : La.hashed;
+    float acc[F];
+    encode_level<F>(fd.table, L, px, py, pz, acc);
+#pragma unroll
+    for (int k = 0; k < F; k++) out[j * F + k] = (_Float16)acc[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    b0[k] = out[k];
+    b1[k] = out[8 + k];
+  }
+}
+
+// ---------------------------------------------------------------- tiny MLPs on MFMA
+// Samples sit on the MFMA column (lane & 31); hidden units on the accumulator rows, so
+// every layer's output is already the next layer's B operand (no LDS round trip).
+// 32x32x16 f16 MFMA: lane (r = lane&31, h = lane>>5) holds A[row r][k = 8h+j],
+// B[k = 8h+j][col r]; D reg i = row (i&3) + 8(i>>2) + 4h, col r.
+
+__device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <bool RELU>
+__device__ __forceinline__ half8 pack8(const f32x16& acc, int base) {
+  half8 r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    float v = acc[base + j];
+    if (RELU) v = v > 0.0f ? v : 0.0f;
+    r[j] = (_Float16)v;
+  }
+  return r;
+}
+
+struct MlpOut {
+  f32x16 dens; // density MLP outputs: rows 0..15 live in regs 0..7 (4 rows per lane half)
+  f32x16 rgb;  // colour MLP outputs: rows 0..2 = r,g,b logits in regs 0..2 of lane half 0
+};
+
+// frag order: D1 (mt,s)=4 | D2 s=4 | R1 (mt,s)=4 | R2 (mt,s)=8 | R3 s=4
+__device__ __forceinline__ MlpOut mlp_forward(const half8* __restrict__ wl, int lane, half8 f0,
+                                              half8 f1, half8 shfrag) {
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  MlpOut out;
+  half8 hf[4];
+  { // density layer 1: 32 -> 64
+    f32x16 a0 = mfma(wl[0 * 64 + lane], f0, zero);
+    f32x16 a1 = mfma(wl[2 * 64 + lane], f0, zero);
+    a0 = mfma(wl[1 * 64 + lane], f1, a0);
+    a1 = mfma(wl[3 * 64 + lane], f1, a1);
+    hf[0] = pack8<true>(a0, 0);
+    hf[1] = pack8<true>(a0, 8);
+    hf[2] = pack8<true>(a1, 0);
+    hf[3] = pack8<true>(a1, 8);
+  }
+  { // density layer 2: 64 -> 16 (rows 16..31 zero padding)
+    f32x16 a = mfma(wl[4 * 64 + lane], hf[0], zero);
+    a = mfma(wl[5 * 64 + lane], hf[1], a);
+    a = mfma(wl[6 * 64 + lane], hf[2], a);
+    a = mfma(wl[7 * 64 + lane], hf[3], a);
+    out.dens = a;
+  }
+  half8 df = pack8<false>(out.dens, 0);
+  { // colour layer 1: [density out 16 | SH 16] -> 64
+    f32x16 a0 = mfma(wl[8 * 64 + lane], df, zero);
+    f32x16 a1 = mfma(wl[10 * 64 + lane], df, zero);
+    a0 = mfma(wl[9 * 64 + lane], shfrag, a0);
+    a1 = mfma(wl[11 * 64 + lane], shfrag, a1);
+    hf[0] = pack8<true>(a0, 0);
+    hf[1] = pack8<true>(a0, 8);
+    hf[2] = pack8<true>(a1, 0);
+    hf[3] = pack8<true>(a1, 8);
+  }
+  { // colour layer 2: 64 -> 64
+    f32x16 a0 = mfma(wl[12 * 64 + lane], hf[0], zero);
+    f32x16 a1 = mfma(wl[16 * 64 + lane], hf[0], zero);
+    a0 = mfma(wl[13 * 64 + lane], hf[1], a0);
+    a1 = mfma(wl[17 * 64 + lane], hf[1], a1);
+    a0 = mfma(wl[14 * 64 + lane], hf[2], a0);
+    a1 = mfma(wl[18 * 64 + lane], hf[2], a1);
+    a0 = mfma(wl[15 * 64 + lane], hf[3], a0);
+    a1 = mfma(wl[19 * 64 + lane], hf[3], a1);
+    hf[0] = pack8<true>(a0, 0);
+    hf[1] = pack8<true>(a0, 8);
+    hf[2] = pack8<true>(a1, 0);
+    hf[3] = pack8<true>(a1, 8);
+  }
+  { // colour layer 3: 64 -> 16 (3 used)
+    f32x16 a = mfma(wl[20 * 64 + lane], hf[0], zero);
+    a = mfma(wl[21 * 64 + lane], hf[1], a);
+    a = mfma(wl[22 * 64 + lane], hf[2], a);
+    a = mfma(wl[23 * 64 + lane], hf[3], a);
+    out.rgb = a;
+  }
+  return out;
+}
+
+// SH fragment of lane half h: coefficients [8h, 8h+8) as fp16
+__device__ __forceinline__ half8 sh_fragment(int h, float dx, float dy, float dz) {
+  float s[16];
+  sh4(dx, dy, dz, s);
+  half8 r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r[j] = (_Float16)(h ? s[8 + j] : s[j]);
+  return r;
+}
+
+__device__ __forceinline__ float linear_to_srgb(float x) {
+  if (x <= 0.0031308f) return 12.92f * x;
+  return 1.055f * powf(x, 0.41666666f) - 0.055f;
+}
+
+// composite over bg, un-premultiply, sRGB, clip, *255+0.5 truncate (upstream write_image recipe)
+__device__ __forceinline__ uint32_t quantize_rgba8(float r, float g, float b, float a,
+                                                   const float bg[4]) {
+  float rem = 1.0f - a;
+  float c[4] = {fmaf(rem, bg[0], r), fmaf(rem, bg[1], g), fmaf(rem, bg[2], b), fmaf(rem, bg[3], a)};
+  uint32_t outw = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float v = c[3] != 0.0f ? c[k] / c[3] : c[k];
+    v = linear_to_srgb(v);
+    v = fminf(fmaxf(v, 0.0f), 1.0f);
+    outw |= ((uint32_t)(v * 255.0f + 0.5f)) << (8 * k);
+  }
+  float v = fminf(fmaxf(c[3], 0.0f), 1.0f);
+  outw |= ((uint32_t)(v * 255.0f + 0.5f)) << 24;
+  return outw;
+}
+
+} // namespace prv

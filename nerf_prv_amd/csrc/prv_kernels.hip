@@ -1,0 +1,473 @@
+// prv_kernels.hip -- hand-written gfx950 kernels of the render + view-scoring path.
+//
+//  K_A  march_compact : one lane per primary ray.  Ray generation from the engine-frame
+//       camera (replaces pyngp's ray init behind run.py:296,304), unit-cube slab test, S
+//       occupancy tests -> 128-bit live-sample mask.  Rays with a non-empty mask are
+//       compacted into the ray queue: wave ballot + popcount prefix, one atomic per wave.
+//  K_B  render_queue  : persistent waves.  A wave owns 32 ray slots; slot r is served by
+//       the lane pair (r, r+32), each lane gathering half of the hash-grid levels of the
+//       slot's next live sample.  The two tiny MLPs run on v_mfma_f32_32x32x16_f16 with the
+//       samples on the MFMA column, weights staged once per block in LDS as prepacked A
+//       fragments, activations never leaving registers.  Front-to-back compositing is
+//       sequential per ray inside one lane (deterministic).  Finished slots are refilled
+//       from the queue with a ballot/prefix-sum claim.
+//  K_S* score kernels : per-view reductions in fp64, fixed reduction order (no float
+//       atomics), so rankings are reproducible bit for bit.
+//
+// Built with -ffp-contract=off: see prv_device.hpp for the arithmetic contract.
+#include "prv_kernels.hpp"
+
+namespace prv {
+
+// ------------------------------------------------------------------ K_A march + compact
+
+__device__ __forceinline__ void morton16(uint32_t i, uint32_t& x, uint32_t& y) {
+  x = (i & 1u) | ((i >> 1) & 2u) | ((i >> 2) & 4u) | ((i >> 3) & 8u);
+  y = ((i >> 1) & 1u) | ((i >> 2) & 2u) | ((i >> 3) & 4u) | ((i >> 4) & 8u);
+}
+
+__global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
+  const uint32_t tile = blockIdx.x, vi = blockIdx.y;
+  const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+  uint32_t ix, iy;
+  morton16(threadIdx.x, ix, iy);
+  const int px = (int)(tx * kTile + ix), py = (int)(ty * kTile + iy);
+  const bool valid = px < P.W && py < P.H;
+  const uint32_t pix = ((uint32_t)vi * (uint32_t)P.H + (uint32_t)py) * (uint32_t)P.W + (uint32_t)px;
+
+  float o[3] = {0, 0, 0}, d[3] = {0, 0, 1}, t0 = 0.f, dt = 0.f;
+  uint32_t m[4] = {0, 0, 0, 0};
+  bool live = false;
+  if (valid) {
+    const CamDev cam = P.cams[P.view_ids[vi]];
+    float ox, oy;
+    spp_offset(P.spp_k, ox, oy);
+    raygen(cam, px, py, ox, oy, o, d);
+    float t1;
+    if (ray_aabb(o, d, t0, t1)) {
+      dt = (t1 - t0) / (float)P.S;
+      for (int i = 0; i < P.S; i++) {
+        float t = fmaf((float)i + 0.5f, dt, t0);
+        bool occ = occupied(P.field, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]));
+        if (occ) m[i >> 5] |= 1u << (i & 31);
+      }
+      live = (m[0] | m[1] | m[2] | m[3]) != 0u;
+    }
+  }
+  // wave-level compaction: ballot + prefix popcount, one atomic per wave
+  const unsigned long long b = __ballot(live);
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (b != 0ull) {
+    if (lane == (int)__builtin_ctzll(b)) base = atomicAdd(P.queue_count, (uint32_t)__popcll(b));
+    base = __shfl(base, (int)__builtin_ctzll(b));
+  }
+  if (live) {
+    uint32_t slot = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    uint4* rec = reinterpret_cast<uint4*>(P.queue) + (size_t)slot * 4;
+    rec[0] = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(t0));
+    rec[1] = make_uint4(__float_as_uint(d[0]), __float_as_uint(d[1]), __float_as_uint(d[2]), __float_as_uint(dt));
+    rec[2] = make_uint4(m[0], m[1], m[2], m[3]);
+    rec[3] = make_uint4(pix, 0u, 0u, 0u);
+  } else if (valid) {
+    // dead ray: contributes exactly zero to its pixel
+    float4* out = reinterpret_cast<float4*>(P.out_f32) + pix;
+    float4 v = P.spp_k == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *out;
+    if (P.last_pass) {
+      v.x *= P.inv_spp; v.y *= P.inv_spp; v.z *= P.inv_spp; v.w *= P.inv_spp;
+      if (P.out_u8) P.out_u8[pix] = quantize_rgba8(v.x, v.y, v.z, v.w, P.bg);
+    }
+    if (P.spp_k == 0 || P.last_pass) *out = v;
+  }
+}
+
+// ------------------------------------------------------------------ K_B render from the queue
+
+template <int F>
+__global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
+  __shared__ half8 wl[kNumFrags * 64];
+  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = P.field.frags[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const uint32_t lt_mask = (1u << r) - 1u;
+  const uint32_t n_rec = *P.queue_count;
+
+  bool active = false;
+  uint32_t pix = 0;
+  float o[3] = {0, 0, 0}, d[3] = {0, 0, 1}, t0 = 0.f, dt = 0.f;
+  uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+  half8 shf = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool drained = false;
+  unsigned long long n_eval = 0ull;
+
+  for (;;) {
+    // ---- refill idle slots: ballot + prefix sum claim on the shared queue head
+    const uint32_t need = (uint32_t)__ballot(!active);
+    const uint32_t cnt = (uint32_t)__popc(need);
+    if (!drained && (cnt >= (uint32_t)P.refill_min || cnt == 32u)) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(P.queue_head, cnt);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base + cnt >= n_rec) drained = true;
+      const uint32_t avail = base < n_rec ? min(cnt, n_rec - base) : 0u;
+      const uint32_t prefix = (uint32_t)__popc(need & lt_mask);
+      if (!active && prefix < avail) {
+        const uint4* rec = reinterpret_cast<const uint4*>(P.queue) + (size_t)(base + prefix) * 4;
+        const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        o[0] = __uint_as_float(q0.x); o[1] = __uint_as_float(q0.y); o[2] = __uint_as_float(q0.z);
+        t0 = __uint_as_float(q0.w);
+        d[0] = __uint_as_float(q1.x); d[1] = __uint_as_float(q1.y); d[2] = __uint_as_float(q1.z);
+        dt = __uint_as_float(q1.w);
+        m0 = q2.x; m1 = q2.y; m2 = q2.z; m3 = q2.w;
+        pix = q3.x;
+        T = 1.f; cr = 0.f; cg = 0.f; cb = 0.f;
+        shf = sh_fragment(h, d[0], d[1], d[2]);
+        active = true;
+      }
+    }
+    const uint32_t act = (uint32_t)__ballot(active);
+    if (act == 0u) {
+      if (drained) break;
+      continue;
+    }
+    n_eval += (unsigned long long)__popc(act);
+
+    // ---- next live sample of every active slot (identical in both lanes of a pair)
+    half8 f0 = {0, 0, 0, 0, 0, 0, 0, 0}, f1 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool last = false;
+    if (active) {
+      uint32_t i;
+      if (m0) { i = (uint32_t)__builtin_ctz(m0); m0 &= m0 - 1u; }
+      else if (m1) { i = 32u + (uint32_t)__builtin_ctz(m1); m1 &= m1 - 1u; }
+      else if (m2) { i = 64u + (uint32_t)__builtin_ctz(m2); m2 &= m2 - 1u; }
+      else { i = 96u + (uint32_t)__builtin_ctz(m3); m3 &= m3 - 1u; }
+      last = (m0 | m1 | m2 | m3) == 0u;
+      const float t = fmaf((float)i + 0.5f, dt, t0);
+      encode_half<F>(P.field, h, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f0, f1);
+    }
+    // ---- both MLPs on the matrix cores (whole wave)
+    const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf);
+
+    // ---- front-to-back compositing (authoritative in lane half 0)
+    bool term = false;
+    if (active) {
+      const float sigma = expf(mo.dens[0] + P.field.density_bias);
+      const float alpha = 1.0f - expf(-(sigma * dt));
+      const float wgt = alpha * T;
+      cr = fmaf(wgt, 1.0f / (1.0f + expf(-mo.rgb[0])), cr);
+      cg = fmaf(wgt, 1.0f / (1.0f + expf(-mo.rgb[1])), cg);
+      cb = fmaf(wgt, 1.0f / (1.0f + expf(-mo.rgb[2])), cb);
+      T = T * (1.0f - alpha);
+      term = T < P.min_T;
+    }
+    const uint32_t tb = (uint32_t)__ballot(term); // low 32 bits: lane half 0
+    const bool done = active && (last || ((tb >> r) & 1u));
+    if (done) {
+      if (h == 0) {
+        float4* out = reinterpret_cast<float4*>(P.out_f32) + pix;
+        float4 v = make_float4(cr, cg, cb, 1.0f - T);
+        if (P.spp_k != 0) {
+          const float4 prev = *out;
+          v.x = prev.x + v.x; v.y = prev.y + v.y; v.z = prev.z + v.z; v.w = prev.w + v.w;
+        }
+        if (P.last_pass) {
+          v.x *= P.inv_spp; v.y *= P.inv_spp; v.z *= P.inv_spp; v.w *= P.inv_spp;
+          if (P.out_u8) P.out_u8[pix] = quantize_rgba8(v.x, v.y, v.z, v.w, P.bg);
+        }
+        *out = v;
+      }
+      active = false;
+    }
+  }
+  if (lane == 0 && n_eval) atomicAdd(P.stat_evaluated, n_eval);
+}
+
+template __global__ void render_queue_kernel<2>(RenderParams);
+template __global__ void render_queue_kernel<4>(RenderParams);
+
+// ------------------------------------------------------------------ quantise
+
+__global__ __launch_bounds__(256) void quantize_kernel(const float4* __restrict__ in, size_t n,
+                                                       float b0, float b1, float b2, float b3,
+                                                       uint32_t* __restrict__ out) {
+  const float bg[4] = {b0, b1, b2, b3};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float4 v = in[i];
+    out[i] = quantize_rgba8(v.x, v.y, v.z, v.w, bg);
+  }
+}
+
+// ------------------------------------------------------------------ score reductions
+
+// fixed-order block reduction of a double: lane shuffles, then 4 wave partials via LDS
+__device__ __forceinline__ double block_reduce_sum(double v, double* sm) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+  __syncthreads();
+  return r;
+}
+
+// ensemble scores from uint8 RGBA images (main.cpp:2053-2086 method 2, 2113-2150 method 3)
+template <int METHOD>
+__global__ __launch_bounds__(256) void score_ensemble_kernel(EnsembleParams P) {
+  __shared__ double sm[4];
+  const int v = blockIdx.y;
+  const size_t npix = P.pixels_per_view;
+  double acc = 0.0;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    uint32_t px[PRV_MAX_MODELS];
+    for (int e = 0; e < P.E; e++) px[e] = P.imgs[e][(size_t)v * npix + p];
+    double var3[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double mean = 0.0;
+      for (int e = 0; e < P.E; e++) mean += (double)((px[e] >> (8 * c)) & 255u);
+      mean /= (double)P.E;
+      double var = 0.0;
+      for (int e = 0; e < P.E; e++) {
+        double dlt = (double)((px[e] >> (8 * c)) & 255u) - mean;
+        var += dlt * dlt;
+      }
+      var3[c] = var / (double)P.E;
+    }
+    if (METHOD == PRV_SCORE_ENSEMBLE_RGB) {
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        if (var3[c] > 1e-10) acc += log(var3[c]);
+    } else {
+      double md = 0.0;
+      for (int e = 0; e < P.E; e++) md += (double)(px[e] >> 24) / 255.0;
+      md /= (double)P.E;
+      acc += (var3[0] + var3[1] + var3[2]) / 3.0;
+      acc += (1.0 - md) * (1.0 - md);
+    }
+  }
+  double s = block_reduce_sum(acc, sm);
+  if (threadIdx.x == 0) P.partial[(size_t)v * gridDim.x + blockIdx.x] = s;
+}
+template __global__ void score_ensemble_kernel<PRV_SCORE_ENSEMBLE_RGB>(EnsembleParams);
+template __global__ void score_ensemble_kernel<PRV_SCORE_ENSEMBLE_RGB_DENSITY>(EnsembleParams);
+
+// PSNR recipe of run.py:257-263 + mean opacity; two partial sums per block
+__global__ __launch_bounds__(256) void score_psnr_kernel(PsnrParams P) {
+  __shared__ double sm[4];
+  const int v = blockIdx.y;
+  const size_t npix = P.pixels_per_view;
+  const float4* img = reinterpret_cast<const float4*>(P.rgba) + (size_t)v * npix;
+  const float4* gt = reinterpret_cast<const float4*>(P.gt) + (size_t)v * npix;
+  double se = 0.0, cov = 0.0;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    const float4 a4 = img[p], r4 = gt[p];
+    const float ra = 1.0f - a4.w, rg = 1.0f - r4.w;
+    const float av[3] = {a4.x, a4.y, a4.z}, rv[3] = {r4.x, r4.y, r4.z};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      float a = fmaf(ra, P.bg[k], av[k]);
+      float rr = fmaf(rg, P.bg[k], rv[k]);
+      a = fminf(fmaxf(linear_to_srgb(a), 0.0f), 1.0f);
+      rr = fminf(fmaxf(linear_to_srgb(rr), 0.0f), 1.0f);
+      double dlt = (double)a - (double)rr;
+      se += dlt * dlt;
+    }
+    cov += (double)a4.w;
+  }
+  double s0 = block_reduce_sum(se, sm);
+  double s1 = block_reduce_sum(cov, sm);
+  if (threadIdx.x == 0) {
+    P.partial[((size_t)v * gridDim.x + blockIdx.x) * 2 + 0] = s0;
+    P.partial[((size_t)v * gridDim.x + blockIdx.x) * 2 + 1] = s1;
+  }
+}
+
+// one thread per view: sum the block partials in block order, emit the record
+__global__ void score_finalize_kernel(const double* __restrict__ partial, int n_views, int n_blocks,
+                                      int method, size_t pixels_per_view,
+                                      prv_score_record* __restrict__ rec) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_views) return;
+  prv_score_record out;
+  out.psnr = 0.f;
+  out.coverage = 0.f;
+  if (method == PRV_SCORE_PSNR_COVERAGE) {
+    double se = 0.0, cov = 0.0;
+    for (int b = 0; b < n_blocks; b++) {
+      se += partial[((size_t)v * n_blocks + b) * 2 + 0];
+      cov += partial[((size_t)v * n_blocks + b) * 2 + 1];
+    }
+    const double mse = se / (double)(pixels_per_view * 3);
+    const double psnr = -10.0 * log10(mse);
+    out.score = -psnr;
+    out.psnr = (float)psnr;
+    out.coverage = (float)(cov / (double)pixels_per_view);
+  } else {
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; b++) s += partial[(size_t)v * n_blocks + b];
+    out.score = s;
+  }
+  rec[v] = out;
+}
+
+// ------------------------------------------------------------------ synthetic table (counter RNG)
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_table_kernel(uint16_t* __restrict__ table, size_t n,
+                                                          unsigned long long seed, float amp) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    unsigned long long hsh = mix64(seed + 1ull * 0xD1B54A32D192ED03ull + (unsigned long long)i * 0x9E3779B97F4A7C15ull);
+    uint32_t u = (uint32_t)(hsh >> 40);
+    float v = (float)u * (1.0f / 8388608.0f) - 1.0f;
+    _Float16 hv = (_Float16)(v * amp);
+    table[i] = __builtin_bit_cast(uint16_t, hv);
+  }
+}
+
+// ------------------------------------------------------------------ stage hooks (parity tests)
+
+__global__ __launch_bounds__(256) void debug_raygen_kernel(CamDev cam, int W, int H, int spp_k,
+                                                           float* __restrict__ o_out,
+                                                           float* __restrict__ d_out,
+                                                           float* __restrict__ t_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W * H) return;
+  const int px = i % W, py = i / W;
+  float ox, oy, o[3], d[3], t0, t1;
+  spp_offset(spp_k, ox, oy);
+  raygen(cam, px, py, ox, oy, o, d);
+  ray_aabb(o, d, t0, t1);
+  for (int a = 0; a < 3; a++) {
+    o_out[i * 3 + a] = o[a];
+    d_out[i * 3 + a] = d[a];
+  }
+  t_out[i * 2] = t0;
+  t_out[i * 2 + 1] = t1;
+}
+
+// one wave = 32 points through exactly the production gather + MFMA code
+template <int F>
+__global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const float* __restrict__ pos,
+                                                          const float* __restrict__ dir, int n,
+                                                          uint16_t* __restrict__ feat,
+                                                          float* __restrict__ out36,
+                                                          int32_t* __restrict__ occ_out) {
+  __shared__ half8 wl[kNumFrags * 64];
+  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = fd.frags[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int idx = wave * 32 + r;
+  const bool ok = idx < n;
+  float p[3] = {0.5f, 0.5f, 0.5f}, dd[3] = {0.f, 0.f, 1.f};
+  if (ok) {
+    for (int a = 0; a < 3; a++) {
+      p[a] = pos[idx * 3 + a];
+      dd[a] = dir ? dir[idx * 3 + a] : dd[a];
+    }
+  }
+  half8 f0, f1;
+  encode_half<F>(fd, h, p[0], p[1], p[2], f0, f1);
+  const half8 shf = sh_fragment(h, dd[0], dd[1], dd[2]);
+  const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf);
+  if (!ok) return;
+  if (feat) {
+    for (int k = 0; k < 8; k++) {
+      feat[idx * 32 + 16 * h + k] = __builtin_bit_cast(uint16_t, f0[k]);
+      feat[idx * 32 + 16 * h + 8 + k] = __builtin_bit_cast(uint16_t, f1[k]);
+    }
+  }
+  if (out36) {
+    float* q = out36 + (size_t)idx * 36;
+    if (h == 0) {
+      q[0] = expf(mo.dens[0] + fd.density_bias);
+      for (int k = 0; k < 3; k++) q[1 + k] = 1.0f / (1.0f + expf(-mo.rgb[k]));
+    }
+    for (int i = 0; i < 8; i++) { // reg i -> row (i&3) + 8(i>>2) + 4h, rows 0..15
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      q[4 + row] = mo.dens[i];
+      q[20 + row] = mo.rgb[i];
+    }
+  }
+  if (occ_out && h == 0) occ_out[idx] = occupied(fd, p[0], p[1], p[2]) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ host-callable launchers
+
+hipError_t launch_march(const MarchParams& P, int n_views, hipStream_t s) {
+  dim3 grid((unsigned)(P.tiles_x * P.tiles_y), (unsigned)n_views);
+  hipLaunchKernelGGL(march_compact_kernel, grid, dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s) {
+  if (P.field.n_features == 4)
+    hipLaunchKernelGGL(render_queue_kernel<4>, dim3(n_blocks), dim3(256), 0, s, P);
+  else
+    hipLaunchKernelGGL(render_queue_kernel<2>, dim3(n_blocks), dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_quantize(const float* in, size_t n, const float bg[4], uint8_t* out, hipStream_t s) {
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(quantize_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(in), n,
+                     bg[0], bg[1], bg[2], bg[3], reinterpret_cast<uint32_t*>(out));
+  return hipGetLastError();
+}
+
+hipError_t launch_score_ensemble(const EnsembleParams& P, int method, int n_views, int n_blocks, hipStream_t s) {
+  dim3 grid((unsigned)n_blocks, (unsigned)n_views);
+  if (method == PRV_SCORE_ENSEMBLE_RGB)
+    hipLaunchKernelGGL(score_ensemble_kernel<PRV_SCORE_ENSEMBLE_RGB>, grid, dim3(256), 0, s, P);
+  else
+    hipLaunchKernelGGL(score_ensemble_kernel<PRV_SCORE_ENSEMBLE_RGB_DENSITY>, grid, dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_score_psnr(const PsnrParams& P, int n_views, int n_blocks, hipStream_t s) {
+  dim3 grid((unsigned)n_blocks, (unsigned)n_views);
+  hipLaunchKernelGGL(score_psnr_kernel, grid, dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_score_finalize(const double* partial, int n_views, int n_blocks, int method,
+                                 size_t pixels_per_view, prv_score_record* rec, hipStream_t s) {
+  hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)((n_views + 63) / 64)), dim3(64), 0, s, partial,
+                     n_views, n_blocks, method, pixels_per_view, rec);
+  return hipGetLastError();
+}
+
+hipError_t launch_synth_table(uint16_t* table, size_t n, uint64_t seed, float amp, hipStream_t s) {
+  hipLaunchKernelGGL(synth_table_kernel, dim3(2048), dim3(256), 0, s, table, n, (unsigned long long)seed, amp);
+  return hipGetLastError();
+}
+
+hipError_t launch_debug_raygen(const CamDev& cam, int W, int H, int spp_k, float* o, float* d, float* t,
+                               hipStream_t s) {
+  hipLaunchKernelGGL(debug_raygen_kernel, dim3((unsigned)((W * H + 255) / 256)), dim3(256), 0, s, cam, W, H,
+                     spp_k, o, d, t);
+  return hipGetLastError();
+}
+
+hipError_t launch_debug_field(const FieldDev& fd, const float* pos, const float* dir, int n, uint16_t* feat,
+                              float* out36, int32_t* occ, hipStream_t s) {
+  unsigned blocks = (unsigned)((n + 127) / 128);
+  if (fd.n_features == 4)
+    hipLaunchKernelGGL(debug_field_kernel<4>, dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+  else
+    hipLaunchKernelGGL(debug_field_kernel<2>, dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+  return hipGetLastError();
+}
+
+} // namespace prv

@@ -1,0 +1,72 @@
+// prv_kernels.hpp -- kernel parameter blocks and host-callable launchers.
+#pragma once
+#include "../../include/prv.h"
+#include "prv_device.hpp"
+
+namespace prv {
+
+// one queue record = 64 bytes = 4 x uint4:
+//   {o.x o.y o.z t0} {d.x d.y d.z dt} {mask0..3} {pixel, 0, 0, 0}
+constexpr size_t kRecordBytes = 64;
+constexpr int kMaxSamples = 128; // live-sample mask is 128 bits
+
+struct MarchParams {
+  FieldDev field;
+  const CamDev* cams;
+  const int* view_ids; // n_views indices into cams
+  int W, H, S, spp_k;
+  uint32_t tiles_x, tiles_y;
+  void* queue;
+  uint32_t* queue_count;
+  float* out_f32; // n_views*H*W*4
+  uint32_t* out_u8; // optional, n_views*H*W
+  float inv_spp;
+  int last_pass;
+  float bg[4];
+};
+
+struct RenderParams {
+  FieldDev field;
+  const void* queue;
+  const uint32_t* queue_count;
+  uint32_t* queue_head;
+  unsigned long long* stat_evaluated;
+  float* out_f32;
+  uint32_t* out_u8;
+  float min_T;
+  float inv_spp;
+  int spp_k;
+  int last_pass;
+  int refill_min;
+  float bg[4];
+};
+
+struct EnsembleParams {
+  const uint32_t* imgs[PRV_MAX_MODELS];
+  int E;
+  size_t pixels_per_view;
+  double* partial;
+};
+
+struct PsnrParams {
+  const float* rgba;
+  const float* gt;
+  size_t pixels_per_view;
+  float bg[4];
+  double* partial;
+};
+
+hipError_t launch_march(const MarchParams& P, int n_views, hipStream_t s);
+hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s);
+hipError_t launch_quantize(const float* in, size_t n, const float bg[4], uint8_t* out, hipStream_t s);
+hipError_t launch_score_ensemble(const EnsembleParams& P, int method, int n_views, int n_blocks, hipStream_t s);
+hipError_t launch_score_psnr(const PsnrParams& P, int n_views, int n_blocks, hipStream_t s);
+hipError_t launch_score_finalize(const double* partial, int n_views, int n_blocks, int method,
+                                 size_t pixels_per_view, prv_score_record* rec, hipStream_t s);
+hipError_t launch_synth_table(uint16_t* table, size_t n, uint64_t seed, float amp, hipStream_t s);
+hipError_t launch_debug_raygen(const CamDev& cam, int W, int H, int spp_k, float* o, float* d, float* t,
+                               hipStream_t s);
+hipError_t launch_debug_field(const FieldDev& fd, const float* pos, const float* dir, int n, uint16_t* feat,
+                              float* out36, int32_t* occ, hipStream_t s);
+
+} // namespace prv

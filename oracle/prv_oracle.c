@@ -1,0 +1,813 @@
+/*
+ * prv_oracle.c -- CPU ORACLE (test infrastructure; see prv_oracle.h header for
+ * scope and the "parity unpinned" statement).  Plain C, scalar, written to be
+ * obviously correct.  Floating-point op ORDER is part of the specification:
+ * compile with -ffp-contract=off so only the explicit fmaf() calls fuse.
+ *
+ * Citations "path:line" are relative to the reference tree (psc0628/NeRF-PRV).
+ */
+#include "prv_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ fp16 */
+
+uint16_t orc_f2h(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  uint32_t absx = x & 0x7fffffffu;
+  if (absx >= 0x7f800000u) /* inf / nan */
+    return (uint16_t)(sign | 0x7c00u | ((absx > 0x7f800000u) ? 0x200u | ((absx >> 13) & 0x3ffu) : 0));
+  if (absx >= 0x477ff000u) /* >= 65520 rounds to inf */
+    return (uint16_t)(sign | 0x7c00u);
+  if (absx < 0x38800000u) { /* subnormal half or zero: value < 2^-14 */
+    if (absx < 0x33000000u) return (uint16_t)sign; /* < 2^-25 -> 0 */
+    uint32_t e = absx >> 23;                       /* biased exp, 102..112 */
+    uint32_t m = (absx & 0x7fffffu) | 0x800000u;   /* 24-bit significand */
+    uint32_t shift = 126u - e;                     /* 14..24: m * 2^(e-150) -> units of 2^-24 */
+    uint32_t r = m >> shift;
+    uint32_t rem = m & ((1u << shift) - 1u);
+    uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1u))) r++;
+    return (uint16_t)(sign | r);
+  }
+  uint32_t e = (absx >> 23) - 112u; /* rebias 127 -> 15 */
+  uint32_t m = absx & 0x7fffffu;
+  uint32_t r = (e << 10) | (m >> 13);
+  uint32_t rem = m & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++; /* may carry into exponent: fine */
+  return (uint16_t)(sign | r);
+}
+
+float orc_h2f(uint16_t h) {
+  uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1fu;
+  uint32_t m = h & 0x3ffu;
+  uint32_t x;
+  if (e == 0) {
+    if (m == 0) {
+      x = sign;
+    } else { /* subnormal: normalise */
+      int s = 0;
+      while (!(m & 0x400u)) { m <<= 1; s++; }
+      m &= 0x3ffu;
+      x = sign | ((uint32_t)(113 - s) << 23) | (m << 13);
+    }
+  } else if (e == 31) {
+    x = sign | 0x7f800000u | (m << 13);
+  } else {
+    x = sign | ((e + 112u) << 23) | (m << 13);
+  }
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+
+/* ------------------------------------------------------------------ RNG */
+/* counter-based: value i of stream s under seed; splitmix64 finaliser */
+static uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static float rng_sym(uint64_t seed, uint64_t stream, uint64_t i, float amp) {
+  uint64_t h = mix64(seed + (stream + 1) * 0xD1B54A32D192ED03ull + i * 0x9E3779B97F4A7C15ull);
+  uint32_t u = (uint32_t)(h >> 40);                /* 24 bits */
+  float v = (float)u * (1.0f / 8388608.0f) - 1.0f; /* exact, in [-1,1) */
+  return v * amp;
+}
+
+/* ------------------------------------------------------------------ field */
+
+int orc_field_levels(const orc_field_desc* d, orc_level* out, uint32_t* total) {
+  if (d->n_levels < 1 || d->n_levels > ORC_MAX_LEVELS) return -1;
+  if (d->n_levels * d->n_features != 32) return -1;
+  if (d->log2_hashmap < 4 || d->log2_hashmap > 28) return -1;
+  double b = (d->n_levels > 1)
+                 ? exp((log((double)d->finest_res) - log((double)d->base_res)) / (double)(d->n_levels - 1))
+                 : 1.0;
+  uint64_t T = 1ull << d->log2_hashmap;
+  uint32_t off = 0;
+  for (int l = 0; l < d->n_levels; l++) {
+    double s = (double)d->base_res * pow(b, (double)l) - 1.0;
+    /* guard pow() round-off so the nominal integer resolutions are hit exactly */
+    double sr = floor(s + 0.5);
+    if (fabs(s - sr) < 1e-9) s = sr;
+    out[l].scale = (float)s;
+    uint32_t res = (uint32_t)ceil(s) + 1u;
+    out[l].res = res;
+    uint64_t dense = (uint64_t)res * res * res;
+    if (dense <= T) {
+      out[l].hashed = 0;
+      out[l].size = (uint32_t)((dense + 7ull) & ~7ull);
+    } else {
+      out[l].hashed = 1;
+      out[l].size = (uint32_t)T;
+    }
+    out[l].offset = off;
+    off += out[l].size;
+  }
+  *total = off;
+  return 0;
+}
+
+static const int kLayerIn[5] = {32, 64, 32, 64, 64};
+static const int kLayerOut[5] = {64, 16, 64, 64, 16};
+
+/* analytic occupancy: union of spheres, cell centre test */
+static const float kBlobs[4][4] = {
+    {0.50f, 0.50f, 0.50f, 0.35f},
+    {0.80f, 0.50f, 0.62f, 0.13f},
+    {0.36f, 0.80f, 0.45f, 0.11f},
+    {0.40f, 0.24f, 0.78f, 0.10f},
+};
+
+static void field_finalize(orc_field* f) {
+  for (int i = 0; i < ORC_MLP_HALFS; i++) f->mlp_f[i] = orc_h2f(f->mlp[i]);
+}
+
+static orc_field* field_alloc(const orc_field_desc* d) {
+  orc_field* f = (orc_field*)calloc(1, sizeof(orc_field));
+  if (!f) return NULL;
+  f->desc = *d;
+  if (orc_field_levels(d, f->levels, &f->total_entries) != 0) {
+    free(f);
+    return NULL;
+  }
+  f->table = (uint16_t*)malloc((size_t)f->total_entries * d->n_features * sizeof(uint16_t));
+  size_t R = (size_t)d->occ_res;
+  f->occ = (uint32_t*)calloc((R * R * R + 31) / 32, sizeof(uint32_t));
+  if (!f->table || !f->occ) {
+    orc_field_free(f);
+    return NULL;
+  }
+  return f;
+}
+
+orc_field* orc_field_synthetic(const orc_field_desc* d, uint64_t seed) {
+  orc_field* f = field_alloc(d);
+  if (!f) return NULL;
+  size_t n = (size_t)f->total_entries * d->n_features;
+  for (size_t i = 0; i < n; i++) f->table[i] = orc_f2h(rng_sym(seed, 0, i, d->table_amp));
+  size_t o = 0;
+  for (int l = 0; l < 5; l++) {
+    float amp = sqrtf(6.0f / (float)(kLayerIn[l] + kLayerOut[l]));
+    size_t cnt = (size_t)kLayerIn[l] * kLayerOut[l];
+    for (size_t i = 0; i < cnt; i++) f->mlp[o + i] = orc_f2h(rng_sym(seed, (uint64_t)(l + 1), i, amp));
+    o += cnt;
+  }
+  int R = d->occ_res;
+  float invR = 1.0f / (float)R;
+  for (int z = 0; z < R; z++)
+    for (int y = 0; y < R; y++)
+      for (int x = 0; x < R; x++) {
+        float cx = ((float)x + 0.5f) * invR, cy = ((float)y + 0.5f) * invR, cz = ((float)z + 0.5f) * invR;
+        int in = 0;
+        for (int b = 0; b < 4 && !in; b++) {
+          float dx = cx - kBlobs[b][0], dy = cy - kBlobs[b][1], dz = cz - kBlobs[b][2];
+          float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+          in = d2 <= kBlobs[b][3] * kBlobs[b][3];
+        }
+        if (in) {
+          size_t bit = (size_t)x + (size_t)R * ((size_t)y + (size_t)R * (size_t)z);
+          f->occ[bit >> 5] |= 1u << (bit & 31);
+        }
+      }
+  field_finalize(f);
+  return f;
+}
+
+orc_field* orc_field_from_params(const orc_field_desc* d, const uint16_t* table, const uint16_t* mlp,
+                                 const uint32_t* occ) {
+  orc_field* f = field_alloc(d);
+  if (!f) return NULL;
+  memcpy(f->table, table, (size_t)f->total_entries * d->n_features * sizeof(uint16_t));
+  memcpy(f->mlp, mlp, sizeof(f->mlp));
+  size_t R = (size_t)d->occ_res;
+  memcpy(f->occ, occ, ((R * R * R + 31) / 32) * sizeof(uint32_t));
+  field_finalize(f);
+  return f;
+}
+
+void orc_field_free(orc_field* f) {
+  if (!f) return;
+  free(f->table);
+  free(f->occ);
+  free(f);
+}
+
+static inline float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+int orc_occupied(const orc_field* f, const float p[3]) {
+  int R = f->desc.occ_res;
+  int c[3];
+  for (int a = 0; a < 3; a++) {
+    int v = (int)(clamp01(p[a]) * (float)R);
+    c[a] = v > R - 1 ? R - 1 : v;
+  }
+  size_t bit = (size_t)c[0] + (size_t)R * ((size_t)c[1] + (size_t)R * (size_t)c[2]);
+  return (f->occ[bit >> 5] >> (bit & 31)) & 1u;
+}
+
+/* multiresolution hash encoding (published instant-ngp / tiny-cuda-nn algorithm,
+ * restated; NOT in the reference tree -- reached through pyngp, run.py:25).
+ * Deviation, documented: corner coordinates are clamped to res-1 instead of the
+ * dense index being wrapped modulo the level size. */
+void orc_encode(const orc_field* f, const float p_in[3], uint16_t feat[32]) {
+  const int F = f->desc.n_features;
+  float p[3] = {clamp01(p_in[0]), clamp01(p_in[1]), clamp01(p_in[2])};
+  for (int l = 0; l < f->desc.n_levels; l++) {
+    const orc_level* L = &f->levels[l];
+    uint32_t c0[3];
+    float w[3];
+    for (int a = 0; a < 3; a++) {
+      float pos = fmaf(L->scale, p[a], 0.5f);
+      float fl = floorf(pos);
+      w[a] = pos - fl;
+      c0[a] = (uint32_t)(int)fl;
+    }
+    float acc[4] = {0, 0, 0, 0};
+    for (int c = 0; c < 8; c++) {
+      uint32_t cc[3];
+      float ww[3];
+      for (int a = 0; a < 3; a++) {
+        uint32_t bit = (c >> a) & 1u;
+        uint32_t v = c0[a] + bit;
+        cc[a] = v > L->res - 1 ? L->res - 1 : v;
+        ww[a] = bit ? w[a] : 1.0f - w[a];
+      }
+      float weight = (ww[0] * ww[1]) * ww[2];
+      uint32_t idx;
+      if (L->hashed)
+        idx = (cc[0] ^ (cc[1] * 2654435761u) ^ (cc[2] * 805459861u)) & (L->size - 1u);
+      else
+        idx = cc[0] + L->res * (cc[1] + L->res * cc[2]);
+      const uint16_t* e = f->table + ((size_t)L->offset + idx) * F;
+      for (int k = 0; k < F; k++) acc[k] = fmaf(weight, orc_h2f(e[k]), acc[k]);
+    }
+    for (int k = 0; k < F; k++) feat[l * F + k] = orc_f2h(acc[k]);
+  }
+}
+
+/* real spherical harmonics, degree 4 (16 coefficients), direction in [-1,1]^3 */
+void orc_sh4(const float d[3], float o[16]) {
+  float x = d[0], y = d[1], z = d[2];
+  float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  o[0] = 0.28209479177387814f;
+  o[1] = -0.48860251190291987f * y;
+  o[2] = 0.48860251190291987f * z;
+  o[3] = -0.48860251190291987f * x;
+  o[4] = 1.0925484305920792f * xy;
+  o[5] = -1.0925484305920792f * yz;
+  o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+  o[7] = -1.0925484305920792f * xz;
+  o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+  o[9] = (0.59004358992664352f * y) * (-3.0f * x2 + y2);
+  o[10] = (2.8906114426405538f * xy) * z;
+  o[11] = (0.45704579946446572f * y) * (1.0f - 5.0f * z2);
+  o[12] = (0.3731763325901154f * z) * (5.0f * z2 - 3.0f);
+  o[13] = (0.45704579946446572f * x) * (1.0f - 5.0f * z2);
+  o[14] = (1.4453057213202769f * z) * (x2 - y2);
+  o[15] = (0.59004358992664352f * x) * (-x2 + 3.0f * y2);
+}
+
+/* one fully-connected layer: fp16 inputs and weights, wide accumulation */
+static void layer(const float* W, int n_in, int n_out, const float* in, float* out) {
+  double acc[64];
+  for (int o = 0; o < n_out; o++) acc[o] = 0.0;
+  for (int k = 0; k < n_in; k++) { /* k ascending per output; products exact in double */
+    double x = (double)in[k];
+    const float* w = W + k * n_out;
+    for (int o = 0; o < n_out; o++) acc[o] += x * (double)w[o];
+  }
+  for (int o = 0; o < n_out; o++) out[o] = (float)acc[o];
+}
+static void relu_round(float* v, int n) {
+  for (int i = 0; i < n; i++) v[i] = orc_h2f(orc_f2h(v[i] > 0.0f ? v[i] : 0.0f));
+}
+
+static void eval_with_sh(const orc_field* f, const float p[3], const float sh[16], float* sigma,
+                         float rgb[3], float* mlp_out) {
+  uint16_t feat[32];
+  orc_encode(f, p, feat);
+  float in[32], h[64], h2[64], od[16], orr[16];
+  for (int k = 0; k < 32; k++) in[k] = orc_h2f(feat[k]);
+  const float* W = f->mlp_f;
+  layer(W, 32, 64, in, h);
+  relu_round(h, 64);
+  layer(W + 2048, 64, 16, h, od);
+  *sigma = expf(od[0] + f->desc.density_bias);
+  for (int k = 0; k < 16; k++) in[k] = orc_h2f(orc_f2h(od[k]));
+  for (int k = 0; k < 16; k++) in[16 + k] = orc_h2f(orc_f2h(sh[k]));
+  layer(W + 3072, 32, 64, in, h);
+  relu_round(h, 64);
+  layer(W + 5120, 64, 64, h, h2);
+  relu_round(h2, 64);
+  layer(W + 9216, 64, 16, h2, orr);
+  for (int k = 0; k < 3; k++) rgb[k] = 1.0f / (1.0f + expf(-orr[k]));
+  if (mlp_out) {
+    memcpy(mlp_out, od, sizeof(od));
+    memcpy(mlp_out + 16, orr, sizeof(orr));
+  }
+}
+
+void orc_eval(const orc_field* f, const float p[3], const float d[3], float* sigma, float rgb[3],
+              float* mlp_out) {
+  float sh[16];
+  orc_sh4(d, sh);
+  eval_with_sh(f, p, sh, sigma, rgb, mlp_out);
+}
+
+/* ------------------------------------------------------------------ 4x4 helpers (double) */
+
+static void mat4_mul(const double* a, const double* b, double* o) {
+  double t[16];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double s = 0;
+      for (int k = 0; k < 4; k++) s += a[i * 4 + k] * b[k * 4 + j];
+      t[i * 4 + j] = s;
+    }
+  memcpy(o, t, sizeof(t));
+}
+static void mat4_inv(const double* m, double* o) {
+  double a[4][8];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      a[i][j] = m[i * 4 + j];
+      a[i][4 + j] = i == j;
+    }
+  for (int c = 0; c < 4; c++) {
+    int piv = c;
+    for (int r = c + 1; r < 4; r++)
+      if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+    if (piv != c)
+      for (int j = 0; j < 8; j++) {
+        double t = a[c][j];
+        a[c][j] = a[piv][j];
+        a[piv][j] = t;
+      }
+    double d = a[c][c]; /* singular -> inf/nan propagate, like Eigen */
+    for (int j = 0; j < 8; j++) a[c][j] /= d;
+    for (int r = 0; r < 4; r++)
+      if (r != c) {
+        double fct = a[r][c];
+        if (fct != 0.0)
+          for (int j = 0; j < 8; j++) a[r][j] -= fct * a[c][j];
+      }
+  }
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) o[i * 4 + j] = a[i][4 + j];
+}
+static void vec3_normalized(double* v) { /* Eigen normalized(): zero stays zero */
+  double n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  if (n2 > 0) {
+    double n = sqrt(n2);
+    v[0] /= n;
+    v[1] /= n;
+    v[2] /= n;
+  }
+}
+static void cross3(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* View::get_next_camera_pos, type_of_pose = 0, now_camera_pose_world = I
+ * (View_Space.hpp:67-140; the only live configuration, Share_Data.hpp:475). */
+void orc_view_pose(const double init_pos[3], const double center[3], double pose[16]) {
+  double view[3] = {init_pos[0], init_pos[1], init_pos[2]};
+  double Z[3] = {center[0] - view[0], center[1] - view[1], center[2] - view[2]};
+  vec3_normalized(Z); /* :79 */
+  double X[3], Y[3];
+  cross3(Z, view, X); /* :81 */
+  vec3_normalized(X);
+  cross3(Z, X, Y); /* :82 */
+  vec3_normalized(Y);
+  double T[16] = {1, 0, 0, -view[0], 0, 1, 0, -view[1], 0, 0, 1, -view[2], 0, 0, 0, 1}; /* :83-87 */
+  double R[16] = {X[0], Y[0], Z[0], 0, X[1], Y[1], Z[1], 0, X[2], Y[2], Z[2], 0, 0, 0, 0, 1}; /* :88-92 */
+  double Rz_min[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  double M[16], Mi[16], MT[16];
+  mat4_inv(R, Mi);
+  mat4_mul(Mi, T, MT); /* R^-1 * T */
+  /* x_ray = MT*(1,0,0,1), y_ray = MT*(0,1,0,1)  :95-100 */
+  double x0 = MT[0] + MT[3];
+  double y1 = MT[5] + MT[7];
+  double min_y = acos(y1); /* :101 */
+  double min_x = acos(x0); /* :102 */
+  for (double i = 5; i < 360; i += 5) { /* :103 */
+    double a = i * acos(-1.0) / 180.0;
+    /* AngleAxis product goes through a quaternion (0,0,sin(a/2); cos(a/2)) then
+     * toRotationMatrix() */
+    double qz = sin(a / 2), qw = cos(a / 2);
+    double tz = 2 * qz, twz = tz * qw, tzz = tz * qz;
+    double Rz[16] = {1 - tzz, -twz, 0, 0, twz, 1 - tzz, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    mat4_mul(R, Rz, M);
+    mat4_inv(M, Mi);
+    mat4_mul(Mi, T, MT);
+    double cx = acos(MT[0] + MT[3]); /* :118 */
+    double cy = acos(MT[5] + MT[7]); /* :117 */
+    if (cy < min_y) { /* :119 (NaN compares false) */
+      memcpy(Rz_min, Rz, sizeof(Rz));
+      min_y = cy;
+      min_x = cx;
+    } else if (fabs(cy - min_y) < 1e-6 && cx < min_x) { /* :124 */
+      memcpy(Rz_min, Rz, sizeof(Rz));
+      min_y = cy;
+      min_x = cx;
+    }
+  }
+  mat4_mul(R, Rz_min, M);
+  mat4_inv(M, Mi);
+  mat4_mul(Mi, T, pose); /* :137 */
+}
+
+/* main.cpp:1626-1641 with now_camera_pose_world = I */
+void orc_transform_matrix(const double pose[16], double out[16]) {
+  static const double P[16] = {0, 0, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1};
+  static const double P1[16] = {1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1};
+  double vi[16], t[16];
+  mat4_inv(pose, vi);
+  mat4_mul(P, vi, t);
+  mat4_mul(t, P1, out);
+}
+
+/* View_Space.hpp:550-556 */
+int orc_view_space(const double* pt, int n, double radius, const double center[3], double* out_pos) {
+  double pt_norm = sqrt(pt[0] * pt[0] + pt[1] * pt[1] + pt[2] * pt[2]); /* Share_Data.hpp:527-528 */
+  int k = 0;
+  for (int i = 0; i < n; i++) {
+    if (pt[i * 3 + 2] < 0) continue;
+    double scale = 1.0 / pt_norm * radius;
+    for (int a = 0; a < 3; a++) out_pos[k * 3 + a] = pt[i * 3 + a] * scale + center[a];
+    k++;
+  }
+  return k;
+}
+
+/* View_Space.hpp:534-548 */
+void orc_bbx(const double* pts, int n, double center[3], double* predicted_size) {
+  center[0] = center[1] = center[2] = 0;
+  for (int i = 0; i < n; i++)
+    for (int a = 0; a < 3; a++) center[a] += pts[i * 3 + a];
+  for (int a = 0; a < 3; a++) center[a] /= n;
+  double sz = 0;
+  for (int i = 0; i < n; i++) {
+    double dx = center[0] - pts[i * 3], dy = center[1] - pts[i * 3 + 1], dz = center[2] - pts[i * 3 + 2];
+    double nn = sqrt(dx * dx + dy * dy + dz * dz);
+    if (nn > sz) sz = nn;
+  }
+  *predicted_size = sz * (17.0 / 16.0);
+}
+
+/* ASSUMED (instant-ngp nerf_matrix_to_ngp, not in tree): negate columns 1,2,
+ * t*scale+offset, cycle rows (y,z,x). */
+void orc_nerf_to_ngp(const double tm[16], double scale, const double offset[3], float out[12]) {
+  double m[3][4];
+  for (int r = 0; r < 3; r++) {
+    m[r][0] = tm[r * 4 + 0];
+    m[r][1] = -tm[r * 4 + 1];
+    m[r][2] = -tm[r * 4 + 2];
+    m[r][3] = tm[r * 4 + 3] * scale + offset[r];
+  }
+  static const int src[3] = {1, 2, 0};
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) out[r * 4 + c] = (float)m[src[r]][c];
+}
+
+/* intr = {ppx, ppy, fx, fy, c0..c4}; model 2 = inverse Brown-Conrady, 1 = modified, 0 = none
+ * Share_Data.hpp:92-137 (only the Brown-Conrady branches are reachable: yaml color_model = 2) */
+void orc_rs2_project(float pixel[2], const float in[9], int model, const float point[3]) {
+  float x = point[0] / point[2], y = point[1] / point[2];
+  const float* c = in + 4;
+  if (model == 1 || model == 2) {
+    float r2 = x * x + y * y;
+    float f = 1 + c[0] * r2 + c[1] * r2 * r2 + c[4] * r2 * r2 * r2;
+    x *= f;
+    y *= f;
+    float dx = x + 2 * c[2] * x * y + c[3] * (r2 + 2 * x * x);
+    float dy = y + 2 * c[3] * x * y + c[2] * (r2 + 2 * y * y);
+    x = dx;
+    y = dy;
+  }
+  pixel[0] = x * in[2] + in[0];
+  pixel[1] = y * in[3] + in[1];
+}
+/* Share_Data.hpp:140-196 */
+void orc_rs2_deproject(float point[3], const float in[9], int model, const float pixel[2], float depth) {
+  float x = (pixel[0] - in[0]) / in[2];
+  float y = (pixel[1] - in[1]) / in[3];
+  const float* c = in + 4;
+  if (model == 2) {
+    float r2 = x * x + y * y;
+    float f = 1 + c[0] * r2 + c[1] * r2 * r2 + c[4] * r2 * r2 * r2;
+    float ux = x * f + 2 * c[2] * x * y + c[3] * (r2 + 2 * x * x);
+    float uy = y * f + 2 * c[3] * x * y + c[2] * (r2 + 2 * y * y);
+    x = ux;
+    y = uy;
+  }
+  point[0] = depth * x;
+  point[1] = depth * y;
+  point[2] = depth;
+}
+
+/* ------------------------------------------------------------------ rays */
+
+/* R2 low-discrepancy sub-pixel sequence; k = 0 is the pixel centre.  The
+ * reference's jitter comes from instant-ngp's RNG (unpinned); this is the
+ * build's own deterministic choice. */
+void orc_spp_offset(int k, float* ox, float* oy) {
+  float fk = (float)k;
+  float a = fmaf(fk, 0.7548776662466927f, 0.5f);
+  float b = fmaf(fk, 0.5698402909980532f, 0.5f);
+  *ox = a - floorf(a);
+  *oy = b - floorf(b);
+}
+
+void orc_raygen(const orc_camera* cam, int px, int py, float ox, float oy, float o[3], float d[3]) {
+  float dx = (((float)px + ox) - cam->cx) / cam->fx;
+  float dy = (((float)py + oy) - cam->cy) / cam->fy;
+  float v[3];
+  for (int r = 0; r < 3; r++) {
+    const float* m = cam->c2w + r * 4;
+    v[r] = fmaf(m[0], dx, fmaf(m[1], dy, m[2]));
+    o[r] = m[3];
+  }
+  float n2 = fmaf(v[0], v[0], fmaf(v[1], v[1], v[2] * v[2]));
+  float inv = 1.0f / sqrtf(n2);
+  for (int r = 0; r < 3; r++) d[r] = v[r] * inv;
+}
+
+int orc_ray_aabb(const float o[3], const float d[3], float* t0, float* t1) {
+  float tmin = 0.0f, tmax = INFINITY;
+  for (int a = 0; a < 3; a++) {
+    float inv = 1.0f / d[a];
+    float ta = (0.0f - o[a]) * inv;
+    float tb = (1.0f - o[a]) * inv;
+    tmin = fmaxf(tmin, fminf(ta, tb));
+    tmax = fminf(tmax, fmaxf(ta, tb));
+  }
+  *t0 = tmin;
+  *t1 = tmax;
+  return tmax > tmin;
+}
+
+/* one ray: S uniform samples between AABB entry/exit, occupancy skip, front-to-back
+ * compositing, early termination at T < min_T (published instant-ngp render loop with
+ * the BASELINE configs' fixed sample count) */
+static void march_ray(const orc_field* f, const float o[3], const float d[3], int S, float min_T,
+                      float out[4], uint64_t* n_eval) {
+  out[0] = out[1] = out[2] = out[3] = 0.0f;
+  float t0, t1;
+  if (!orc_ray_aabb(o, d, &t0, &t1)) return;
+  float dt = (t1 - t0) / (float)S;
+  float sh[16];
+  orc_sh4(d, sh);
+  float T = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+  for (int i = 0; i < S; i++) {
+    float t = fmaf((float)i + 0.5f, dt, t0);
+    float p[3] = {fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2])};
+    if (!orc_occupied(f, p)) continue;
+    float sigma, c[3];
+    eval_with_sh(f, p, sh, &sigma, c, NULL);
+    float alpha = 1.0f - expf(-(sigma * dt));
+    float wgt = alpha * T;
+    r = fmaf(wgt, c[0], r);
+    g = fmaf(wgt, c[1], g);
+    b = fmaf(wgt, c[2], b);
+    T = T * (1.0f - alpha);
+    (*n_eval)++;
+    if (T < min_T) break;
+  }
+  out[0] = r;
+  out[1] = g;
+  out[2] = b;
+  out[3] = 1.0f - T;
+}
+
+typedef struct {
+  const orc_field* f;
+  const orc_camera* cam;
+  int w, h, y0, y1, S, spp, tid, nth;
+  float min_T;
+  float* rgba;
+  uint64_t n_eval;
+} render_job;
+
+static void* render_worker(void* arg) {
+  render_job* j = (render_job*)arg;
+  float inv_spp = 1.0f / (float)j->spp;
+  for (int y = j->y0 + j->tid; y < j->y1; y += j->nth)
+    for (int x = 0; x < j->w; x++) {
+      float acc[4] = {0, 0, 0, 0};
+      for (int k = 0; k < j->spp; k++) {
+        float ox, oy, o[3], d[3], px[4];
+        orc_spp_offset(k, &ox, &oy);
+        orc_raygen(j->cam, x, y, ox, oy, o, d);
+        march_ray(j->f, o, d, j->S, j->min_T, px, &j->n_eval);
+        for (int c = 0; c < 4; c++) acc[c] += px[c];
+      }
+      float* dst = j->rgba + ((size_t)y * j->w + x) * 4;
+      for (int c = 0; c < 4; c++) dst[c] = acc[c] * inv_spp;
+    }
+  return NULL;
+}
+
+void orc_render_rows(const orc_field* f, const orc_camera* cam, int w, int h, int y0, int y1, int S,
+                     int spp, float min_T, float* rgba, uint64_t* n_evaluated, int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  render_job jobs[256];
+  pthread_t th[256];
+  for (int t = 0; t < n_threads; t++) {
+    render_job jb = {f, cam, w, h, y0, y1, S, spp, t, n_threads, min_T, rgba, 0};
+    jobs[t] = jb;
+    if (t > 0) pthread_create(&th[t], NULL, render_worker, &jobs[t]);
+  }
+  render_worker(&jobs[0]);
+  uint64_t tot = jobs[0].n_eval;
+  for (int t = 1; t < n_threads; t++) {
+    pthread_join(th[t], NULL);
+    tot += jobs[t].n_eval;
+  }
+  if (n_evaluated) *n_evaluated = tot;
+}
+
+void orc_render(const orc_field* f, const orc_camera* cam, int w, int h, int S, int spp, float min_T,
+                float* rgba, uint64_t* n_evaluated, int n_threads) {
+  orc_render_rows(f, cam, w, h, 0, h, S, spp, min_T, rgba, n_evaluated, n_threads);
+}
+
+/* ------------------------------------------------------------------ image post + scores */
+
+float orc_linear_to_srgb(float x) {
+  if (x <= 0.0031308f) return 12.92f * x;
+  return 1.055f * powf(x, 0.41666666f) - 0.055f; /* 1/2.4 */
+}
+
+/* ASSUMED from upstream scripts/common.py write_image (absent from the tree):
+ * composite over background, un-premultiply, sRGB, clip, *255 + 0.5 truncate. */
+void orc_quantize_rgba8(const float* rgba, size_t npix, const float bg[4], uint8_t* out) {
+  for (size_t i = 0; i < npix; i++) {
+    const float* s = rgba + i * 4;
+    float a = s[3];
+    float rem = 1.0f - a;
+    float c[4] = {fmaf(rem, bg[0], s[0]), fmaf(rem, bg[1], s[1]), fmaf(rem, bg[2], s[2]), fmaf(rem, bg[3], a)};
+    for (int k = 0; k < 3; k++) {
+      float v = c[3] != 0.0f ? c[k] / c[3] : c[k];
+      v = orc_linear_to_srgb(v);
+      v = fminf(fmaxf(v, 0.0f), 1.0f);
+      out[i * 4 + k] = (uint8_t)(v * 255.0f + 0.5f);
+    }
+    float v = fminf(fmaxf(c[3], 0.0f), 1.0f);
+    out[i * 4 + 3] = (uint8_t)(v * 255.0f + 0.5f);
+  }
+}
+
+/* main.cpp:2053-2086 -- channels 0..2 of a 4-channel uint8 image, E members */
+double orc_score_ensemble_rgb(const uint8_t* const* imgs, int E, size_t npix) {
+  double view_uncertainty = 0.0;
+  for (size_t p = 0; p < npix; p++) {
+    for (int c = 0; c < 3; c++) {
+      double mean = 0.0;
+      for (int e = 0; e < E; e++) mean += imgs[e][p * 4 + c];
+      mean /= E;
+      double var = 0.0;
+      for (int e = 0; e < E; e++) {
+        double dlt = imgs[e][p * 4 + c] - mean;
+        var += dlt * dlt;
+      }
+      var /= E;
+      if (var > 1e-10) view_uncertainty += log(var); /* :2082-2084 */
+    }
+  }
+  return view_uncertainty;
+}
+
+/* main.cpp:2113-2150 */
+double orc_score_ensemble_rgbdensity(const uint8_t* const* imgs, int E, size_t npix) {
+  double view_uncertainty = 0.0;
+  for (size_t p = 0; p < npix; p++) {
+    double var3[3];
+    for (int c = 0; c < 3; c++) {
+      double mean = 0.0;
+      for (int e = 0; e < E; e++) mean += imgs[e][p * 4 + c];
+      mean /= E;
+      double var = 0.0;
+      for (int e = 0; e < E; e++) {
+        double dlt = imgs[e][p * 4 + c] - mean;
+        var += dlt * dlt;
+      }
+      var3[c] = var / E;
+    }
+    double mean_density = 0.0;
+    for (int e = 0; e < E; e++) mean_density += imgs[e][p * 4 + 3] / 255.0; /* :2127 */
+    mean_density /= E;
+    view_uncertainty += (var3[0] + var3[1] + var3[2]) / 3.0;         /* :2147 */
+    view_uncertainty += (1.0 - mean_density) * (1.0 - mean_density); /* :2148 */
+  }
+  return view_uncertainty;
+}
+
+/* run.py:257-263: A = clip(srgb(img)), R = clip(srgb(ref)), mse over HxWx3, psnr = -10 log10(mse).
+ * Images are first composited over the background (run.py:226).  coverage = mean opacity. */
+void orc_score_psnr_coverage(const float* rgba, const float* gt, size_t npix, const float bg[4],
+                             double* psnr, double* coverage) {
+  double se = 0.0, cov = 0.0;
+  for (size_t i = 0; i < npix; i++) {
+    float ra = 1.0f - rgba[i * 4 + 3], rg = 1.0f - gt[i * 4 + 3];
+    for (int k = 0; k < 3; k++) {
+      float a = fmaf(ra, bg[k], rgba[i * 4 + k]);
+      float r = fmaf(rg, bg[k], gt[i * 4 + k]);
+      a = fminf(fmaxf(orc_linear_to_srgb(a), 0.0f), 1.0f);
+      r = fminf(fmaxf(orc_linear_to_srgb(r), 0.0f), 1.0f);
+      double dlt = (double)a - (double)r;
+      se += dlt * dlt;
+    }
+    cov += rgba[i * 4 + 3];
+  }
+  double mse = se / (double)(npix * 3);
+  *psnr = -10.0 * log10(mse);
+  *coverage = cov / (double)npix;
+}
+
+/* arg-max with strict '>' over ascending ids, initial best -1e100 (main.cpp:1971, 2088-2091) */
+int orc_argmax(const double* scores, const int* ids, int n) {
+  double best = -1e100;
+  int best_id = -1;
+  for (int i = 0; i < n; i++)
+    if (scores[i] > best) {
+      best = scores[i];
+      best_id = ids[i];
+    }
+  return best_id;
+}
+
+/* full ranking = repeated arg-max: descending score, ties -> lower id first */
+void orc_rank(const double* scores, const int* ids, int n, int* order) {
+  for (int i = 0; i < n; i++) order[i] = i;
+  for (int i = 1; i < n; i++) { /* insertion sort, stable */
+    int k = order[i];
+    int j = i - 1;
+    while (j >= 0) {
+      int q = order[j];
+      int before = scores[k] > scores[q] || (scores[k] == scores[q] && ids[k] < ids[q]);
+      if (!before) break;
+      order[j + 1] = q;
+      j--;
+    }
+    order[j + 1] = k;
+  }
+  for (int i = 0; i < n; i++) order[i] = ids[order[i]];
+}
+
+/* first occupied cell along a ray (Amanatides-Woo DDA over the occupancy grid): the
+ * build's analogue of Perception_3D::precept_thread_process's castRay (main.cpp:253-258) */
+int orc_first_hit(const orc_field* f, const float o[3], const float d[3], float max_range, int cell[3]) {
+  float t0, t1;
+  if (!orc_ray_aabb(o, d, &t0, &t1)) return 0;
+  if (t1 > max_range) t1 = max_range;
+  if (t1 <= t0) return 0;
+  int R = f->desc.occ_res;
+  float fR = (float)R;
+  float ts = t0 + 1e-6f;
+  int c[3], step[3];
+  float tmax[3], tdelta[3];
+  for (int a = 0; a < 3; a++) {
+    float p = clamp01(fmaf(ts, d[a], o[a])) * fR;
+    int v = (int)p;
+    c[a] = v > R - 1 ? R - 1 : v;
+    if (d[a] > 0) {
+      step[a] = 1;
+      tmax[a] = (((float)(c[a] + 1)) / fR - o[a]) / d[a];
+      tdelta[a] = 1.0f / (fR * d[a]);
+    } else if (d[a] < 0) {
+      step[a] = -1;
+      tmax[a] = (((float)c[a]) / fR - o[a]) / d[a];
+      tdelta[a] = -1.0f / (fR * d[a]);
+    } else {
+      step[a] = 0;
+      tmax[a] = INFINITY;
+      tdelta[a] = INFINITY;
+    }
+  }
+  for (;;) {
+    size_t bit = (size_t)c[0] + (size_t)R * ((size_t)c[1] + (size_t)R * (size_t)c[2]);
+    if ((f->occ[bit >> 5] >> (bit & 31)) & 1u) {
+      cell[0] = c[0];
+      cell[1] = c[1];
+      cell[2] = c[2];
+      return 1;
+    }
+    int a = tmax[0] < tmax[1] ? (tmax[0] < tmax[2] ? 0 : 2) : (tmax[1] < tmax[2] ? 1 : 2);
+    if (tmax[a] > t1) return 0;
+    c[a] += step[a];
+    if (c[a] < 0 || c[a] >= R) return 0;
+    tmax[a] += tdelta[a];
+  }
+}

@@ -1,0 +1,140 @@
+/*
+ * prv_oracle.h -- CPU ORACLE for the NeRF-PRV render + view-scoring hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check in
+ * __graft_entry__.py and the cpu_baseline leg of bench.py may load it.  The
+ * shipped path (nerf_prv_amd/csrc, include/prv.h) never links or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" against the reference *binary*.
+ *   - The reference (psc0628/NeRF-PRV) cannot be compiled here (Win32 headers,
+ *     Eigen, OpenCV, PCL, OctoMap, Gurobi, JsonCpp, Boost all absent; see
+ *     DESIGN.md) and ships no tests or golden vectors.
+ *   - The field arithmetic (hash grid, MLPs, marching, compositing) lives in
+ *     NVlabs/instant-ngp + tiny-cuda-nn, which the reference imports as `pyngp`
+ *     (Instantngp_scripts/run.py:25) without vendoring or pinning a version.
+ *     It is restated here from the published algorithm (Mueller et al. 2022).
+ *   - What IS restated literally from in-tree reference code, with file:line
+ *     cited at each function: camera pose search (View_Space.hpp:67-140), view
+ *     set (View_Space.hpp:517-558), transforms.json matrices
+ *     (main.cpp:1623-1641), candidate header (main.cpp:1793-1811), ensemble
+ *     scores + arg-max (main.cpp:2053-2096, 2113-2160), PSNR recipe
+ *     (run.py:257-271), pinhole/Brown-Conrady camera (Share_Data.hpp:92-196).
+ *   - Pins used instead: the reference's Hemisphere/N.txt data files, hand-derived
+ *     known answers, and an independent numpy restatement
+ *     (tests/golden/gen_golden.py) whose outputs are committed as fixtures.
+ */
+#ifndef PRV_ORACLE_H
+#define PRV_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 16
+#define ORC_MLP_HALFS 10240 /* 32*64 + 64*16 + 32*64 + 64*64 + 64*16 */
+
+typedef struct {
+  int32_t n_levels;     /* L */
+  int32_t n_features;   /* F ; L*F must be 32 */
+  int32_t log2_hashmap; /* log2 T */
+  int32_t base_res;     /* N_min */
+  int32_t finest_res;   /* N_max */
+  int32_t occ_res;      /* occupancy grid resolution (cells per axis) */
+  float density_bias;   /* sigma = exp(out0 + density_bias) */
+  float table_amp;      /* synthetic table ~ U(-amp, amp) */
+} orc_field_desc;
+
+typedef struct {
+  float scale;     /* pos = fmaf(scale, x, 0.5) */
+  uint32_t res;    /* vertices per axis */
+  uint32_t offset; /* first entry of the level in the table (entries of F halfs) */
+  uint32_t size;   /* entries in the level */
+  uint32_t hashed; /* 1: spatial hash, 0: dense */
+} orc_level;
+
+typedef struct {
+  orc_field_desc desc;
+  orc_level levels[ORC_MAX_LEVELS];
+  uint32_t total_entries;
+  uint16_t* table;             /* total_entries * F fp16 bit patterns */
+  uint16_t mlp[ORC_MLP_HALFS]; /* canonical [in][out] row-major, layers d1,d2,r1,r2,r3 */
+  uint32_t* occ;               /* occ_res^3 bits, bit = x + R*(y + R*z) */
+  float mlp_f[ORC_MLP_HALFS];  /* mlp[] widened to float once (exact), for speed only */
+} orc_field;
+
+/* ---- fp16 helpers (IEEE binary16, round-to-nearest-even) ---- */
+uint16_t orc_f2h(float f);
+float orc_h2f(uint16_t h);
+
+/* ---- field ---- */
+int orc_field_levels(const orc_field_desc* d, orc_level* out, uint32_t* total);
+orc_field* orc_field_synthetic(const orc_field_desc* d, uint64_t seed);
+orc_field* orc_field_from_params(const orc_field_desc* d, const uint16_t* table,
+                                 const uint16_t* mlp, const uint32_t* occ);
+void orc_field_free(orc_field* f);
+void orc_encode(const orc_field* f, const float p[3], uint16_t feat[32]);
+void orc_sh4(const float d[3], float out[16]);
+/* full field evaluation; mlp_out (optional) receives [density 16 | rgb 16] raw outputs */
+void orc_eval(const orc_field* f, const float p[3], const float d[3], float* sigma, float rgb[3],
+              float* mlp_out);
+int orc_occupied(const orc_field* f, const float p[3]);
+
+/* ---- cameras (reference in-tree math) ---- */
+/* View::get_next_camera_pos type 0 with now_camera_pose_world = I (View_Space.hpp:67-140) */
+void orc_view_pose(const double init_pos[3], const double center[3], double pose[16]);
+/* transform_matrix = P * pose^-1 * diag(1,-1,-1,1)  (main.cpp:1626-1641) */
+void orc_transform_matrix(const double pose[16], double out[16]);
+/* View_Space::get_view_space positions (View_Space.hpp:550-556); returns #views kept */
+int orc_view_space(const double* pt_sphere, int n, double radius, const double center[3],
+                   double* out_pos);
+/* centroid + 17/16 * max radius (View_Space.hpp:534-548) */
+void orc_bbx(const double* pts, int n, double center[3], double* predicted_size);
+/* assumed instant-ngp nerf_matrix_to_ngp: out = 3x4 row-major float */
+void orc_nerf_to_ngp(const double tm[16], double scale, const double offset[3], float out[12]);
+/* Share_Data.hpp:92-137 / 140-196, float32 */
+void orc_rs2_project(float pixel[2], const float intr[9], int model, const float point[3]);
+void orc_rs2_deproject(float point[3], const float intr[9], int model, const float pixel[2],
+                       float depth);
+
+typedef struct {
+  float c2w[12]; /* ngp frame, row-major 3x4 */
+  float fx, fy, cx, cy;
+} orc_camera;
+
+/* sub-pixel offset of sample k of spp (k=0 -> pixel centre) */
+void orc_spp_offset(int k, float* ox, float* oy);
+void orc_raygen(const orc_camera* cam, int px, int py, float ox, float oy, float o[3], float d[3]);
+int orc_ray_aabb(const float o[3], const float d[3], float* t0, float* t1);
+
+/* ---- render: linear premultiplied RGBA float32, no background ---- */
+void orc_render(const orc_field* f, const orc_camera* cam, int w, int h, int n_samples, int spp,
+                float min_T, float* rgba, uint64_t* n_evaluated, int n_threads);
+/* rows [y0,y1) only -- for bounded CPU-baseline timing */
+void orc_render_rows(const orc_field* f, const orc_camera* cam, int w, int h, int y0, int y1,
+                     int n_samples, int spp, float min_T, float* rgba, uint64_t* n_evaluated,
+                     int n_threads);
+
+/* ---- image post + scores ---- */
+float orc_linear_to_srgb(float x);
+/* shade over background bg[4], un-premultiply, sRGB, quantise (assumed upstream common.py) */
+void orc_quantize_rgba8(const float* rgba, size_t npix, const float bg[4], uint8_t* out);
+/* main.cpp:2053-2086 */
+double orc_score_ensemble_rgb(const uint8_t* const* imgs, int E, size_t npix);
+/* main.cpp:2113-2150 */
+double orc_score_ensemble_rgbdensity(const uint8_t* const* imgs, int E, size_t npix);
+/* run.py:257-263 (PSNR of sRGB-clipped images) + mean opacity */
+void orc_score_psnr_coverage(const float* rgba, const float* gt_rgba, size_t npix,
+                             const float bg[4], double* psnr, double* coverage);
+/* full ranking: stable sort by (-score, id)  (arg-max rule main.cpp:2088-2091) */
+void orc_rank(const double* scores, const int* ids, int n, int* order);
+int orc_argmax(const double* scores, const int* ids, int n);
+
+/* first-hit voxel DDA over the occupancy grid (CPU-path analogue of main.cpp:238-284) */
+int orc_first_hit(const orc_field* f, const float o[3], const float d[3], float max_range,
+                  int cell[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,36 @@
+"""shared helpers for the parity tests (test infrastructure)"""
+import math
+
+import numpy as np
+
+SEED_A = 0x5EED0001
+SEED_B = 0x5EED0002
+
+SMALL = dict(n_levels=8, n_features=4, log2_hashmap=14, base_res=8, finest_res=96, occ_res=32)
+SMALL_F2 = dict(n_levels=16, n_features=2, log2_hashmap=13, base_res=4, finest_res=80, occ_res=32)
+
+
+def fibonacci_hemisphere(n):
+    """n unit vectors with z >= 0, row 0 = (0,0,1): same 3-floats-per-row format as Hemisphere/N.txt"""
+    pts = [(0.0, 0.0, 1.0)]
+    golden = math.pi * (3.0 - math.sqrt(5.0))
+    for i in range(1, n):
+        z = 1.0 - (i / float(n))  # (0,1): strictly above the equator
+        r = math.sqrt(max(0.0, 1.0 - z * z))
+        th = golden * i
+        pts.append((r * math.cos(th), r * math.sin(th), z))
+    return np.array(pts, np.float64)
+
+
+def hemisphere_transforms(orc, pts, radius=0.3, predicted_size=0.1, center=(1e-10, 1e-10, 1e-10)):
+    """view positions -> transform_matrix list + (scale, offset) exactly as the planner emits them
+    (View_Space.hpp:550-556, main.cpp:1599-1602,1626-1641), via the oracle's restatement"""
+    center = np.asarray(center, np.float64)
+    pos = orc.view_space(pts, radius, center)
+    tms = np.stack([orc.transform_matrix(orc.view_pose(p, center)) for p in pos])
+    scale = 0.5 / predicted_size
+    offset = np.array([0.5 + center[2], 0.5 + center[0], 0.5 + center[1]])
+    return tms, scale, offset
+
+
+FOV_X = 2.0 * math.atan(0.5 * 1280 / 915.60668945312500)  # DefaultConfiguration.yaml:38,40 -> 69.9 deg
