@@ -98,7 +98,8 @@ void prv_destroy(prv_ctx* ctx);
  * on failure (main.cpp:1695-1698).  ctx may be NULL for the last error of a failed create. */
 const char* prv_last_error(const prv_ctx* ctx);
 int prv_abi_version(void);
-/* enqueue all work on this hipStream_t (NULL = the context's own stream) */
+/* enqueue all work on this hipStream_t from now on; NULL is HIP's legacy default stream.
+ * Until this is called the context uses a private non-blocking stream. */
 int prv_set_stream(prv_ctx* ctx, void* hip_stream);
 int prv_synchronize(prv_ctx* ctx);
 int prv_device_count(void);

@@ -428,7 +428,7 @@ void prv_destroy(prv_ctx* c) {
 int prv_set_stream(prv_ctx* c, void* s) {
   if (!c) return PRV_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  c->stream = (hipStream_t)s; // NULL is HIP's legacy default stream (what torch uses by default)
   return PRV_OK;
 }
 

@@ -126,6 +126,27 @@ __device__ __forceinline__ void sh4(float x, float y, float z, float o[16]) {
 }
 
 // ---------------------------------------------------------------- hash-grid gather
+// one table entry = F halfs: an 8-byte (F = 4) or 4-byte (F = 2) load
+template <int F> struct Entry;
+template <> struct Entry<4> {
+  uint32_t w[2];
+  __device__ __forceinline__ static Entry load(const char* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    Entry e;
+    e.w[0] = v.x;
+    e.w[1] = v.y;
+    return e;
+  }
+};
+template <> struct Entry<2> {
+  uint32_t w[1];
+  __device__ __forceinline__ static Entry load(const char* p) {
+    Entry e;
+    e.w[0] = *reinterpret_cast<const uint32_t*>(p);
+    return e;
+  }
+};
+
 // One level, one sample, one lane: 8 corner loads of F halfs, trilinear blend in fp32
 // (corner order dx + 2dy + 4dz, weight = (wx*wy)*wz, acc = fmaf(w, v, acc)).
 template <int F>
@@ -150,8 +171,7 @@ __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table,
   float wxy[4] = {w0[0] * w0[1], w1[0] * w0[1], w0[0] * w1[1], w1[0] * w1[1]};
   float wz[2] = {w0[2], w1[2]};
   constexpr int BYTES = F * 2;
-  typedef uint32_t ldvec __attribute__((ext_vector_type(F / 2)));
-  ldvec v[8];
+  Entry<F> v[8];
 #pragma unroll
   for (int c = 0; c < 8; c++) {
     int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
@@ -159,7 +179,7 @@ __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table,
     uint32_t ix = tx[dx] ^ ty[dy] ^ tz[dz];
     uint32_t idx = (L.hashed ? ix : ia) & L.mask;
     uint32_t byte_off = (L.offset + idx) * (uint32_t)BYTES;
-    v[c] = *reinterpret_cast<const ldvec*>(reinterpret_cast<const char*>(table) + byte_off);
+    v[c] = Entry<F>::load(reinterpret_cast<const char*>(table) + byte_off);
   }
 #pragma unroll
   for (int k = 0; k < F; k++) acc[k] = 0.0f;
@@ -168,7 +188,7 @@ __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table,
     float w = wxy[c & 3] * wz[c >> 2];
 #pragma unroll
     for (int k = 0; k < F; k += 2) {
-      half2v hv = __builtin_bit_cast(half2v, v[c][k / 2]);
+      half2v hv = __builtin_bit_cast(half2v, v[c].w[k / 2]);
       acc[k] = fmaf(w, (float)hv[0], acc[k]);
       acc[k + 1] = fmaf(w, (float)hv[1], acc[k + 1]);
     }

@@ -380,11 +380,10 @@ __global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const flo
   const half8 shf = sh_fragment(h, dd[0], dd[1], dd[2]);
   const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf);
   if (!ok) return;
-  if (feat) {
-    for (int k = 0; k < 8; k++) {
-      feat[idx * 32 + 16 * h + k] = __builtin_bit_cast(uint16_t, f0[k]);
-      feat[idx * 32 + 16 * h + 8 + k] = __builtin_bit_cast(uint16_t, f1[k]);
-    }
+  if (feat) { // two 16-byte vector stores per lane (canonical features [16h, 16h+16))
+    half8* dst = reinterpret_cast<half8*>(feat + (size_t)idx * 32 + 16 * h);
+    dst[0] = f0;
+    dst[1] = f1;
   }
   if (out36) {
     float* q = out36 + (size_t)idx * 36;
@@ -392,6 +391,7 @@ __global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const flo
       q[0] = expf(mo.dens[0] + fd.density_bias);
       for (int k = 0; k < 3; k++) q[1 + k] = 1.0f / (1.0f + expf(-mo.rgb[k]));
     }
+#pragma unroll
     for (int i = 0; i < 8; i++) { // reg i -> row (i&3) + 8(i>>2) + 4h, rows 0..15
       const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
       q[4 + row] = mo.dens[i];

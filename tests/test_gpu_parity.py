@@ -196,8 +196,16 @@ def test_score_views_ensemble_and_ranking(ctx, oracle, fields, cams, method, E):
 
 def test_error_behaviour(ctx, fields, cams):
     cs, ocams, w, h = cams
-    with pytest.raises(api.PrvError):
-        ctx.render(7, cs, None, api.render_opts(w, h))  # empty slot
+    with pytest.raises(api.PrvError) as e:
+        ctx.render(8, cs, None, api.render_opts(w, h))  # slot out of range
+    assert e.value.code == api.L.PRV_E_INVALID
+    fresh = api.Context(0)
+    cs2 = fresh.cameras_from_matrices(np.eye(4)[None], util.FOV_X, w, h, 1.0, [0.5, 0.5, 0.5])
+    with pytest.raises(api.PrvError) as e:
+        fresh.render(0, cs2, None, api.render_opts(w, h))  # empty slot
+    assert e.value.code == api.L.PRV_E_STATE
+    cs2.close()
+    fresh.close()
     with pytest.raises(api.PrvError):
         ctx.render(0, cs, None, api.render_opts(w, h, samples_per_ray=129))
     with pytest.raises(api.PrvError):
