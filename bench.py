@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of NeRF-PRV on MI355X: render + score candidate views.
+
+One "step" = one scoring round of the planner over this rank's shard of the candidate set:
+march + render every view (800x800, 128 samples/ray) of the synthetic 256^3 hash-grid field,
+reduce each to a PSNR/coverage score against reference images already resident in HBM,
+all-gather the 16-byte records over RCCL (N > 1), rank.  BASELINE.json configs[1].
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+SEED_A, SEED_B = 0x5EED0001, 0x5EED0002
+BYTES_PER_SAMPLE = 512  # L*8 corners*F*2 B = 8*8*4*2: hash-table gather per field evaluation
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(args, tms, scale, offset, fov_x):
+    """the oracle (a scalar C port of the same algorithm) on the host cores, bounded sample"""
+    from oracle import oracle as orc
+
+    threads = os.cpu_count() or 1
+    f = orc.OracleField(orc.desc(), seed=SEED_A)
+    cams = orc.cameras_from_transforms(tms, fov_x, args.width, args.height, scale, offset)
+    rows = (args.height // 2 - 8, args.height // 2 + 8)
+    f.render(cams[0], args.width, args.height, args.samples, 1, 1e-4, threads=threads, rows=(rows[0], rows[0] + 1))
+    n_eval, n_views, t0 = 0, 0, time.perf_counter()
+    for v in range(len(cams)):
+        _, ne = f.render(cams[v], args.width, args.height, args.samples, 1, 1e-4, threads=threads, rows=rows)
+        n_eval += ne
+        n_views += 1
+        if time.perf_counter() - t0 > args.cpu_seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_eval / dt,
+        "unit": "ray-samples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"rows {rows[0]}-{rows[1]} of {n_views} views at {args.width}x{args.height}, "
+                  f"{args.samples} samples/ray, {n_eval} samples evaluated in {dt:.1f} s "
+                  f"(oracle/prv_oracle.c, pthreads over rows)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--views-per-gpu", type=int, default=64)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--field", choices=["256", "512"], default="256")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from nerf_prv_amd import api, planner
+
+    ctx = api.Context(local_rank)  # raises when libprv_hip.so / the GPU is missing: no fallback
+    fdict = dict(api.FIELD_256 if args.field == "256" else api.FIELD_512)
+    desc = api.L.FieldDesc(**fdict)
+    ctx.synthetic_model(0, desc, SEED_A)  # the field being scored
+    ctx.synthetic_model(1, desc, SEED_B)  # the field the reference images come from
+
+    # candidate set: generated hemisphere, radius 0.3 around the origin (+1e-10), object size 0.1
+    # -> cameras at 1.5 cube units from the centre of the unit cube
+    n_views = args.views_per_gpu * world
+    pts = planner.hemisphere_generate(n_views)
+    fov_x = 2.0 * np.arctan(0.5 * 1280 / 915.60668945312500)  # the reference camera's 69.9 deg
+    tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
+    cams = ctx.cameras_from_matrices(tms, fov_x, args.width, args.height, scale, offset)
+    my_ids, per_rank = planner.shard_views(n_views, rank, world)
+    opts = api.render_opts(args.width, args.height, args.samples, 1, 1e-4)
+
+    # reference images of this rank's views, resident in HBM before the timed region
+    gt, _ = ctx.render(1, cams, my_ids, opts, want_stats=False)
+    rec_dev = torch.zeros(per_rank * 16, dtype=torch.uint8, device=device)
+
+    def step(want_stats=False):
+        _, st = ctx.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cams, my_ids, opts, gt=gt, records_dev=rec_dev,
+                                to_host=False, want_stats=want_stats)
+        records = planner.gather_records(rec_dev, per_rank, n_views, device=device)  # the ONE collective
+        order = api.rank_host(records, np.arange(n_views, dtype=np.int32))
+        return st, records, order
+
+    st, records, order = step(want_stats=True)  # also sizes every workspace
+    evaluated_per_step, nominal_per_step, rays_per_step = st.samples_evaluated, st.samples_nominal, st.rays
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, records, order = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_end()
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    tot = torch.tensor([float(evaluated_per_step), float(nominal_per_step), float(rays_per_step)], dtype=torch.float64,
+                       device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(tmax.item())
+    ev_all, nom_all, rays_all = (float(x) for x in tot.tolist())
+
+    if rank == 0:
+        k = args.steps
+        launches = max(1, prof["render_launches"])
+        kernel_s = prof["render_ms"] * 1e-3 / launches  # average render_queue launch duration
+        samples_per_launch = evaluated_per_step * k / launches
+        achieved = samples_per_launch * BYTES_PER_SAMPLE / kernel_s / 1e9
+        out = {
+            "metric": "ray-samples/s (field evaluations composited; candidate views rendered + scored)",
+            "value": ev_all * k / elapsed,
+            "unit": "ray-samples/s",
+            "n_gpus": world,
+            "steps": k,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / k * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16 table+MLP operands, f32 accumulate/compositing",
+            "data": "synthetic",
+            "config": {
+                "workload": f"render+score {args.views_per_gpu} hemisphere views/GPU, {args.width}x{args.height}, "
+                            f"{args.samples} samples/ray, synthetic {args.field}^3 hash-grid field "
+                            f"(L={fdict['n_levels']} F={fdict['n_features']} log2T={fdict['log2_hashmap']}), "
+                            "PSNR+coverage score vs resident reference images",
+                "views_total": n_views,
+                "parallelism": f"views sharded {args.views_per_gpu}/GPU, one all-gather of 16-B records",
+            },
+            "nominal_ray_samples_per_s": nom_all * k / elapsed,
+            "rays_per_s": rays_all * k / elapsed,
+            "views_scored_per_s": n_views * k / elapsed,
+            "samples_evaluated_per_step_per_gpu": evaluated_per_step,
+            "samples_nominal_per_step_per_gpu": nominal_per_step,
+            "ranking_head": [int(x) for x in order[:8]],
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "render_queue_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_unit": BYTES_PER_SAMPLE,
+                "units_per_launch": samples_per_launch,
+                "avg_launch_ms": kernel_s * 1e3,
+                "launches": launches,
+                "march_avg_launch_ms": prof["march_ms"] / max(1, prof["march_launches"]),
+                "mfma_tflops": samples_per_launch * 20480 / kernel_s / 1e12,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, tms, scale, offset, fov_x)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

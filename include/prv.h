@@ -104,6 +104,13 @@ int prv_set_stream(prv_ctx* ctx, void* hip_stream);
 int prv_synchronize(prv_ctx* ctx);
 int prv_device_count(void);
 
+/* Per-kernel timing with HIP events on the context's stream (for roofline accounting):
+ * between begin and end every march_compact and render_queue launch is bracketed by an
+ * event pair.  end synchronises and returns summed durations and launch counts. */
+int prv_profile_begin(prv_ctx* ctx);
+int prv_profile_end(prv_ctx* ctx, double* render_ms, int* render_launches, double* march_ms,
+                    int* march_launches);
+
 /* thin device-memory helpers so a C/C++ host needs no HIP headers */
 int prv_malloc(prv_ctx* ctx, void** dev_ptr, size_t bytes);
 int prv_free(prv_ctx* ctx, void* dev_ptr);

@@ -1,0 +1,76 @@
+/*
+ * prv_host.h -- C ABI of the planner-side host library (libprv_host.so, pure C++17, no GPU).
+ *
+ * These are the pieces of PRV_simulation that sit on either side of the render boundary:
+ * the candidate-view set, the per-view camera pose search, the transforms.json camera
+ * interface, the config file, and the next-best-view loop.  The C++ classes behind this
+ * ABI keep the reference's names (Share_Data, View, View_Space, NBV_Net_Labeler) in
+ * nerf_prv_amd/host/; this header is what tests and non-C++ hosts bind.
+ */
+#ifndef PRV_HOST_H
+#define PRV_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* View::get_next_camera_pos(now_camera_pose_world = I, object_center_world, type 0)
+ * (View_Space.hpp:67-140): pose = world->camera 4x4, row-major */
+void prvh_view_pose(const double init_pos[3], const double center[3], double pose[16]);
+/* frame transform_matrix = P * pose^-1 * diag(1,-1,-1,1)  (main.cpp:1626-1641) */
+void prvh_transform_matrix(const double pose[16], double tm[16]);
+/* View_Space::get_view_space candidate positions (View_Space.hpp:550-556); returns count */
+int prvh_view_space(const double* pt_sphere, int n, double radius, const double center[3], double* out_pos);
+/* centroid and 17/16 x bounding radius of a cloud (View_Space.hpp:534-548) */
+void prvh_bbx(const double* pts, int n, double center[3], double* predicted_size);
+/* read Hemisphere/<N>.txt style files: n rows of 3 numbers (Share_Data.hpp:517-525); returns rows read */
+int prvh_hemisphere_read(const char* path, int n, double* out_xyz);
+/* generated view set for synthetic configs: Fibonacci hemisphere, row 0 = (0,0,1), z > 0 */
+int prvh_hemisphere_generate(int n, double* out_xyz);
+
+typedef struct prvh_intrinsics { /* Share_Data::color_intrinsics (Share_Data.hpp:79-89) */
+  int32_t width, height;
+  double ppx, ppy, fx, fy;
+  double coeffs[5]; /* k1 k2 k3 p1 p2 in the YAML order (Share_Data.hpp:395-399) */
+} prvh_intrinsics;
+
+/* transforms.json as get_coverage / nbv_loop emit it (main.cpp:1584-1602, 1793-1811):
+ * candidate_header != 0 selects the 1/16-resolution, zero-distortion header of the render json.
+ * frames: init_pos[n*3] world positions -> pose search -> transform_matrix; file_path =
+ * "<path_prefix><id>.png".  Returns 0 or a negative error. */
+int prvh_write_transforms(const char* path, const prvh_intrinsics* intr, int candidate_header,
+                          double candidate_divisor, int aabb_scale, double predicted_size,
+                          const double center[3], const double* init_pos, const int* ids, int n,
+                          const char* path_prefix);
+
+/* ---- config (Share_Data) ---- */
+typedef struct prvh_share_data prvh_share_data;
+/* Share_Data(config, name, num_of_views, id_of_batch, method) (Share_Data.hpp:334) */
+prvh_share_data* prvh_share_data_create(const char* yaml_path, const char* test_name, int num_of_views,
+                                        int id_of_batch, int test_method);
+void prvh_share_data_destroy(prvh_share_data*);
+const char* prvh_share_data_error(void);
+/* string / number lookups by the reference's field names, e.g. "save_path", "ensemble_num" */
+const char* prvh_share_data_string(const prvh_share_data*, const char* field);
+double prvh_share_data_number(const prvh_share_data*, const char* field);
+int prvh_share_data_views(const prvh_share_data*, double* out_xyz /* num_of_views*3 or NULL */);
+void prvh_share_data_intrinsics(const prvh_share_data*, prvh_intrinsics* out);
+
+/* ---- the planner loop (NBV_Net_Labeler::nbv_loop, main.cpp:1718-2277) ---- */
+/* scorer: the render boundary as seen from the loop.  Given the render json of this
+ * iteration and the candidate ids in it, fill one score per candidate (larger = better).
+ * Production wires this to prv_score_views; tests may wire anything. */
+typedef int (*prvh_score_fn)(void* user, int method, int iteration, const char* scene_json,
+                             const char* render_json, const int* candidate_ids, int n, double* scores);
+typedef struct prvh_loop_result {
+  int n_chosen;
+  int chosen[1024];
+  double total_movement; /* always 0: path cost planning is out of scope */
+} prvh_loop_result;
+int prvh_nbv_loop(prvh_share_data* sd, const double center[3], double predicted_size, int first_view_id,
+                  int test_id, prvh_score_fn score, void* user, prvh_loop_result* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

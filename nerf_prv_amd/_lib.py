@@ -69,6 +69,8 @@ SIGNATURES = {
     "prv_set_stream": (_i, [_vp, _vp]),
     "prv_synchronize": (_i, [_vp]),
     "prv_device_count": (_i, []),
+    "prv_profile_begin": (_i, [_vp]),
+    "prv_profile_end": (_i, [_vp, _P(C.c_double), _P(_i), _P(C.c_double), _P(_i)]),
     "prv_malloc": (_i, [_vp, _P(_vp), C.c_size_t]),
     "prv_free": (_i, [_vp, _vp]),
     "prv_memcpy_h2d": (_i, [_vp, _vp, _vp, C.c_size_t]),

@@ -128,6 +128,15 @@ class Context:
     def synchronize(self):
         self._chk(self.lib.prv_synchronize(self.handle))
 
+    def profile_begin(self):
+        self._chk(self.lib.prv_profile_begin(self.handle))
+
+    def profile_end(self):
+        """-> dict(render_ms, render_launches, march_ms, march_launches) from HIP events"""
+        rm, mm, rn, mn = C.c_double(), C.c_double(), C.c_int(), C.c_int()
+        self._chk(self.lib.prv_profile_end(self.handle, C.byref(rm), C.byref(rn), C.byref(mm), C.byref(mn)))
+        return dict(render_ms=rm.value, render_launches=rn.value, march_ms=mm.value, march_launches=mn.value)
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.prv_destroy(self.handle)

@@ -55,6 +55,8 @@ struct prv_ctx {
   // grow-only workspaces
   Buffer queue, counters, view_ids, img_f32, partial, records, dbg[6];
   Buffer img_u8[PRV_MAX_MODELS];
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs
   int blocks_per_cu = 4;
   int refill_min = 8;
   size_t queue_budget = (size_t)1 << 30;
@@ -323,7 +325,16 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
       mp.inv_spp = 1.0f / (float)o->spp;
       mp.last_pass = k == o->spp - 1;
       memcpy(mp.bg, o->background, sizeof(mp.bg));
+      if (c->profiling) {
+        hipEvent_t a, b;
+        HIPCHK(c, hipEventCreate(&a));
+        HIPCHK(c, hipEventCreate(&b));
+        c->ev_march.push_back(a);
+        c->ev_march.push_back(b);
+        HIPCHK(c, hipEventRecord(a, c->stream));
+      }
       HIPCHK(c, launch_march(mp, nb, c->stream));
+      if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_march.back(), c->stream));
       RenderParams rp;
       memset(&rp, 0, sizeof(rp));
       rp.field = m.dev;
@@ -339,7 +350,16 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
       rp.last_pass = mp.last_pass;
       rp.refill_min = c->refill_min;
       memcpy(rp.bg, o->background, sizeof(rp.bg));
+      if (c->profiling) {
+        hipEvent_t a, b;
+        HIPCHK(c, hipEventCreate(&a));
+        HIPCHK(c, hipEventCreate(&b));
+        c->ev_render.push_back(a);
+        c->ev_render.push_back(b);
+        HIPCHK(c, hipEventRecord(a, c->stream));
+      }
       HIPCHK(c, launch_render(rp, n_blocks, c->stream));
+      if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_render.back(), c->stream));
     }
   }
   return PRV_OK;
@@ -436,6 +456,38 @@ int prv_synchronize(prv_ctx* c) {
   if (!c) return PRV_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return PRV_OK;
+}
+
+static int drain_events(prv_ctx* c, std::vector<hipEvent_t>& ev, double* ms, int* n) {
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+    float t = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+    tot += t;
+  }
+  if (ms) *ms = tot;
+  if (n) *n = (int)(ev.size() / 2);
+  for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  ev.clear();
+  return PRV_OK;
+}
+
+int prv_profile_begin(prv_ctx* c) {
+  if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  drain_events(c, c->ev_render, nullptr, nullptr);
+  drain_events(c, c->ev_march, nullptr, nullptr);
+  c->profiling = true;
+  return PRV_OK;
+}
+
+int prv_profile_end(prv_ctx* c, double* render_ms, int* render_n, double* march_ms, int* march_n) {
+  if (!c) return PRV_E_INVALID;
+  c->profiling = false;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = drain_events(c, c->ev_render, render_ms, render_n);
+  if (rc != PRV_OK) return rc;
+  return drain_events(c, c->ev_march, march_ms, march_n);
 }
 
 int prv_malloc(prv_ctx* c, void** p, size_t bytes) {

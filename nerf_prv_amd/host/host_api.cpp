@@ -1,0 +1,183 @@
+// host_api.cpp -- C ABI of the planner-side host library (include/prv_host.h).
+#include "../../include/prv_host.h"
+
+#include <cstring>
+#include <string>
+
+#include "planner.hpp"
+
+using namespace prvhost;
+
+namespace {
+thread_local std::string g_error;
+}
+
+struct prvh_share_data {
+  std::shared_ptr<Share_Data> sd;
+  std::string scratch;
+};
+
+extern "C" {
+
+void prvh_view_pose(const double init_pos[3], const double center[3], double pose[16]) {
+  View v(Vec3(init_pos[0], init_pos[1], init_pos[2]));
+  v.get_next_camera_pos(Mat4::Identity(), Vec3(center[0], center[1], center[2]));
+  memcpy(pose, v.pose.m.data(), sizeof(double) * 16);
+}
+
+void prvh_transform_matrix(const double pose[16], double tm[16]) {
+  Mat4 p;
+  memcpy(p.m.data(), pose, sizeof(double) * 16);
+  Mat4 P = Mat4::Identity(), P1 = Mat4::Identity();
+  P.m = {0, 0, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1};
+  P1.m = {1, 0, 0, 0, 0, -1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1};
+  const Mat4 r = P * p.inverse() * P1;
+  memcpy(tm, r.m.data(), sizeof(double) * 16);
+}
+
+int prvh_view_space(const double* pt, int n, double radius, const double center[3], double* out_pos) {
+  if (n <= 0) return 0;
+  const double pt_norm = std::sqrt(pt[0] * pt[0] + pt[1] * pt[1] + pt[2] * pt[2]);
+  int k = 0;
+  for (int i = 0; i < n; i++) {
+    if (pt[i * 3 + 2] < 0) continue;
+    const double scale = 1.0 / pt_norm * radius;
+    for (int a = 0; a < 3; a++) out_pos[k * 3 + a] = pt[i * 3 + a] * scale + center[a];
+    k++;
+  }
+  return k;
+}
+
+void prvh_bbx(const double* pts, int n, double center[3], double* predicted_size) {
+  Vec3 c(0, 0, 0);
+  for (int i = 0; i < n; i++) c = c + Vec3(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]);
+  c = Vec3(c.x / n, c.y / n, c.z / n);
+  double s = 0;
+  for (int i = 0; i < n; i++) s = std::max(s, (c - Vec3(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2])).norm());
+  center[0] = c.x; center[1] = c.y; center[2] = c.z;
+  *predicted_size = s * (17.0 / 16.0);
+}
+
+int prvh_hemisphere_read(const char* path, int n, double* out) {
+  std::ifstream f(path);
+  if (!f.is_open()) return -1;
+  int rows = 0;
+  for (; rows < n; rows++) {
+    double v[3];
+    if (!(f >> v[0] >> v[1] >> v[2])) break;
+    memcpy(out + rows * 3, v, sizeof(v));
+  }
+  return rows;
+}
+
+int prvh_hemisphere_generate(int n, double* out) {
+  if (n < 1) return 0;
+  out[0] = 0; out[1] = 0; out[2] = 1; // the top view every reference set contains (main.cpp:2212)
+  const double golden = std::acos(-1.0) * (3.0 - std::sqrt(5.0));
+  for (int i = 1; i < n; i++) {
+    const double z = 1.0 - (double)i / (double)n; // strictly above the equator
+    const double r = std::sqrt(std::max(0.0, 1.0 - z * z));
+    const double th = golden * i;
+    out[i * 3] = r * std::cos(th);
+    out[i * 3 + 1] = r * std::sin(th);
+    out[i * 3 + 2] = z;
+  }
+  return n;
+}
+
+int prvh_write_transforms(const char* path, const prvh_intrinsics* in, int candidate_header, double divisor,
+                          int aabb_scale, double predicted_size, const double center[3], const double* init_pos,
+                          const int* ids, int n, const char* path_prefix) {
+  if (!path || !in || !center || (n > 0 && !init_pos)) return -1;
+  rs2_intrinsics K;
+  K.width = in->width; K.height = in->height;
+  K.ppx = (float)in->ppx; K.ppy = (float)in->ppy; K.fx = (float)in->fx; K.fy = (float)in->fy;
+  for (int i = 0; i < 5; i++) K.coeffs[i] = (float)in->coeffs[i];
+  const Vec3 c(center[0], center[1], center[2]);
+  Value root = transforms_header(K, aabb_scale, predicted_size, c, candidate_header ? divisor : 0.0);
+  const Mat4 cam = Mat4::Identity();
+  for (int i = 0; i < n; i++) {
+    View v(Vec3(init_pos[i * 3], init_pos[i * 3 + 1], init_pos[i * 3 + 2]));
+    Value view_image;
+    view_image["file_path"] = Value(std::string(path_prefix ? path_prefix : "") + std::to_string(ids ? ids[i] : i) + ".png");
+    view_image["transform_matrix"] = matrix_json(view_transform_matrix(v, cam, c));
+    root["frames"].append(view_image);
+  }
+  return write_text(path, prvjson::to_styled_string(root)) ? 0 : -3;
+}
+
+prvh_share_data* prvh_share_data_create(const char* yaml, const char* name, int num_of_views, int id_of_batch, int method) {
+  auto sd = std::make_shared<Share_Data>(yaml ? yaml : "", name ? name : "", num_of_views, id_of_batch, method);
+  if (!sd->ok) {
+    g_error = sd->error;
+    return nullptr;
+  }
+  auto* h = new prvh_share_data();
+  h->sd = sd;
+  return h;
+}
+void prvh_share_data_destroy(prvh_share_data* h) { delete h; }
+const char* prvh_share_data_error(void) { return g_error.c_str(); }
+
+const char* prvh_share_data_string(const prvh_share_data* h, const char* f) {
+  if (!h || !f) return "";
+  const Share_Data& s = *h->sd;
+  const std::string k = f;
+  const std::string* v = nullptr;
+  if (k == "pre_path") v = &s.pre_path; else if (k == "model_path") v = &s.model_path;
+  else if (k == "viewspace_path") v = &s.viewspace_path; else if (k == "instant_ngp_path") v = &s.instant_ngp_path;
+  else if (k == "name_of_pcd") v = &s.name_of_pcd; else if (k == "gt_path") v = &s.gt_path;
+  else if (k == "save_path") v = &s.save_path; else if (k == "yaml_file_path") v = &s.yaml_file_path;
+  else if (k == "shape_net") v = &s.shape_net; else if (k == "pvb_path") v = &s.pvb_path;
+  else if (k == "orginalviews_path") v = &s.orginalviews_path;
+  return v ? v->c_str() : "";
+}
+
+double prvh_share_data_number(const prvh_share_data* h, const char* f) {
+  if (!h || !f) return 0;
+  const Share_Data& s = *h->sd;
+  const std::string k = f;
+#define NUM(name) if (k == #name) return (double)s.name;
+  NUM(num_of_views) NUM(method_of_IG) NUM(num_of_thread) NUM(n_steps) NUM(evaluate) NUM(ensemble_num)
+  NUM(num_of_max_iteration) NUM(id_of_batch) NUM(is_shape_net) NUM(coverage_view_num_max) NUM(coverage_view_num_add)
+  NUM(ray_casting_aabb_scale) NUM(num_of_novel_test_views) NUM(view_space_radius) NUM(octomap_resolution)
+  NUM(ground_truth_resolution) NUM(depth_scale) NUM(pt_norm) NUM(render_width) NUM(render_height)
+  NUM(samples_per_ray) NUM(screenshot_spp) NUM(candidate_divisor) NUM(min_transmittance) NUM(cost_on) NUM(cost_rate) NUM(show)
+#undef NUM
+  return 0;
+}
+
+int prvh_share_data_views(const prvh_share_data* h, double* out) {
+  if (!h) return -1;
+  const auto& p = h->sd->pt_sphere;
+  if (out)
+    for (size_t i = 0; i < p.size(); i++)
+      for (int j = 0; j < 3; j++) out[i * 3 + j] = p[i][j];
+  return (int)p.size();
+}
+
+void prvh_share_data_intrinsics(const prvh_share_data* h, prvh_intrinsics* o) {
+  if (!h || !o) return;
+  const rs2_intrinsics& K = h->sd->color_intrinsics;
+  o->width = K.width; o->height = K.height;
+  o->ppx = K.ppx; o->ppy = K.ppy; o->fx = K.fx; o->fy = K.fy;
+  for (int i = 0; i < 5; i++) o->coeffs[i] = K.coeffs[i];
+}
+
+int prvh_nbv_loop(prvh_share_data* h, const double center[3], double predicted_size, int first_view_id, int test_id,
+                  prvh_score_fn score, void* user, prvh_loop_result* out) {
+  if (!h || !center || !out) return -1;
+  Scorer s = [score, user](int method, int iteration, const std::string& scene, const std::string& render,
+                           const std::vector<int>& ids, std::vector<double>& scores) -> int {
+    if (!score) return -12;
+    return score(user, method, iteration, scene.c_str(), render.c_str(), ids.data(), (int)ids.size(), scores.data());
+  };
+  NBV_Net_Labeler labeler(h->sd, Vec3(center[0], center[1], center[2]), predicted_size, s);
+  const int rc = labeler.nbv_loop(first_view_id, test_id);
+  out->n_chosen = (int)std::min<size_t>(labeler.chosen_nbvs.size(), 1024);
+  for (int i = 0; i < out->n_chosen; i++) out->chosen[i] = labeler.chosen_nbvs[i];
+  out->total_movement = 0.0;
+  return rc;
+}
+
+} // extern "C"

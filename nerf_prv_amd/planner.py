@@ -1,0 +1,246 @@
+"""Planner-side host pieces in Python: binding of libprv_host.so (the C++ planner shell)
+and the multi-GPU scoring round (views sharded across ranks, ONE all-gather of 16-byte
+score records, identical ranking on every rank).
+
+The sharding layer is backend-agnostic: it takes a `score_shard(view_ids) -> records`
+callable.  In production that callable is `Context.score_views` (HIP); the CPU tests of the
+N>1 path plug a checker in its place and run over gloo.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib as L
+from .api import RECORD_DTYPE, rank_host
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "libprv_host.so")
+
+
+class Intrinsics(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("ppx", C.c_double), ("ppy", C.c_double),
+                ("fx", C.c_double), ("fy", C.c_double), ("coeffs", C.c_double * 5)]
+
+
+class LoopResult(C.Structure):
+    _fields_ = [("n_chosen", C.c_int), ("chosen", C.c_int * 1024), ("total_movement", C.c_double)]
+
+
+SCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int,
+                       C.POINTER(C.c_double))
+
+_vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+HOST_SIGNATURES = {
+    "prvh_view_pose": (None, [_vp, _vp, _vp]),
+    "prvh_transform_matrix": (None, [_vp, _vp]),
+    "prvh_view_space": (_i, [_vp, _i, _d, _vp, _vp]),
+    "prvh_bbx": (None, [_vp, _i, _vp, C.POINTER(_d)]),
+    "prvh_hemisphere_read": (_i, [C.c_char_p, _i, _vp]),
+    "prvh_hemisphere_generate": (_i, [_i, _vp]),
+    "prvh_write_transforms": (_i, [C.c_char_p, C.POINTER(Intrinsics), _i, _d, _i, _d, _vp, _vp, _vp, _i, C.c_char_p]),
+    "prvh_share_data_create": (_vp, [C.c_char_p, C.c_char_p, _i, _i, _i]),
+    "prvh_share_data_destroy": (None, [_vp]),
+    "prvh_share_data_error": (C.c_char_p, []),
+    "prvh_share_data_string": (C.c_char_p, [_vp, C.c_char_p]),
+    "prvh_share_data_number": (_d, [_vp, C.c_char_p]),
+    "prvh_share_data_views": (_i, [_vp, _vp]),
+    "prvh_share_data_intrinsics": (None, [_vp, C.POINTER(Intrinsics)]),
+    "prvh_nbv_loop": (_i, [_vp, _vp, _d, _i, _i, SCORE_FN, _vp, C.POINTER(LoopResult)]),
+}
+
+_host = None
+
+
+def host():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise ImportError(f"{HOST_LIB_PATH} is missing: run __graft_entry__.build()")
+        lib = C.CDLL(HOST_LIB_PATH)
+        for name, (res, args) in HOST_SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError = missing export: fail loudly
+            fn.restype, fn.argtypes = res, args
+        _host = lib
+    return _host
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- pose / view set (C++ View, View_Space) ---------------------------------------------
+
+def view_pose(init_pos, center):
+    a, b = np.ascontiguousarray(init_pos, np.float64), np.ascontiguousarray(center, np.float64)
+    out = np.zeros(16, np.float64)
+    host().prvh_view_pose(_p(a), _p(b), _p(out))
+    return out.reshape(4, 4)
+
+
+def transform_matrix(pose):
+    a = np.ascontiguousarray(pose, np.float64).reshape(16)
+    out = np.zeros(16, np.float64)
+    host().prvh_transform_matrix(_p(a), _p(out))
+    return out.reshape(4, 4)
+
+
+def view_space(pt_sphere, radius, center):
+    pts = np.ascontiguousarray(pt_sphere, np.float64).reshape(-1, 3)
+    c = np.ascontiguousarray(center, np.float64)
+    out = np.zeros_like(pts)
+    n = host().prvh_view_space(_p(pts), len(pts), float(radius), _p(c), _p(out))
+    return out[:n]
+
+
+def bbx(points):
+    pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    c, s = np.zeros(3, np.float64), C.c_double()
+    host().prvh_bbx(_p(pts), len(pts), _p(c), C.byref(s))
+    return c, s.value
+
+
+def hemisphere_generate(n):
+    out = np.zeros((n, 3), np.float64)
+    host().prvh_hemisphere_generate(n, _p(out))
+    return out
+
+
+def hemisphere_read(path, n):
+    out = np.zeros((n, 3), np.float64)
+    rows = host().prvh_hemisphere_read(str(path).encode(), n, _p(out))
+    if rows != n:
+        raise IOError(f"{path}: expected {n} rows, read {rows}")
+    return out
+
+
+def hemisphere_transforms(pt_sphere, radius, predicted_size, center):
+    """candidate set -> (transform_matrix[n,4,4], scale, offset) as the planner's json carries them
+    (View_Space.hpp:550-556, main.cpp:1599-1602, 1626-1641)"""
+    center = np.asarray(center, np.float64)
+    pos = view_space(pt_sphere, radius, center)
+    tms = np.stack([transform_matrix(view_pose(p, center)) for p in pos])
+    scale = 0.5 / predicted_size
+    offset = np.array([0.5 + center[2], 0.5 + center[0], 0.5 + center[1]])
+    return tms, scale, offset
+
+
+def write_transforms(path, intr, positions, center, predicted_size, ids=None, candidate=False, divisor=16.0,
+                     aabb_scale=1, path_prefix="rgbaClip_"):
+    pos = np.ascontiguousarray(positions, np.float64).reshape(-1, 3)
+    c = np.ascontiguousarray(center, np.float64)
+    idp = None if ids is None else _p(np.ascontiguousarray(ids, np.int32))
+    rc = host().prvh_write_transforms(str(path).encode(), C.byref(intr), int(candidate), float(divisor), int(aabb_scale),
+                                      float(predicted_size), _p(c), _p(pos), idp, len(pos), path_prefix.encode())
+    if rc != 0:
+        raise IOError(f"cannot write {path} (rc={rc})")
+
+
+class ShareData:
+    """binding of the C++ Share_Data (constructor signature of Share_Data.hpp:334)"""
+
+    def __init__(self, config_file_path, test_name="", num_of_views=-1, id_of_batch=-1, test_method=-1):
+        self.h = host().prvh_share_data_create(str(config_file_path).encode(), test_name.encode(), num_of_views,
+                                               id_of_batch, test_method)
+        if not self.h:
+            raise IOError(host().prvh_share_data_error().decode())
+
+    def string(self, field):
+        return host().prvh_share_data_string(self.h, field.encode()).decode()
+
+    def number(self, field):
+        return host().prvh_share_data_number(self.h, field.encode())
+
+    def views(self):
+        n = host().prvh_share_data_views(self.h, None)
+        out = np.zeros((n, 3), np.float64)
+        host().prvh_share_data_views(self.h, _p(out))
+        return out
+
+    def intrinsics(self):
+        k = Intrinsics()
+        host().prvh_share_data_intrinsics(self.h, C.byref(k))
+        return k
+
+    def nbv_loop(self, center, predicted_size, score_fn, first_view_id=-1, test_id=0):
+        """run NBV_Net_Labeler::nbv_loop; score_fn(method, iteration, scene_json, render_json, ids) -> scores"""
+        def cb(user, method, iteration, scene, render, ids, n, scores):
+            try:
+                vals = score_fn(method, iteration, scene.decode(), render.decode(), [ids[i] for i in range(n)])
+                for i in range(n):
+                    scores[i] = float(vals[i])
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                self.last_error = e
+                return -13
+
+        c = np.ascontiguousarray(center, np.float64)
+        res = LoopResult()
+        keep = SCORE_FN(cb)
+        rc = host().prvh_nbv_loop(self.h, _p(c), float(predicted_size), first_view_id, test_id, keep, None, C.byref(res))
+        if rc != 0:
+            raise RuntimeError(f"nbv_loop failed rc={rc}: {getattr(self, 'last_error', '')}")
+        return [res.chosen[i] for i in range(res.n_chosen)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            host().prvh_share_data_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- multi-GPU scoring round --------------------------------------------------------------
+
+def shard_views(n_views, rank, world):
+    """contiguous block of rank: ids [rank*ceil(N/R), min(N, (rank+1)*ceil(N/R)))"""
+    per = -(-n_views // world)
+    lo = min(n_views, rank * per)
+    return np.arange(lo, min(n_views, lo + per), dtype=np.int32), per
+
+
+def gather_records(local, per_rank, n_views, group=None, device=None):
+    """ONE all-gather of the per-rank record blocks (16 bytes per view), padded to per_rank.
+
+    `local` is either a numpy RECORD_DTYPE array (host; gloo) or a torch uint8 tensor of
+    per_rank*16 bytes already on the device (RCCL).  Returns a host RECORD_DTYPE array of
+    n_views records in view order, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if isinstance(local, np.ndarray):
+        buf = np.zeros(per_rank, RECORD_DTYPE)
+        buf[: len(local)] = local
+        send = torch.from_numpy(buf.view(np.uint8).copy())
+        if device is not None:
+            send = send.to(device)
+    else:
+        send = local
+    if world == 1:
+        out = send
+    else:
+        out = torch.empty(world * per_rank * 16, dtype=torch.uint8, device=send.device)
+        dist.all_gather_into_tensor(out, send, group=group)
+    host_bytes = out.cpu().numpy()
+    return host_bytes.view(RECORD_DTYPE)[:n_views].copy()
+
+
+def scoring_round(n_views, score_shard, group=None, device=None):
+    """the distributed scoring round: shard -> score -> all-gather -> identical ranking.
+
+    score_shard(view_ids) returns RECORD_DTYPE (host) or a uint8 device tensor of
+    per_rank*16 bytes.  Returns (records[n_views], order[n_views])."""
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    ids, per = shard_views(n_views, rank, world)
+    local = score_shard(ids)
+    records = gather_records(local, per, n_views, group, device)
+    order = rank_host(records, np.arange(n_views, dtype=np.int32))
+    return records, order
