@@ -1,0 +1,170 @@
+"""Planner-side host library (C++ Share_Data / View / View_Space / NBV_Net_Labeler) on CPU:
+against the golden camera fixtures, the oracle, and the reference's file formats."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nerf_prv_amd import planner
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+YAML = """%YAML:1.0
+pre_path: "{pre}/"
+viewspace_path: "{vs}/"
+instant_ngp_path: "unused/"
+name_of_pcd: "synthetic_object"
+is_shape_net: 1
+id_of_batch: -1
+method_of_IG : 0
+n_steps: 2500
+ensemble_num: 5
+num_of_max_iteration: 3   # short loop for the test
+num_of_views : 5
+ray_casting_aabb_scale : 1
+view_space_radius : 0.3
+color_width: 1280
+color_height: 720
+color_fx: 9.1560668945312500e+02
+color_fy: 9.1332666015625000e+02
+color_ppx: 6.4714532470703125e+02
+color_ppy: 3.7251531982421875e+02
+color_model: 2
+color_k1: 1.2042199820280075e-01
+color_k2: -2.1373499929904938e-01
+color_k3: 5.3860000334680080e-03
+color_p1: -2.1210000850260258e-03
+color_p2: 0.
+depth_scale: 1.0000000474974513e-03
+"""
+
+
+@pytest.fixture()
+def config(tmp_path):
+    p = tmp_path / "DefaultConfiguration.yaml"
+    p.write_text(YAML.format(pre=tmp_path, vs=os.path.join(GOLD, "hemisphere")))
+    return p
+
+
+@pytest.mark.parametrize("n", ["5", "64"])
+def test_pose_matches_golden_and_oracle(oracle, n):
+    g = json.load(open(os.path.join(GOLD, "golden_cameras.json")))[n]
+    pts = planner.hemisphere_read(os.path.join(GOLD, "hemisphere", f"{n}.txt"), int(n))
+    pos = planner.view_space(pts, g["radius"], g["center"])
+    np.testing.assert_allclose(pos, g["positions"], rtol=0, atol=1e-15)
+    for p, want in zip(pos, g["transform_matrix"]):
+        pose = planner.view_pose(p, g["center"])
+        tm = planner.transform_matrix(pose)
+        np.testing.assert_allclose(tm, want, atol=1e-6)  # ill-conditioned roll axis, see test_oracle_golden
+        np.testing.assert_allclose(tm, oracle.transform_matrix(oracle.view_pose(p, g["center"])), atol=1e-6)
+        # pose is world->camera: the view position maps to the camera origin
+        np.testing.assert_allclose(pose @ np.append(p, 1.0), [0, 0, 0, 1], atol=1e-12)
+        np.testing.assert_allclose(pose[:3, :3] @ pose[:3, :3].T, np.eye(3), atol=1e-6)  # X from a 1e-10 cross product
+
+
+def test_bbx_and_generated_hemisphere(oracle):
+    g = json.load(open(os.path.join(GOLD, "golden_cameras.json")))["bbx"]
+    c, s = planner.bbx(np.array(g["cloud"]))
+    np.testing.assert_allclose(c, g["center"], rtol=1e-13)
+    np.testing.assert_allclose(s, g["predicted_size"], rtol=1e-13)
+    for n in (1, 64, 1024):
+        pts = planner.hemisphere_generate(n)
+        np.testing.assert_allclose(np.linalg.norm(pts, axis=1), 1.0, atol=1e-12)
+        assert (pts[:, 2] > 0).all() and pts[0].tolist() == [0, 0, 1]
+        assert len({tuple(np.round(p, 9)) for p in pts}) == n  # no duplicate views (main.cpp:1241-1243)
+
+
+def test_share_data_constructor_semantics(config, tmp_path):
+    sd = planner.ShareData(config)
+    assert sd.number("num_of_views") == 5 and sd.number("ensemble_num") == 5 and sd.number("n_steps") == 2500
+    assert sd.string("gt_path") == f"{tmp_path}/Coverage_images/ShapeNet/synthetic_object"
+    assert sd.string("save_path") == f"{tmp_path}/Compare/ShapeNet/synthetic_object"
+    assert abs(sd.number("pt_norm") - 1.0) < 1e-5 and sd.views().shape == (5, 3)
+    k = sd.intrinsics()
+    assert (k.width, k.height) == (1280, 720) and abs(k.fx - 915.60668945312500) < 1e-4
+    assert abs(k.coeffs[2] - 5.3860000334680080e-03) < 1e-9 and k.coeffs[4] == 0.0  # YAML order k1,k2,k3,p1,p2
+    assert sd.number("candidate_divisor") == 16 and sd.number("screenshot_spp") == 16  # main.cpp:1796, run.py:48
+    # overrides: name, views, batch, method (Share_Data.hpp:402-405); method 2 forces E=2, 3 forces E=5
+    sd2 = planner.ShareData(config, "obj7", 64, 3, 2)
+    assert sd2.number("num_of_views") == 64 and sd2.number("ensemble_num") == 2
+    assert sd2.string("save_path") == f"{tmp_path}/Compare/ShapeNet_3/obj7_m2"
+    assert planner.ShareData(config, "", -1, -1, 3).number("ensemble_num") == 5
+    with pytest.raises(IOError):
+        planner.ShareData(tmp_path / "missing.yaml")
+    with pytest.raises(IOError):
+        planner.ShareData(config, "", 7)  # no 7.txt among the fixtures
+
+
+def test_transforms_json_schema_and_candidate_header(config, tmp_path):
+    sd = planner.ShareData(config)
+    k = sd.intrinsics()
+    c = [1e-10] * 3
+    pos = planner.view_space(sd.views(), 0.3, c)
+    path = tmp_path / "5.json"
+    planner.write_transforms(path, k, pos, c, 0.1, path_prefix="5/rgbaClip_")
+    root = json.load(open(path))
+    assert list(root) == sorted(root)  # JsonCpp object order
+    assert abs(root["camera_angle_x"] - 2 * np.arctan(0.5 * 1280 / 915.60668945312500)) < 1e-12
+    assert root["w"] == 1280 and root["h"] == 720 and root["aabb_scale"] == 1
+    assert abs(root["scale"] - 5.0) < 1e-12 and np.allclose(root["offset"], 0.5 + 1e-10)
+    assert abs(root["k3"] - 5.3860000334680080e-03) < 1e-9 and abs(root["p1"] + 2.1210000850260258e-03) < 1e-9
+    assert [f["file_path"] for f in root["frames"]] == [f"5/rgbaClip_{i}.png" for i in range(5)]
+    g = json.load(open(os.path.join(GOLD, "golden_cameras.json")))["5"]
+    for f, want in zip(root["frames"], g["transform_matrix"]):
+        np.testing.assert_allclose(f["transform_matrix"], want, atol=1e-6)
+    # the text survives %.17g: re-reading gives back the doubles the library computed
+    tm0 = planner.transform_matrix(planner.view_pose(pos[0], c))
+    assert np.array_equal(np.array(root["frames"][0]["transform_matrix"]), tm0)
+    # candidate (render) header: fl, c, w, h divided by 16 and written as doubles, distortion zeroed (main.cpp:1796-1806)
+    planner.write_transforms(tmp_path / "r.json", k, pos[1:], c, 0.1, ids=[1, 2, 3, 4], candidate=True)
+    r = json.load(open(tmp_path / "r.json"))
+    assert r["w"] == 80.0 and r["h"] == 45.0 and r["k1"] == 0 and r["p2"] == 0
+    assert abs(r["fl_x"] - 915.60668945312500 / 16) < 1e-9 and r["camera_angle_x"] == root["camera_angle_x"]
+    assert '"w" : 80.0' in open(tmp_path / "r.json").read()
+
+
+def test_nbv_loop_bookkeeping_and_argmax(config, tmp_path):
+    """nbv_loop with a scripted scorer: chosen views, per-iteration files, resume (main.cpp:1751-2264)"""
+    sd = planner.ShareData(config, "", -1, -1, 3)  # EnsembleRGBDensity
+    calls = []
+
+    def scorer(method, iteration, scene_json, render_json, ids):
+        scene, render = json.load(open(scene_json)), json.load(open(render_json))
+        assert method == 3 and len(render["frames"]) == len(ids) and len(scene["frames"]) == iteration + 1
+        assert render["w"] == 80.0 and scene["w"] == 1280
+        calls.append(list(ids))
+        table = {0: [0.1, 0.9, 0.9, 0.2], 1: [5.0, 1.0, 5.0], 2: [-1e99, -1e99]}
+        return table[iteration][: len(ids)]
+
+    chosen = sd.nbv_loop([1e-10] * 3, 0.1, scorer, first_view_id=1)
+    # it0: candidates [0,2,3,4] -> tie 0.9 at ids 2,3 -> lowest id 2; it1: [0,3,4] -> tie 5.0 -> 0; it2: [3,4] -> 3
+    assert calls == [[0, 2, 3, 4], [0, 3, 4], [3, 4]]
+    assert chosen == [1, 2, 0, 3]
+    save = sd.string("save_path")
+    assert save.endswith("_m3_v1_t0")
+    for sub in ("json", "render_json", "metrics", "render", "train_time", "infer_time", "movement"):
+        assert os.path.isdir(os.path.join(save, sub))
+    assert sorted(os.listdir(os.path.join(save, "json"))) == ["0.json", "1.json", "2.json", "3.json"]
+    assert open(os.path.join(save, "movement", "1.txt")).read().split("\t")[0] == "0"
+    assert float(open(os.path.join(save, "run_time.txt")).read()) >= 0
+    frames = json.load(open(os.path.join(save, "json", "3.json")))["frames"]
+    assert [int(f["file_path"].split("_")[-1][:-4]) for f in frames] == [0, 1, 2, 3]  # chosen set, ascending view id
+    assert frames[0]["file_path"].startswith("../../../../Coverage_images/ShapeNet/synthetic_object/5/rgbaClip_")
+    # idempotent resume: a finished run is skipped without scoring (main.cpp:1761-1770)
+    sd_again = planner.ShareData(config, "", -1, -1, 3)
+    n_before = len(calls)
+    sd_again.nbv_loop([1e-10] * 3, 0.1, scorer, first_view_id=1)
+    assert len(calls) == n_before
+
+
+def test_nbv_loop_random_method_and_error_path(config):
+    sd = planner.ShareData(config, "rand", -1, -1, 0)  # RandomIterative: never calls the boundary
+    chosen = sd.nbv_loop([1e-10] * 3, 0.1, lambda *a: 1 / 0)
+    assert len(chosen) == 4 and len(set(chosen)) == 4 and chosen[0] == 0
+    sd2 = planner.ShareData(config, "boom", -1, -1, 2)
+    with pytest.raises(RuntimeError):
+        sd2.nbv_loop([1e-10] * 3, 0.1, lambda *a: 1 / 0)  # scorer failure surfaces as an error code, no hang
+    sd3 = planner.ShareData(config, "oneshot", -1, -1, 1)
+    with pytest.raises(RuntimeError):
+        sd3.nbv_loop([1e-10] * 3, 0.1, lambda *a: [0])  # RandomOneshot needs the TSP planner: out of scope
