@@ -14,7 +14,13 @@ CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
 ROOT = os.path.dirname(HERE)
 
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall"]
+# -ffp-contract=off: op order is part of the arithmetic contract with the oracle.
+# -fno-slp-vectorize: keeps the trilinear blend on v_fma_mix_f32 instead of cvt + v_pk_fma_f32.
+# -amdgpu-mfma-vgpr-form: MFMA results land in arch VGPRs (no v_accvgpr_read copies before the VALU epilogues).
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize",
+             "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall"]
+if os.environ.get("PRV_ABLATE"):
+    HIP_FLAGS.append("-DPRV_ABLATE=" + os.environ["PRV_ABLATE"])
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off"]
 
 

@@ -33,7 +33,7 @@ struct Model {
   prv_field_desc desc{};
   FieldDev dev{};
   uint64_t table_halfs = 0, occ_words = 0;
-  Buffer table, occ, frags, mlp; // mlp = canonical weights kept for export
+  Buffer table, phys, occ, frags, mlp; // table/mlp = canonical (ABI) copies kept for export; phys = kernel layout
 };
 
 } // namespace
@@ -59,6 +59,7 @@ struct prv_ctx {
   std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs
   int blocks_per_cu = 4;
   int refill_min = 8;
+  int dbg_flags = 0;
   size_t queue_budget = (size_t)1 << 30;
 };
 
@@ -201,7 +202,7 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   const uint64_t R = (uint64_t)d.occ_res;
   m.occ_words = (R * R * R + 31) / 32;
   int rc;
-  if ((rc = ensure(c, m.table, m.table_halfs * 2 + 16)) != PRV_OK) return rc;
+  if ((rc = ensure(c, m.table, m.table_halfs * 2)) != PRV_OK) return rc;
   if ((rc = ensure(c, m.occ, m.occ_words * 4)) != PRV_OK) return rc;
   if ((rc = ensure(c, m.frags, (size_t)kNumFrags * kFragHalfs * 2)) != PRV_OK) return rc;
   if ((rc = ensure(c, m.mlp, PRV_MLP_HALFS * 2)) != PRV_OK) return rc;
@@ -212,9 +213,38 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   HIPCHK(c, hipMemcpyAsync(m.frags.p, frags.data(), frags.size() * 2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(m.mlp.p, mlp, PRV_MLP_HALFS * 2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream)); // host staging vectors go out of scope
+  // ---- physical layout: power-of-two strides for dense levels, size-aligned level offsets
+  const uint32_t ebytes = (uint32_t)d.n_features * 2u;
+  uint32_t psize[kMaxLevels], sx[kMaxLevels], poff[kMaxLevels];
+  int order[kMaxLevels];
+  auto ceil_log2 = [](uint32_t v) { uint32_t s = 0; while ((1u << s) < v) s++; return s; };
+  for (int l = 0; l < d.n_levels; l++) {
+    order[l] = l;
+    if (lv[l].hashed) {
+      sx[l] = 0;
+      psize[l] = lv[l].size;
+    } else {
+      sx[l] = ceil_log2(lv[l].res);
+      psize[l] = 1u << ceil_log2(lv[l].res << (2 * sx[l]));
+    }
+  }
+  std::stable_sort(order, order + d.n_levels, [&](int a, int b) { return psize[a] > psize[b]; });
+  uint64_t ptotal = 0;
+  for (int k = 0; k < d.n_levels; k++) {
+    poff[order[k]] = (uint32_t)ptotal; // multiple of every later (smaller or equal) power of two
+    ptotal += psize[order[k]];
+  }
+  if (ptotal * ebytes >= (1ull << 32)) return fail(c, PRV_E_INVALID, "field too large for 32-bit gather offsets");
+  if ((rc = ensure(c, m.phys, ptotal * ebytes)) != PRV_OK) return rc;
+  HIPCHK(c, hipMemsetAsync(m.phys.p, 0, ptotal * ebytes, c->stream));
+  for (int l = 0; l < d.n_levels; l++) {
+    RepackLevel R{lv[l].offset, poff[l], lv[l].size, lv[l].res, sx[l], lv[l].hashed};
+    HIPCHK(c, launch_repack_level((const uint16_t*)m.table.p, (uint16_t*)m.phys.p, R, d.n_features, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   FieldDev& f = m.dev;
   memset(&f, 0, sizeof(f));
-  f.table = (const uint16_t*)m.table.p;
+  f.table = (const uint16_t*)m.phys.p;
   f.occ = (const uint32_t*)m.occ.p;
   f.frags = (const half8*)m.frags.p;
   f.n_levels = d.n_levels;
@@ -226,12 +256,17 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
     LevelDev& L = f.levels[l];
     L.scale = lv[l].scale;
     L.res_m1 = lv[l].res - 1;
-    L.offset = lv[l].offset;
-    L.hashed = lv[l].hashed;
-    L.mask = lv[l].hashed ? lv[l].size - 1u : 0xffffffffu;
-    L.my = lv[l].hashed ? 2654435761u : lv[l].res;
-    L.mz = lv[l].hashed ? 805459861u : lv[l].res * lv[l].res;
-    L.pad = 0;
+    if (lv[l].hashed) {
+      L.my_b = 2654435761u * ebytes;
+      L.mz_b = 805459861u * ebytes;
+      L.m_b = (lv[l].size - 1u) * ebytes;
+    } else {
+      L.my_b = ebytes << sx[l];
+      L.mz_b = ebytes << (2 * sx[l]);
+      L.m_b = 0xffffffffu;
+    }
+    L.off_b = poff[l] * ebytes;
+    L.pad0 = L.pad1 = 0;
   }
   m.loaded = true;
   return PRV_OK;
@@ -349,6 +384,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
       rp.spp_k = k;
       rp.last_pass = mp.last_pass;
       rp.refill_min = c->refill_min;
+      rp.dbg = c->dbg_flags;
       memcpy(rp.bg, o->background, sizeof(rp.bg));
       if (c->profiling) {
         hipEvent_t a, b;
@@ -418,6 +454,7 @@ int prv_create(prv_ctx** out, int device_id) {
   c->stream = c->own_stream;
   if (const char* s = getenv("PRV_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(s));
   if (const char* s = getenv("PRV_REFILL_MIN")) c->refill_min = std::min(32, std::max(1, atoi(s)));
+  if (const char* s = getenv("PRV_DBG")) c->dbg_flags = atoi(s);
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
   *out = c;
   return PRV_OK;
@@ -429,6 +466,7 @@ void prv_destroy(prv_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& m : c->models) {
     release(m.table);
+    release(m.phys);
     release(m.occ);
     release(m.frags);
     release(m.mlp);
@@ -572,7 +610,7 @@ int prv_model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t 
         }
       }
   Model& m = c->models[slot];
-  int rc = ensure(c, m.table, total * (uint64_t)d->n_features * 2 + 16);
+  int rc = ensure(c, m.table, total * (uint64_t)d->n_features * 2);
   if (rc != PRV_OK) return rc;
   HIPCHK(c, launch_synth_table((uint16_t*)m.table.p, total * (uint64_t)d->n_features, seed, d->table_amp, c->stream));
   return install_model(c, slot, *d, mlp.data(), occ.data(), nullptr);

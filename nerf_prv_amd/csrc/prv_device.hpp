@@ -23,18 +23,25 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// One level of the PHYSICAL table layout (private to the kernels; the C ABI keeps the
+// canonical level-major layout).  Dense levels are stored with power-of-two y/z strides and
+// every level starts at a multiple of its own power-of-two size, so the byte offset of
+// vertex (x,y,z) is a pure XOR of three per-axis terms:
+//   ((x << esh) & m_b) ^ ((y * my_b) & m_b) ^ (((z * mz_b) & m_b) | off_b)
+// dense : my_b = ebytes << sx, mz_b = ebytes << 2sx, m_b = ~0      (disjoint bit fields)
+// hashed: my_b = ebytes * 2654435761, mz_b = ebytes * 805459861, m_b = (T-1) * ebytes
+// (AND and << distribute over XOR, so this equals ((x ^ y*p1 ^ z*p2) & (T-1)) * ebytes.)
 struct LevelDev {
-  float scale;      // pos = fmaf(scale, x, 0.5)
-  uint32_t res_m1;  // vertices per axis - 1 (corner clamp)
-  uint32_t offset;  // first entry of the level
-  uint32_t mask;    // hashed: size-1 ; dense: 0xffffffff
-  uint32_t my, mz;  // dense: res, res*res ; hashed: 2654435761, 805459861
-  uint32_t hashed;  // combine with xor (1) or add (0)
-  uint32_t pad;
+  float scale;     // pos = fmaf(scale, x, 0.5)
+  uint32_t res_m1; // vertices per axis - 1 (clamp of the +1 corner)
+  uint32_t my_b, mz_b;
+  uint32_t m_b;
+  uint32_t off_b;  // byte offset of the level, aligned to its size
+  uint32_t pad0, pad1;
 };
 
 struct FieldDev {
-  const uint16_t* table;  // fp16 bit patterns, entries of F halfs, level-major
+  const uint16_t* table;  // PHYSICAL layout (see LevelDev), fp16 bit patterns, entries of F halfs
   const uint32_t* occ;    // occ_res^3 bits, x fastest
   const half8* frags;     // kNumFrags * 64 half8, MFMA A fragments (prepacked weights)
   LevelDev levels[kMaxLevels];
@@ -127,6 +134,9 @@ __device__ __forceinline__ void sh4(float x, float y, float z, float o[16]) {
 
 // ---------------------------------------------------------------- hash-grid gather
 // one table entry = F halfs: an 8-byte (F = 4) or 4-byte (F = 2) load
+template <int F> struct EntryWord;
+template <> struct EntryWord<4> { typedef uint2 type; };
+template <> struct EntryWord<2> { typedef uint32_t type; };
 template <int F> struct Entry;
 template <> struct Entry<4> {
   uint32_t w[2];
@@ -152,43 +162,36 @@ template <> struct Entry<2> {
 template <int F>
 __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table, const LevelDev& L,
                                              float px, float py, float pz, float acc[F]) {
-  float pos[3] = {fmaf(L.scale, px, 0.5f), fmaf(L.scale, py, 0.5f), fmaf(L.scale, pz, 0.5f)};
+  constexpr int ESH = F == 4 ? 3 : 2; // log2(entry bytes)
+  const float pos[3] = {fmaf(L.scale, px, 0.5f), fmaf(L.scale, py, 0.5f), fmaf(L.scale, pz, 0.5f)};
   uint32_t c0[3], c1[3];
   float w1[3], w0[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) {
-    float fl = floorf(pos[a]);
-    w1[a] = pos[a] - fl;
+    w1[a] = __builtin_amdgcn_fractf(pos[a]); // pos >= 0.5: pos - floor(pos), exact
     w0[a] = 1.0f - w1[a];
-    uint32_t c = (uint32_t)(int)fl;
-    c0[a] = min(c, L.res_m1);
-    c1[a] = min(c + 1u, L.res_m1);
+    c0[a] = (uint32_t)(int)pos[a];           // truncation = floor; never exceeds res-1
+    c1[a] = min(c0[a] + 1u, L.res_m1);
   }
-  // per-axis index terms; dense: x + y*res + z*res^2, hashed: x ^ y*p1 ^ z*p2
-  uint32_t ty[2] = {c0[1] * L.my, c1[1] * L.my};
-  uint32_t tz[2] = {c0[2] * L.mz, c1[2] * L.mz};
-  uint32_t tx[2] = {c0[0], c1[0]};
-  float wxy[4] = {w0[0] * w0[1], w1[0] * w0[1], w0[0] * w1[1], w1[0] * w1[1]};
-  float wz[2] = {w0[2], w1[2]};
-  constexpr int BYTES = F * 2;
+  const uint32_t tx[2] = {(c0[0] << ESH) & L.m_b, (c1[0] << ESH) & L.m_b};
+  const uint32_t ty[2] = {(c0[1] * L.my_b) & L.m_b, (c1[1] * L.my_b) & L.m_b};
+  const uint32_t tz[2] = {((c0[2] * L.mz_b) & L.m_b) | L.off_b, ((c1[2] * L.mz_b) & L.m_b) | L.off_b};
+  const float wxy[4] = {w0[0] * w0[1], w1[0] * w0[1], w0[0] * w1[1], w1[0] * w1[1]};
+  const float wz[2] = {w0[2], w1[2]};
   Entry<F> v[8];
 #pragma unroll
   for (int c = 0; c < 8; c++) {
-    int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
-    uint32_t ia = tx[dx] + ty[dy] + tz[dz];
-    uint32_t ix = tx[dx] ^ ty[dy] ^ tz[dz];
-    uint32_t idx = (L.hashed ? ix : ia) & L.mask;
-    uint32_t byte_off = (L.offset + idx) * (uint32_t)BYTES;
+    const uint32_t byte_off = tx[c & 1] ^ ty[(c >> 1) & 1] ^ tz[c >> 2];
     v[c] = Entry<F>::load(reinterpret_cast<const char*>(table) + byte_off);
   }
 #pragma unroll
   for (int k = 0; k < F; k++) acc[k] = 0.0f;
 #pragma unroll
   for (int c = 0; c < 8; c++) {
-    float w = wxy[c & 3] * wz[c >> 2];
+    const float w = wxy[c & 3] * wz[c >> 2];
 #pragma unroll
     for (int k = 0; k < F; k += 2) {
-      half2v hv = __builtin_bit_cast(half2v, v[c].w[k / 2]);
+      const half2v hv = __builtin_bit_cast(half2v, v[c].w[k / 2]);
       acc[k] = fmaf(w, (float)hv[0], acc[k]);
       acc[k + 1] = fmaf(w, (float)hv[1], acc[k + 1]);
     }
@@ -196,10 +199,11 @@ __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table,
 }
 
 // The 16 canonical features [16*h, 16*h+16) of one sample, as the two MFMA B fragments
-// (k-steps 0,1) of lane half h.  Lane half h gathers levels [h*L/2, (h+1)*L/2).
+// (k-steps 0,1) of lane half h.  Lane half h gathers levels [h*L/2, (h+1)*L/2); the level
+// constants come from LDS (two broadcast ds_read_b128 per level: off the VALU path).
 template <int F>
-__device__ __forceinline__ void encode_half(const FieldDev& fd, int h, float px, float py, float pz,
-                                            half8& b0, half8& b1) {
+__device__ __forceinline__ void encode_half(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv,
+                                            int h, float px, float py, float pz, half8& b0, half8& b1) {
   constexpr int LH = 16 / F; // levels per lane half
   px = clamp01(px);
   py = clamp01(py);
@@ -207,25 +211,29 @@ __device__ __forceinline__ void encode_half(const FieldDev& fd, int h, float px,
   _Float16 out[16];
 #pragma unroll
   for (int j = 0; j < LH; j++) {
-    // level parameters are wave-uniform per half: two scalar reads + select
-    LevelDev La = fd.levels[j], Lb = fd.levels[j + LH], L;
-    L.scale = h ? Lb.scale : La.scale;
-    L.res_m1 = h ? Lb.res_m1 : La.res_m1;
-    L.offset = h ? Lb.offset : La.offset;
-    L.mask = h ? Lb.mask : La.mask;
-    L.my = h ? Lb.my : La.my;
-    L.mz = h ? Lb.mz : La.mz;
-    L.hashed = h ? Lb.hashed : La.hashed;
+    const LevelDev L = lv[h * LH + j];
     float acc[F];
-    encode_level<F>(fd.table, L, px, py, pz, acc);
+    encode_level<F>(table, L, px, py, pz, acc);
 #pragma unroll
-    for (int k = 0; k < F; k++) out[j * F + k] = (_Float16)acc[k];
+    for (int k = 0; k < F; k++) {
+      // The feature is DEFINED as fp16(round_fp32(blend)).  Without this barrier hipcc fuses the
+      // last fma with the conversion into v_fma_mixlo/hi_f16, which rounds the exact result once
+      // and differs from the definition in the last fp16 bit for ~1e-4 of the values.
+      asm volatile("" : "+v"(acc[k]));
+      out[j * F + k] = (_Float16)acc[k];
+    }
   }
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     b0[k] = out[k];
     b1[k] = out[8 + k];
   }
+}
+
+// stage the level table into LDS (call with all threads of the block, then __syncthreads)
+__device__ __forceinline__ void stage_levels(const FieldDev& fd, LevelDev* lds_levels) {
+  static_assert(sizeof(LevelDev) == 32, "LevelDev must be two 16-byte words");
+  if (threadIdx.x < (unsigned)fd.n_levels) lds_levels[threadIdx.x] = fd.levels[threadIdx.x];
 }
 
 // ---------------------------------------------------------------- tiny MLPs on MFMA
@@ -238,14 +246,23 @@ __device__ __forceinline__ f32x16 mfma(half8 a, half8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// accumulator rows [base, base+8) -> one fp16 B fragment.  ReLU is applied AFTER the fp16
+// rounding (relu(round(x)) == round(relu(x))): the conversion result is canonical, so the
+// compiler emits one v_pk_max_f16 per pair instead of two v_max_f32 per value.
 template <bool RELU>
 __device__ __forceinline__ half8 pack8(const f32x16& acc, int base) {
   half8 r;
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    float v = acc[base + j];
-    if (RELU) v = v > 0.0f ? v : 0.0f;
-    r[j] = (_Float16)v;
+  for (int j = 0; j < 8; j += 2) {
+    half2v p;
+    p[0] = (_Float16)acc[base + j];
+    p[1] = (_Float16)acc[base + j + 1];
+    if (RELU) {
+      const half2v z = {(_Float16)0.0f, (_Float16)0.0f};
+      p = __builtin_elementwise_max(p, z);
+    }
+    r[j] = p[0];
+    r[j + 1] = p[1];
   }
   return r;
 }
@@ -322,6 +339,10 @@ __device__ __forceinline__ half8 sh_fragment(int h, float dx, float dy, float dz
   for (int j = 0; j < 8; j++) r[j] = (_Float16)(h ? s[8 + j] : s[j]);
   return r;
 }
+
+// exp via the hardware exp2 (v_exp_f32) and a hardware reciprocal: ~1 ulp each
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 
 __device__ __forceinline__ float linear_to_srgb(float x) {
   if (x <= 0.0031308f) return 12.92f * x;

@@ -17,6 +17,10 @@
 // Built with -ffp-contract=off: see prv_device.hpp for the arithmetic contract.
 #include "prv_kernels.hpp"
 
+#ifndef PRV_ABLATE
+#define PRV_ABLATE 0 // dev-only timing ablations: 1 no gather, 2 no MLP, 4 no compositing math (wrong pixels!)
+#endif
+
 namespace prv {
 
 // ------------------------------------------------------------------ K_A march + compact
@@ -86,7 +90,9 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
 template <int F>
 __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
   __shared__ half8 wl[kNumFrags * 64];
+  __shared__ LevelDev lvl[kMaxLevels];
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = P.field.frags[i];
+  stage_levels(P.field, lvl);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -145,23 +151,42 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
       else { i = 96u + (uint32_t)__builtin_ctz(m3); m3 &= m3 - 1u; }
       last = (m0 | m1 | m2 | m3) == 0u;
       const float t = fmaf((float)i + 0.5f, dt, t0);
-      encode_half<F>(P.field, h, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f0, f1);
+#if PRV_ABLATE & 1
+      f0[0] = (_Float16)t; f1[3] = (_Float16)dt;
+#else
+      encode_half<F>(P.field.table, lvl, h, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f0, f1);
+#endif
     }
     // ---- both MLPs on the matrix cores (whole wave)
+#if PRV_ABLATE & 2
+    MlpOut mo;
+    for (int q = 0; q < 16; q++) { mo.dens[q] = (float)f0[q & 7]; mo.rgb[q] = (float)f1[q & 7]; }
+#else
     const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf);
+#endif
 
     // ---- front-to-back compositing (authoritative in lane half 0)
     bool term = false;
+#if PRV_ABLATE & 4
     if (active) {
-      const float sigma = expf(mo.dens[0] + P.field.density_bias);
-      const float alpha = 1.0f - expf(-(sigma * dt));
-      const float wgt = alpha * T;
-      cr = fmaf(wgt, 1.0f / (1.0f + expf(-mo.rgb[0])), cr);
-      cg = fmaf(wgt, 1.0f / (1.0f + expf(-mo.rgb[1])), cg);
-      cb = fmaf(wgt, 1.0f / (1.0f + expf(-mo.rgb[2])), cb);
+      const float alpha = mo.dens[0] * 0.001f + 0.05f;
+      cr += mo.rgb[0]; cg += mo.rgb[1]; cb += mo.rgb[2];
       T = T * (1.0f - alpha);
       term = T < P.min_T;
     }
+#else
+    if (active) {
+      // hardware exp2 / rcp (about 1 ulp each): well inside the 1e-3 pixel tolerance
+      const float sigma = fast_exp(mo.dens[0] + P.field.density_bias);
+      const float alpha = 1.0f - fast_exp(-(sigma * dt));
+      const float wgt = alpha * T;
+      cr = fmaf(wgt, fast_sigmoid(mo.rgb[0]), cr);
+      cg = fmaf(wgt, fast_sigmoid(mo.rgb[1]), cg);
+      cb = fmaf(wgt, fast_sigmoid(mo.rgb[2]), cb);
+      T = T * (1.0f - alpha);
+      term = T < P.min_T;
+    }
+#endif
     const uint32_t tb = (uint32_t)__ballot(term); // low 32 bits: lane half 0
     const bool done = active && (last || ((tb >> r) & 1u));
     if (done) {
@@ -333,6 +358,22 @@ __global__ __launch_bounds__(256) void synth_table_kernel(uint16_t* __restrict__
   }
 }
 
+// canonical (ABI) table -> physical layout of one level; one thread per canonical entry
+template <int F>
+__global__ __launch_bounds__(256) void repack_level_kernel(const uint16_t* __restrict__ canon,
+                                                           uint16_t* __restrict__ phys, RepackLevel L) {
+  typedef typename EntryWord<F>::type word_t;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < L.n; i += gridDim.x * 256) {
+    uint32_t dst = i;
+    if (!L.hashed) {
+      const uint32_t x = i % L.res, y = (i / L.res) % L.res, z = i / (L.res * L.res);
+      if (z >= L.res) continue; // canonical padding entries
+      dst = x | (y << L.sx) | (z << (2 * L.sx));
+    }
+    reinterpret_cast<word_t*>(phys)[L.phys_off + dst] = reinterpret_cast<const word_t*>(canon)[L.canon_off + i];
+  }
+}
+
 // ------------------------------------------------------------------ stage hooks (parity tests)
 
 __global__ __launch_bounds__(256) void debug_raygen_kernel(CamDev cam, int W, int H, int spp_k,
@@ -362,7 +403,9 @@ __global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const flo
                                                           float* __restrict__ out36,
                                                           int32_t* __restrict__ occ_out) {
   __shared__ half8 wl[kNumFrags * 64];
+  __shared__ LevelDev lvl[kMaxLevels];
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = fd.frags[i];
+  stage_levels(fd, lvl);
   __syncthreads();
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -376,7 +419,7 @@ __global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const flo
     }
   }
   half8 f0, f1;
-  encode_half<F>(fd, h, p[0], p[1], p[2], f0, f1);
+  encode_half<F>(fd.table, lvl, h, p[0], p[1], p[2], f0, f1);
   const half8 shf = sh_fragment(h, dd[0], dd[1], dd[2]);
   const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf);
   if (!ok) return;
@@ -388,8 +431,8 @@ __global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const flo
   if (out36) {
     float* q = out36 + (size_t)idx * 36;
     if (h == 0) {
-      q[0] = expf(mo.dens[0] + fd.density_bias);
-      for (int k = 0; k < 3; k++) q[1 + k] = 1.0f / (1.0f + expf(-mo.rgb[k]));
+      q[0] = fast_exp(mo.dens[0] + fd.density_bias);
+      for (int k = 0; k < 3; k++) q[1 + k] = fast_sigmoid(mo.rgb[k]);
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) { // reg i -> row (i&3) + 8(i>>2) + 4h, rows 0..15
@@ -450,6 +493,17 @@ hipError_t launch_score_finalize(const double* partial, int n_views, int n_block
 
 hipError_t launch_synth_table(uint16_t* table, size_t n, uint64_t seed, float amp, hipStream_t s) {
   hipLaunchKernelGGL(synth_table_kernel, dim3(2048), dim3(256), 0, s, table, n, (unsigned long long)seed, amp);
+  return hipGetLastError();
+}
+
+hipError_t launch_repack_level(const uint16_t* canon, uint16_t* phys, const RepackLevel& L, int F, hipStream_t s) {
+  unsigned blocks = (L.n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) return hipSuccess;
+  if (F == 4)
+    hipLaunchKernelGGL(repack_level_kernel<4>, dim3(blocks), dim3(256), 0, s, canon, phys, L);
+  else
+    hipLaunchKernelGGL(repack_level_kernel<2>, dim3(blocks), dim3(256), 0, s, canon, phys, L);
   return hipGetLastError();
 }
 

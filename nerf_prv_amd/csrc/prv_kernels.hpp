@@ -38,6 +38,7 @@ struct RenderParams {
   int spp_k;
   int last_pass;
   int refill_min;
+  int dbg; // dev-only ablation bits (PRV_DBG env): 1 no table loads, 2 no MLP, 4 no compositing math
   float bg[4];
 };
 
@@ -55,6 +56,11 @@ struct PsnrParams {
   float bg[4];
   double* partial;
 };
+
+struct RepackLevel { // canonical -> physical copy of one level (entries, not bytes)
+  uint32_t canon_off, phys_off, n, res, sx, hashed;
+};
+hipError_t launch_repack_level(const uint16_t* canon, uint16_t* phys, const RepackLevel& L, int F, hipStream_t s);
 
 hipError_t launch_march(const MarchParams& P, int n_views, hipStream_t s);
 hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s);

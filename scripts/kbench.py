@@ -1,0 +1,40 @@
+"""kernel-level microbench of the render path on the standard workload (dev tool, not bench.py)"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--views", type=int, default=64)
+ap.add_argument("--size", type=int, default=800)
+ap.add_argument("--samples", type=int, default=128)
+ap.add_argument("--field", default="256")
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--bias", type=float, default=None)
+ap.add_argument("--tag", default="")
+args = ap.parse_args()
+import torch
+from nerf_prv_amd import api, planner
+ctx = api.Context(0)
+fd = dict(api.FIELD_256 if args.field == "256" else api.FIELD_512)
+if args.bias is not None: fd["density_bias"] = args.bias
+ctx.synthetic_model(0, api.L.FieldDesc(**fd), 0x5EED0001)
+pts = planner.hemisphere_generate(args.views)
+fov = 2.0 * np.arctan(0.5 * 1280 / 915.60668945312500)
+tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
+cams = ctx.cameras_from_matrices(tms, fov, args.size, args.size, scale, offset)
+opts = api.render_opts(args.size, args.size, args.samples, 1, 1e-4)
+out = torch.empty((args.views, args.size, args.size, 4), dtype=torch.float32, device="cuda")
+_, st = ctx.render(0, cams, None, opts, out=out)
+ctx.profile_begin()
+t0 = time.perf_counter()
+for _ in range(args.reps):
+    ctx.render(0, cams, None, opts, out=out, want_stats=False)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.reps
+p = ctx.profile_end()
+rms, mms = p["render_ms"] / args.reps, p["march_ms"] / args.reps
+print(f"{args.tag} BPC={os.environ.get('PRV_BLOCKS_PER_CU','4')} RM={os.environ.get('PRV_REFILL_MIN','8')} "
+      f"eval={st.samples_evaluated/1e6:.1f}M ({100*st.samples_evaluated/st.samples_nominal:.2f}% of nominal) "
+      f"render={rms:.2f}ms march={mms:.2f}ms wall={dt*1e3:.2f}ms "
+      f"kernel_rate={st.samples_evaluated/rms/1e6:.2f} Gsamp/s wall_rate={st.samples_evaluated/dt/1e9:.2f} Gsamp/s "
+      f"frac={st.samples_evaluated/rms/1e6*512/8000:.3f}")
