@@ -59,8 +59,8 @@ def cpu_baseline(args, tms, scale, offset, fov_x):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--views-per-gpu", type=int, default=64)
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=800)

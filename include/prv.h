@@ -88,6 +88,7 @@ typedef struct prv_stats {
   uint64_t rays;              /* primary rays generated (pixels x spp) */
   uint64_t samples_nominal;   /* rays x samples_per_ray */
   uint64_t samples_evaluated; /* field evaluations actually composited */
+  uint64_t wave_rounds;       /* render_queue wave iterations (32 sample slots each): slot utilisation */
 } prv_stats;
 
 /* ---- context ------------------------------------------------------------- */

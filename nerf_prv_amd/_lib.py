@@ -53,7 +53,8 @@ class ScoreRecord(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("samples_nominal", C.c_uint64), ("samples_evaluated", C.c_uint64)]
+    _fields_ = [("rays", C.c_uint64), ("samples_nominal", C.c_uint64), ("samples_evaluated", C.c_uint64),
+                ("wave_rounds", C.c_uint64)]
 
 
 _vp = C.c_void_p

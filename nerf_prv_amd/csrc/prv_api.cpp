@@ -58,9 +58,9 @@ struct prv_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs
   int blocks_per_cu = 4;
-  int refill_min = 8;
+  int refill_min = 32;
   int dbg_flags = 0;
-  size_t queue_budget = (size_t)1 << 30;
+  size_t queue_budget = (size_t)4 << 30; // ray-queue bytes per batch of views (288 GB of HBM: one batch for 64 views at 800x800)
 };
 
 namespace {
@@ -256,14 +256,16 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
     LevelDev& L = f.levels[l];
     L.scale = lv[l].scale;
     L.res_m1 = lv[l].res - 1;
-    if (lv[l].hashed) {
-      L.my_b = 2654435761u * ebytes;
-      L.mz_b = 805459861u * ebytes;
+    if (lv[l].hashed) { // the kernel multiplies with v_mul_u32_u24: keep the low 24 bits
+      L.my_b = (2654435761u * ebytes) & 0xffffffu;
+      L.mz_b = (805459861u * ebytes) & 0xffffffu;
       L.m_b = (lv[l].size - 1u) * ebytes;
+      if (L.m_b >= (1u << 24)) return fail(c, PRV_E_INVALID, "hashed level larger than 16 MiB (log2_hashmap too big for F=%d)", d.n_features);
     } else {
       L.my_b = ebytes << sx[l];
       L.mz_b = ebytes << (2 * sx[l]);
       L.m_b = 0xffffffffu;
+      if (L.mz_b >= (1u << 24) || lv[l].res > 4096) return fail(c, PRV_E_INVALID, "dense level too large");
     }
     L.off_b = poff[l] * ebytes;
     L.pad0 = L.pad1 = 0;
@@ -312,7 +314,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   uint32_t* q_count = (uint32_t*)c->counters.p;
   uint32_t* q_head = q_count + 1;
   unsigned long long* stat = (unsigned long long*)((char*)c->counters.p + 16);
-  if (zero_stats) HIPCHK(c, hipMemsetAsync(stat, 0, 8, c->stream));
+  if (zero_stats) HIPCHK(c, hipMemsetAsync(stat, 0, 16, c->stream));
   if (n_views == 0) return PRV_OK;
 
   // cameras at this resolution, uploaded per call (tiny)
@@ -403,9 +405,11 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
 
 int fetch_stats(prv_ctx* c, const prv_render_opts* o, int n_views, int n_models, prv_stats* st) {
   if (!st) return PRV_OK;
-  unsigned long long ev = 0;
-  HIPCHK(c, hipMemcpyAsync(&ev, (char*)c->counters.p + 16, 8, hipMemcpyDeviceToHost, c->stream));
+  unsigned long long ev2[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(ev2, (char*)c->counters.p + 16, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  const unsigned long long ev = ev2[0];
+  st->wave_rounds = ev2[1];
   st->rays = (uint64_t)n_views * n_models * o->width * o->height * o->spp;
   st->samples_nominal = st->rays * (uint64_t)o->samples_per_ray;
   st->samples_evaluated = ev;

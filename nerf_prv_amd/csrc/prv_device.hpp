@@ -29,7 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // vertex (x,y,z) is a pure XOR of three per-axis terms:
 //   ((x << esh) & m_b) ^ ((y * my_b) & m_b) ^ (((z * mz_b) & m_b) | off_b)
 // dense : my_b = ebytes << sx, mz_b = ebytes << 2sx, m_b = ~0      (disjoint bit fields)
-// hashed: my_b = ebytes * 2654435761, mz_b = ebytes * 805459861, m_b = (T-1) * ebytes
+// hashed: my_b = ebytes * 2654435761 mod 2^24, mz_b = ebytes * 805459861 mod 2^24, m_b = (T-1) * ebytes < 2^24
 // (AND and << distribute over XOR, so this equals ((x ^ y*p1 ^ z*p2) & (T-1)) * ebytes.)
 struct LevelDev {
   float scale;     // pos = fmaf(scale, x, 0.5)
@@ -174,8 +174,10 @@ __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table,
     c1[a] = min(c0[a] + 1u, L.res_m1);
   }
   const uint32_t tx[2] = {(c0[0] << ESH) & L.m_b, (c1[0] << ESH) & L.m_b};
-  const uint32_t ty[2] = {(c0[1] * L.my_b) & L.m_b, (c1[1] * L.my_b) & L.m_b};
-  const uint32_t tz[2] = {((c0[2] * L.mz_b) & L.m_b) | L.off_b, ((c1[2] * L.mz_b) & L.m_b) | L.off_b};
+  // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): c < 2^12, my_b/mz_b hold the low
+  // 24 bits of the multiplier, and only bits below m_b < 2^24 of the product are kept.
+  const uint32_t ty[2] = {__umul24(c0[1], L.my_b) & L.m_b, __umul24(c1[1], L.my_b) & L.m_b};
+  const uint32_t tz[2] = {(__umul24(c0[2], L.mz_b) & L.m_b) | L.off_b, (__umul24(c1[2], L.mz_b) & L.m_b) | L.off_b};
   const float wxy[4] = {w0[0] * w0[1], w1[0] * w0[1], w0[0] * w1[1], w1[0] * w1[1]};
   const float wz[2] = {w0[2], w1[2]};
   Entry<F> v[8];

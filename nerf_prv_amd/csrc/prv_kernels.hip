@@ -68,11 +68,14 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
   }
   if (live) {
     uint32_t slot = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-    uint4* rec = reinterpret_cast<uint4*>(P.queue) + (size_t)slot * 4;
+    uint4* rec = reinterpret_cast<uint4*>(P.queue) + (size_t)slot * kRecordWords;
     rec[0] = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(t0));
     rec[1] = make_uint4(__float_as_uint(d[0]), __float_as_uint(d[1]), __float_as_uint(d[2]), __float_as_uint(dt));
     rec[2] = make_uint4(m[0], m[1], m[2], m[3]);
     rec[3] = make_uint4(pix, 0u, 0u, 0u);
+    // direction encoding once per ray, here, so a slot refill in K_B is loads only
+    reinterpret_cast<half8*>(rec)[4] = sh_fragment(0, d[0], d[1], d[2]);
+    reinterpret_cast<half8*>(rec)[5] = sh_fragment(1, d[0], d[1], d[2]);
   } else if (valid) {
     // dead ray: contributes exactly zero to its pixel
     float4* out = reinterpret_cast<float4*>(P.out_f32) + pix;
@@ -106,22 +109,29 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
   float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
   half8 shf = {0, 0, 0, 0, 0, 0, 0, 0};
   bool drained = false;
-  unsigned long long n_eval = 0ull;
+  unsigned long long n_eval = 0ull, n_rounds = 0ull;
+  uint32_t q_cur = 0, q_end = 0; // this wave's claimed range of queue records (wave-uniform)
 
   for (;;) {
-    // ---- refill idle slots: ballot + prefix sum claim on the shared queue head
+    // ---- refill idle slots from the wave's claimed range: ballot + prefix sum hand-out;
+    //      one atomic on the shared head per kClaim records
     const uint32_t need = (uint32_t)__ballot(!active);
     const uint32_t cnt = (uint32_t)__popc(need);
     if (!drained && (cnt >= (uint32_t)P.refill_min || cnt == 32u)) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(P.queue_head, cnt);
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (base + cnt >= n_rec) drained = true;
-      const uint32_t avail = base < n_rec ? min(cnt, n_rec - base) : 0u;
+      if (q_cur == q_end) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(P.queue_head, kClaim);
+        base = __builtin_amdgcn_readfirstlane(base);
+        q_cur = min(base, n_rec);
+        q_end = min(base + kClaim, n_rec);
+        if (q_cur == q_end) drained = true;
+      }
+      const uint32_t avail = min(cnt, q_end - q_cur);
       const uint32_t prefix = (uint32_t)__popc(need & lt_mask);
       if (!active && prefix < avail) {
-        const uint4* rec = reinterpret_cast<const uint4*>(P.queue) + (size_t)(base + prefix) * 4;
+        const uint4* rec = reinterpret_cast<const uint4*>(P.queue) + (size_t)(q_cur + prefix) * kRecordWords;
         const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        shf = reinterpret_cast<const half8*>(rec)[4 + h];
         o[0] = __uint_as_float(q0.x); o[1] = __uint_as_float(q0.y); o[2] = __uint_as_float(q0.z);
         t0 = __uint_as_float(q0.w);
         d[0] = __uint_as_float(q1.x); d[1] = __uint_as_float(q1.y); d[2] = __uint_as_float(q1.z);
@@ -129,9 +139,9 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
         m0 = q2.x; m1 = q2.y; m2 = q2.z; m3 = q2.w;
         pix = q3.x;
         T = 1.f; cr = 0.f; cg = 0.f; cb = 0.f;
-        shf = sh_fragment(h, d[0], d[1], d[2]);
         active = true;
       }
+      q_cur += avail;
     }
     const uint32_t act = (uint32_t)__ballot(active);
     if (act == 0u) {
@@ -139,6 +149,7 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
       continue;
     }
     n_eval += (unsigned long long)__popc(act);
+    n_rounds++;
 
     // ---- next live sample of every active slot (identical in both lanes of a pair)
     half8 f0 = {0, 0, 0, 0, 0, 0, 0, 0}, f1 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -206,7 +217,10 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
       active = false;
     }
   }
-  if (lane == 0 && n_eval) atomicAdd(P.stat_evaluated, n_eval);
+  if (lane == 0 && n_eval) {
+    atomicAdd(P.stat_evaluated, n_eval);
+    atomicAdd(P.stat_evaluated + 1, n_rounds); // wave-rounds: slot utilisation = evaluated / (32 * rounds)
+  }
 }
 
 template __global__ void render_queue_kernel<2>(RenderParams);

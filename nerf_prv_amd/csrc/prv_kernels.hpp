@@ -5,9 +5,11 @@
 
 namespace prv {
 
-// one queue record = 64 bytes = 4 x uint4:
-//   {o.x o.y o.z t0} {d.x d.y d.z dt} {mask0..3} {pixel, 0, 0, 0}
-constexpr size_t kRecordBytes = 64;
+// one queue record = 96 bytes = 6 x uint4:
+//   {o.x o.y o.z t0} {d.x d.y d.z dt} {mask0..3} {pixel, 0, 0, 0} {SH coeffs 0..7 fp16} {SH 8..15 fp16}
+constexpr size_t kRecordBytes = 96;
+constexpr int kRecordWords = 6;   // uint4 per record
+constexpr uint32_t kClaim = 64;   // records a wave claims per atomic on the queue head
 constexpr int kMaxSamples = 128; // live-sample mask is 128 bits
 
 struct MarchParams {

@@ -37,4 +37,5 @@ print(f"{args.tag} BPC={os.environ.get('PRV_BLOCKS_PER_CU','4')} RM={os.environ.
       f"eval={st.samples_evaluated/1e6:.1f}M ({100*st.samples_evaluated/st.samples_nominal:.2f}% of nominal) "
       f"render={rms:.2f}ms march={mms:.2f}ms wall={dt*1e3:.2f}ms "
       f"kernel_rate={st.samples_evaluated/rms/1e6:.2f} Gsamp/s wall_rate={st.samples_evaluated/dt/1e9:.2f} Gsamp/s "
-      f"frac={st.samples_evaluated/rms/1e6*512/8000:.3f}")
+      f"frac={st.samples_evaluated/rms/1e6*512/8000:.3f} util={st.samples_evaluated/max(1,32*st.wave_rounds):.3f} "
+      f"ns/round/SIMD={rms*1e6/max(1,st.wave_rounds/1024):.0f}")
