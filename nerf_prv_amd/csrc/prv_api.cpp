@@ -60,6 +60,7 @@ struct prv_ctx {
   int blocks_per_cu = 4;
   int refill_min = 32;
   int dbg_flags = 0;
+  size_t dehash_budget = 0; // bytes per hashed level allowed for a physically dense copy (0 = keep hashed)
   size_t queue_budget = (size_t)4 << 30; // ray-queue bytes per batch of views (288 GB of HBM: one batch for 64 views at 800x800)
 };
 
@@ -218,9 +219,14 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   uint32_t psize[kMaxLevels], sx[kMaxLevels], poff[kMaxLevels];
   int order[kMaxLevels];
   auto ceil_log2 = [](uint32_t v) { uint32_t s = 0; while ((1u << s) < v) s++; return s; };
+  bool dehash[kMaxLevels];
   for (int l = 0; l < d.n_levels; l++) {
     order[l] = l;
-    if (lv[l].hashed) {
+    // a hashed level may be STORED densely (coherent gathers) when that fits the budget
+    const uint32_t sxl = ceil_log2(lv[l].res);
+    const uint64_t dense_entries = 1ull << (3 * sxl); // >= pow2 ceiling of res << 2sx
+    dehash[l] = lv[l].hashed && sxl <= 9 && dense_entries * ebytes <= c->dehash_budget;
+    if (lv[l].hashed && !dehash[l]) {
       sx[l] = 0;
       psize[l] = lv[l].size;
     } else {
@@ -238,7 +244,7 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   if ((rc = ensure(c, m.phys, ptotal * ebytes)) != PRV_OK) return rc;
   HIPCHK(c, hipMemsetAsync(m.phys.p, 0, ptotal * ebytes, c->stream));
   for (int l = 0; l < d.n_levels; l++) {
-    RepackLevel R{lv[l].offset, poff[l], lv[l].size, lv[l].res, sx[l], lv[l].hashed};
+    RepackLevel R{lv[l].offset, poff[l], lv[l].size, lv[l].res, sx[l], lv[l].hashed, dehash[l] ? 1u : 0u};
     HIPCHK(c, launch_repack_level((const uint16_t*)m.table.p, (uint16_t*)m.phys.p, R, d.n_features, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -256,7 +262,7 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
     LevelDev& L = f.levels[l];
     L.scale = lv[l].scale;
     L.res_m1 = lv[l].res - 1;
-    if (lv[l].hashed) { // the kernel multiplies with v_mul_u32_u24: keep the low 24 bits
+    if (lv[l].hashed && !dehash[l]) { // the kernel multiplies with v_mul_u32_u24: keep the low 24 bits
       L.my_b = (2654435761u * ebytes) & 0xffffffu;
       L.mz_b = (805459861u * ebytes) & 0xffffffu;
       L.m_b = (lv[l].size - 1u) * ebytes;
@@ -458,6 +464,7 @@ int prv_create(prv_ctx** out, int device_id) {
   c->stream = c->own_stream;
   if (const char* s = getenv("PRV_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(s));
   if (const char* s = getenv("PRV_REFILL_MIN")) c->refill_min = std::min(32, std::max(1, atoi(s)));
+  if (const char* s = getenv("PRV_DEHASH_MB")) c->dehash_budget = (size_t)std::max(0, atoi(s)) << 20;
   if (const char* s = getenv("PRV_DBG")) c->dbg_flags = atoi(s);
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
   *out = c;

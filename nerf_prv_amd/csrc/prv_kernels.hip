@@ -372,19 +372,34 @@ __global__ __launch_bounds__(256) void synth_table_kernel(uint16_t* __restrict__
   }
 }
 
-// canonical (ABI) table -> physical layout of one level; one thread per canonical entry
+// canonical (ABI) table -> physical layout of one level.
+//  dense level            : one thread per canonical entry, scattered to power-of-two strides
+//  hashed level           : straight copy
+//  hashed, stored densely : one thread per VERTEX, gathers T[hash(x,y,z)] into a power-of-two-
+//                           strided dense grid (a spatially coherent copy; same values by construction)
 template <int F>
 __global__ __launch_bounds__(256) void repack_level_kernel(const uint16_t* __restrict__ canon,
                                                            uint16_t* __restrict__ phys, RepackLevel L) {
   typedef typename EntryWord<F>::type word_t;
+  const word_t* src = reinterpret_cast<const word_t*>(canon) + L.canon_off;
+  word_t* dst = reinterpret_cast<word_t*>(phys) + L.phys_off;
+  if (L.hashed && L.dehash) {
+    const uint32_t nv = L.res * L.res * L.res;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nv; i += gridDim.x * 256) {
+      const uint32_t x = i % L.res, y = (i / L.res) % L.res, z = i / (L.res * L.res);
+      const uint32_t hsh = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & (L.n - 1u);
+      dst[x | (y << L.sx) | (z << (2 * L.sx))] = src[hsh];
+    }
+    return;
+  }
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < L.n; i += gridDim.x * 256) {
-    uint32_t dst = i;
+    uint32_t to = i;
     if (!L.hashed) {
       const uint32_t x = i % L.res, y = (i / L.res) % L.res, z = i / (L.res * L.res);
       if (z >= L.res) continue; // canonical padding entries
-      dst = x | (y << L.sx) | (z << (2 * L.sx));
+      to = x | (y << L.sx) | (z << (2 * L.sx));
     }
-    reinterpret_cast<word_t*>(phys)[L.phys_off + dst] = reinterpret_cast<const word_t*>(canon)[L.canon_off + i];
+    dst[to] = src[i];
   }
 }
 
@@ -511,8 +526,8 @@ hipError_t launch_synth_table(uint16_t* table, size_t n, uint64_t seed, float am
 }
 
 hipError_t launch_repack_level(const uint16_t* canon, uint16_t* phys, const RepackLevel& L, int F, hipStream_t s) {
-  unsigned blocks = (L.n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  unsigned blocks = ((L.dehash ? L.res * L.res * L.res : L.n) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
   if (blocks == 0) return hipSuccess;
   if (F == 4)
     hipLaunchKernelGGL(repack_level_kernel<4>, dim3(blocks), dim3(256), 0, s, canon, phys, L);

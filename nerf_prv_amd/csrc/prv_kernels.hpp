@@ -60,7 +60,7 @@ struct PsnrParams {
 };
 
 struct RepackLevel { // canonical -> physical copy of one level (entries, not bytes)
-  uint32_t canon_off, phys_off, n, res, sx, hashed;
+  uint32_t canon_off, phys_off, n, res, sx, hashed, dehash;
 };
 hipError_t launch_repack_level(const uint16_t* canon, uint16_t* phys, const RepackLevel& L, int F, hipStream_t s);
 
