@@ -28,6 +28,18 @@ BYTES_PER_SAMPLE = 512  # L*8 corners*F*2 B = 8*8*4*2: hash-table ga
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def measured_traffic(args, samples_per_launch):
+    """HBM-side bytes per render_queue launch from the committed PMC pass (profiles/), scaled by the
+    evaluated-sample count; None unless the workload is the one that was profiled"""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path) or (args.width, args.height, args.samples, args.field) != (800, 800, 128, "256"):
+        return None
+    with open(path) as f:
+        k = json.load(f)["render_queue_kernel"]
+    per_sample = (k["fetch_kib_per_launch"] + k["write_kib_per_launch"]) * 1024.0 / k["samples_evaluated_per_launch"]
+    return per_sample * samples_per_launch
+
+
 def cpu_baseline(args, tms, scale, offset, fov_x):
     """the oracle (a scalar C port of the same algorithm) on the host cores, bounded sample"""
     from oracle import oracle as orc
@@ -35,7 +47,7 @@ def cpu_baseline(args, tms, scale, offset, fov_x):
     threads = os.cpu_count() or 1
     f = orc.OracleField(orc.desc(), seed=SEED_A)
     cams = orc.cameras_from_transforms(tms, fov_x, args.width, args.height, scale, offset)
-    rows = (args.height // 2 - 8, args.height // 2 + 8)
+    rows = (args.height // 2 - 32, args.height // 2 + 32)
     f.render(cams[0], args.width, args.height, args.samples, 1, 1e-4, threads=threads, rows=(rows[0], rows[0] + 1))
     n_eval, n_views, t0 = 0, 0, time.perf_counter()
     for v in range(len(cams)):
@@ -182,7 +194,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(args, samples_per_launch),
                 "bytes_per_unit": BYTES_PER_SAMPLE,
                 "units_per_launch": samples_per_launch,
                 "avg_launch_ms": kernel_s * 1e3,
