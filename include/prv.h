@@ -130,6 +130,10 @@ int prv_model_load(prv_ctx* ctx, int slot, const prv_field_desc* desc, const uin
 /* deterministic synthetic field (counter-based RNG), generated on the device */
 int prv_model_synthetic(prv_ctx* ctx, int slot, const prv_field_desc* desc, uint64_t seed);
 int prv_model_export(prv_ctx* ctx, int slot, uint16_t* table, uint16_t* mlp, uint32_t* occ);
+/* replaces: testbed.save_snapshot / load_snapshot (run.py:123-127, 210-211).  File = "PRVF" magic,
+ * ABI version, prv_field_desc, then table / mlp / occupancy arrays in the canonical layout. */
+int prv_model_save_file(prv_ctx* ctx, int slot, const char* path);
+int prv_model_load_file(prv_ctx* ctx, int slot, const char* path);
 
 /* ---- cameras ------------------------------------------------------------- */
 /* replaces: json.load(--screenshot_transforms) + set_nerf_camera_matrix + fov from

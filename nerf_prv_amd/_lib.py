@@ -80,6 +80,8 @@ SIGNATURES = {
     "prv_model_load": (_i, [_vp, _i, _P(FieldDesc), _vp, _vp, _vp]),
     "prv_model_synthetic": (_i, [_vp, _i, _P(FieldDesc), C.c_uint64]),
     "prv_model_export": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "prv_model_save_file": (_i, [_vp, _i, C.c_char_p]),
+    "prv_model_load_file": (_i, [_vp, _i, C.c_char_p]),
     "prv_cameras_from_json": (_i, [_vp, C.c_char_p, _P(_vp)]),
     "prv_cameras_from_matrices": (_i, [_vp, _vp, _i, C.c_double, _i, _i, C.c_double, _vp, _P(_vp)]),
     "prv_camset_count": (_i, [_vp]),

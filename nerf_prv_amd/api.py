@@ -167,6 +167,12 @@ class Context:
         self._chk(self.lib.prv_model_export(self.handle, slot, _ptr(table), _ptr(mlp), _ptr(occ)))
         return table, mlp, occ
 
+    def save_model(self, slot, path):
+        self._chk(self.lib.prv_model_save_file(self.handle, slot, str(path).encode()))
+
+    def load_model_file(self, slot, path):
+        self._chk(self.lib.prv_model_load_file(self.handle, slot, str(path).encode()))
+
     # -- cameras
     def cameras_from_json(self, path):
         h = C.c_void_p()
@@ -340,6 +346,13 @@ class Testbed:
     def synthetic_model(self, desc, seed):
         self.ctx.synthetic_model(self._slot, desc, seed)
         self._have_model = True
+
+    def load_snapshot(self, path):  # run.py:127
+        self.ctx.load_model_file(self._slot, path)
+        self._have_model = True
+
+    def save_snapshot(self, path, include_optimizer_state=False):  # run.py:211
+        self.ctx.save_model(self._slot, path)
 
     def set_nerf_camera_matrix(self, m):
         m = np.asarray(m, np.float64)

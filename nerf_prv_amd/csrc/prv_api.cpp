@@ -639,6 +639,46 @@ int prv_model_export(prv_ctx* c, int slot, uint16_t* table, uint16_t* mlp, uint3
   return PRV_OK;
 }
 
+int prv_model_save_file(prv_ctx* c, int slot, const char* path) {
+  if (!c) return PRV_E_INVALID;
+  int rc = check_model(c, slot);
+  if (rc != PRV_OK) return rc;
+  if (!path) return fail(c, PRV_E_INVALID, "path is NULL");
+  const Model& m = c->models[slot];
+  std::vector<uint16_t> table(m.table_halfs), mlp(PRV_MLP_HALFS);
+  std::vector<uint32_t> occ(m.occ_words);
+  if ((rc = prv_model_export(c, slot, table.data(), mlp.data(), occ.data())) != PRV_OK) return rc;
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(c, PRV_E_IO, "cannot write %s", path);
+  const uint32_t head[2] = {0x46565250u /* "PRVF" */, (uint32_t)PRV_ABI_VERSION};
+  bool ok = fwrite(head, sizeof(head), 1, f) == 1 && fwrite(&m.desc, sizeof(m.desc), 1, f) == 1 &&
+            fwrite(table.data(), 2, table.size(), f) == table.size() && fwrite(mlp.data(), 2, mlp.size(), f) == mlp.size() &&
+            fwrite(occ.data(), 4, occ.size(), f) == occ.size();
+  ok = (fclose(f) == 0) && ok;
+  return ok ? PRV_OK : fail(c, PRV_E_IO, "short write to %s", path);
+}
+
+int prv_model_load_file(prv_ctx* c, int slot, const char* path) {
+  if (!c) return PRV_E_INVALID;
+  if (!path) return fail(c, PRV_E_INVALID, "path is NULL");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(c, PRV_E_IO, "cannot read %s", path);
+  uint32_t head[2] = {0, 0};
+  prv_field_desc d;
+  uint64_t th = 0, mh = 0, ow = 0;
+  if (fread(head, sizeof(head), 1, f) != 1 || head[0] != 0x46565250u || head[1] != (uint32_t)PRV_ABI_VERSION ||
+      fread(&d, sizeof(d), 1, f) != 1 || prv_model_sizes(&d, &th, &mh, &ow) != PRV_OK) {
+    fclose(f);
+    return fail(c, PRV_E_IO, "%s is not a PRVF model file of ABI version %d", path, PRV_ABI_VERSION);
+  }
+  std::vector<uint16_t> table(th), mlp(mh);
+  std::vector<uint32_t> occ(ow);
+  const bool ok = fread(table.data(), 2, th, f) == th && fread(mlp.data(), 2, mh, f) == mh && fread(occ.data(), 4, ow, f) == ow;
+  fclose(f);
+  if (!ok) return fail(c, PRV_E_IO, "%s is truncated", path);
+  return prv_model_load(c, slot, &d, table.data(), mlp.data(), occ.data());
+}
+
 // ------------------------------------------------------------------ cameras
 
 // transform_matrix (NeRF convention, as written at main.cpp:1626-1641) -> engine frame:

@@ -1,0 +1,215 @@
+// main.cpp -- prv_planner: the planner executable.  Mirrors the console protocol of the
+// reference's main() (PRV_simulation/main.cpp:2294-2309): read a mode number, then object
+// names until "-1", from stdin.  Mode 21 (ViewPlanning, main.cpp:3834-4004) is the one on
+// the hot path; every render/score goes through the C ABI of include/prv.h in-process.
+//
+//   prv_planner [config.yaml]      (default "../DefaultConfiguration.yaml", main.cpp:2312)
+//
+// Ensemble members / the field under test come from model files
+//   <model_path>/<object>/member_<e>.prvf  (prv_model_save_file format)
+// or, when the config carries `synthetic_seed`, from the deterministic synthetic generator
+// (member e = seed + e; reference images for method 5 from seed + 4096).
+#include <cstdio>
+#include <iostream>
+#include <string>
+#include <vector>
+
+extern "C" {
+#include "../../include/prv.h"
+}
+#include "planner.hpp"
+
+using namespace prvhost;
+
+namespace {
+
+enum { ViewPlanning = 21 };
+
+struct HipScorer {
+  prv_ctx* ctx = nullptr;
+  std::shared_ptr<Share_Data> sd;
+  int n_members = 1;
+  float* gt_dev = nullptr; // method 5: reference images of ALL views at the candidate size
+  int gt_w = 0, gt_h = 0;
+
+  int operator()(int method, int /*iteration*/, const std::string& /*scene_json*/, const std::string& render_json,
+                 const std::vector<int>& ids, std::vector<double>& scores) {
+    prv_camset* cams = nullptr;
+    if (prv_cameras_from_json(ctx, render_json.c_str(), &cams) != PRV_OK) {
+      std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+      return -20;
+    }
+    int w = 0, h = 0;
+    prv_camset_size(cams, &w, &h);
+    const int n = prv_camset_count(cams);
+    prv_render_opts o{};
+    o.width = sd->render_width > 0 ? sd->render_width : w;
+    o.height = sd->render_height > 0 ? sd->render_height : h;
+    o.samples_per_ray = sd->samples_per_ray;
+    o.spp = sd->screenshot_spp;
+    o.min_transmittance = (float)sd->min_transmittance;
+    o.background[0] = o.background[1] = o.background[2] = 0.f;
+    o.background[3] = 1.f; // run.py:94
+    std::vector<int> slots(n_members);
+    for (int e = 0; e < n_members; e++) slots[e] = e;
+    std::vector<prv_score_record> rec(n);
+    int rc;
+    if (method == PSNRCoverage) {
+      // frame k of the render json is candidate ids[k]: pick its reference image out of the full set
+      const size_t px = (size_t)o.width * o.height * 4;
+      float* gt_sel = nullptr;
+      if (prv_malloc(ctx, (void**)&gt_sel, (size_t)n * px * sizeof(float)) != PRV_OK) return -21;
+      std::vector<float> tmp(px);
+      for (int k = 0; k < n; k++) { // device-to-device through the host keeps this file free of HIP headers
+        prv_memcpy_d2h(ctx, tmp.data(), gt_dev + (size_t)ids[k] * px, px * sizeof(float));
+        prv_memcpy_h2d(ctx, gt_sel + (size_t)k * px, tmp.data(), px * sizeof(float));
+      }
+      o.background[3] = 0.f;
+      rc = prv_score_views(ctx, PRV_SCORE_PSNR_COVERAGE, slots.data(), 1, cams, nullptr, n, &o, gt_sel, rec.data(), nullptr, nullptr);
+      prv_free(ctx, gt_sel);
+    } else {
+      rc = prv_score_views(ctx, method, slots.data(), n_members, cams, nullptr, n, &o, nullptr, rec.data(), nullptr, nullptr);
+    }
+    prv_camset_destroy(cams);
+    if (rc != PRV_OK) {
+      std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+      return rc;
+    }
+    for (int k = 0; k < n; k++) scores[k] = rec[k].score;
+    return 0;
+  }
+};
+
+prv_field_desc field_from_config(const FileStorage& fs) {
+  prv_field_desc d{};
+  auto get = [&](const char* k, double dflt) { return fs.has(k) ? fs.num(k) : dflt; };
+  d.n_levels = (int)get("field_levels", 8);
+  d.n_features = (int)get("field_features", 4);
+  d.log2_hashmap = (int)get("field_log2_hashmap", 19);
+  d.base_res = (int)get("field_base_res", 16);
+  d.finest_res = (int)get("field_finest_res", 256);
+  d.occ_res = (int)get("field_occ_res", 128);
+  d.density_bias = (float)get("field_density_bias", 3.0);
+  d.table_amp = (float)get("synthetic_table_amp", 4.0);
+  return d;
+}
+
+int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name, int method) {
+  auto sd = std::make_shared<Share_Data>(cfg, name, -1, -1, method); // main.cpp:3876
+  if (!sd->ok) {
+    std::cerr << sd->error << std::endl;
+    return -1;
+  }
+  FileStorage fs;
+  fs.open(cfg);
+  const prv_field_desc desc = field_from_config(fs);
+  const int members = (method == EnsembleRGB || method == EnsembleRGBDensity) ? sd->ensemble_num : 1;
+  for (int e = 0; e < members; e++) {
+    int rc;
+    if (fs.has("synthetic_seed")) rc = prv_model_synthetic(ctx, e, &desc, (uint64_t)fs.num("synthetic_seed") + (uint64_t)e);
+    else rc = prv_model_load_file(ctx, e, (sd->model_path + name + "/member_" + std::to_string(e) + ".prvf").c_str());
+    if (rc != PRV_OK) {
+      std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+      return rc;
+    }
+  }
+  // synthetic objects sit at the origin (+1e-10, main.cpp:447) with the configured size
+  const double size = fs.has("object_size") ? fs.num("object_size") : 0.1;
+  const Vec3 center(1e-10, 1e-10, 1e-10);
+  HipScorer scorer;
+  scorer.ctx = ctx;
+  scorer.sd = sd;
+  scorer.n_members = members;
+  NBV_Net_Labeler labeler(sd, center, size, scorer);
+  labeler.get_coverage(); // <gt_path>/<N>.json (main.cpp:3882-3978, json part)
+  if (method == PSNRCoverage) { // reference images of every view, rendered once from the reference field
+    int rc = fs.has("synthetic_seed") ? prv_model_synthetic(ctx, 7, &desc, (uint64_t)fs.num("synthetic_seed") + 4096)
+                                      : prv_model_load_file(ctx, 7, (sd->model_path + name + "/reference.prvf").c_str());
+    if (rc != PRV_OK) {
+      std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+      return rc;
+    }
+    // all views with the candidate header (divisor 16) so the images match the render json
+    const std::string all_json = sd->gt_path + "/" + std::to_string(sd->num_of_views) + "_render.json";
+    Value root = transforms_header(sd->color_intrinsics, sd->ray_casting_aabb_scale, size, center, sd->candidate_divisor);
+    for (size_t i = 0; i < labeler.view_space->views.size(); i++) {
+      Value v;
+      v["file_path"] = Value("rgbaClip_" + std::to_string(i) + ".png");
+      v["transform_matrix"] = matrix_json(view_transform_matrix(labeler.view_space->views[i], Mat4::Identity(), center));
+      root["frames"].append(v);
+    }
+    write_text(all_json, prvjson::to_styled_string(root));
+    prv_camset* cams = nullptr;
+    if (prv_cameras_from_json(ctx, all_json.c_str(), &cams) != PRV_OK) return -22;
+    int w, h;
+    prv_camset_size(cams, &w, &h);
+    prv_render_opts o{};
+    o.width = sd->render_width > 0 ? sd->render_width : w;
+    o.height = sd->render_height > 0 ? sd->render_height : h;
+    o.samples_per_ray = sd->samples_per_ray;
+    o.spp = sd->screenshot_spp;
+    o.min_transmittance = (float)sd->min_transmittance;
+    const int n = prv_camset_count(cams);
+    if (prv_malloc(ctx, (void**)&scorer.gt_dev, (size_t)n * o.width * o.height * 16) != PRV_OK) return -23;
+    rc = prv_render(ctx, 7, cams, nullptr, n, &o, scorer.gt_dev, nullptr);
+    prv_camset_destroy(cams);
+    if (rc != PRV_OK) {
+      std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+      return rc;
+    }
+    labeler.scorer = scorer;
+  }
+  // first view = the (0,0,r) top view of the set (main.cpp:3985-3995)
+  int first_view_id = -1;
+  for (size_t i = 0; i < labeler.view_space->views.size(); i++) {
+    const Vec3& p = labeler.view_space->views[i].init_pos;
+    if (std::fabs(p.x) < 1e-6 && std::fabs(p.y) < 1e-6 && std::fabs(p.z - sd->view_space_radius) < 1e-6) first_view_id = (int)i;
+  }
+  if (first_view_id == -1) std::cout << "can not find now view id" << std::endl; // main.cpp:3993-3995
+  const int rc = labeler.nbv_loop(first_view_id, 0);
+  if (scorer.gt_dev) prv_free(ctx, scorer.gt_dev);
+  std::cout << "chosen_nbvs:";
+  for (int v : labeler.chosen_nbvs) std::cout << ' ' << v;
+  std::cout << std::endl;
+  return rc;
+}
+
+} // namespace
+
+int main(int argc, char** argv) {
+  const std::string cfg = argc > 1 ? argv[1] : "../DefaultConfiguration.yaml";
+  int mode = -1;
+  std::cout << "input mode:" << std::endl;
+  if (!(std::cin >> mode)) return 2;
+  std::vector<std::string> names;
+  std::cout << "input object names (-1 to stop):" << std::endl; // main.cpp:2299-2309
+  std::string name;
+  while (std::cin >> name && name != "-1") names.push_back(name);
+  if (mode != ViewPlanning) {
+    std::cerr << "mode " << mode << " is outside the render/score path this build covers (only 21 = ViewPlanning)" << std::endl;
+    return 3;
+  }
+  prv_ctx* ctx = nullptr;
+  if (prv_create(&ctx, 0) != PRV_OK) {
+    std::cerr << "prv: " << prv_last_error(nullptr) << std::endl;
+    return 4;
+  }
+  FileStorage fs;
+  if (!fs.open(cfg)) {
+    std::cerr << "cannot open " << cfg << std::endl;
+    return 5;
+  }
+  // main.cpp:3838-3840 runs methods {4,0,1,2,3}; here: the configured one, or all that are in scope
+  std::vector<int> methods;
+  if (fs.has("method_of_IG") && fs.num("method_of_IG") >= 0) methods.push_back((int)fs.num("method_of_IG"));
+  else methods = {RandomIterative, EnsembleRGB, EnsembleRGBDensity, PSNRCoverage};
+  int worst = 0;
+  for (const auto& n : names)
+    for (int m : methods) {
+      std::cout << "object " << n << " method " << m << std::endl;
+      const int rc = view_planning(ctx, cfg, n, m);
+      if (rc != 0) worst = rc;
+    }
+  prv_destroy(ctx);
+  return worst == 0 ? 0 : 1;
+}

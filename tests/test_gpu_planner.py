@@ -1,0 +1,171 @@
+"""The two host sides of the boundary on the GPU: the run.py-style Testbed loop and the C++
+planner executable (prv_planner) driving libprv_hip.so in-process."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from nerf_prv_amd import api, planner
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+YAML = """%YAML:1.0
+pre_path: "{pre}/"
+model_path: "{pre}/models/"
+viewspace_path: "{vs}/"
+name_of_pcd: "objA"
+is_shape_net: 1
+id_of_batch: -1
+method_of_IG : {method}
+ensemble_num: 5
+num_of_max_iteration: 3
+num_of_views : 5
+ray_casting_aabb_scale : 1
+view_space_radius : 0.3
+color_width: 1280
+color_height: 720
+color_fx: 9.1560668945312500e+02
+color_fy: 9.1332666015625000e+02
+color_ppx: 6.4714532470703125e+02
+color_ppy: 3.7251531982421875e+02
+color_model: 2
+candidate_divisor: 16
+screenshot_spp: 2
+samples_per_ray: 64
+min_transmittance: 0.01
+object_size: 0.1
+{model_source}
+field_levels: 8
+field_features: 4
+field_log2_hashmap: 14
+field_base_res: 8
+field_finest_res: 96
+field_occ_res: 32
+field_density_bias: 3.0
+synthetic_table_amp: 4.0
+"""
+SEED = 777
+
+
+def small_desc():
+    return api.field_desc(**util.SMALL)
+
+
+def test_testbed_screenshot_loop_reads_like_run_py(ctx, tmp_path):
+    """run.py:284-309 against api.Testbed; same pixels as the C-ABI batch render"""
+    pts = planner.hemisphere_read(os.path.join(GOLD, "hemisphere", "5.txt"), 5)
+    c = [1e-10] * 3
+    pos = planner.view_space(pts, 0.3, c)
+    k = planner.Intrinsics(width=1280, height=720, ppx=647.1, ppy=372.5, fx=915.60668945312500, fy=913.3)
+    rj = tmp_path / "render.json"
+    planner.write_transforms(rj, k, pos, c, 0.1, candidate=True)
+    ref_transforms = json.load(open(rj))
+
+    testbed = api.Testbed(0)
+    testbed.background_color = [0.0, 0.0, 0.0, 1.0]  # run.py:94
+    testbed.load_training_data(str(rj))
+    testbed.synthetic_model(small_desc(), SEED)
+    testbed.nerf.render_min_transmittance = 0.01
+    testbed.fov_axis = 0  # run.py:285
+    testbed.fov = ref_transforms["camera_angle_x"] * 180 / np.pi
+    images = []
+    for f in ref_transforms["frames"]:
+        testbed.set_nerf_camera_matrix(np.matrix(f["transform_matrix"])[:-1, :])  # run.py:296
+        images.append(testbed.render(int(ref_transforms["w"]), int(ref_transforms["h"]), 2, True))  # run.py:304
+    assert images[0].shape == (45, 80, 4) and images[0].dtype == np.float32
+
+    ctx.synthetic_model(0, small_desc(), SEED)
+    cams = ctx.cameras_from_json(rj)
+    assert len(cams) == 5 and cams.size == (80, 45)
+    batch, _ = ctx.render(0, cams, None, api.render_opts(80, 45, 128, 2, 0.01))
+    batch = batch.cpu().numpy()
+    for img, b in zip(images, batch):
+        want = b + (1.0 - b[..., 3:4]) * np.array([0, 0, 0, 1], np.float32)
+        np.testing.assert_array_equal(img, want)
+        assert (img[..., 3] == 1.0).all()  # opaque background
+    testbed.snap_to_pixel_centers = True  # run.py:231: every sub-sample at the pixel centre == spp 1
+    testbed.set_nerf_camera_matrix(np.matrix(ref_transforms["frames"][0]["transform_matrix"])[:-1, :])
+    one = testbed.render(80, 45, 8, True)
+    spp1, _ = ctx.render(0, cams, [0], api.render_opts(80, 45, 128, 1, 0.01))
+    np.testing.assert_array_equal(one[..., :3], spp1[0].cpu().numpy()[..., :3])
+    with pytest.raises(ValueError):
+        testbed.set_nerf_camera_matrix(np.eye(4))
+    testbed.ctx.close()
+
+
+def test_model_file_roundtrip(ctx, tmp_path):
+    d = small_desc()
+    ctx.synthetic_model(0, d, 99)
+    path = tmp_path / "member_0.prvf"
+    ctx.save_model(0, path)
+    ctx.load_model_file(1, path)
+    a, b = ctx.export_model(0, d), ctx.export_model(1, d)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    (tmp_path / "bad.prvf").write_bytes(b"nope")
+    with pytest.raises(api.PrvError) as e:
+        ctx.load_model_file(2, tmp_path / "bad.prvf")
+    assert e.value.code == api.L.PRV_E_IO
+
+
+@pytest.mark.parametrize("method", [2, 3, 5])
+def test_planner_executable_matches_python_driven_loop(ctx, tmp_path, method):
+    """prv_planner (C++ nbv_loop + C ABI, in-process) chooses the same views as the same loop driven
+    from Python through the same C ABI; both write the reference's directory tree"""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    assert os.path.exists(exe), "prv_planner missing: run __graft_entry__.build()"
+    runs = {}
+    for who in ("cpp", "py"):
+        pre = tmp_path / f"{who}_{method}"
+        pre.mkdir()
+        cfg = pre / "cfg.yaml"
+        cfg.write_text(YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=method,
+                                   model_source=f"synthetic_seed: {SEED}"))
+        if who == "cpp":
+            out = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
+            assert out.returncode == 0, out.stdout + out.stderr
+            line = [l for l in out.stdout.splitlines() if l.startswith("chosen_nbvs:")][-1]
+            runs[who] = [int(x) for x in line.split(":")[1].split()]
+        else:
+            sd = planner.ShareData(cfg, "objA", -1, -1, method)
+            E = int(sd.number("ensemble_num")) if method in (2, 3) else 1
+            d = small_desc()
+            for e in range(E):
+                ctx.synthetic_model(e, d, SEED + e)
+            gt_all = None
+            if method == 5:
+                ctx.synthetic_model(7, d, SEED + 4096)
+                pos = planner.view_space(sd.views(), 0.3, [1e-10] * 3)
+                allj = pre / "all.json"
+                planner.write_transforms(allj, sd.intrinsics(), pos, [1e-10] * 3, 0.1, candidate=True)
+                gt_all, _ = ctx.render(7, ctx.cameras_from_json(allj), None, api.render_opts(80, 45, 64, 2, 0.01))
+
+            def score(m, it, scene_json, render_json, ids):
+                cams = ctx.cameras_from_json(render_json)
+                if m == 5:
+                    opts = api.render_opts(80, 45, 64, 2, 0.01)
+                    rec, _ = ctx.score_views(5, [0], cams, None, opts, gt=gt_all[ids].contiguous())
+                else:
+                    opts = api.render_opts(80, 45, 64, 2, 0.01, background=(0, 0, 0, 1))
+                    rec, _ = ctx.score_views(m, list(range(E)), cams, None, opts)
+                return rec["score"]
+
+            top = 1  # 5.txt: row 1 is (0,0,1)
+            runs[who] = sd.nbv_loop([1e-10] * 3, 0.1, score, first_view_id=top)
+        save = pre / "Compare" / "ShapeNet" / f"objA_m{method}_v1_t0"
+        assert (save / "run_time.txt").exists() and (save / "json" / "3.json").exists()
+        assert (save / "train_time" / "0.txt").exists() and (save / "movement" / "2.txt").exists()
+    assert runs["cpp"] == runs["py"] and len(runs["cpp"]) == 4 and runs["cpp"][0] == 1
+    assert len(set(runs["cpp"])) == 4
+
+
+def test_planner_executable_error_paths(tmp_path):
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    out = subprocess.run([exe, str(tmp_path / "missing.yaml")], input="21\nx\n-1\n", text=True, capture_output=True)
+    assert out.returncode != 0 and "cannot open" in out.stderr
+    out = subprocess.run([exe, str(tmp_path / "missing.yaml")], input="4\nx\n-1\n", text=True, capture_output=True)
+    assert out.returncode == 3 and "outside the render/score path" in out.stderr
