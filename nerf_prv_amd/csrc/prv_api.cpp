@@ -33,7 +33,7 @@ struct Model {
   prv_field_desc desc{};
   FieldDev dev{};
   uint64_t table_halfs = 0, occ_words = 0;
-  Buffer table, phys, occ, frags, mlp; // table/mlp = canonical (ABI) copies kept for export; phys = kernel layout
+  Buffer table, phys, occ, occ_coarse, frags, mlp; // table/mlp = canonical (ABI) copies kept for export; phys = kernel layout
 };
 
 } // namespace
@@ -209,6 +209,41 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   if ((rc = ensure(c, m.mlp, PRV_MLP_HALFS * 2)) != PRV_OK) return rc;
   if (table_host) HIPCHK(c, hipMemcpyAsync(m.table.p, table_host, m.table_halfs * 2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(m.occ.p, occ_host, m.occ_words * 4, hipMemcpyHostToDevice, c->stream));
+  // dilated coarse occupancy for the march pass: coarse cell = 4^3 fine cells; bit set when any fine
+  // cell of the block or of its 26 neighbour blocks is occupied
+  std::vector<uint32_t> coarse;
+  if (d.occ_res % 4 == 0 && d.occ_res >= 8) {
+    const int R = d.occ_res, Rc = R / 4;
+    std::vector<uint8_t> blk((size_t)Rc * Rc * Rc, 0);
+    for (int z = 0; z < R; z++)
+      for (int y = 0; y < R; y++)
+        for (int x = 0; x < R; x += 32) { // 32 fine cells of a row = one word (R is a multiple of 4; handle R < 32 too)
+          const size_t bit0 = (size_t)x + (size_t)R * ((size_t)y + (size_t)R * (size_t)z);
+          for (int k = 0; k < 32 && x + k < R; k++) {
+            const size_t b = bit0 + k;
+            if ((occ_host[b >> 5] >> (b & 31)) & 1u) blk[(size_t)((x + k) / 4) + (size_t)Rc * ((size_t)(y / 4) + (size_t)Rc * (size_t)(z / 4))] = 1;
+          }
+        }
+    coarse.assign(((size_t)Rc * Rc * Rc + 31) / 32, 0u);
+    for (int z = 0; z < Rc; z++)
+      for (int y = 0; y < Rc; y++)
+        for (int x = 0; x < Rc; x++) {
+          bool any = false;
+          for (int dz = -1; dz <= 1 && !any; dz++)
+            for (int dy = -1; dy <= 1 && !any; dy++)
+              for (int dx = -1; dx <= 1 && !any; dx++) {
+                const int xx = x + dx, yy = y + dy, zz = z + dz;
+                if (xx < 0 || yy < 0 || zz < 0 || xx >= Rc || yy >= Rc || zz >= Rc) continue;
+                any = blk[(size_t)xx + (size_t)Rc * ((size_t)yy + (size_t)Rc * (size_t)zz)] != 0;
+              }
+          if (any) {
+            const size_t b = (size_t)x + (size_t)Rc * ((size_t)y + (size_t)Rc * (size_t)z);
+            coarse[b >> 5] |= 1u << (b & 31);
+          }
+        }
+    if ((rc = ensure(c, m.occ_coarse, coarse.size() * 4)) != PRV_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(m.occ_coarse.p, coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice, c->stream));
+  }
   std::vector<uint16_t> frags;
   prepack_fragments(mlp, frags);
   HIPCHK(c, hipMemcpyAsync(m.frags.p, frags.data(), frags.size() * 2, hipMemcpyHostToDevice, c->stream));
@@ -252,6 +287,7 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   memset(&f, 0, sizeof(f));
   f.table = (const uint16_t*)m.phys.p;
   f.occ = (const uint32_t*)m.occ.p;
+  f.occ_coarse = (d.occ_res % 4 == 0 && d.occ_res >= 8) ? (const uint32_t*)m.occ_coarse.p : nullptr;
   f.frags = (const half8*)m.frags.p;
   f.n_levels = d.n_levels;
   f.n_features = d.n_features;
@@ -478,6 +514,7 @@ void prv_destroy(prv_ctx* c) {
   for (auto& m : c->models) {
     release(m.table);
     release(m.phys);
+    release(m.occ_coarse);
     release(m.occ);
     release(m.frags);
     release(m.mlp);

@@ -43,6 +43,7 @@ struct LevelDev {
 struct FieldDev {
   const uint16_t* table;  // PHYSICAL layout (see LevelDev), fp16 bit patterns, entries of F halfs
   const uint32_t* occ;    // occ_res^3 bits, x fastest
+  const uint32_t* occ_coarse; // (occ_res/4)^3 bits: any occupied fine cell in the 4^3 block OR its 26 neighbours (or null)
   const half8* frags;     // kNumFrags * 64 half8, MFMA A fragments (prepacked weights)
   LevelDev levels[kMaxLevels];
   int n_levels, n_features, occ_res;
@@ -109,6 +110,17 @@ __device__ __forceinline__ bool occupied(const FieldDev& f, float px, float py, 
   int cz = min((int)(clamp01(pz) * fR), R - 1);
   uint32_t bit = (uint32_t)cx + (uint32_t)R * ((uint32_t)cy + (uint32_t)R * (uint32_t)cz);
   return (f.occ[bit >> 5] >> (bit & 31)) & 1u;
+}
+
+// dilated coarse occupancy: 0 means no occupied fine cell within one coarse cell of p
+__device__ __forceinline__ bool occupied_coarse(const FieldDev& f, float px, float py, float pz) {
+  const int R = f.occ_res >> 2;
+  const float fR = (float)R;
+  const int cx = min((int)(clamp01(px) * fR), R - 1);
+  const int cy = min((int)(clamp01(py) * fR), R - 1);
+  const int cz = min((int)(clamp01(pz) * fR), R - 1);
+  const uint32_t bit = (uint32_t)cx + (uint32_t)R * ((uint32_t)cy + (uint32_t)R * (uint32_t)cz);
+  return (f.occ_coarse[bit >> 5] >> (bit & 31)) & 1u;
 }
 
 // real spherical harmonics degree 4; op order identical to the oracle

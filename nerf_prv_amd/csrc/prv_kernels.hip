@@ -50,10 +50,21 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
     float t1;
     if (ray_aabb(o, d, t0, t1)) {
       dt = (t1 - t0) / (float)P.S;
-      for (int i = 0; i < P.S; i++) {
-        float t = fmaf((float)i + 0.5f, dt, t0);
-        bool occ = occupied(P.field, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]));
-        if (occ) m[i >> 5] |= 1u << (i & 31);
+      // Two-level test, bit-identical to testing every sample: samples g..g+3 all lie within 1.5*dt of
+      // the point at parameter g+2; when that is less than one coarse cell and the DILATED coarse bit
+      // there is clear, none of the four can be in an occupied fine cell.
+      const bool coarse_ok = P.field.occ_coarse != nullptr && 1.5f * dt <= 0.99f * 4.0f / (float)P.field.occ_res;
+      for (int g = 0; g < P.S; g += 4) {
+        if (coarse_ok) {
+          const float tm = fmaf((float)g + 2.0f, dt, t0);
+          if (!occupied_coarse(P.field, fmaf(tm, d[0], o[0]), fmaf(tm, d[1], o[1]), fmaf(tm, d[2], o[2]))) continue;
+        }
+        const int hi = min(g + 4, P.S);
+        for (int i = g; i < hi; i++) {
+          const float t = fmaf((float)i + 0.5f, dt, t0);
+          const bool occ = occupied(P.field, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]));
+          if (occ) m[i >> 5] |= 1u << (i & 31);
+        }
       }
       live = (m[0] | m[1] | m[2] | m[3]) != 0u;
     }
