@@ -169,20 +169,24 @@ template <> struct Entry<2> {
   }
 };
 
-// One level, one sample, one lane: 8 corner loads of F halfs, trilinear blend in fp32
-// (corner order dx + 2dy + 4dz, weight = (wx*wy)*wz, acc = fmaf(w, v, acc)).
+// One level, one sample, one lane: 8 corner loads of F halfs and the trilinear blend in
+// packed binary16 (as tiny-cuda-nn does for fp16 tables): weights rounded to fp16,
+// w = fp16(fp16(wx*wy)*wz), acc = fp16 fma(w, v, acc), corners in order dx + 2dy + 4dz.
+// Every op is an IEEE RNE fp16 op (v_pk_mul_f16 / v_pk_fma_f16), so the result is
+// bit-identical to the oracle.  out = F/2 packed pairs.
 template <int F>
 __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table, const LevelDev& L,
-                                             float px, float py, float pz, float acc[F]) {
+                                             float px, float py, float pz, half2v out[F / 2]) {
   constexpr int ESH = F == 4 ? 3 : 2; // log2(entry bytes)
   const float pos[3] = {fmaf(L.scale, px, 0.5f), fmaf(L.scale, py, 0.5f), fmaf(L.scale, pz, 0.5f)};
   uint32_t c0[3], c1[3];
-  float w1[3], w0[3];
+  half2v wa[3]; // (1-w, w) per axis, fp16
 #pragma unroll
   for (int a = 0; a < 3; a++) {
-    w1[a] = __builtin_amdgcn_fractf(pos[a]); // pos >= 0.5: pos - floor(pos), exact
-    w0[a] = 1.0f - w1[a];
-    c0[a] = (uint32_t)(int)pos[a];           // truncation = floor; never exceeds res-1
+    const float w1 = __builtin_amdgcn_fractf(pos[a]); // pos >= 0.5: pos - floor(pos), exact
+    wa[a][0] = (_Float16)(1.0f - w1);
+    wa[a][1] = (_Float16)w1;
+    c0[a] = (uint32_t)(int)pos[a];                    // truncation = floor; never exceeds res-1
     c1[a] = min(c0[a] + 1u, L.res_m1);
   }
   const uint32_t tx[2] = {(c0[0] << ESH) & L.m_b, (c1[0] << ESH) & L.m_b};
@@ -190,25 +194,27 @@ __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table,
   // 24 bits of the multiplier, and only bits below m_b < 2^24 of the product are kept.
   const uint32_t ty[2] = {__umul24(c0[1], L.my_b) & L.m_b, __umul24(c1[1], L.my_b) & L.m_b};
   const uint32_t tz[2] = {(__umul24(c0[2], L.mz_b) & L.m_b) | L.off_b, (__umul24(c1[2], L.mz_b) & L.m_b) | L.off_b};
-  const float wxy[4] = {w0[0] * w0[1], w1[0] * w0[1], w0[0] * w1[1], w1[0] * w1[1]};
-  const float wz[2] = {w0[2], w1[2]};
   Entry<F> v[8];
 #pragma unroll
   for (int c = 0; c < 8; c++) {
     const uint32_t byte_off = tx[c & 1] ^ ty[(c >> 1) & 1] ^ tz[c >> 2];
     v[c] = Entry<F>::load(reinterpret_cast<const char*>(table) + byte_off);
   }
+  // pair weights over x for each (dy, dz): (wx0, wx1) * wy[dy] * wz[dz]
+  half2v wp[4];
 #pragma unroll
-  for (int k = 0; k < F; k++) acc[k] = 0.0f;
+  for (int q = 0; q < 4; q++) {
+    const half2v wy = {wa[1][q & 1], wa[1][q & 1]}, wz = {wa[2][q >> 1], wa[2][q >> 1]};
+    wp[q] = (wa[0] * wy) * wz;
+  }
+#pragma unroll
+  for (int k = 0; k < F / 2; k++) out[k] = half2v{(_Float16)0.0f, (_Float16)0.0f};
 #pragma unroll
   for (int c = 0; c < 8; c++) {
-    const float w = wxy[c & 3] * wz[c >> 2];
+    const _Float16 w = wp[c >> 1][c & 1];
+    const half2v ww = {w, w};
 #pragma unroll
-    for (int k = 0; k < F; k += 2) {
-      const half2v hv = __builtin_bit_cast(half2v, v[c].w[k / 2]);
-      acc[k] = fmaf(w, (float)hv[0], acc[k]);
-      acc[k + 1] = fmaf(w, (float)hv[1], acc[k + 1]);
-    }
+    for (int k = 0; k < F / 2; k++) out[k] = __builtin_elementwise_fma(ww, __builtin_bit_cast(half2v, v[c].w[k]), out[k]);
   }
 }
 
@@ -222,25 +228,18 @@ __device__ __forceinline__ void encode_half(const uint16_t* __restrict__ table, 
   px = clamp01(px);
   py = clamp01(py);
   pz = clamp01(pz);
-  _Float16 out[16];
+  half2v out[8];
 #pragma unroll
   for (int j = 0; j < LH; j++) {
     const LevelDev L = lv[h * LH + j];
-    float acc[F];
-    encode_level<F>(table, L, px, py, pz, acc);
-#pragma unroll
-    for (int k = 0; k < F; k++) {
-      // The feature is DEFINED as fp16(round_fp32(blend)).  Without this barrier hipcc fuses the
-      // last fma with the conversion into v_fma_mixlo/hi_f16, which rounds the exact result once
-      // and differs from the definition in the last fp16 bit for ~1e-4 of the values.
-      asm volatile("" : "+v"(acc[k]));
-      out[j * F + k] = (_Float16)acc[k];
-    }
+    encode_level<F>(table, L, px, py, pz, out + j * (F / 2));
   }
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    b0[k] = out[k];
-    b1[k] = out[8 + k];
+  for (int k = 0; k < 4; k++) {
+    b0[2 * k] = out[k][0];
+    b0[2 * k + 1] = out[k][1];
+    b1[2 * k] = out[4 + k][0];
+    b1[2 * k + 1] = out[4 + k][1];
   }
 }
 

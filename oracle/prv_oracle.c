@@ -67,6 +67,37 @@ float orc_h2f(uint16_t h) {
   return f;
 }
 
+/* double -> binary16, round-to-nearest-even in ONE rounding (used to model fp16 fma/mul exactly:
+ * the exact product/sum of binary16 operands fits a double) */
+uint16_t orc_d2h(double v) {
+  uint64_t x;
+  memcpy(&x, &v, 8);
+  uint16_t sign = (uint16_t)((x >> 48) & 0x8000u);
+  uint64_t absx = x & 0x7fffffffffffffffull;
+  if (absx >= 0x7ff0000000000000ull) return (uint16_t)(sign | 0x7c00u | (absx > 0x7ff0000000000000ull ? 0x200u : 0));
+  int e = (int)(absx >> 52) - 1023;          /* unbiased exponent */
+  uint64_t m = (absx & 0xfffffffffffffull) | (absx >> 52 ? 0x10000000000000ull : 0); /* 53-bit significand */
+  if (absx == 0) return sign;
+  if (e >= 16) return (uint16_t)(sign | 0x7c00u); /* >= 65536 */
+  int shift;                                  /* bits to drop from the 53-bit significand */
+  int he;                                     /* half exponent field */
+  if (e >= -14) { shift = 42; he = e + 15; }  /* normal half: keep 11 bits */
+  else { shift = 42 + (-14 - e); he = 0; }    /* subnormal half: value = r * 2^-24 */
+  if (shift >= 64) return sign;
+  uint64_t r = m >> shift;
+  uint64_t rem = m & ((1ull << shift) - 1ull);
+  uint64_t half = 1ull << (shift - 1);
+  if (rem > half || (rem == half && (r & 1ull))) r++;
+  /* r has up to 11 bits (+carry); assemble: for normals the implicit bit adds to the exponent field */
+  uint32_t out = he ? (uint32_t)(((uint32_t)(he - 1) << 10) + (uint32_t)r) : (uint32_t)r;
+  if (out >= 0x7c00u) out = 0x7c00u; /* rounded up to infinity */
+  return (uint16_t)(sign | out);
+}
+static inline uint16_t h_mul(uint16_t a, uint16_t b) { return orc_d2h((double)orc_h2f(a) * (double)orc_h2f(b)); }
+static inline uint16_t h_fma(uint16_t a, uint16_t b, uint16_t c) {
+  return orc_d2h((double)orc_h2f(a) * (double)orc_h2f(b) + (double)orc_h2f(c));
+}
+
 /* ------------------------------------------------------------------ RNG */
 /* counter-based: value i of stream s under seed; splitmix64 finaliser */
 static uint64_t mix64(uint64_t z) {
@@ -230,26 +261,31 @@ void orc_encode(const orc_field* f, const float p_in[3], uint16_t feat[32]) {
       w[a] = pos - fl;
       c0[a] = (uint32_t)(int)fl;
     }
-    float acc[4] = {0, 0, 0, 0};
+    /* trilinear blend in binary16, as tiny-cuda-nn does for fp16 tables: weights rounded to fp16,
+     * w = fp16(fp16(wx*wy)*wz), acc = fp16 fma(w, v, acc) over the corners in order dx + 2dy + 4dz */
+    uint16_t wh[3][2];
+    for (int a = 0; a < 3; a++) {
+      wh[a][0] = orc_f2h(1.0f - w[a]);
+      wh[a][1] = orc_f2h(w[a]);
+    }
+    uint16_t acc[4] = {0, 0, 0, 0};
     for (int c = 0; c < 8; c++) {
       uint32_t cc[3];
-      float ww[3];
       for (int a = 0; a < 3; a++) {
         uint32_t bit = (c >> a) & 1u;
         uint32_t v = c0[a] + bit;
         cc[a] = v > L->res - 1 ? L->res - 1 : v;
-        ww[a] = bit ? w[a] : 1.0f - w[a];
       }
-      float weight = (ww[0] * ww[1]) * ww[2];
+      uint16_t weight = h_mul(h_mul(wh[0][c & 1], wh[1][(c >> 1) & 1]), wh[2][c >> 2]);
       uint32_t idx;
       if (L->hashed)
         idx = (cc[0] ^ (cc[1] * 2654435761u) ^ (cc[2] * 805459861u)) & (L->size - 1u);
       else
         idx = cc[0] + L->res * (cc[1] + L->res * cc[2]);
       const uint16_t* e = f->table + ((size_t)L->offset + idx) * F;
-      for (int k = 0; k < F; k++) acc[k] = fmaf(weight, orc_h2f(e[k]), acc[k]);
+      for (int k = 0; k < F; k++) acc[k] = h_fma(weight, e[k], acc[k]);
     }
-    for (int k = 0; k < F; k++) feat[l * F + k] = orc_f2h(acc[k]);
+    for (int k = 0; k < F; k++) feat[l * F + k] = acc[k];
   }
 }
 

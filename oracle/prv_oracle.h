@@ -65,6 +65,7 @@ typedef struct {
 
 /* ---- fp16 helpers (IEEE binary16, round-to-nearest-even) ---- */
 uint16_t orc_f2h(float f);
+uint16_t orc_d2h(double v); /* one rounding, for modelling fp16 mul/fma */
 float orc_h2f(uint16_t h);
 
 /* ---- field ---- */

@@ -7,7 +7,7 @@ mkdir -p $OUT
 declare -A S
 S[1]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU"
 S[2]="SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES"
-S[3]="SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM SQ_IFETCH SQ_INSTS_BRANCH"
+S[3]="SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_INST_LEVEL_VMEM SQ_INSTS_VALU SQ_INSTS_MFMA"
 S[4]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
 S[5]="FETCH_SIZE"
 S[6]="WRITE_SIZE"

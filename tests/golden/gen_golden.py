@@ -246,22 +246,21 @@ class FieldNP:
             pos = [f32(np.float64(L["scale"]) * np.float64(p[a]) + 0.5) for a in range(3)]  # fma: exact in f64, one rounding
             c0 = [int(math.floor(x)) for x in pos]
             w = [f32(pos[a] - f32(c0[a])) for a in range(3)]
-            acc = [f32(0)] * F
+            # blend in binary16 (tiny-cuda-nn style): fp16 weights, fp16 products, fp16 fma chain
+            h = np.float16
+            wh = [(h(f32(1.0) - w[a]), h(w[a])) for a in range(3)]
+            acc = [h(0)] * F
             for c in range(8):
-                cc, ww = [], []
-                for a in range(3):
-                    bit = (c >> a) & 1
-                    cc.append(min(c0[a] + bit, L["res"] - 1))
-                    ww.append(w[a] if bit else f32(f32(1.0) - w[a]))
-                weight = f32(f32(ww[0] * ww[1]) * ww[2])
+                cc = [min(c0[a] + ((c >> a) & 1), L["res"] - 1) for a in range(3)]
+                weight = h(np.float32(h(np.float32(wh[0][c & 1]) * np.float32(wh[1][(c >> 1) & 1]))) * np.float32(wh[2][c >> 2]))
                 if L["hashed"]:
                     idx = (cc[0] ^ ((cc[1] * 2654435761) & 0xFFFFFFFF) ^ ((cc[2] * 805459861) & 0xFFFFFFFF)) & (L["size"] - 1)
                 else:
                     idx = cc[0] + L["res"] * (cc[1] + L["res"] * cc[2])
                 e = self.table[(L["offset"] + idx) * F:(L["offset"] + idx) * F + F]
-                for k in range(F):
-                    acc[k] = f32(np.float64(weight) * np.float64(e[k]) + np.float64(acc[k]))  # fmaf
-            feat[l * F:(l + 1) * F] = np.array(acc, np.float32).astype(np.float16)
+                for k in range(F):  # fp16 fma: exact in float64, ONE rounding to binary16
+                    acc[k] = (np.float64(weight) * np.float64(e[k]) + np.float64(acc[k])).astype(np.float16)
+            feat[l * F:(l + 1) * F] = np.array(acc, np.float16)
         return feat
 
     @staticmethod
