@@ -164,6 +164,13 @@ int prv_render_rgba8(prv_ctx* ctx, int model_slot, const prv_camset* cs, const i
 int prv_quantize_rgba8(prv_ctx* ctx, const float* rgba_dev, size_t n_pixels, const float bg[4],
                        uint8_t* out_rgba8_dev);
 
+/* replaces: Perception_3D::precept / precept_thread_process, the reference's CPU render path
+ * (main.cpp:98-284: project -> ray -> OctoMap castRay, max range main.cpp:258).  Per pixel the
+ * first occupied voxel of the model's occupancy grid along the ray: out_cell_dev[n_views*h*w] =
+ * x + R*(y + R*z), or -1 for no hit within max_range (in unit-cube units). */
+int prv_first_hit(prv_ctx* ctx, int model_slot, const prv_camset* cs, const int* view_ids, int n_views,
+                  int width, int height, float max_range, int32_t* out_cell_dev);
+
 /* ---- scores -------------------------------------------------------------- */
 /* replaces: the per-view loops main.cpp:2045-2094 (method 2) / 2105-2158 (method 3).
  * imgs_dev[e] = n_views*pixels_per_view*4 uint8 of ensemble member e. */

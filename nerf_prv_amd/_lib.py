@@ -90,6 +90,7 @@ SIGNATURES = {
     "prv_camset_destroy": (None, [_vp]),
     "prv_render": (_i, [_vp, _i, _vp, _vp, _i, _P(RenderOpts), _vp, _P(Stats)]),
     "prv_render_rgba8": (_i, [_vp, _i, _vp, _vp, _i, _P(RenderOpts), _vp, _P(Stats)]),
+    "prv_first_hit": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, C.c_float, _vp]),
     "prv_quantize_rgba8": (_i, [_vp, _vp, C.c_size_t, _vp, _vp]),
     "prv_score_ensemble_images": (_i, [_vp, _i, _vp, _i, _i, C.c_size_t, _vp]),
     "prv_score_psnr_images": (_i, [_vp, _vp, _vp, _i, C.c_size_t, _vp, _vp]),

@@ -211,6 +211,13 @@ class Context:
                                             _ptr(out), C.byref(st) if want_stats else None))
         return out, st
 
+    def first_hit(self, slot, camset, view_ids, width, height, max_range=1e30):
+        ids = self._ids(camset, view_ids)
+        out = self.torch.empty((len(ids), height, width), dtype=self.torch.int32, device=self.device)
+        self._chk(self.lib.prv_first_hit(self.handle, slot, camset.handle, _ptr(ids), len(ids), width, height,
+                                         float(max_range), _ptr(out)))
+        return out
+
     def quantize_rgba8(self, rgba, background):
         out = self.torch.empty(rgba.shape, dtype=self.torch.uint8, device=self.device)
         bg = np.asarray(background, np.float32)

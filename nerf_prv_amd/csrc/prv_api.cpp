@@ -831,6 +831,28 @@ int prv_render_rgba8(prv_ctx* c, int slot, const prv_camset* cs, const int* view
   return fetch_stats(c, o, n_views, 1, st);
 }
 
+int prv_first_hit(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, int n_views, int W, int H,
+                  float max_range, int32_t* out) {
+  if (!c) return PRV_E_INVALID;
+  int rc;
+  if ((rc = check_model(c, slot)) != PRV_OK) return rc;
+  if (!cs || n_views < 0 || W < 1 || H < 1 || W > 16384 || H > 16384 || (!out && n_views > 0))
+    return fail(c, PRV_E_INVALID, "bad argument");
+  if (n_views == 0) return PRV_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<CamDev> cams(n_views);
+  for (int i = 0; i < n_views; i++) {
+    const int v = view_ids ? view_ids[i] : i;
+    if (v < 0 || v >= (int)cs->cams.size()) return fail(c, PRV_E_INVALID, "view id %d out of range", v);
+    cams[i] = cam_at(cs->cams[v], cs->width, W, H);
+  }
+  if ((rc = ensure(c, c->view_ids, (size_t)n_views * (sizeof(CamDev) + sizeof(int)))) != PRV_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->view_ids.p, cams.data(), (size_t)n_views * sizeof(CamDev), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, launch_first_hit(c->models[slot].dev, (const CamDev*)c->view_ids.p, n_views, W, H, max_range, out, c->stream));
+  return PRV_OK;
+}
+
 int prv_quantize_rgba8(prv_ctx* c, const float* rgba, size_t n, const float bg[4], uint8_t* out) {
   if (!c) return PRV_E_INVALID;
   if (!rgba || !out || !bg) return fail(c, PRV_E_INVALID, "NULL argument");

@@ -237,6 +237,64 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
 template __global__ void render_queue_kernel<2>(RenderParams);
 template __global__ void render_queue_kernel<4>(RenderParams);
 
+// ------------------------------------------------------------------ first-hit ray cast (a13)
+// GPU twin of the reference's CPU render path Perception_3D::precept_thread_process
+// (main.cpp:238-284): per pixel, the first occupied voxel along the ray (there: OctoMap
+// castRay, here: Amanatides-Woo DDA over the occupancy bitfield), max_range like main.cpp:258.
+// out = linear cell index x + R*(y + R*z), or -1.  Same float op order as the oracle.
+__global__ __launch_bounds__(256) void first_hit_kernel(FieldDev fd, const CamDev* __restrict__ cams, int W, int H,
+                                                        float max_range, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W * H) return;
+  const int v = blockIdx.y;
+  const int px = i % W, py = i / W;
+  float o[3], d[3], t0, t1;
+  raygen(cams[v], px, py, 0.5f, 0.5f, o, d);
+  int32_t result = -1;
+  if (ray_aabb(o, d, t0, t1)) {
+    if (t1 > max_range) t1 = max_range;
+    if (t1 > t0) {
+      const int R = fd.occ_res;
+      const float fR = (float)R;
+      const float ts = t0 + 1e-6f;
+      int c[3], step[3];
+      float tmax[3], tdelta[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const float p = clamp01(fmaf(ts, d[a], o[a])) * fR;
+        c[a] = min((int)p, R - 1);
+        if (d[a] > 0.f) {
+          step[a] = 1;
+          tmax[a] = (((float)(c[a] + 1)) / fR - o[a]) / d[a];
+          tdelta[a] = 1.0f / (fR * d[a]);
+        } else if (d[a] < 0.f) {
+          step[a] = -1;
+          tmax[a] = (((float)c[a]) / fR - o[a]) / d[a];
+          tdelta[a] = -1.0f / (fR * d[a]);
+        } else {
+          step[a] = 0;
+          tmax[a] = __builtin_inff();
+          tdelta[a] = __builtin_inff();
+        }
+      }
+      for (;;) {
+        const uint32_t bit = (uint32_t)c[0] + (uint32_t)R * ((uint32_t)c[1] + (uint32_t)R * (uint32_t)c[2]);
+        if ((fd.occ[bit >> 5] >> (bit & 31)) & 1u) {
+          result = (int32_t)bit;
+          break;
+        }
+        const int a = tmax[0] < tmax[1] ? (tmax[0] < tmax[2] ? 0 : 2) : (tmax[1] < tmax[2] ? 1 : 2);
+        const float tm = a == 0 ? tmax[0] : (a == 1 ? tmax[1] : tmax[2]);
+        if (tm > t1) break;
+        if (a == 0) { c[0] += step[0]; tmax[0] += tdelta[0]; if (c[0] < 0 || c[0] >= R) break; }
+        else if (a == 1) { c[1] += step[1]; tmax[1] += tdelta[1]; if (c[1] < 0 || c[1] >= R) break; }
+        else { c[2] += step[2]; tmax[2] += tdelta[2]; if (c[2] < 0 || c[2] >= R) break; }
+      }
+    }
+  }
+  out[(size_t)v * W * H + i] = result;
+}
+
 // ------------------------------------------------------------------ quantise
 
 __global__ __launch_bounds__(256) void quantize_kernel(const float4* __restrict__ in, size_t n,
@@ -497,6 +555,13 @@ hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s) {
     hipLaunchKernelGGL(render_queue_kernel<4>, dim3(n_blocks), dim3(256), 0, s, P);
   else
     hipLaunchKernelGGL(render_queue_kernel<2>, dim3(n_blocks), dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_first_hit(const FieldDev& fd, const CamDev* cams, int n_views, int W, int H, float max_range,
+                            int32_t* out, hipStream_t s) {
+  dim3 grid((unsigned)((W * H + 255) / 256), (unsigned)n_views);
+  hipLaunchKernelGGL(first_hit_kernel, grid, dim3(256), 0, s, fd, cams, W, H, max_range, out);
   return hipGetLastError();
 }
 

@@ -66,6 +66,8 @@ hipError_t launch_repack_level(const uint16_t* canon, uint16_t* phys, const Repa
 
 hipError_t launch_march(const MarchParams& P, int n_views, hipStream_t s);
 hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s);
+hipError_t launch_first_hit(const FieldDev& fd, const CamDev* cams, int n_views, int W, int H, float max_range,
+                            int32_t* out, hipStream_t s);
 hipError_t launch_quantize(const float* in, size_t n, const float bg[4], uint8_t* out, hipStream_t s);
 hipError_t launch_score_ensemble(const EnsembleParams& P, int method, int n_views, int n_blocks, hipStream_t s);
 hipError_t launch_score_psnr(const PsnrParams& P, int n_views, int n_blocks, hipStream_t s);

@@ -237,6 +237,19 @@ def raygen(cam, w, h, spp_index=0):
     return o, d, t
 
 
+def first_hit_image(field, cam, w, h, max_range=1e30):
+    """oracle: linear cell index of the first occupied voxel per pixel, or -1"""
+    out = np.full((h, w), -1, np.int32)
+    R = field.desc.occ_res
+    o, d, cell = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(3, np.int32)
+    for y in range(h):
+        for x in range(w):
+            lib().orc_raygen(C.byref(cam), x, y, C.c_float(0.5), C.c_float(0.5), _p(o), _p(d))
+            if lib().orc_first_hit(field.ptr, _p(o), _p(d), C.c_float(max_range), _p(cell)):
+                out[y, x] = cell[0] + R * (cell[1] + R * cell[2])
+    return out
+
+
 def quantize_rgba8(rgba, bg):
     rgba = np.ascontiguousarray(rgba, np.float32)
     out = np.zeros(rgba.shape, np.uint8)

@@ -196,6 +196,20 @@ def test_score_views_ensemble_and_ranking(ctx, oracle, fields, cams, method, E):
     assert np.array_equal(ctx.rank(rec, ids), oracle.rank(want, ids))
 
 
+def test_first_hit_ray_cast_bit_exact(ctx, oracle, fields, cams):
+    """a13: GPU twin of the reference's CPU ray-caster, integer voxel ids must match exactly"""
+    d_o, d_p, f = fields
+    cs, ocams, w, h = cams
+    got = ctx.first_hit(0, cs, None, w, h).cpu().numpy()
+    for v, oc in enumerate(ocams):
+        want = oracle.first_hit_image(f, oc, w, h)
+        assert np.array_equal(got[v], want)
+        assert (want >= 0).sum() > 50 and (want < 0).sum() > 50  # both hits and misses are exercised
+    near = ctx.first_hit(0, cs, [0], w, h, max_range=1.2).cpu().numpy()[0]  # main.cpp:258 passes a max range
+    want = oracle.first_hit_image(f, ocams[0], w, h, max_range=1.2)
+    assert np.array_equal(near, want) and (near >= 0).sum() < (got[0] >= 0).sum()
+
+
 def test_error_behaviour(ctx, fields, cams):
     cs, ocams, w, h = cams
     with pytest.raises(api.PrvError) as e:
