@@ -92,8 +92,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PRV_FORCE_DIST") == "1"  # the latter: exercise RCCL with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from nerf_prv_amd import api, planner
@@ -132,7 +134,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -148,7 +150,7 @@ def main():
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     tot = torch.tensor([float(evaluated_per_step), float(nominal_per_step), float(rays_per_step)], dtype=torch.float64,
                        device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
@@ -203,10 +205,10 @@ def main():
                 "mfma_tflops": samples_per_launch * 20480 / kernel_s / 1e12,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, tms, scale, offset, fov_x)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

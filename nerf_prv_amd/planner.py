@@ -221,7 +221,7 @@ def gather_records(local, per_rank, n_views, group=None, device=None):
             send = send.to(device)
     else:
         send = local
-    if world == 1:
+    if not dist.is_initialized():
         out = send
     else:
         out = torch.empty(world * per_rank * 16, dtype=torch.uint8, device=send.device)
