@@ -181,6 +181,18 @@ int prv_score_ensemble_images(prv_ctx* ctx, int method, const uint8_t* const* im
 int prv_score_psnr_images(prv_ctx* ctx, const float* rgba_dev, const float* gt_rgba_dev,
                           int n_views, size_t pixels_per_view, const float bg[4],
                           prv_score_record* records_host);
+/* replaces: the per-image metrics of the evaluation block, run.py:257-267:
+ *   A,R = clip(srgb(img)), mse -> psnr = -10 log10(mse), ssim = SSIM(A,R)   (SSIM recipe assumed from
+ *   instant-ngp's scripts/common.py, which the reference does not vendor).
+ * Images: n_views * h * w * 4 float (dev).  psnr_host / ssim_host: n_views doubles each. */
+int prv_evaluate_images(prv_ctx* ctx, const float* rgba_dev, const float* gt_rgba_dev, int n_views,
+                        int width, int height, const float bg[4], double* psnr_host, double* ssim_host);
+/* replaces: the evaluation loop run.py:240-277 for one model: render every listed view at opts,
+ * compare with the reference images, return the MEAN of the per-image PSNRs and SSIMs (run.py:271-272;
+ * what --save_metrics writes as "PSNR\t..\nSSIM\t..", consumed at main.cpp:1957-1961). */
+int prv_evaluate(prv_ctx* ctx, int model_slot, const prv_camset* cs, const int* view_ids, int n_views,
+                 const prv_render_opts* opts, const float* gt_rgba_dev, double* mean_psnr, double* mean_ssim);
+
 /* The whole scoring round of nbv_loop for one shard of views, on the device end to end:
  * render every view with every model slot listed, reduce to one record per view.
  *   methods 2,3: model_slots = the ensemble (main.cpp:2041-2043 + 2045-2094);

@@ -43,6 +43,11 @@ int prvh_write_transforms(const char* path, const prvh_intrinsics* intr, int can
                           const double center[3], const double* init_pos, const int* ids, int n,
                           const char* path_prefix);
 
+/* the metrics file of --save_metrics: "PSNR\t<psnr>\nSSIM\t<ssim>" (run.py:274-277), read back with
+ * fscanf / >> at main.cpp:1957-1961 and NeRF_fit_curve.cpp:103-115 */
+int prvh_write_metrics(const char* path, double psnr, double ssim);
+int prvh_read_metrics(const char* path, double* psnr, double* ssim);
+
 /* ---- config (Share_Data) ---- */
 typedef struct prvh_share_data prvh_share_data;
 /* Share_Data(config, name, num_of_views, id_of_batch, method) (Share_Data.hpp:334) */

@@ -94,6 +94,8 @@ SIGNATURES = {
     "prv_quantize_rgba8": (_i, [_vp, _vp, C.c_size_t, _vp, _vp]),
     "prv_score_ensemble_images": (_i, [_vp, _i, _vp, _i, _i, C.c_size_t, _vp]),
     "prv_score_psnr_images": (_i, [_vp, _vp, _vp, _i, C.c_size_t, _vp, _vp]),
+    "prv_evaluate_images": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "prv_evaluate": (_i, [_vp, _i, _vp, _vp, _i, _P(RenderOpts), _vp, _P(C.c_double), _P(C.c_double)]),
     "prv_score_views": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _P(RenderOpts), _vp, _vp, _vp, _P(Stats)]),
     "prv_rank": (_i, [_vp, _vp, _i, _vp]),
     "prv_argmax": (_i, [_vp, _vp, _i]),

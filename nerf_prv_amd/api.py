@@ -241,6 +241,22 @@ class Context:
         self._chk(self.lib.prv_score_psnr_images(self.handle, _ptr(rgba), _ptr(gt), n_views, npix, _ptr(bg), _ptr(rec)))
         return rec
 
+    def evaluate_images(self, rgba, gt, background=(0, 0, 0, 0)):
+        """per-image PSNR and SSIM (run.py:257-263) -> (psnr[n], ssim[n]) float64"""
+        n, h, w = rgba.shape[0], rgba.shape[1], rgba.shape[2]
+        bg = np.asarray(background, np.float32)
+        ps, ss = np.zeros(n, np.float64), np.zeros(n, np.float64)
+        self._chk(self.lib.prv_evaluate_images(self.handle, _ptr(rgba), _ptr(gt), n, w, h, _ptr(bg), _ptr(ps), _ptr(ss)))
+        return ps, ss
+
+    def evaluate(self, slot, camset, view_ids, opts, gt):
+        """the evaluation loop of run.py:240-277 -> (mean psnr, mean ssim)"""
+        ids = self._ids(camset, view_ids)
+        p, s = C.c_double(), C.c_double()
+        self._chk(self.lib.prv_evaluate(self.handle, slot, camset.handle, _ptr(ids), len(ids), C.byref(opts), _ptr(gt),
+                                        C.byref(p), C.byref(s)))
+        return p.value, s.value
+
     def score_views(self, method, slots, camset, view_ids, opts, gt=None, records_dev=None, to_host=True,
                     want_stats=False):
         ids = self._ids(camset, view_ids)

@@ -924,6 +924,56 @@ int prv_score_psnr_images(prv_ctx* c, const float* rgba, const float* gt, int n_
   return prv_memcpy_d2h(c, rec_host, c->records.p, (size_t)n_views * sizeof(prv_score_record));
 }
 
+int prv_evaluate_images(prv_ctx* c, const float* rgba, const float* gt, int n_views, int W, int H, const float bg[4],
+                        double* psnr_host, double* ssim_host) {
+  if (!c) return PRV_E_INVALID;
+  if (!rgba || !gt || !bg || n_views < 0 || W < 5 || H < 5) return fail(c, PRV_E_INVALID, "bad argument (images must be at least 5x5)");
+  if (n_views == 0) return PRV_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t npix = (size_t)W * H;
+  int rc;
+  if (psnr_host) {
+    std::vector<prv_score_record> rec(n_views);
+    if ((rc = prv_score_psnr_images(c, rgba, gt, n_views, npix, bg, rec.data())) != PRV_OK) return rc;
+    // the record carries psnr as float; recompute in double from the score (= -psnr) for the metrics file
+    for (int i = 0; i < n_views; i++) psnr_host[i] = -rec[i].score;
+  }
+  if (ssim_host) {
+    const int nblk = score_blocks(npix);
+    if ((rc = ensure(c, c->dbg[0], (size_t)n_views * npix * 4)) != PRV_OK || (rc = ensure(c, c->dbg[1], (size_t)n_views * npix * 4)) != PRV_OK ||
+        (rc = ensure(c, c->partial, (size_t)n_views * nblk * 2 * sizeof(double))) != PRV_OK ||
+        (rc = ensure(c, c->dbg[2], (size_t)n_views * sizeof(double))) != PRV_OK)
+      return rc;
+    HIPCHK(c, launch_ssim(rgba, gt, n_views, W, H, bg, (float*)c->dbg[0].p, (float*)c->dbg[1].p, (double*)c->partial.p, nblk,
+                          (double*)c->dbg[2].p, c->stream));
+    if ((rc = prv_memcpy_d2h(c, ssim_host, c->dbg[2].p, (size_t)n_views * sizeof(double))) != PRV_OK) return rc;
+  }
+  return PRV_OK;
+}
+
+int prv_evaluate(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, int n_views, const prv_render_opts* o,
+                 const float* gt, double* mean_psnr, double* mean_ssim) {
+  if (!c) return PRV_E_INVALID;
+  int rc;
+  if ((rc = check_model(c, slot)) != PRV_OK || (rc = check_opts(c, o)) != PRV_OK) return rc;
+  if (!cs || !gt || n_views < 1) return fail(c, PRV_E_INVALID, "bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t npix = (size_t)o->width * o->height;
+  if ((rc = ensure(c, c->img_f32, (size_t)n_views * npix * 16)) != PRV_OK) return rc;
+  if ((rc = render_views(c, slot, cs, view_ids, n_views, o, (float*)c->img_f32.p, nullptr, true)) != PRV_OK) return rc;
+  std::vector<double> ps(n_views), ss(n_views);
+  if ((rc = prv_evaluate_images(c, (const float*)c->img_f32.p, gt, n_views, o->width, o->height, o->background, ps.data(), ss.data())) != PRV_OK)
+    return rc;
+  double tp = 0, ts = 0; // totpsnr / totssim of run.py:261-264, in image order
+  for (int i = 0; i < n_views; i++) {
+    tp += ps[i];
+    ts += ss[i];
+  }
+  if (mean_psnr) *mean_psnr = tp / n_views;
+  if (mean_ssim) *mean_ssim = ts / n_views;
+  return PRV_OK;
+}
+
 int prv_score_views(prv_ctx* c, int method, const int* model_slots, int n_models, const prv_camset* cs,
                     const int* view_ids, int n_views, const prv_render_opts* o, const float* gt,
                     prv_score_record* rec_host, prv_score_record* rec_dev, prv_stats* st) {

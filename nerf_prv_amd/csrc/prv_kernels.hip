@@ -17,6 +17,8 @@
 // Built with -ffp-contract=off: see prv_device.hpp for the arithmetic contract.
 #include "prv_kernels.hpp"
 
+#include <algorithm>
+
 #ifndef PRV_ABLATE
 #define PRV_ABLATE 0 // dev-only timing ablations: 1 no gather, 2 no MLP, 4 no compositing math (wrong pixels!)
 #endif
@@ -394,6 +396,85 @@ __global__ __launch_bounds__(256) void score_psnr_kernel(PsnrParams P) {
   }
 }
 
+// ---- SSIM of run.py:260 (recipe assumed from upstream common.py; see oracle orc_ssim)
+__device__ __forceinline__ float ssim_lum(const float4 p, const float bg[4]) {
+  const float rem = 1.0f - p.w;
+  const float c[3] = {p.x, p.y, p.z};
+  const float kw[3] = {0.2126f, 0.7152f, 0.0722f};
+  float l = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float v = fmaf(rem, bg[k], c[k]);
+    v = fminf(fmaxf(linear_to_srgb(v), 0.0f), 1.0f);
+    l = fmaf(kw[k], powf(fmaxf(v, 0.0f), 0.4545454545f), l);
+  }
+  return l;
+}
+
+__global__ __launch_bounds__(256) void ssim_lum_kernel(const float4* __restrict__ img, const float4* __restrict__ gt,
+                                                       size_t n, float b0, float b1, float b2, float b3,
+                                                       float* __restrict__ la, float* __restrict__ lb) {
+  const float bg[4] = {b0, b1, b2, b3};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    la[i] = ssim_lum(img[i], bg);
+    lb[i] = ssim_lum(gt[i], bg);
+  }
+}
+
+__global__ __launch_bounds__(256) void ssim_map_kernel(const float* __restrict__ la_all, const float* __restrict__ lb_all,
+                                                       int W, int H, double* __restrict__ partial) {
+  __shared__ double sm[4];
+  const int v = blockIdx.y;
+  const float* la = la_all + (size_t)v * W * H;
+  const float* lb = lb_all + (size_t)v * W * H;
+  const int ow = W - 4, oh = H - 4;
+  const float tap[5] = {0.120078f, 0.233881f, 0.292082f, 0.233881f, 0.120078f};
+  const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+  double acc = 0.0;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < ow * oh; p += gridDim.x * 256) {
+    const int x = p % ow, y = p / ow;
+    float r[5][5]; // per window row: blurred a, b, aa, bb, ab
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      float sa = 0.f, sb = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const float a = la[(size_t)(y + i) * W + (x + j)], b = lb[(size_t)(y + i) * W + (x + j)];
+        sa = fmaf(tap[j], a, sa);
+        sb = fmaf(tap[j], b, sb);
+        saa = fmaf(tap[j], a * a, saa);
+        sbb = fmaf(tap[j], b * b, sbb);
+        sab = fmaf(tap[j], a * b, sab);
+      }
+      r[i][0] = sa; r[i][1] = sb; r[i][2] = saa; r[i][3] = sbb; r[i][4] = sab;
+    }
+    float q[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 5; i++) s = fmaf(tap[i], r[i][k], s);
+      q[k] = s;
+    }
+    const float mA = q[0], mB = q[1];
+    const float sA = q[2] - mA * mA, sB = q[3] - mB * mB, sAB = q[4] - mA * mB;
+    const float p1 = (2.0f * mA * mB + c1) / (mA * mA + mB * mB + c1);
+    const float p2 = (2.0f * sAB + c2) / (sA + sB + c2);
+    acc += (double)(p1 * p2);
+  }
+  const double s = block_reduce_sum(acc, sm);
+  if (threadIdx.x == 0) partial[(size_t)v * gridDim.x + blockIdx.x] = s;
+}
+
+__global__ void ssim_finalize_kernel(const double* __restrict__ partial, int n_views, int n_blocks, double count,
+                                     double* __restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_views) return;
+  double s = 0.0;
+  for (int b = 0; b < n_blocks; b++) s += partial[(size_t)v * n_blocks + b];
+  out[v] = s / count;
+}
+
 // one thread per view: sum the block partials in block order, emit the record
 __global__ void score_finalize_kernel(const double* __restrict__ partial, int n_views, int n_blocks,
                                       int method, size_t pixels_per_view,
@@ -586,6 +667,18 @@ hipError_t launch_score_ensemble(const EnsembleParams& P, int method, int n_view
 hipError_t launch_score_psnr(const PsnrParams& P, int n_views, int n_blocks, hipStream_t s) {
   dim3 grid((unsigned)n_blocks, (unsigned)n_views);
   hipLaunchKernelGGL(score_psnr_kernel, grid, dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_ssim(const float* img, const float* gt, int n_views, int W, int H, const float bg[4], float* la,
+                       float* lb, double* partial, int n_blocks, double* out, hipStream_t s) {
+  const size_t n = (size_t)n_views * W * H;
+  unsigned blocks = (unsigned)std::min<size_t>(4096, (n + 255) / 256);
+  hipLaunchKernelGGL(ssim_lum_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(img),
+                     reinterpret_cast<const float4*>(gt), n, bg[0], bg[1], bg[2], bg[3], la, lb);
+  hipLaunchKernelGGL(ssim_map_kernel, dim3((unsigned)n_blocks, (unsigned)n_views), dim3(256), 0, s, la, lb, W, H, partial);
+  hipLaunchKernelGGL(ssim_finalize_kernel, dim3((unsigned)((n_views + 63) / 64)), dim3(64), 0, s, partial, n_views,
+                     n_blocks, (double)(W - 4) * (double)(H - 4), out);
   return hipGetLastError();
 }
 

@@ -71,6 +71,8 @@ hipError_t launch_first_hit(const FieldDev& fd, const CamDev* cams, int n_views,
 hipError_t launch_quantize(const float* in, size_t n, const float bg[4], uint8_t* out, hipStream_t s);
 hipError_t launch_score_ensemble(const EnsembleParams& P, int method, int n_views, int n_blocks, hipStream_t s);
 hipError_t launch_score_psnr(const PsnrParams& P, int n_views, int n_blocks, hipStream_t s);
+hipError_t launch_ssim(const float* img, const float* gt, int n_views, int W, int H, const float bg[4], float* la,
+                       float* lb, double* partial, int n_blocks, double* out, hipStream_t s);
 hipError_t launch_score_finalize(const double* partial, int n_views, int n_blocks, int method,
                                  size_t pixels_per_view, prv_score_record* rec, hipStream_t s);
 hipError_t launch_synth_table(uint16_t* table, size_t n, uint64_t seed, float amp, hipStream_t s);

@@ -106,6 +106,29 @@ int prvh_write_transforms(const char* path, const prvh_intrinsics* in, int candi
   return write_text(path, prvjson::to_styled_string(root)) ? 0 : -3;
 }
 
+int prvh_write_metrics(const char* path, double psnr, double ssim) {
+  if (!path) return -1;
+  char buf[128];
+  // python's str(float) is the shortest round-trip form; %.17g round-trips too and every reader
+  // on the path parses with strtod
+  snprintf(buf, sizeof(buf), "PSNR\t%.17g\nSSIM\t%.17g", psnr, ssim);
+  return write_text(path, buf) ? 0 : -3;
+}
+
+int prvh_read_metrics(const char* path, double* psnr, double* ssim) {
+  if (!path) return -1;
+  std::ifstream f(path);
+  if (!f.is_open()) return -3;
+  std::string name;
+  double value;
+  int got = 0;
+  while (f >> name >> value) { // main.cpp:1958-1961
+    if (name == "PSNR" && psnr) { *psnr = value; got |= 1; }
+    if (name == "SSIM" && ssim) { *ssim = value; got |= 2; }
+  }
+  return got == 3 ? 0 : -3;
+}
+
 prvh_share_data* prvh_share_data_create(const char* yaml, const char* name, int num_of_views, int id_of_batch, int method) {
   auto sd = std::make_shared<Share_Data>(yaml ? yaml : "", name ? name : "", num_of_views, id_of_batch, method);
   if (!sd->ok) {

@@ -39,6 +39,8 @@ HOST_SIGNATURES = {
     "prvh_hemisphere_read": (_i, [C.c_char_p, _i, _vp]),
     "prvh_hemisphere_generate": (_i, [_i, _vp]),
     "prvh_write_transforms": (_i, [C.c_char_p, C.POINTER(Intrinsics), _i, _d, _i, _d, _vp, _vp, _vp, _i, C.c_char_p]),
+    "prvh_write_metrics": (_i, [C.c_char_p, _d, _d]),
+    "prvh_read_metrics": (_i, [C.c_char_p, C.POINTER(_d), C.POINTER(_d)]),
     "prvh_share_data_create": (_vp, [C.c_char_p, C.c_char_p, _i, _i, _i]),
     "prvh_share_data_destroy": (None, [_vp]),
     "prvh_share_data_error": (C.c_char_p, []),
@@ -134,6 +136,18 @@ def write_transforms(path, intr, positions, center, predicted_size, ids=None, ca
                                       float(predicted_size), _p(c), _p(pos), idp, len(pos), path_prefix.encode())
     if rc != 0:
         raise IOError(f"cannot write {path} (rc={rc})")
+
+
+def write_metrics(path, psnr, ssim):
+    if host().prvh_write_metrics(str(path).encode(), float(psnr), float(ssim)) != 0:
+        raise IOError(f"cannot write {path}")
+
+
+def read_metrics(path):
+    p, s = C.c_double(), C.c_double()
+    if host().prvh_read_metrics(str(path).encode(), C.byref(p), C.byref(s)) != 0:
+        raise IOError(f"cannot read metrics from {path}")
+    return p.value, s.value
 
 
 class ShareData:

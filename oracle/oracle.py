@@ -82,6 +82,7 @@ def lib():
         L.orc_score_ensemble_rgbdensity.restype = C.c_double
         L.orc_score_ensemble_rgbdensity.argtypes = [vp, C.c_int, C.c_size_t]
         L.orc_score_psnr_coverage.argtypes = [vp, vp, C.c_size_t, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_ssim.restype, L.orc_ssim.argtypes = C.c_double, [vp, vp, C.c_int, C.c_int, vp]
         L.orc_rank.argtypes = [vp, vp, C.c_int, vp]
         L.orc_argmax.restype, L.orc_argmax.argtypes = C.c_int, [vp, vp, C.c_int]
         L.orc_first_hit.argtypes = [C.POINTER(Field), vp, vp, C.c_float, vp]
@@ -280,6 +281,12 @@ def score_psnr_coverage(rgba, gt, bg=(0, 0, 0, 0)):
     p, c = C.c_double(), C.c_double()
     lib().orc_score_psnr_coverage(_p(a), _p(g), a.size // 4, _p(b), C.byref(p), C.byref(c))
     return p.value, c.value
+
+
+def ssim(rgba, gt, bg=(0, 0, 0, 0)):
+    a, g = np.ascontiguousarray(rgba, np.float32), np.ascontiguousarray(gt, np.float32)
+    b = np.asarray(bg, np.float32)
+    return lib().orc_ssim(_p(a), _p(g), a.shape[1], a.shape[0], _p(b))
 
 
 def rank(scores, ids):

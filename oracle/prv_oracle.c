@@ -772,6 +772,62 @@ void orc_score_psnr_coverage(const float* rgba, const float* gt, size_t npix, co
   *coverage = cov / (double)npix;
 }
 
+/* SSIM as run.py:260 calls it: compute_error("SSIM", A, R) on the sRGB-clipped images.
+ * ASSUMED from upstream scripts/common.py (absent from the tree, unpinned): luminance
+ * 0.2126 r' + 0.7152 g' + 0.0722 b' with c' = max(0,c)^0.4545454545, separable 5-tap blur
+ * [0.120078 0.233881 0.292082 0.233881 0.120078] over the valid region, c1 = 0.01^2,
+ * c2 = 0.03^2, mean of the SSIM map.  float32 arithmetic, taps accumulated in ascending order. */
+static const float kSsimTap[5] = {0.120078f, 0.233881f, 0.292082f, 0.233881f, 0.120078f};
+static float ssim_lum(const float* rgba, const float bg[4]) {
+  float rem = 1.0f - rgba[3];
+  float l = 0.0f;
+  static const float kw[3] = {0.2126f, 0.7152f, 0.0722f};
+  for (int k = 0; k < 3; k++) {
+    float c = fmaf(rem, bg[k], rgba[k]);
+    c = fminf(fmaxf(orc_linear_to_srgb(c), 0.0f), 1.0f); /* A / R of run.py:257-258 */
+    l = fmaf(kw[k], powf(fmaxf(c, 0.0f), 0.4545454545f), l);
+  }
+  return l;
+}
+static float ssim_blur(const float* img, int w, int x, int y) { /* img = 5 rows window origin */
+  float rows[5];
+  for (int i = 0; i < 5; i++) {
+    float acc = 0.0f;
+    for (int j = 0; j < 5; j++) acc = fmaf(kSsimTap[j], img[(size_t)(y + i) * w + (x + j)], acc);
+    rows[i] = acc;
+  }
+  float acc = 0.0f;
+  for (int i = 0; i < 5; i++) acc = fmaf(kSsimTap[i], rows[i], acc);
+  return acc;
+}
+double orc_ssim(const float* rgba, const float* gt, int w, int h, const float bg[4]) {
+  if (w < 5 || h < 5) return 0.0;
+  size_t n = (size_t)w * h;
+  float* la = (float*)malloc(n * 5 * sizeof(float));
+  float *lb = la + n, *aa = lb + n, *bb = aa + n, *ab = bb + n;
+  for (size_t i = 0; i < n; i++) {
+    la[i] = ssim_lum(rgba + i * 4, bg);
+    lb[i] = ssim_lum(gt + i * 4, bg);
+    aa[i] = la[i] * la[i];
+    bb[i] = lb[i] * lb[i];
+    ab[i] = la[i] * lb[i];
+  }
+  const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+  double sum = 0.0;
+  for (int y = 0; y + 4 < h; y++)
+    for (int x = 0; x + 4 < w; x++) {
+      float mA = ssim_blur(la, w, x, y), mB = ssim_blur(lb, w, x, y);
+      float sA = ssim_blur(aa, w, x, y) - mA * mA;
+      float sB = ssim_blur(bb, w, x, y) - mB * mB;
+      float sAB = ssim_blur(ab, w, x, y) - mA * mB;
+      float p1 = (2.0f * mA * mB + c1) / (mA * mA + mB * mB + c1);
+      float p2 = (2.0f * sAB + c2) / (sA + sB + c2);
+      sum += (double)(p1 * p2);
+    }
+  free(la);
+  return sum / (double)((size_t)(w - 4) * (h - 4));
+}
+
 /* arg-max with strict '>' over ascending ids, initial best -1e100 (main.cpp:1971, 2088-2091) */
 int orc_argmax(const double* scores, const int* ids, int n) {
   double best = -1e100;

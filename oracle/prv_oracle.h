@@ -127,6 +127,8 @@ double orc_score_ensemble_rgbdensity(const uint8_t* const* imgs, int E, size_t n
 /* run.py:257-263 (PSNR of sRGB-clipped images) + mean opacity */
 void orc_score_psnr_coverage(const float* rgba, const float* gt_rgba, size_t npix,
                              const float bg[4], double* psnr, double* coverage);
+/* mean SSIM of two images (run.py:260; recipe assumed from upstream common.py) */
+double orc_ssim(const float* rgba, const float* gt_rgba, int w, int h, const float bg[4]);
 /* full ranking: stable sort by (-score, id)  (arg-max rule main.cpp:2088-2091) */
 void orc_rank(const double* scores, const int* ids, int n, int* order);
 int orc_argmax(const double* scores, const int* ids, int n);

@@ -131,6 +131,28 @@ def psnr_coverage_np(img, gt):
     return float(-10.0 * math.log10(mse)), float(img[..., 3].astype(np.float64).mean())
 
 
+def ssim_np(img, gt):
+    """mean SSIM as instant-ngp's scripts/common.py computes it (ASSUMED recipe, see oracle orc_ssim)"""
+    k = np.array([0.120078, 0.233881, 0.292082, 0.233881, 0.120078], np.float32)
+
+    def lum(x):
+        c = np.clip(srgb_np(x[..., :3]), 0, 1).astype(np.float32)
+        c = np.power(np.maximum(c, f32(0)), f32(0.4545454545)).astype(np.float32)
+        return (f32(0.2126) * c[..., 0] + f32(0.7152) * c[..., 1] + f32(0.0722) * c[..., 2]).astype(np.float32)
+
+    def blur(a):
+        h, w = a.shape
+        t = sum(k[j] * a[:, j:w - 4 + j] for j in range(5)).astype(np.float32)
+        return sum(k[i] * t[i:h - 4 + i, :] for i in range(5)).astype(np.float32)
+
+    a, b = lum(img), lum(gt)
+    mA, mB = blur(a), blur(b)
+    sA, sB, sAB = blur(a * a) - mA * mA, blur(b * b) - mB * mB, blur(a * b) - mA * mB
+    c1, c2 = f32(0.01) ** 2, f32(0.03) ** 2
+    m = ((f32(2) * mA * mB + c1) / (mA * mA + mB * mB + c1)) * ((f32(2) * sAB + c2) / (sA + sB + c2))
+    return float(m.astype(np.float64).mean())
+
+
 def quantize_np(rgba, bg):
     rgba = np.asarray(rgba, np.float32)
     bg = np.asarray(bg, np.float32)
@@ -159,6 +181,10 @@ def gen_scores():
     gt = np.clip(img + rng.normal(size=img.shape).astype(np.float32) * 0.05, 0, 1).astype(np.float32)
     p, c = psnr_coverage_np(img, gt)
     out["psnr"] = {"img": img.tolist(), "gt": gt.tolist(), "psnr": p, "coverage": c}
+    opaque_img, opaque_gt = img.copy(), gt.copy()
+    opaque_img[..., 3] = 1
+    opaque_gt[..., 3] = 1
+    out["ssim"] = {"value": ssim_np(opaque_img, opaque_gt), "self": ssim_np(opaque_img, opaque_img)}
     q_in = rng.random((64, 4)).astype(np.float32)
     q_in[:4] = [[0, 0, 0, 0], [1, 1, 1, 1], [0.001, 0.002, 0.003, 0.5], [0.2, 0.1, 0.05, 0.25]]
     out["quantize"] = {"rgba": q_in.tolist(), "bg_opaque": quantize_np(q_in, [0, 0, 0, 1]).tolist(),

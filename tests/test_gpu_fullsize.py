@@ -89,3 +89,28 @@ def test_ensemble_round_at_reference_candidate_size(ctx, oracle, scene):
         want = np.array([fn([im[v] for im in imgs]) for v in range(8)])
         np.testing.assert_allclose(rec["score"], want, rtol=1e-12)  # same bytes in -> fp64 round-off out
         assert (imgs[0][..., 3] == 255).all()  # opaque background: alpha carries nothing
+
+
+def test_evaluation_path_psnr_ssim_and_metrics_file(ctx, oracle, scene, tmp_path):
+    """run.py:226-277 on the device: spp 8 snapped to pixel centres == spp 1, min_T 1e-4, black opaque
+    background; mean PSNR / SSIM over the test views; the metrics file other tools read"""
+    desc, cams, (tms, scale, offset) = scene
+    w, h = 200, 112  # a 16:9 test size; the oracle's SSIM is a scalar loop
+    small = ctx.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+    bg = (0.0, 0.0, 0.0, 1.0)  # run.py:226
+    opts = api.render_opts(w, h, S, 1, 1e-4, background=bg)
+    gt, _ = ctx.render(1, small, None, opts)
+    img, _ = ctx.render(0, small, None, opts)
+    ps, ss = ctx.evaluate_images(img, gt, bg)
+    x, g = img.cpu().numpy(), gt.cpu().numpy()
+    for v in range(len(x)):
+        want_p, _ = oracle.score_psnr_coverage(x[v], g[v], bg)
+        np.testing.assert_allclose(ps[v], want_p, rtol=1e-6)
+        np.testing.assert_allclose(ss[v], oracle.ssim(x[v], g[v], bg), rtol=1e-5)
+    same_p, same_s = ctx.evaluate_images(img, img, bg)
+    np.testing.assert_allclose(same_s, 1.0, atol=1e-6)
+    mp, ms = ctx.evaluate(0, small, None, opts, gt)
+    assert abs(mp - ps.mean()) < 1e-9 and abs(ms - ss.mean()) < 1e-12
+    path = tmp_path / "64.txt"
+    planner.write_metrics(path, mp, ms)
+    assert planner.read_metrics(path) == (mp, ms)

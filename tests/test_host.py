@@ -168,3 +168,17 @@ def test_nbv_loop_random_method_and_error_path(config):
     sd3 = planner.ShareData(config, "oneshot", -1, -1, 1)
     with pytest.raises(RuntimeError):
         sd3.nbv_loop([1e-10] * 3, 0.1, lambda *a: [0])  # RandomOneshot needs the TSP planner: out of scope
+
+
+def test_metrics_file_format_and_roundtrip(tmp_path):
+    """--save_metrics file: 'PSNR\\t<v>\\nSSIM\\t<v>' (run.py:274-277), read back like main.cpp:1957-1961"""
+    path = tmp_path / "37.txt"
+    planner.write_metrics(path, 31.415926535897931, 0.9731)
+    text = open(path).read()
+    lines = text.split("\n")
+    assert len(lines) == 2 and lines[0].startswith("PSNR\t") and lines[1].startswith("SSIM\t") and not text.endswith("\n")
+    assert float(lines[0].split("\t")[1]) == 31.415926535897931 and float(lines[1].split("\t")[1]) == 0.9731
+    assert planner.read_metrics(path) == (31.415926535897931, 0.9731)
+    (tmp_path / "bad.txt").write_text("PSNR\t1.0")
+    with pytest.raises(IOError):
+        planner.read_metrics(tmp_path / "bad.txt")

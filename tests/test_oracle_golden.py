@@ -63,6 +63,12 @@ def test_scores_against_numpy(oracle):
     psnr, cov = oracle.score_psnr_coverage(np.array(p["img"], np.float32), np.array(p["gt"], np.float32))
     np.testing.assert_allclose(psnr, p["psnr"], rtol=1e-6)  # powf: libm vs numpy
     np.testing.assert_allclose(cov, p["coverage"], rtol=1e-12)
+    a = np.array(p["img"], np.float32)
+    b = np.array(p["gt"], np.float32)
+    a[..., 3] = 1
+    b[..., 3] = 1
+    np.testing.assert_allclose(oracle.ssim(a, b), g["ssim"]["value"], rtol=1e-5)  # fma vs mul+add, powf
+    assert abs(oracle.ssim(a, a) - 1.0) < 1e-6 and abs(g["ssim"]["self"] - 1.0) < 1e-6
     q = g["quantize"]
     rgba = np.array(q["rgba"], np.float32)
     for key, bg in (("bg_opaque", (0, 0, 0, 1)), ("bg_clear", (0, 0, 0, 0))):
