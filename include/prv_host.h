@@ -48,6 +48,15 @@ int prvh_write_transforms(const char* path, const prvh_intrinsics* intr, int can
 int prvh_write_metrics(const char* path, double psnr, double ssim);
 int prvh_read_metrics(const char* path, double* psnr, double* ssim);
 
+/* ---- stopping criterion (Origin_scripts/NeRF_fit_curve.cpp:56-212) ---- */
+/* fit y = y0 + A*Phi((ln x - xc)/w) to (views, psnr); params_out = {y0, A, xc, w}; converged_out as in
+ * label.txt (solver outcome AND no data point above max_psnr, :143-151).  Returns 0 or < 0. */
+int prvh_fit_curve(const double* x, const double* y, int n, double max_psnr, double params_out[4], int* converged_out);
+/* labels of :186-206 from a fitted curve: gap_out[11] (k = 0..10 %), gradient_out[20] (g = 0.01..0.20) */
+void prvh_fit_labels(const double params[4], double max_psnr, int gap_out[11], int gradient_out[20]);
+/* label.txt in the reference's format */
+int prvh_write_label(const char* path, const double params[4], int converged, double max_psnr);
+
 /* ---- config (Share_Data) ---- */
 typedef struct prvh_share_data prvh_share_data;
 /* Share_Data(config, name, num_of_views, id_of_batch, method) (Share_Data.hpp:334) */

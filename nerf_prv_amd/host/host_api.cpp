@@ -4,6 +4,7 @@
 #include <cstring>
 #include <string>
 
+#include "fit_curve.hpp"
 #include "planner.hpp"
 
 using namespace prvhost;
@@ -127,6 +128,30 @@ int prvh_read_metrics(const char* path, double* psnr, double* ssim) {
     if (name == "SSIM" && ssim) { *ssim = value; got |= 2; }
   }
   return got == 3 ? 0 : -3;
+}
+
+int prvh_fit_curve(const double* x, const double* y, int n, double max_psnr, double params_out[4], int* converged_out) {
+  if (!x || !y || n < 4 || !params_out) return -1;
+  const FitResult r = fit_lognormal_cdf(std::vector<double>(x, x + n), std::vector<double>(y, y + n), max_psnr);
+  params_out[0] = r.f.y0; params_out[1] = r.f.A; params_out[2] = r.f.xc; params_out[3] = r.f.w;
+  if (converged_out) *converged_out = r.converged ? 1 : 0;
+  return std::isfinite(r.rss) ? 0 : -2;
+}
+
+void prvh_fit_labels(const double params[4], double max_psnr, int gap_out[11], int gradient_out[20]) {
+  LognormalCDF f;
+  f.y0 = params[0]; f.A = params[1]; f.xc = params[2]; f.w = params[3];
+  const Labels L = make_labels(f, max_psnr);
+  if (gap_out) std::copy(L.gap, L.gap + 11, gap_out);
+  if (gradient_out) std::copy(L.gradient, L.gradient + 20, gradient_out);
+}
+
+int prvh_write_label(const char* path, const double params[4], int converged, double max_psnr) {
+  if (!path || !params) return -1;
+  FitResult r;
+  r.f.y0 = params[0]; r.f.A = params[1]; r.f.xc = params[2]; r.f.w = params[3];
+  r.converged = converged != 0;
+  return write_label_file(path, r, max_psnr) ? 0 : -3;
 }
 
 prvh_share_data* prvh_share_data_create(const char* yaml, const char* name, int num_of_views, int id_of_batch, int method) {

@@ -41,6 +41,9 @@ HOST_SIGNATURES = {
     "prvh_write_transforms": (_i, [C.c_char_p, C.POINTER(Intrinsics), _i, _d, _i, _d, _vp, _vp, _vp, _i, C.c_char_p]),
     "prvh_write_metrics": (_i, [C.c_char_p, _d, _d]),
     "prvh_read_metrics": (_i, [C.c_char_p, C.POINTER(_d), C.POINTER(_d)]),
+    "prvh_fit_curve": (_i, [_vp, _vp, _i, _d, _vp, C.POINTER(_i)]),
+    "prvh_fit_labels": (None, [_vp, _d, _vp, _vp]),
+    "prvh_write_label": (_i, [C.c_char_p, _vp, _i, _d]),
     "prvh_share_data_create": (_vp, [C.c_char_p, C.c_char_p, _i, _i, _i]),
     "prvh_share_data_destroy": (None, [_vp]),
     "prvh_share_data_error": (C.c_char_p, []),
@@ -148,6 +151,30 @@ def read_metrics(path):
     if host().prvh_read_metrics(str(path).encode(), C.byref(p), C.byref(s)) != 0:
         raise IOError(f"cannot read metrics from {path}")
     return p.value, s.value
+
+
+def fit_curve(views, psnr, max_psnr):
+    """PSNR-vs-#views LognormalCDF fit -> (params[y0,A,xc,w], converged)"""
+    x, y = np.ascontiguousarray(views, np.float64), np.ascontiguousarray(psnr, np.float64)
+    out, conv = np.zeros(4, np.float64), C.c_int()
+    rc = host().prvh_fit_curve(_p(x), _p(y), len(x), float(max_psnr), _p(out), C.byref(conv))
+    if rc != 0:
+        raise ValueError(f"curve fit failed rc={rc}")
+    return out, bool(conv.value)
+
+
+def fit_labels(params, max_psnr):
+    """-> (gap[11] view counts for 0..10 %, gradient[20] view counts for 0.01..0.20)"""
+    p = np.ascontiguousarray(params, np.float64)
+    gap, grad = np.zeros(11, np.int32), np.zeros(20, np.int32)
+    host().prvh_fit_labels(_p(p), float(max_psnr), _p(gap), _p(grad))
+    return gap, grad
+
+
+def write_label(path, params, converged, max_psnr):
+    p = np.ascontiguousarray(params, np.float64)
+    if host().prvh_write_label(str(path).encode(), _p(p), int(converged), float(max_psnr)) != 0:
+        raise IOError(f"cannot write {path}")
 
 
 class ShareData:

@@ -182,3 +182,43 @@ def test_metrics_file_format_and_roundtrip(tmp_path):
     (tmp_path / "bad.txt").write_text("PSNR\t1.0")
     with pytest.raises(IOError):
         planner.read_metrics(tmp_path / "bad.txt")
+
+
+def test_stopping_criterion_fit_and_labels(tmp_path):
+    """NeRF_fit_curve.cpp:119-206: LognormalCDF fit of PSNR vs #views, gap / gradient labels, label.txt"""
+    from scipy.optimize import curve_fit
+    from scipy.stats import norm
+
+    model = lambda x, y0, A, xc, w: y0 + A * norm.cdf((np.log(x) - xc) / w)
+    true = (14.0, 16.5, 1.9, 0.85)
+    x = np.arange(3, 51, 2, dtype=np.float64)  # 3..49 step 2 (ShapeNet_view_num_max/add, :41-42)
+    rng = np.random.default_rng(4)
+    y = model(x, *true) + rng.normal(0, 0.05, x.shape)
+    max_psnr = float(model(100.0, *true)) + 0.2
+    params, conv = planner.fit_curve(x, y, max_psnr)
+    assert conv
+    ref, _ = curve_fit(model, x, y, p0=(y.min(), y.max() - y.min(), 2.0, 1.0), maxfev=20000)
+    xs = np.arange(3, 101, dtype=np.float64)
+    np.testing.assert_allclose(model(xs, *params), model(xs, *ref), atol=2e-3)  # same least-squares curve
+    assert np.abs(model(xs, *params) - model(xs, *true)).max() < 0.15
+    gap, grad = planner.fit_labels(params, max_psnr)
+    fit_y = model(xs, *params)
+    for k in range(11):  # literal restatement of :186-195
+        idx = np.nonzero(fit_y / max_psnr >= 1.0 - 0.01 * k)[0]
+        assert gap[k] == (idx[0] + 3 if len(idx) else -1)
+    assert list(gap) == sorted(gap, reverse=True) or gap[0] == -1  # a looser gap is reached no later
+    d = np.diff(fit_y)
+    for gi in range(20):  # :197-206
+        idx = np.nonzero(d <= 0.01 * (gi + 1) + 1e-12)[0]
+        assert grad[gi] == (idx[0] + 4 if len(idx) else -1)
+    # a data point above the 100-view PSNR marks the object as not converged (:149-151)
+    _, conv2 = planner.fit_curve(x, y, float(y.max()) - 0.1)
+    assert not conv2
+    path = tmp_path / "label.txt"
+    planner.write_label(path, params, conv, max_psnr)
+    lines = open(path).read().splitlines()
+    assert lines[0] == "Converged 1" and lines[1].startswith("3 ") and lines[98].startswith("100 ")
+    assert lines[99] == f"gap 0% {gap[0]}" and lines[110] == f"gradient 0.01 {grad[0]}" and len(lines) == 1 + 98 + 11 + 20
+    assert abs(float(lines[1].split()[1]) - fit_y[0]) < 1e-6
+    with pytest.raises(ValueError):
+        planner.fit_curve([3, 5, 7], [1, 2, 3], 10.0)
