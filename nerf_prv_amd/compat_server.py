@@ -1,0 +1,102 @@
+"""Flag-file compatibility server: lets the UNMODIFIED reference executable drive this build.
+
+Protocol (reference side): `NBV_Net_Labeler::train_by_instantNGP` writes
+`<instant_ngp_path>/interact/run_with_c++.py` containing one `os.system('python .../run.py ...')`
+line, touches `interact/ready_c++.txt`, then polls `interact/ready_py.txt` once a second
+(main.cpp:1661-1701).  The reference's `train_server.py:7-14` polls the other way, deletes the
+flag, runs the script and touches `ready_py.txt`.
+
+This server honours the same files but never spawns anything: it parses the run.py command line
+out of the script and answers it in-process through the C ABI:
+  --screenshot_transforms J --screenshot_dir D   -> render every frame of J, write D/<basename>.png
+                                                    (run.py:284-309)
+  --test_transforms J --save_metrics M           -> evaluate against reference images, write M
+                                                    (run.py:213-277)
+Training (`--train --n_steps`) is out of scope: the field comes from `load_model`, a callable the
+embedding application provides (e.g. loading `.prvf` files); `--scene` is passed to it.
+PNG encoding uses PIL (present in the image); the byte rule is the library's (prv_render_rgba8).
+"""
+import json
+import os
+import re
+import shlex
+import time
+
+import numpy as np
+
+from . import api
+
+CMD_RE = re.compile(r"os\.system\('(.*)'\)")
+
+
+def parse_command(script_text):
+    """the run.py arguments of the one-line script the reference writes (main.cpp:1665-1688)"""
+    m = CMD_RE.search(script_text)
+    if not m:
+        raise ValueError("no os.system('...') line in run_with_c++.py")
+    toks = shlex.split(m.group(1))
+    args, i = {"flags": set()}, 0
+    while i < len(toks):
+        t = toks[i]
+        if t.startswith("--"):
+            if i + 1 < len(toks) and not toks[i + 1].startswith("--"):
+                args[t[2:]] = toks[i + 1]
+                i += 2
+                continue
+            args["flags"].add(t[2:])
+        i += 1
+    return args
+
+
+class CompatServer:
+    def __init__(self, interact_dir, ctx, load_model, samples_per_ray=128, screenshot_spp=16, reference_images=None):
+        self.dir, self.ctx, self.load_model = interact_dir, ctx, load_model
+        self.samples_per_ray, self.spp = samples_per_ray, screenshot_spp  # run.py:48 default spp 16
+        self.reference_images = reference_images  # callable(test_json) -> device tensor, for --test_transforms
+
+    def serve_one(self, args):
+        slot = self.load_model(args.get("scene"), self.ctx)  # stands in for load_training_data + training
+        if "screenshot_transforms" in args:
+            from PIL import Image
+
+            with open(args["screenshot_transforms"]) as f:
+                ref_transforms = json.load(f)
+            cams = self.ctx.cameras_from_json(args["screenshot_transforms"])
+            w, h = int(ref_transforms["w"]), int(ref_transforms["h"])  # run.py:304
+            opts = api.render_opts(w, h, self.samples_per_ray, self.spp, 0.01, background=(0.0, 0.0, 0.0, 1.0))
+            u8, _ = self.ctx.render_rgba8(slot, cams, None, opts)
+            u8 = u8.cpu().numpy()
+            os.makedirs(args["screenshot_dir"], exist_ok=True)
+            for frame, img in zip(ref_transforms["frames"], u8):
+                name = os.path.basename(frame["file_path"])  # run.py:297
+                if not os.path.splitext(name)[1]:
+                    name += ".png"
+                Image.fromarray(img, "RGBA").save(os.path.join(args["screenshot_dir"], name))
+            cams.close()
+        elif "test_transforms" in args:
+            from . import planner
+
+            cams = self.ctx.cameras_from_json(args["test_transforms"])
+            w, h = cams.size
+            gt = self.reference_images(args["test_transforms"])
+            opts = api.render_opts(w, h, self.samples_per_ray, 1, 1e-4, background=(0.0, 0.0, 0.0, 1.0))  # run.py:226-235
+            psnr, ssim = self.ctx.evaluate(slot, cams, None, opts, gt)
+            planner.write_metrics(args["save_metrics"], psnr, ssim)
+            cams.close()
+
+    def poll_once(self):
+        """one iteration of the train_server.py loop; returns True when a request was served"""
+        flag = os.path.join(self.dir, "ready_c++.txt")
+        if not os.path.exists(flag):
+            return False
+        os.remove(flag)  # train_server.py:11
+        with open(os.path.join(self.dir, "run_with_c++.py")) as f:
+            args = parse_command(f.read())
+        self.serve_one(args)
+        open(os.path.join(self.dir, "ready_py.txt"), "w").close()  # train_server.py:13
+        return True
+
+    def serve_forever(self, poll_seconds=0.1):
+        while True:
+            if not self.poll_once():
+                time.sleep(poll_seconds)  # train_server.py:9

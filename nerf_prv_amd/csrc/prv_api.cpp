@@ -60,6 +60,7 @@ struct prv_ctx {
   int blocks_per_cu = 4;
   int refill_min = 32;
   int dbg_flags = 0;
+  int sort_rays = 1;
   size_t dehash_budget = 0; // bytes per hashed level allowed for a physically dense copy (0 = keep hashed)
   size_t queue_budget = (size_t)4 << 30; // ray-queue bytes per batch of views (288 GB of HBM: one batch for 64 views at 800x800)
 };
@@ -403,6 +404,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
       mp.out_u8 = out_u8 ? (uint32_t*)out_u8 + b0 * npix : nullptr;
       mp.inv_spp = 1.0f / (float)o->spp;
       mp.last_pass = k == o->spp - 1;
+      mp.sort_rays = c->sort_rays;
       memcpy(mp.bg, o->background, sizeof(mp.bg));
       if (c->profiling) {
         hipEvent_t a, b;
@@ -501,6 +503,7 @@ int prv_create(prv_ctx** out, int device_id) {
   if (const char* s = getenv("PRV_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(s));
   if (const char* s = getenv("PRV_REFILL_MIN")) c->refill_min = std::min(32, std::max(1, atoi(s)));
   if (const char* s = getenv("PRV_DEHASH_MB")) c->dehash_budget = (size_t)std::max(0, atoi(s)) << 20;
+  if (const char* s = getenv("PRV_SORT_RAYS")) c->sort_rays = atoi(s);
   if (const char* s = getenv("PRV_DBG")) c->dbg_flags = atoi(s);
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
   *out = c;

@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
       live = (m[0] | m[1] | m[2] | m[3]) != 0u;
     }
   }
-  // wave-level compaction: ballot + prefix popcount, one atomic per wave
+  // wave-level compaction: ballot + prefix popcount, one atomic per wave.  Within the wave the
+  // live rays are written in order of their live-sample count (8-bucket counting sort on ballots):
+  // the 32 rays a render wave later marches in lockstep then have similar lengths.
   const unsigned long long b = __ballot(live);
   const int lane = threadIdx.x & 63;
   uint32_t base = 0;
@@ -79,8 +81,21 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
     if (lane == (int)__builtin_ctzll(b)) base = atomicAdd(P.queue_count, (uint32_t)__popcll(b));
     base = __shfl(base, (int)__builtin_ctzll(b));
   }
+  uint32_t rank_in_wave = 0;
+  {
+    const uint32_t pc = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
+    const uint32_t bucket = pc <= 4 ? 0 : pc <= 8 ? 1 : pc <= 12 ? 2 : pc <= 16 ? 3 : pc <= 24 ? 4 : pc <= 32 ? 5 : pc <= 48 ? 6 : 7;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+      const unsigned long long mk = __ballot(live && bucket == k);
+      if (bucket == k) rank_in_wave = before + (uint32_t)__popcll(mk & lt);
+      before += (uint32_t)__popcll(mk);
+    }
+  }
   if (live) {
-    uint32_t slot = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    const uint32_t slot = P.sort_rays ? base + rank_in_wave : base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
     uint4* rec = reinterpret_cast<uint4*>(P.queue) + (size_t)slot * kRecordWords;
     rec[0] = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(t0));
     rec[1] = make_uint4(__float_as_uint(d[0]), __float_as_uint(d[1]), __float_as_uint(d[2]), __float_as_uint(dt));

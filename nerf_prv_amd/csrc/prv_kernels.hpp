@@ -24,6 +24,7 @@ struct MarchParams {
   uint32_t* out_u8; // optional, n_views*H*W
   float inv_spp;
   int last_pass;
+  int sort_rays; // order each wave's live rays by live-sample count in the queue
   float bg[4];
 };
 

@@ -169,3 +169,45 @@ def test_planner_executable_error_paths(tmp_path):
     assert out.returncode != 0 and "cannot open" in out.stderr
     out = subprocess.run([exe, str(tmp_path / "missing.yaml")], input="4\nx\n-1\n", text=True, capture_output=True)
     assert out.returncode == 3 and "outside the render/score path" in out.stderr
+
+
+def test_flag_file_compat_server_answers_the_reference_handshake(ctx, tmp_path):
+    """the file protocol of main.cpp:1661-1701 / train_server.py:7-14, served in-process"""
+    from PIL import Image
+
+    from nerf_prv_amd import compat_server
+
+    interact = tmp_path / "interact"
+    interact.mkdir()
+    pts = planner.hemisphere_read(os.path.join(GOLD, "hemisphere", "5.txt"), 5)
+    c = [1e-10] * 3
+    pos = planner.view_space(pts, 0.3, c)
+    k = planner.Intrinsics(width=1280, height=720, ppx=647.1, ppy=372.5, fx=915.60668945312500, fy=913.3)
+    rj = tmp_path / "render_json" / "0.json"
+    rj.parent.mkdir()
+    planner.write_transforms(rj, k, pos[1:], c, 0.1, ids=[1, 2, 3, 4], candidate=True,
+                             path_prefix="../../../../Coverage_images/ShapeNet/objA/5/rgbaClip_")
+    out_dir = tmp_path / "render" / "0" / "ensemble_1"
+    # what train_by_instantNGP writes (main.cpp:1663-1689), verbatim shape
+    cmd = (f"python D:/instant-ngp/scripts/run.py --train --n_steps 2500 --scene {tmp_path}/json/0.json "
+           f" --screenshot_transforms {rj}  --screenshot_dir {out_dir}/")
+    (interact / "run_with_c++.py").write_text("import os\nos.system('" + cmd + "')\n")
+    (interact / "ready_c++.txt").write_text("")
+
+    def load_model(scene, cx):
+        assert scene.endswith("json/0.json")
+        cx.synthetic_model(0, small_desc(), SEED + 1)  # ensemble member 1
+        return 0
+
+    srv = compat_server.CompatServer(str(interact), ctx, load_model, samples_per_ray=64, screenshot_spp=2)
+    assert srv.poll_once() is True
+    assert not (interact / "ready_c++.txt").exists() and (interact / "ready_py.txt").exists()
+    assert srv.poll_once() is False  # nothing pending
+    names = sorted(os.listdir(out_dir))
+    assert names == [f"rgbaClip_{i}.png" for i in (1, 2, 3, 4)]  # basename of file_path (run.py:297)
+    cams = ctx.cameras_from_json(rj)
+    want, _ = ctx.render_rgba8(0, cams, None, api.render_opts(80, 45, 64, 2, 0.01, background=(0, 0, 0, 1)))
+    got = np.array(Image.open(out_dir / "rgbaClip_3.png"))
+    assert got.shape == (45, 80, 4) and np.array_equal(got, want[2].cpu().numpy())
+    args = compat_server.parse_command((interact / "run_with_c++.py").read_text())
+    assert args["n_steps"] == "2500" and "train" in args["flags"] and args["screenshot_dir"].endswith("ensemble_1/")
