@@ -53,14 +53,14 @@ struct prv_ctx {
   std::string err;
   Model models[PRV_MAX_MODELS];
   // grow-only workspaces
-  Buffer queue, counters, view_ids, img_f32, partial, records, dbg[6];
+  Buffer queue, stage, counters, view_ids, img_f32, partial, records, dbg[6];
   Buffer img_u8[PRV_MAX_MODELS];
   bool profiling = false;
   std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs
   int blocks_per_cu = 4;
   int refill_min = 32;
   int dbg_flags = 0;
-  int sort_rays = 1;
+  size_t stage_budget = (size_t)4 << 30; // staging bytes for multi-sample renders (spp x batch x image)
   size_t dehash_budget = 0; // bytes per hashed level allowed for a physically dense copy (0 = keep hashed)
   size_t queue_budget = (size_t)4 << 30; // ray-queue bytes per batch of views (288 GB of HBM: one batch for 64 views at 800x800)
 };
@@ -376,73 +376,87 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   HIPCHK(c, hipMemcpyAsync(ids_dev, ids.data(), (size_t)n_views * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream)); // staging vectors are stack-owned
 
-  size_t batch = std::max<size_t>(1, c->queue_budget / (npix * kRecordBytes));
+  // all spp sub-samples of a batch of views go through ONE march + ONE render launch: sub-sample k of
+  // view v is image (k*nb + v) of a staging buffer, reduced over k in order afterwards (spp = 1 renders
+  // straight into the output).  Batches keep queue and staging within their budgets.
+  const int spp = o->spp;
+  size_t batch = std::max<size_t>(1, c->queue_budget / (npix * kRecordBytes * (size_t)spp));
   batch = std::min<size_t>(batch, (size_t)n_views);
-  if (batch * npix >= (1ull << 32)) batch = ((1ull << 32) - 1) / npix; // 32-bit pixel ids
-  if (batch == 0) return fail(c, PRV_E_INVALID, "image too large");
-  if ((rc = ensure(c, c->queue, batch * npix * kRecordBytes)) != PRV_OK) return rc;
+  if (spp > 1) batch = std::min<size_t>(batch, std::max<size_t>(1, c->stage_budget / (npix * 16 * (size_t)spp)));
+  if (batch * npix * (size_t)spp >= (1ull << 32)) batch = ((1ull << 32) - 1) / (npix * (size_t)spp); // 32-bit pixel ids
+  if (batch == 0) return fail(c, PRV_E_INVALID, "image x spp too large");
+  if ((rc = ensure(c, c->queue, batch * npix * (size_t)spp * kRecordBytes)) != PRV_OK) return rc;
+  if (spp > 1 && (rc = ensure(c, c->stage, batch * npix * (size_t)spp * 16)) != PRV_OK) return rc;
 
   const int n_blocks = c->n_cu * c->blocks_per_cu;
   for (size_t b0 = 0; b0 < (size_t)n_views; b0 += batch) {
     const int nb = (int)std::min(batch, (size_t)n_views - b0);
-    for (int k = 0; k < o->spp; k++) {
-      HIPCHK(c, hipMemsetAsync(q_count, 0, 8, c->stream));
-      MarchParams mp;
-      memset(&mp, 0, sizeof(mp));
-      mp.field = m.dev;
-      mp.cams = cams_dev;
-      mp.view_ids = ids_dev + b0;
-      mp.W = W;
-      mp.H = H;
-      mp.S = o->samples_per_ray;
-      mp.spp_k = k;
-      mp.tiles_x = (uint32_t)((W + kTile - 1) / kTile);
-      mp.tiles_y = (uint32_t)((H + kTile - 1) / kTile);
-      mp.queue = c->queue.p;
-      mp.queue_count = q_count;
-      mp.out_f32 = out_f32 + b0 * npix * 4;
-      mp.out_u8 = out_u8 ? (uint32_t*)out_u8 + b0 * npix : nullptr;
-      mp.inv_spp = 1.0f / (float)o->spp;
-      mp.last_pass = k == o->spp - 1;
-      mp.sort_rays = c->sort_rays;
-      memcpy(mp.bg, o->background, sizeof(mp.bg));
-      if (c->profiling) {
-        hipEvent_t a, b;
-        HIPCHK(c, hipEventCreate(&a));
-        HIPCHK(c, hipEventCreate(&b));
-        c->ev_march.push_back(a);
-        c->ev_march.push_back(b);
-        HIPCHK(c, hipEventRecord(a, c->stream));
-      }
-      HIPCHK(c, launch_march(mp, nb, c->stream));
-      if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_march.back(), c->stream));
-      RenderParams rp;
-      memset(&rp, 0, sizeof(rp));
-      rp.field = m.dev;
-      rp.queue = c->queue.p;
-      rp.queue_count = q_count;
-      rp.queue_head = q_head;
-      rp.stat_evaluated = stat;
-      rp.out_f32 = mp.out_f32;
-      rp.out_u8 = mp.out_u8;
-      rp.min_T = o->min_transmittance;
-      rp.inv_spp = mp.inv_spp;
-      rp.spp_k = k;
-      rp.last_pass = mp.last_pass;
-      rp.refill_min = c->refill_min;
-      rp.dbg = c->dbg_flags;
-      memcpy(rp.bg, o->background, sizeof(rp.bg));
-      if (c->profiling) {
-        hipEvent_t a, b;
-        HIPCHK(c, hipEventCreate(&a));
-        HIPCHK(c, hipEventCreate(&b));
-        c->ev_render.push_back(a);
-        c->ev_render.push_back(b);
-        HIPCHK(c, hipEventRecord(a, c->stream));
-      }
-      HIPCHK(c, launch_render(rp, n_blocks, c->stream));
-      if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_render.back(), c->stream));
+    float* dst_f32 = out_f32 + b0 * npix * 4;
+    uint32_t* dst_u8 = out_u8 ? (uint32_t*)out_u8 + b0 * npix : nullptr;
+    HIPCHK(c, hipMemsetAsync(q_count, 0, 8, c->stream));
+    MarchParams mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.field = m.dev;
+    mp.cams = cams_dev;
+    mp.view_ids = ids_dev + b0;
+    mp.W = W;
+    mp.H = H;
+    mp.S = o->samples_per_ray;
+    mp.spp_k = 0;
+    // 256 threads = (256 / spp) pixels x spp sub-samples when spp is a power of two <= 64
+    int inner = 0;
+    if (spp > 1 && spp <= 64 && (spp & (spp - 1)) == 0)
+      while ((1 << inner) < spp) inner++;
+    const int pix_log2 = 8 - inner; // pixels per block, Morton-ordered: x gets the extra bit
+    mp.spp_inner_log2 = inner;
+    mp.tile_w_log2 = (pix_log2 + 1) / 2;
+    mp.tile_h_log2 = pix_log2 / 2;
+    mp.tiles_x = (uint32_t)((W + (1 << mp.tile_w_log2) - 1) >> mp.tile_w_log2);
+    mp.tiles_y = (uint32_t)((H + (1 << mp.tile_h_log2) - 1) >> mp.tile_h_log2);
+    mp.queue = c->queue.p;
+    mp.queue_count = q_count;
+    mp.out_f32 = spp > 1 ? (float*)c->stage.p : dst_f32;
+    mp.out_u8 = spp > 1 ? nullptr : dst_u8;
+    mp.inv_spp = 1.0f;
+    mp.last_pass = spp == 1; // staged sub-samples are written raw; scaling / bytes happen in the reduce
+    memcpy(mp.bg, o->background, sizeof(mp.bg));
+    if (c->profiling) {
+      hipEvent_t a, b;
+      HIPCHK(c, hipEventCreate(&a));
+      HIPCHK(c, hipEventCreate(&b));
+      c->ev_march.push_back(a);
+      c->ev_march.push_back(b);
+      HIPCHK(c, hipEventRecord(a, c->stream));
     }
+    HIPCHK(c, launch_march(mp, nb, spp, c->stream));
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_march.back(), c->stream));
+    RenderParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.field = m.dev;
+    rp.queue = c->queue.p;
+    rp.queue_count = q_count;
+    rp.queue_head = q_head;
+    rp.stat_evaluated = stat;
+    rp.out_f32 = mp.out_f32;
+    rp.out_u8 = mp.out_u8;
+    rp.min_T = o->min_transmittance;
+    rp.inv_spp = 1.0f;
+    rp.spp_k = 0;
+    rp.last_pass = mp.last_pass;
+    rp.refill_min = c->refill_min;
+    rp.dbg = c->dbg_flags;
+    memcpy(rp.bg, o->background, sizeof(rp.bg));
+    if (c->profiling) {
+      hipEvent_t a, b;
+      HIPCHK(c, hipEventCreate(&a));
+      HIPCHK(c, hipEventCreate(&b));
+      c->ev_render.push_back(a);
+      c->ev_render.push_back(b);
+      HIPCHK(c, hipEventRecord(a, c->stream));
+    }
+    HIPCHK(c, launch_render(rp, n_blocks, c->stream));
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_render.back(), c->stream));
+    if (spp > 1) HIPCHK(c, launch_spp_reduce((const float*)c->stage.p, (size_t)nb * npix, spp, o->background, dst_f32, dst_u8, c->stream));
   }
   return PRV_OK;
 }
@@ -503,7 +517,6 @@ int prv_create(prv_ctx** out, int device_id) {
   if (const char* s = getenv("PRV_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(s));
   if (const char* s = getenv("PRV_REFILL_MIN")) c->refill_min = std::min(32, std::max(1, atoi(s)));
   if (const char* s = getenv("PRV_DEHASH_MB")) c->dehash_budget = (size_t)std::max(0, atoi(s)) << 20;
-  if (const char* s = getenv("PRV_SORT_RAYS")) c->sort_rays = atoi(s);
   if (const char* s = getenv("PRV_DBG")) c->dbg_flags = atoi(s);
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
   *out = c;
@@ -523,6 +536,7 @@ void prv_destroy(prv_ctx* c) {
     release(m.mlp);
   }
   release(c->queue);
+  release(c->stage);
   release(c->counters);
   release(c->view_ids);
   release(c->img_f32);

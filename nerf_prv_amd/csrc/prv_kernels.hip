@@ -35,11 +35,21 @@ __device__ __forceinline__ void morton16(uint32_t i, uint32_t& x, uint32_t& y) {
 __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
   const uint32_t tile = blockIdx.x, vi = blockIdx.y;
   const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-  uint32_t ix, iy;
-  morton16(threadIdx.x, ix, iy);
-  const int px = (int)(tx * kTile + ix), py = (int)(ty * kTile + iy);
+  // Multi-sample launches: with a power-of-two spp the sub-samples of a pixel sit on ADJACENT lanes
+  // (a wave = 64/spp pixels x spp sub-samples: rays that share nearly every grid cell); otherwise the
+  // sub-sample index is on grid.z.
+  uint32_t ix, iy, kk;
+  if (P.spp_inner_log2 > 0) {
+    kk = threadIdx.x & ((1u << P.spp_inner_log2) - 1u);
+    morton16(threadIdx.x >> P.spp_inner_log2, ix, iy);
+  } else {
+    kk = blockIdx.z;
+    morton16(threadIdx.x, ix, iy);
+  }
+  const int spp_k = P.spp_k + (int)kk;
+  const int px = (int)((tx << P.tile_w_log2) + ix), py = (int)((ty << P.tile_h_log2) + iy);
   const bool valid = px < P.W && py < P.H;
-  const uint32_t pix = ((uint32_t)vi * (uint32_t)P.H + (uint32_t)py) * (uint32_t)P.W + (uint32_t)px;
+  const uint32_t pix = ((kk * gridDim.y + (uint32_t)vi) * (uint32_t)P.H + (uint32_t)py) * (uint32_t)P.W + (uint32_t)px;
 
   float o[3] = {0, 0, 0}, d[3] = {0, 0, 1}, t0 = 0.f, dt = 0.f;
   uint32_t m[4] = {0, 0, 0, 0};
@@ -47,7 +57,7 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
   if (valid) {
     const CamDev cam = P.cams[P.view_ids[vi]];
     float ox, oy;
-    spp_offset(P.spp_k, ox, oy);
+    spp_offset(spp_k, ox, oy);
     raygen(cam, px, py, ox, oy, o, d);
     float t1;
     if (ray_aabb(o, d, t0, t1)) {
@@ -71,9 +81,7 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
       live = (m[0] | m[1] | m[2] | m[3]) != 0u;
     }
   }
-  // wave-level compaction: ballot + prefix popcount, one atomic per wave.  Within the wave the
-  // live rays are written in order of their live-sample count (8-bucket counting sort on ballots):
-  // the 32 rays a render wave later marches in lockstep then have similar lengths.
+  // wave-level compaction: ballot + prefix popcount, one atomic per wave
   const unsigned long long b = __ballot(live);
   const int lane = threadIdx.x & 63;
   uint32_t base = 0;
@@ -81,21 +89,8 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
     if (lane == (int)__builtin_ctzll(b)) base = atomicAdd(P.queue_count, (uint32_t)__popcll(b));
     base = __shfl(base, (int)__builtin_ctzll(b));
   }
-  uint32_t rank_in_wave = 0;
-  {
-    const uint32_t pc = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
-    const uint32_t bucket = pc <= 4 ? 0 : pc <= 8 ? 1 : pc <= 12 ? 2 : pc <= 16 ? 3 : pc <= 24 ? 4 : pc <= 32 ? 5 : pc <= 48 ? 6 : 7;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t before = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-      const unsigned long long mk = __ballot(live && bucket == k);
-      if (bucket == k) rank_in_wave = before + (uint32_t)__popcll(mk & lt);
-      before += (uint32_t)__popcll(mk);
-    }
-  }
   if (live) {
-    const uint32_t slot = P.sort_rays ? base + rank_in_wave : base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    uint32_t slot = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
     uint4* rec = reinterpret_cast<uint4*>(P.queue) + (size_t)slot * kRecordWords;
     rec[0] = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(t0));
     rec[1] = make_uint4(__float_as_uint(d[0]), __float_as_uint(d[1]), __float_as_uint(d[2]), __float_as_uint(dt));
@@ -310,6 +305,25 @@ __global__ __launch_bounds__(256) void first_hit_kernel(FieldDev fd, const CamDe
     }
   }
   out[(size_t)v * W * H + i] = result;
+}
+
+// ------------------------------------------------------------------ multi-sample reduce
+// stage[k][pixel] -> out[pixel] = (((s0 + s1) + s2) + ...) * inv_spp : the summation order of the
+// per-pass accumulation it replaces (and of the oracle), so results are bit-identical.
+__global__ __launch_bounds__(256) void spp_reduce_kernel(const float4* __restrict__ stage, size_t n, int spp, float inv_spp,
+                                                         float b0, float b1, float b2, float b3,
+                                                         float4* __restrict__ out, uint32_t* __restrict__ out_u8) {
+  const float bg[4] = {b0, b1, b2, b3};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float4 a = stage[i];
+    for (int k = 1; k < spp; k++) {
+      const float4 v = stage[(size_t)k * n + i];
+      a.x = a.x + v.x; a.y = a.y + v.y; a.z = a.z + v.z; a.w = a.w + v.w;
+    }
+    a.x *= inv_spp; a.y *= inv_spp; a.z *= inv_spp; a.w *= inv_spp;
+    out[i] = a;
+    if (out_u8) out_u8[i] = quantize_rgba8(a.x, a.y, a.z, a.w, bg);
+  }
 }
 
 // ------------------------------------------------------------------ quantise
@@ -640,8 +654,16 @@ __global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const flo
 
 // ------------------------------------------------------------------ host-callable launchers
 
-hipError_t launch_march(const MarchParams& P, int n_views, hipStream_t s) {
-  dim3 grid((unsigned)(P.tiles_x * P.tiles_y), (unsigned)n_views);
+hipError_t launch_spp_reduce(const float* stage, size_t n_pixels, int spp, const float bg[4], float* out, uint32_t* out_u8,
+                             hipStream_t s) {
+  unsigned blocks = (unsigned)std::min<size_t>(4096, (n_pixels + 255) / 256);
+  hipLaunchKernelGGL(spp_reduce_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(stage), n_pixels, spp,
+                     1.0f / (float)spp, bg[0], bg[1], bg[2], bg[3], reinterpret_cast<float4*>(out), out_u8);
+  return hipGetLastError();
+}
+
+hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_t s) {
+  dim3 grid((unsigned)(P.tiles_x * P.tiles_y), (unsigned)n_views, (unsigned)(P.spp_inner_log2 > 0 ? 1 : n_spp));
   hipLaunchKernelGGL(march_compact_kernel, grid, dim3(256), 0, s, P);
   return hipGetLastError();
 }

@@ -18,13 +18,14 @@ struct MarchParams {
   const int* view_ids; // n_views indices into cams
   int W, H, S, spp_k;
   uint32_t tiles_x, tiles_y;
+  int tile_w_log2, tile_h_log2; // pixel tile of one 256-thread block
+  int spp_inner_log2;           // > 0: sub-samples on adjacent lanes (spp = 2^n), 0: on grid.z
   void* queue;
   uint32_t* queue_count;
   float* out_f32; // n_views*H*W*4
   uint32_t* out_u8; // optional, n_views*H*W
   float inv_spp;
   int last_pass;
-  int sort_rays; // order each wave's live rays by live-sample count in the queue
   float bg[4];
 };
 
@@ -65,7 +66,9 @@ struct RepackLevel { // canonical -> physical copy of one level (entries, not by
 };
 hipError_t launch_repack_level(const uint16_t* canon, uint16_t* phys, const RepackLevel& L, int F, hipStream_t s);
 
-hipError_t launch_march(const MarchParams& P, int n_views, hipStream_t s);
+hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_t s);
+hipError_t launch_spp_reduce(const float* stage, size_t n_pixels, int spp, const float bg[4], float* out, uint32_t* out_u8,
+                             hipStream_t s);
 hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s);
 hipError_t launch_first_hit(const FieldDev& fd, const CamDev* cams, int n_views, int W, int H, float max_range,
                             int32_t* out, hipStream_t s);
