@@ -48,6 +48,15 @@ int prvh_write_transforms(const char* path, const prvh_intrinsics* intr, int can
 int prvh_write_metrics(const char* path, double psnr, double ssim);
 int prvh_read_metrics(const char* path, double* psnr, double* ssim);
 
+/* ---- movement cost and visiting order (View_Space.hpp:206-305, main.cpp:398-594) ---- */
+/* get_local_path: straight segment, or detour on the sphere (O, r); *type_out = 0 line, 1 arc, -1 wrong */
+double prvh_local_path(const double M[3], const double N[3], const double O[3], double r, int* type_out);
+/* Global_Path_Planner: shortest path through the n positions from start (end = -1: free end), edge cost
+ * = prvh_local_path; order_out[n] = visiting order (indices), *exact_out = 1 when provably optimal
+ * (n <= 20, Held-Karp; the reference uses Gurobi).  Returns the path length, or < 0. */
+double prvh_global_path(const double* positions, int n, int start, int end, const double O[3], double r,
+                        int* order_out, int* exact_out);
+
 /* ---- stopping criterion (Origin_scripts/NeRF_fit_curve.cpp:56-212) ---- */
 /* fit y = y0 + A*Phi((ln x - xc)/w) to (views, psnr); params_out = {y0, A, xc, w}; converged_out as in
  * label.txt (solver outcome AND no data point above max_psnr, :143-151).  Returns 0 or < 0. */
@@ -79,7 +88,7 @@ typedef int (*prvh_score_fn)(void* user, int method, int iteration, const char* 
 typedef struct prvh_loop_result {
   int n_chosen;
   int chosen[1024];
-  double total_movement; /* always 0: path cost planning is out of scope */
+  double total_movement; /* sum of get_local_path costs between consecutive chosen views (main.cpp:2256-2264) */
 } prvh_loop_result;
 int prvh_nbv_loop(prvh_share_data* sd, const double center[3], double predicted_size, int first_view_id,
                   int test_id, prvh_score_fn score, void* user, prvh_loop_result* out);

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "fit_curve.hpp"
+#include "path_planner.hpp"
 #include "planner.hpp"
 
 using namespace prvhost;
@@ -130,6 +131,28 @@ int prvh_read_metrics(const char* path, double* psnr, double* ssim) {
   return got == 3 ? 0 : -3;
 }
 
+double prvh_local_path(const double M[3], const double N[3], const double O[3], double r, int* type_out) {
+  const auto lp = get_local_path(Vec3(M[0], M[1], M[2]), Vec3(N[0], N[1], N[2]), Vec3(O[0], O[1], O[2]), r);
+  if (type_out) *type_out = lp.first;
+  return lp.second;
+}
+
+double prvh_global_path(const double* pos, int n, int start, int end, const double O[3], double r, int* order_out, int* exact_out) {
+  if (!pos || n < 1 || start < 0 || start >= n || end >= n || !O) return -1.0;
+  std::vector<View> views;
+  std::vector<int> label;
+  for (int i = 0; i < n; i++) {
+    views.emplace_back(Vec3(pos[i * 3], pos[i * 3 + 1], pos[i * 3 + 2]));
+    label.push_back(i);
+  }
+  Global_Path_Planner gp(views, label, start, Vec3(O[0], O[1], O[2]), r, end);
+  const double len = gp.solve();
+  const auto path = gp.get_path_id_set();
+  if (order_out) std::copy(path.begin(), path.end(), order_out);
+  if (exact_out) *exact_out = gp.exact ? 1 : 0;
+  return len;
+}
+
 int prvh_fit_curve(const double* x, const double* y, int n, double max_psnr, double params_out[4], int* converged_out) {
   if (!x || !y || n < 4 || !params_out) return -1;
   const FitResult r = fit_lognormal_cdf(std::vector<double>(x, x + n), std::vector<double>(y, y + n), max_psnr);
@@ -224,7 +247,7 @@ int prvh_nbv_loop(prvh_share_data* h, const double center[3], double predicted_s
   const int rc = labeler.nbv_loop(first_view_id, test_id);
   out->n_chosen = (int)std::min<size_t>(labeler.chosen_nbvs.size(), 1024);
   for (int i = 0; i < out->n_chosen; i++) out->chosen[i] = labeler.chosen_nbvs[i];
-  out->total_movement = 0.0;
+  out->total_movement = labeler.total_movement_cost;
   return rc;
 }
 

@@ -17,6 +17,7 @@
 #include "../csrc/prv_json.hpp"
 #include "Share_Data.hpp"
 #include "View_Space.hpp"
+#include "path_planner.hpp"
 
 namespace prvhost {
 
@@ -99,6 +100,7 @@ public:
   Scorer scorer;
   std::vector<int> chosen_nbvs;
   std::vector<double> last_scores;
+  double total_movement_cost = 0.0;
 
   NBV_Net_Labeler(const std::shared_ptr<Share_Data>& sd, const Vec3& center, double predicted_size, Scorer s)
       : share_data(sd), scorer(std::move(s)) {
@@ -157,6 +159,7 @@ public:
                                                 view_space->object_center_world, sd.candidate_divisor);
     write_text(sd.save_path + "/movement/-1.txt", std::to_string(first_view_id) + "\t0\t0\n"); // :1868-1870
     chosen_nbvs.assign(1, first_view_id);
+    total_movement_cost = 0.0; // :1867
     std::set<int> chosen_nbvs_set{first_view_id};
     std::mt19937 rng(12345); // the reference seeds rand() with clock() (Share_Data.hpp:514): unreproducible by design
     const std::clock_t loop_t0 = std::clock();
@@ -218,8 +221,13 @@ public:
       chosen_nbvs_set.insert(next_view_id);
       write_text(sd.save_path + "/infer_time/" + it + ".txt",
                  std::to_string(double(std::clock() - infer_t0) / CLOCKS_PER_SEC) + "\n"); // :2250-2253
-      // movement/<it>.txt = id \t local \t total (:2262-2264); path cost planning is out of scope -> 0
-      write_text(sd.save_path + "/movement/" + it + ".txt", std::to_string(next_view_id) + "\t0\t0\n");
+      // movement cost: view id \t local path \t running total (:2256-2264)
+      const auto local_path = get_local_path(view_space->views[chosen_nbvs[iteration]].init_pos,
+                                             view_space->views[next_view_id].init_pos,
+                                             view_space->object_center_world + Vec3(1e-10, 1e-10, 1e-10), view_space->predicted_size);
+      total_movement_cost += local_path.second;
+      write_text(sd.save_path + "/movement/" + it + ".txt",
+                 std::to_string(next_view_id) + "\t" + std::to_string(local_path.second) + "\t" + std::to_string(total_movement_cost) + "\n");
       iteration++;
     }
     return 0;

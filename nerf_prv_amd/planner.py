@@ -41,6 +41,8 @@ HOST_SIGNATURES = {
     "prvh_write_transforms": (_i, [C.c_char_p, C.POINTER(Intrinsics), _i, _d, _i, _d, _vp, _vp, _vp, _i, C.c_char_p]),
     "prvh_write_metrics": (_i, [C.c_char_p, _d, _d]),
     "prvh_read_metrics": (_i, [C.c_char_p, C.POINTER(_d), C.POINTER(_d)]),
+    "prvh_local_path": (_d, [_vp, _vp, _vp, _d, C.POINTER(_i)]),
+    "prvh_global_path": (_d, [_vp, _i, _i, _i, _vp, _d, _vp, C.POINTER(_i)]),
     "prvh_fit_curve": (_i, [_vp, _vp, _i, _d, _vp, C.POINTER(_i)]),
     "prvh_fit_labels": (None, [_vp, _d, _vp, _vp]),
     "prvh_write_label": (_i, [C.c_char_p, _vp, _i, _d]),
@@ -151,6 +153,25 @@ def read_metrics(path):
     if host().prvh_read_metrics(str(path).encode(), C.byref(p), C.byref(s)) != 0:
         raise IOError(f"cannot read metrics from {path}")
     return p.value, s.value
+
+
+def local_path(M, N, O, r):
+    """get_local_path (View_Space.hpp:206-305) -> (type, length)"""
+    a, b, c = (np.ascontiguousarray(v, np.float64) for v in (M, N, O))
+    t = C.c_int()
+    d = host().prvh_local_path(_p(a), _p(b), _p(c), float(r), C.byref(t))
+    return t.value, d
+
+
+def global_path(positions, start, end=-1, center=(1e-10, 1e-10, 1e-10), radius=0.0):
+    """Global_Path_Planner -> (visiting order, length, exact)"""
+    pos = np.ascontiguousarray(positions, np.float64).reshape(-1, 3)
+    c = np.ascontiguousarray(center, np.float64)
+    order, exact = np.zeros(len(pos), np.int32), C.c_int()
+    d = host().prvh_global_path(_p(pos), len(pos), int(start), int(end), _p(c), float(radius), _p(order), C.byref(exact))
+    if d < 0:
+        raise ValueError("global path: bad arguments")
+    return order.tolist(), d, bool(exact.value)
 
 
 def fit_curve(views, psnr, max_psnr):

@@ -93,7 +93,7 @@ def test_share_data_constructor_semantics(config, tmp_path):
     with pytest.raises(IOError):
         planner.ShareData(tmp_path / "missing.yaml")
     with pytest.raises(IOError):
-        planner.ShareData(config, "", 7)  # no 7.txt among the fixtures
+        planner.ShareData(config, "", 15)  # no 15.txt among the fixtures
 
 
 def test_transforms_json_schema_and_candidate_header(config, tmp_path):
@@ -146,7 +146,8 @@ def test_nbv_loop_bookkeeping_and_argmax(config, tmp_path):
     for sub in ("json", "render_json", "metrics", "render", "train_time", "infer_time", "movement"):
         assert os.path.isdir(os.path.join(save, sub))
     assert sorted(os.listdir(os.path.join(save, "json"))) == ["0.json", "1.json", "2.json", "3.json"]
-    assert open(os.path.join(save, "movement", "1.txt")).read().split("\t")[0] == "0"
+    mv = open(os.path.join(save, "movement", "1.txt")).read().split("\t")
+    assert mv[0] == "0" and float(mv[1]) > 0 and float(mv[2]) >= float(mv[1])  # id, local path, running total
     assert float(open(os.path.join(save, "run_time.txt")).read()) >= 0
     frames = json.load(open(os.path.join(save, "json", "3.json")))["frames"]
     assert [int(f["file_path"].split("_")[-1][:-4]) for f in frames] == [0, 1, 2, 3]  # chosen set, ascending view id
@@ -222,3 +223,59 @@ def test_stopping_criterion_fit_and_labels(tmp_path):
     assert abs(float(lines[1].split()[1]) - fit_y[0]) < 1e-6
     with pytest.raises(ValueError):
         planner.fit_curve([3, 5, 7], [1, 2, 3], 10.0)
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
+def test_global_path_matches_the_reference_stored_tours(n):
+    """REFERENCE-PINNED: Hemisphere/N_path.txt are outputs of the reference's Global_Path_Planner
+    (Gurobi TSP, main.cpp:3652-3655, 3826-3830).  The exact planner here must reach the same length
+    (orders may differ only between equally short mirror tours) and start at the (0,0,1) view."""
+    d = os.path.join(GOLD, "hemisphere")
+    pts = planner.hemisphere_read(os.path.join(d, f"{n}.txt"), n)
+    ref = [int(x) for x in open(os.path.join(d, f"{n}_path.txt")).read().split()]
+    assert sorted(ref) == list(range(n))
+    top = int(np.argmin(np.linalg.norm(pts - [0, 0, 1], axis=1)))
+    assert ref[0] == top  # main.cpp:3642-3644: the path starts at the top view
+    order, length, exact = planner.global_path(pts, top)  # unit view sphere, no obstacle (r = 0)
+    assert exact and sorted(order) == list(range(n)) and order[0] == top
+    seg = lambda p: sum(np.linalg.norm(pts[p[i]] - pts[p[i + 1]]) for i in range(n - 1))
+    assert abs(seg(order) - length) < 1e-12
+    assert abs(length - seg(ref)) < 2e-6  # the files carry 6 significant digits
+    if n in (6, 10, 11, 12):
+        assert order == ref  # unique optimum: the same visiting order
+
+
+def test_local_path_line_arc_and_blocked_cases():
+    """get_local_path (View_Space.hpp:206-305)"""
+    O = [0.0, 0.0, 0.0]
+    t, d = planner.local_path([-2, 0, 1.5], [2, 0, 1.5], O, 1.0)  # passes above the sphere
+    assert t == 0 and abs(d - 4.0) < 1e-12
+    t, d = planner.local_path([-2, 0.3, 0.2], [2, 0.3, 0.2], O, 1.0)  # crosses it: go round
+    assert t == 1
+    P = np.array([-np.sqrt(1 - 0.13), 0.3, 0.2])
+    Q = np.array([np.sqrt(1 - 0.13), 0.3, 0.2])
+    arc = np.arccos(np.clip(P @ Q, -1, 1)) * 1.0
+    assert abs(d - ((2 - np.sqrt(0.87)) * 2 + arc)) < 1e-6 and d > 4.0
+    t, d = planner.local_path([0.2, 0, 0], [3, 0, 0.1], O, 1.0)  # starts inside the obstacle
+    assert t == -1 and d == 1e10
+    t, d = planner.local_path([-2, 0, 0.5], [-1.5, 0, 0.5], O, 1.0)  # line hits the sphere beyond the segment
+    assert t == 0 and abs(d - 0.5) < 1e-12
+
+
+def test_global_path_fixed_end_and_large_sets():
+    pts = planner.hemisphere_generate(9)
+    order, length, exact = planner.global_path(pts, 0, end=5)
+    assert exact and order[0] == 0 and order[-1] == 5 and sorted(order) == list(range(9))
+    free, free_len, _ = planner.global_path(pts, 0)
+    assert free_len <= length + 1e-12  # pinning the end can only lengthen the path
+    big = planner.hemisphere_generate(64)
+    order, length, exact = planner.global_path(big, 0)
+    assert not exact and sorted(order) == list(range(64)) and order[0] == 0
+    nn = [0]
+    left = set(range(1, 64))
+    while left:  # plain nearest neighbour is an upper bound the 2-opt result must beat or match
+        k = min(left, key=lambda j: np.linalg.norm(big[nn[-1]] - big[j]))
+        nn.append(k)
+        left.remove(k)
+    nn_len = sum(np.linalg.norm(big[nn[i]] - big[nn[i + 1]]) for i in range(63))
+    assert length <= nn_len + 1e-9
