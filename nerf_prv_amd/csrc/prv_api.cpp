@@ -33,6 +33,7 @@ struct Model {
   prv_field_desc desc{};
   FieldDev dev{};
   uint64_t table_halfs = 0, occ_words = 0;
+  float occ_lo[3] = {0, 0, 0}, occ_hi[3] = {1, 1, 1};
   Buffer table, phys, occ, occ_coarse, frags, mlp; // table/mlp = canonical (ABI) copies kept for export; phys = kernel layout
 };
 
@@ -210,6 +211,26 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   if ((rc = ensure(c, m.mlp, PRV_MLP_HALFS * 2)) != PRV_OK) return rc;
   if (table_host) HIPCHK(c, hipMemcpyAsync(m.table.p, table_host, m.table_halfs * 2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(m.occ.p, occ_host, m.occ_words * 4, hipMemcpyHostToDevice, c->stream));
+  // bounding box of the occupied cells (grown by one cell) for the march pass
+  {
+    const int R = d.occ_res;
+    int lo[3] = {R, R, R}, hi[3] = {-1, -1, -1};
+    for (int z = 0; z < R; z++)
+      for (int y = 0; y < R; y++)
+        for (int x = 0; x < R; x++) {
+          const size_t b = (size_t)x + (size_t)R * ((size_t)y + (size_t)R * (size_t)z);
+          if (!((occ_host[b >> 5] >> (b & 31)) & 1u)) continue;
+          const int cxyz[3] = {x, y, z};
+          for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], cxyz[a]);
+            hi[a] = std::max(hi[a], cxyz[a]);
+          }
+        }
+    for (int a = 0; a < 3; a++) {
+      m.occ_lo[a] = hi[a] < 0 ? 2.0f : (float)(lo[a] - 1) / (float)R; // empty grid: an empty box
+      m.occ_hi[a] = hi[a] < 0 ? -1.0f : (float)(hi[a] + 2) / (float)R;
+    }
+  }
   // dilated coarse occupancy for the march pass: coarse cell = 4^3 fine cells; bit set when any fine
   // cell of the block or of its 26 neighbour blocks is occupied
   std::vector<uint32_t> coarse;
@@ -294,6 +315,10 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   f.n_features = d.n_features;
   f.occ_res = d.occ_res;
   f.density_bias = d.density_bias;
+  for (int a = 0; a < 3; a++) {
+    f.occ_lo[a] = m.occ_lo[a];
+    f.occ_hi[a] = m.occ_hi[a];
+  }
   // Level order seen by the kernel: lane half h gathers canonical levels [h*L/2, (h+1)*L/2).
   for (int l = 0; l < d.n_levels; l++) {
     LevelDev& L = f.levels[l];

@@ -48,6 +48,7 @@ struct FieldDev {
   LevelDev levels[kMaxLevels];
   int n_levels, n_features, occ_res;
   float density_bias;
+  float occ_lo[3], occ_hi[3]; // bounding box of the occupied cells, grown by one cell (march pass clips to it)
 };
 
 struct CamDev {  // engine-frame camera

@@ -66,7 +66,27 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
       // the point at parameter g+2; when that is less than one coarse cell and the DILATED coarse bit
       // there is clear, none of the four can be in an occupied fine cell.
       const bool coarse_ok = P.field.occ_coarse != nullptr && 1.5f * dt <= 0.99f * 4.0f / (float)P.field.occ_res;
-      for (int g = 0; g < P.S; g += 4) {
+      // only samples inside the (one-cell-grown) bounding box of the occupied cells can be live: clip the
+      // loop to the box's parameter range, with two samples of slack either side and group alignment
+      int g_lo = 0, g_hi = P.S;
+      {
+        float ta = t0, tb = t1;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const float inv = 1.0f / d[a];
+          const float u = (P.field.occ_lo[a] - o[a]) * inv, w = (P.field.occ_hi[a] - o[a]) * inv;
+          ta = fmaxf(ta, fminf(u, w));
+          tb = fminf(tb, fmaxf(u, w));
+        }
+        if (!(tb > ta)) {
+          g_hi = 0; // misses the occupied region altogether
+        } else if (dt > 0.0f) {
+          const float inv_dt = 1.0f / dt;
+          g_lo = max(0, (int)((ta - t0) * inv_dt) - 2) & ~3;
+          g_hi = min(P.S, (int)((tb - t0) * inv_dt) + 3);
+        }
+      }
+      for (int g = g_lo; g < g_hi; g += 4) {
         if (coarse_ok) {
           const float tm = fmaf((float)g + 2.0f, dt, t0);
           if (!occupied_coarse(P.field, fmaf(tm, d[0], o[0]), fmaf(tm, d[1], o[1]), fmaf(tm, d[2], o[2]))) continue;
