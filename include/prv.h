@@ -171,6 +171,23 @@ int prv_quantize_rgba8(prv_ctx* ctx, const float* rgba_dev, size_t n_pixels, con
 int prv_first_hit(prv_ctx* ctx, int model_slot, const prv_camset* cs, const int* view_ids, int n_views,
                   int width, int height, float max_range, int32_t* out_cell_dev);
 
+/* The reference's camera intrinsics (rs2_intrinsics, Share_Data.hpp:79-89); coeffs in the YAML order
+ * k1,k2,k3,p1,p2 (Share_Data.hpp:395-399); model 2 = inverse Brown-Conrady (yaml color_model). */
+typedef struct prv_rs2_intrinsics {
+  int32_t width, height;
+  float ppx, ppy, fx, fy;
+  int32_t model;
+  float coeffs[5];
+} prv_rs2_intrinsics;
+/* replaces: Perception_3D::precept + precept_thread_process (main.cpp:98-284) in full: for every
+ * ground-truth voxel centre, rs2_project_point_to_pixel -> cull -> integer pixel ->
+ * project_pixel_to_ray_end (rs2_deproject_pixel_to_point at depth 1, Share_Data.hpp:719-726) ->
+ * castRay from the camera within max_range.  voxels_dev = n x 3 float (unit-cube coordinates),
+ * c2w = camera-to-world 4x4 row-major double (+Z forward, the reference's view_pose_world).
+ * out_cell_dev[n] = first occupied cell x + R*(y + R*z), or -1 (culled / no hit). */
+int prv_precept(prv_ctx* ctx, int model_slot, const float* voxels_dev, int n, const double c2w[16],
+                const prv_rs2_intrinsics* intr, float max_range, int32_t* out_cell_dev);
+
 /* ---- scores -------------------------------------------------------------- */
 /* replaces: the per-view loops main.cpp:2045-2094 (method 2) / 2105-2158 (method 3).
  * imgs_dev[e] = n_views*pixels_per_view*4 uint8 of ensemble member e. */

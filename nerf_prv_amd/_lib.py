@@ -48,6 +48,11 @@ class RenderOpts(C.Structure):
     ]
 
 
+class Rs2Intrinsics(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("ppx", C.c_float), ("ppy", C.c_float), ("fx", C.c_float),
+                ("fy", C.c_float), ("model", C.c_int32), ("coeffs", C.c_float * 5)]
+
+
 class ScoreRecord(C.Structure):
     _fields_ = [("score", C.c_double), ("psnr", C.c_float), ("coverage", C.c_float)]
 
@@ -91,6 +96,7 @@ SIGNATURES = {
     "prv_render": (_i, [_vp, _i, _vp, _vp, _i, _P(RenderOpts), _vp, _P(Stats)]),
     "prv_render_rgba8": (_i, [_vp, _i, _vp, _vp, _i, _P(RenderOpts), _vp, _P(Stats)]),
     "prv_first_hit": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, C.c_float, _vp]),
+    "prv_precept": (_i, [_vp, _i, _vp, _i, _vp, _P(Rs2Intrinsics), C.c_float, _vp]),
     "prv_quantize_rgba8": (_i, [_vp, _vp, C.c_size_t, _vp, _vp]),
     "prv_score_ensemble_images": (_i, [_vp, _i, _vp, _i, _i, C.c_size_t, _vp]),
     "prv_score_psnr_images": (_i, [_vp, _vp, _vp, _i, C.c_size_t, _vp, _vp]),

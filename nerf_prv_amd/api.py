@@ -218,6 +218,14 @@ class Context:
                                          float(max_range), _ptr(out)))
         return out
 
+    def precept(self, slot, voxels, c2w, intr, max_range=1.0):
+        """Perception_3D::precept per voxel (main.cpp:98-284): voxels = device float tensor n x 3 -> int32 cells"""
+        c = np.ascontiguousarray(c2w, np.float64).reshape(16)
+        out = self.torch.empty((voxels.shape[0],), dtype=self.torch.int32, device=self.device)
+        self._chk(self.lib.prv_precept(self.handle, slot, _ptr(voxels), voxels.shape[0], _ptr(c), C.byref(intr),
+                                       float(max_range), _ptr(out)))
+        return out
+
     def quantize_rgba8(self, rgba, background):
         out = self.torch.empty(rgba.shape, dtype=self.torch.uint8, device=self.device)
         bg = np.asarray(background, np.float32)

@@ -895,6 +895,48 @@ int prv_first_hit(prv_ctx* c, int slot, const prv_camset* cs, const int* view_id
   return PRV_OK;
 }
 
+int prv_precept(prv_ctx* c, int slot, const float* voxels, int n, const double c2w[16], const prv_rs2_intrinsics* k,
+                float max_range, int32_t* out) {
+  if (!c) return PRV_E_INVALID;
+  int rc;
+  if ((rc = check_model(c, slot)) != PRV_OK) return rc;
+  if (n < 0 || !c2w || !k || (n > 0 && (!voxels || !out))) return fail(c, PRV_E_INVALID, "bad argument");
+  if (n == 0) return PRV_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  PreceptPose pose;
+  memcpy(pose.c2w, c2w, sizeof(pose.c2w));
+  { // w2c = inverse of the rigid c2w, in double (view_pose_world.inverse(), main.cpp:243)
+    double a[4][8];
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) {
+        a[i][j] = c2w[i * 4 + j];
+        a[i][4 + j] = i == j;
+      }
+    for (int col = 0; col < 4; col++) {
+      int piv = col;
+      for (int r = col + 1; r < 4; r++)
+        if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+      if (std::fabs(a[piv][col]) < 1e-300) return fail(c, PRV_E_INVALID, "singular camera pose");
+      for (int j = 0; j < 8; j++) std::swap(a[col][j], a[piv][j]);
+      const double dd = a[col][col];
+      for (int j = 0; j < 8; j++) a[col][j] /= dd;
+      for (int r = 0; r < 4; r++)
+        if (r != col) {
+          const double f = a[r][col];
+          for (int j = 0; j < 8; j++) a[r][j] -= f * a[col][j];
+        }
+    }
+    for (int i = 0; i < 4; i++)
+      for (int j = 0; j < 4; j++) pose.w2c[i * 4 + j] = a[i][4 + j];
+  }
+  Rs2Intr in;
+  in.ppx = k->ppx; in.ppy = k->ppy; in.fx = k->fx; in.fy = k->fy;
+  for (int i = 0; i < 5; i++) in.c[i] = k->coeffs[i];
+  in.width = k->width; in.height = k->height; in.model = k->model;
+  HIPCHK(c, launch_precept(c->models[slot].dev, voxels, n, pose, in, max_range, out, c->stream));
+  return PRV_OK;
+}
+
 int prv_quantize_rgba8(prv_ctx* c, const float* rgba, size_t n, const float bg[4], uint8_t* out) {
   if (!c) return PRV_E_INVALID;
   if (!rgba || !out || !bg) return fail(c, PRV_E_INVALID, "NULL argument");

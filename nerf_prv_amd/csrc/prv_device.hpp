@@ -124,6 +124,43 @@ __device__ __forceinline__ bool occupied_coarse(const FieldDev& f, float px, flo
   return (f.occ_coarse[bit >> 5] >> (bit & 31)) & 1u;
 }
 
+// librealsense-style camera of the reference (Share_Data.hpp:79-196): intr = {ppx, ppy, fx, fy, c0..c4},
+// coefficients in the YAML order k1,k2,k3,p1,p2 (Share_Data.hpp:395-399); model 2 = inverse Brown-Conrady
+struct Rs2Intr {
+  float ppx, ppy, fx, fy, c[5];
+  int width, height, model;
+};
+__device__ __forceinline__ void rs2_project(float pixel[2], const Rs2Intr& in, const float point[3]) {
+  float x = point[0] / point[2], y = point[1] / point[2];
+  if (in.model == 1 || in.model == 2) { // Share_Data.hpp:96-108
+    const float r2 = x * x + y * y;
+    const float f = 1 + in.c[0] * r2 + in.c[1] * r2 * r2 + in.c[4] * r2 * r2 * r2;
+    x *= f;
+    y *= f;
+    const float dx = x + 2 * in.c[2] * x * y + in.c[3] * (r2 + 2 * x * x);
+    const float dy = y + 2 * in.c[3] * x * y + in.c[2] * (r2 + 2 * y * y);
+    x = dx;
+    y = dy;
+  }
+  pixel[0] = x * in.fx + in.ppx;
+  pixel[1] = y * in.fy + in.ppy;
+}
+__device__ __forceinline__ void rs2_deproject(float point[3], const Rs2Intr& in, const float pixel[2], float depth) {
+  float x = (pixel[0] - in.ppx) / in.fx;
+  float y = (pixel[1] - in.ppy) / in.fy;
+  if (in.model == 2) { // Share_Data.hpp:147-155
+    const float r2 = x * x + y * y;
+    const float f = 1 + in.c[0] * r2 + in.c[1] * r2 * r2 + in.c[4] * r2 * r2 * r2;
+    const float ux = x * f + 2 * in.c[2] * x * y + in.c[3] * (r2 + 2 * x * x);
+    const float uy = y * f + 2 * in.c[3] * x * y + in.c[2] * (r2 + 2 * y * y);
+    x = ux;
+    y = uy;
+  }
+  point[0] = depth * x;
+  point[1] = depth * y;
+  point[2] = depth;
+}
+
 // real spherical harmonics degree 4; op order identical to the oracle
 __device__ __forceinline__ void sh4(float x, float y, float z, float o[16]) {
   float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;

@@ -270,18 +270,9 @@ template __global__ void render_queue_kernel<2>(RenderParams);
 template __global__ void render_queue_kernel<4>(RenderParams);
 
 // ------------------------------------------------------------------ first-hit ray cast (a13)
-// GPU twin of the reference's CPU render path Perception_3D::precept_thread_process
-// (main.cpp:238-284): per pixel, the first occupied voxel along the ray (there: OctoMap
-// castRay, here: Amanatides-Woo DDA over the occupancy bitfield), max_range like main.cpp:258.
-// out = linear cell index x + R*(y + R*z), or -1.  Same float op order as the oracle.
-__global__ __launch_bounds__(256) void first_hit_kernel(FieldDev fd, const CamDev* __restrict__ cams, int W, int H,
-                                                        float max_range, int32_t* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= W * H) return;
-  const int v = blockIdx.y;
-  const int px = i % W, py = i / W;
-  float o[3], d[3], t0, t1;
-  raygen(cams[v], px, py, 0.5f, 0.5f, o, d);
+// first occupied cell along (o, d) within max_range, or -1: Amanatides-Woo over the occupancy bits
+__device__ __forceinline__ int32_t first_hit_dda(const FieldDev& fd, const float o[3], const float d[3], float max_range) {
+  float t0, t1;
   int32_t result = -1;
   if (ray_aabb(o, d, t0, t1)) {
     if (t1 > max_range) t1 = max_range;
@@ -324,7 +315,60 @@ __global__ __launch_bounds__(256) void first_hit_kernel(FieldDev fd, const CamDe
       }
     }
   }
+  return result;
+}
+
+// GPU twin of the reference's CPU render path Perception_3D::precept_thread_process
+// (main.cpp:238-284): per pixel, the first occupied voxel along the ray (there: OctoMap
+// castRay, here: Amanatides-Woo DDA over the occupancy bitfield), max_range like main.cpp:258.
+// out = linear cell index x + R*(y + R*z), or -1.  Same float op order as the oracle.
+__global__ __launch_bounds__(256) void first_hit_kernel(FieldDev fd, const CamDev* __restrict__ cams, int W, int H,
+                                                        float max_range, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W * H) return;
+  const int v = blockIdx.y;
+  const int px = i % W, py = i / W;
+  float o[3], d[3], t0, t1;
+  raygen(cams[v], px, py, 0.5f, 0.5f, o, d);
+  (void)t0;
+  (void)t1;
+  const int32_t result = first_hit_dda(fd, o, d, max_range);
   out[(size_t)v * W * H + i] = result;
+}
+
+// Perception_3D::precept_thread_process per ground-truth voxel (main.cpp:238-284): project through
+// the RealSense model, cull, integer pixel, deproject at depth 1, cast from the camera, first hit.
+__global__ __launch_bounds__(256) void precept_kernel(FieldDev fd, const float* __restrict__ voxels, int n, PreceptPose pose,
+                                                      Rs2Intr in, float max_range, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float origin[3] = {(float)pose.c2w[3], (float)pose.c2w[7], (float)pose.c2w[11]};
+  double v[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    v[r] = pose.w2c[r * 4] * (double)voxels[i * 3] + pose.w2c[r * 4 + 1] * (double)voxels[i * 3 + 1] +
+           pose.w2c[r * 4 + 2] * (double)voxels[i * 3 + 2] + pose.w2c[r * 4 + 3];
+  const float point_3d[3] = {(float)v[0], (float)v[1], (float)v[2]};
+  float pixel[2];
+  rs2_project(pixel, in, point_3d);
+  int32_t result = -1;
+  if (!(pixel[0] < 0 || pixel[0] > (float)in.width || pixel[1] < 0 || pixel[1] > (float)in.height)) { // :248-251
+    const float ipx[2] = {(float)(int)pixel[0], (float)(int)pixel[1]}; // :253 int x, int y
+    float pt[3], d[3];
+    rs2_deproject(pt, in, ipx, 1.0f);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const float e = (float)(pose.c2w[r * 4] * (double)pt[0] + pose.c2w[r * 4 + 1] * (double)pt[1] +
+                              pose.c2w[r * 4 + 2] * (double)pt[2] + pose.c2w[r * 4 + 3]);
+      d[r] = e - origin[r];
+    }
+    const float n2 = fmaf(d[0], d[0], fmaf(d[1], d[1], d[2] * d[2]));
+    const float inv = 1.0f / sqrtf(n2);
+#pragma unroll
+    for (int r = 0; r < 3; r++) d[r] = d[r] * inv;
+    result = first_hit_dda(fd, origin, d, max_range);
+  }
+  out[i] = result;
 }
 
 // ------------------------------------------------------------------ multi-sample reduce
@@ -700,6 +744,12 @@ hipError_t launch_first_hit(const FieldDev& fd, const CamDev* cams, int n_views,
                             int32_t* out, hipStream_t s) {
   dim3 grid((unsigned)((W * H + 255) / 256), (unsigned)n_views);
   hipLaunchKernelGGL(first_hit_kernel, grid, dim3(256), 0, s, fd, cams, W, H, max_range, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_precept(const FieldDev& fd, const float* voxels, int n, const PreceptPose& pose, const Rs2Intr& in,
+                          float max_range, int32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(precept_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fd, voxels, n, pose, in, max_range, out);
   return hipGetLastError();
 }
 

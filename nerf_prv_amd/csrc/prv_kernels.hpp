@@ -70,6 +70,11 @@ hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_
 hipError_t launch_spp_reduce(const float* stage, size_t n_pixels, int spp, const float bg[4], float* out, uint32_t* out_u8,
                              hipStream_t s);
 hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s);
+struct PreceptPose {
+  double w2c[16], c2w[16];
+};
+hipError_t launch_precept(const FieldDev& fd, const float* voxels, int n, const PreceptPose& pose, const Rs2Intr& in,
+                          float max_range, int32_t* out, hipStream_t s);
 hipError_t launch_first_hit(const FieldDev& fd, const CamDev* cams, int n_views, int W, int H, float max_range,
                             int32_t* out, hipStream_t s);
 hipError_t launch_quantize(const float* in, size_t n, const float bg[4], uint8_t* out, hipStream_t s);

@@ -86,6 +86,7 @@ def lib():
         L.orc_rank.argtypes = [vp, vp, C.c_int, vp]
         L.orc_argmax.restype, L.orc_argmax.argtypes = C.c_int, [vp, vp, C.c_int]
         L.orc_first_hit.argtypes = [C.POINTER(Field), vp, vp, C.c_float, vp]
+        L.orc_precept.argtypes = [C.POINTER(Field), vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]
         _lib = L
     return _lib
 
@@ -248,6 +249,16 @@ def first_hit_image(field, cam, w, h, max_range=1e30):
             lib().orc_raygen(C.byref(cam), x, y, C.c_float(0.5), C.c_float(0.5), _p(o), _p(d))
             if lib().orc_first_hit(field.ptr, _p(o), _p(d), C.c_float(max_range), _p(cell)):
                 out[y, x] = cell[0] + R * (cell[1] + R * cell[2])
+    return out
+
+
+def precept(field, voxels, c2w, intr9, width, height, model=2, max_range=1.0):
+    v = np.ascontiguousarray(voxels, np.float32).reshape(-1, 3)
+    c = np.ascontiguousarray(c2w, np.float64).reshape(16)
+    w = np.ascontiguousarray(np.linalg.inv(c.reshape(4, 4)), np.float64).reshape(16)
+    k = np.ascontiguousarray(intr9, np.float32)
+    out = np.zeros(len(v), np.int32)
+    lib().orc_precept(field.ptr, _p(v), len(v), _p(w), _p(c), _p(k), width, height, model, C.c_float(max_range), _p(out))
     return out
 
 

@@ -903,3 +903,41 @@ int orc_first_hit(const orc_field* f, const float o[3], const float d[3], float 
     tmax[a] += tdelta[a];
   }
 }
+
+/* Perception_3D::precept_thread_process for every voxel (main.cpp:238-284), on the occupancy grid:
+ * voxel -> camera frame (double) -> rs2_project (float) -> cull outside [0,w]x[0,h] (:248-251) ->
+ * integer pixel (:253, the int parameters of project_pixel_to_ray_end) -> rs2_deproject at depth 1
+ * (Share_Data.hpp:719-726) -> world (double, stored as float like octomap::point3d) -> direction =
+ * end - origin -> first hit within max_range (castRay, :258).  out[i] = cell index or -1.
+ * Coordinates are unit-cube coordinates; origin = camera position (the reference snaps it to a voxel
+ * centre of its octree, which has no counterpart here). */
+void orc_precept(const orc_field* f, const float* voxels, int n, const double w2c[16], const double c2w[16],
+                 const float intr[9], int width, int height, int model, float max_range, int32_t* out) {
+  const float origin[3] = {(float)c2w[3], (float)c2w[7], (float)c2w[11]};
+  for (int i = 0; i < n; i++) {
+    out[i] = -1;
+    double v[3];
+    for (int r = 0; r < 3; r++)
+      v[r] = w2c[r * 4] * (double)voxels[i * 3] + w2c[r * 4 + 1] * (double)voxels[i * 3 + 1] + w2c[r * 4 + 2] * (double)voxels[i * 3 + 2] + w2c[r * 4 + 3];
+    const float point_3d[3] = {(float)v[0], (float)v[1], (float)v[2]};
+    float pixel[2];
+    orc_rs2_project(pixel, intr, model, point_3d);
+    if (pixel[0] < 0 || pixel[0] > (float)width || pixel[1] < 0 || pixel[1] > (float)height) continue;
+    const float ipx[2] = {(float)(int)pixel[0], (float)(int)pixel[1]};
+    float pt[3];
+    orc_rs2_deproject(pt, intr, model, ipx, 1.0f);
+    float end[3], d[3];
+    for (int r = 0; r < 3; r++) {
+      end[r] = (float)(c2w[r * 4] * (double)pt[0] + c2w[r * 4 + 1] * (double)pt[1] + c2w[r * 4 + 2] * (double)pt[2] + c2w[r * 4 + 3]);
+      d[r] = end[r] - origin[r];
+    }
+    const float n2 = fmaf(d[0], d[0], fmaf(d[1], d[1], d[2] * d[2]));
+    const float inv = 1.0f / sqrtf(n2);
+    for (int r = 0; r < 3; r++) d[r] = d[r] * inv;
+    int cell[3];
+    if (orc_first_hit(f, origin, d, max_range, cell)) {
+      const int R = f->desc.occ_res;
+      out[i] = cell[0] + R * (cell[1] + R * cell[2]);
+    }
+  }
+}

@@ -210,6 +210,45 @@ def test_first_hit_ray_cast_bit_exact(ctx, oracle, fields, cams):
     assert np.array_equal(near, want) and (near >= 0).sum() < (got[0] >= 0).sum()
 
 
+def test_precept_per_voxel_ray_cast_with_realsense_model(ctx, oracle, fields):
+    """a13 + a14: the reference's CPU render path in full (main.cpp:98-284): every ground-truth voxel is
+    projected through the inverse Brown-Conrady RealSense model of DefaultConfiguration.yaml, culled,
+    snapped to an integer pixel, deprojected and ray-cast.  Integer voxel ids must match exactly."""
+    import torch
+
+    d_o, d_p, f = fields
+    _, _, occ = f.params()
+    R = d_o.occ_res
+    bits = np.unpackbits(occ.view(np.uint8), bitorder="little")[: R ** 3]
+    idx = np.nonzero(bits)[0]  # the "ground-truth leaves": centres of the occupied cells
+    vox = np.stack([(idx % R + 0.5) / R, (idx // R % R + 0.5) / R, (idx // (R * R) + 0.5) / R], axis=1).astype(np.float32)
+    # a camera 1.5 cube units from the centre, +Z looking at it, slightly rolled
+    eye = np.array([0.5 + 1.2, 0.5 - 0.6, 0.5 + 0.7])
+    z = (np.array([0.5, 0.5, 0.5]) - eye) / np.linalg.norm(np.array([0.5, 0.5, 0.5]) - eye)
+    x = np.cross(z, [0.1, 0.2, 1.0]); x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    c2w = np.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = x, y, z, eye
+    intr = api.L.Rs2Intrinsics(width=1280, height=720, ppx=647.14532470703125, ppy=372.51531982421875,
+                               fx=915.60668945312500, fy=913.32666015625000, model=2)
+    for i, v in enumerate([1.2042199820280075e-01, -2.1373499929904938e-01, 5.3860000334680080e-03,
+                           -2.1210000850260258e-03, 0.0]):  # yaml color_k1,k2,k3,p1,p2 -> coeffs[0..4]
+        intr.coeffs[i] = v
+    got = ctx.precept(0, torch.from_numpy(vox).cuda(), c2w, intr, max_range=3.0).cpu().numpy()
+    k9 = np.array([intr.ppx, intr.ppy, intr.fx, intr.fy] + list(intr.coeffs), np.float32)
+    want = oracle.precept(f, vox, c2w, k9, 1280, 720, 2, 3.0)
+    assert np.array_equal(got, want)
+    hit = want >= 0
+    assert hit.sum() > 100  # most leaves project into the image and are hit
+    # a hit is never behind the voxel that generated the ray: the first occupied cell is at most as far
+    cells = np.stack([want[hit] % R, want[hit] // R % R, want[hit] // (R * R)], axis=1)
+    d_hit = np.linalg.norm((cells + 0.5) / R - eye, axis=1)
+    d_vox = np.linalg.norm(vox[hit] - eye, axis=1)
+    assert (d_hit <= d_vox + 2.0 * np.sqrt(3) / R).all()
+    short = ctx.precept(0, torch.from_numpy(vox).cuda(), c2w, intr, max_range=1.0).cpu().numpy()  # main.cpp:258
+    assert np.array_equal(short, oracle.precept(f, vox, c2w, k9, 1280, 720, 2, 1.0)) and (short >= 0).sum() < hit.sum()
+
+
 def test_error_behaviour(ctx, fields, cams):
     cs, ocams, w, h = cams
     with pytest.raises(api.PrvError) as e:
