@@ -173,7 +173,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16 table+MLP operands, f32 accumulate/compositing",
+            "dtype": "f16",
+            "dtype_note": "fp16 table, blend and MLP operands (MFMA f16 -> f32 accumulate); f32 rays, positions, compositing",
             "data": "synthetic",
             "config": {
                 "workload": f"render+score {args.views_per_gpu} hemisphere views/GPU, {args.width}x{args.height}, "

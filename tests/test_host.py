@@ -227,12 +227,11 @@ def test_stopping_criterion_fit_and_labels(tmp_path):
 
 @pytest.mark.parametrize("n", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
 def test_global_path_matches_the_reference_stored_tours(n):
-    """REFERENCE-PINNED: Hemisphere/N_path.txt are outputs of the reference's Global_Path_Planner
+    """REFERENCE-PINNED (fixture tests/golden/reference_tours.json): Hemisphere/N_path.txt are outputs of the reference's Global_Path_Planner
     (Gurobi TSP, main.cpp:3652-3655, 3826-3830).  The exact planner here must reach the same length
     (orders may differ only between equally short mirror tours) and start at the (0,0,1) view."""
-    d = os.path.join(GOLD, "hemisphere")
-    pts = planner.hemisphere_read(os.path.join(d, f"{n}.txt"), n)
-    ref = [int(x) for x in open(os.path.join(d, f"{n}_path.txt")).read().split()]
+    tour = json.load(open(os.path.join(GOLD, "reference_tours.json")))["tours"][str(n)]
+    pts, ref = np.array(tour["points"], np.float64), tour["path"]
     assert sorted(ref) == list(range(n))
     top = int(np.argmin(np.linalg.norm(pts - [0, 0, 1], axis=1)))
     assert ref[0] == top  # main.cpp:3642-3644: the path starts at the top view
