@@ -48,11 +48,32 @@ def parse_command(script_text):
     return args
 
 
+def load_reference_images(ctx, test_json):
+    """the reference images of a transforms.json, as instant-ngp's load_training_data takes them: each frame's
+    `file_path` PNG relative to the json (run.py:238), sRGB -> linear, premultiplied alpha, float32 on the
+    device.  ASSUMED from upstream (the loader is inside pyngp): standard sRGB EOTF, straight-alpha PNGs."""
+    from PIL import Image
+
+    with open(test_json) as f:
+        meta = json.load(f)
+    base = os.path.dirname(os.path.abspath(test_json))
+    imgs = []
+    for frame in meta["frames"]:
+        path = os.path.join(base, frame["file_path"])
+        if not os.path.splitext(path)[1]:
+            path += ".png"
+        a = np.asarray(Image.open(path).convert("RGBA"), np.float32) / 255.0
+        rgb = np.where(a[..., :3] <= 0.04045, a[..., :3] / 12.92, ((a[..., :3] + 0.055) / 1.055) ** 2.4)
+        imgs.append(np.concatenate([rgb * a[..., 3:4], a[..., 3:4]], axis=-1).astype(np.float32))
+    return ctx.torch.from_numpy(np.stack(imgs)).to(ctx.device)
+
+
 class CompatServer:
     def __init__(self, interact_dir, ctx, load_model, samples_per_ray=128, screenshot_spp=16, reference_images=None):
         self.dir, self.ctx, self.load_model = interact_dir, ctx, load_model
         self.samples_per_ray, self.spp = samples_per_ray, screenshot_spp  # run.py:48 default spp 16
-        self.reference_images = reference_images  # callable(test_json) -> device tensor, for --test_transforms
+        # callable(test_json) -> device tensor, for --test_transforms; default: the PNGs the json points at
+        self.reference_images = reference_images or (lambda test_json: load_reference_images(ctx, test_json))
 
     def serve_one(self, args):
         slot = self.load_model(args.get("scene"), self.ctx)  # stands in for load_training_data + training

@@ -68,3 +68,25 @@ def test_product_never_imports_the_oracle():
                     if lines:
                         bad.append((f, lines[:2]))
     assert not bad, bad
+
+
+def test_headers_are_plain_c(tmp_path):
+    """the boundary is a C ABI: both headers must compile as C99 and a C caller must link"""
+    src = tmp_path / "c_caller.c"
+    src.write_text(
+        '#include "prv.h"\n#include "prv_host.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "  prv_ctx* ctx = NULL; prv_field_desc d = {8, 4, 14, 8, 96, 32, 3.0f, 4.0f};\n"
+        "  uint64_t t = 0, m = 0, o = 0; double pose[16], tm[16]; double pos[3] = {0.1, 0.2, 0.25}, c[3] = {1e-10, 1e-10, 1e-10};\n"
+        "  if (prv_abi_version() != PRV_ABI_VERSION) return 1;\n"
+        "  if (prv_model_sizes(&d, &t, &m, &o) != PRV_OK || m != PRV_MLP_HALFS) return 2;\n"
+        "  prvh_view_pose(pos, c, pose); prvh_transform_matrix(pose, tm);\n"
+        "  if (prv_create(&ctx, 0) == PRV_OK) prv_destroy(ctx); else printf(\"%s\\n\", prv_last_error(NULL));\n"
+        '  printf("table halfs %llu tm03 %.6f\\n", (unsigned long long)t, tm[3]);\n  return 0;\n}\n')
+    inc, libdir = os.path.join(ROOT, "include"), os.path.join(ROOT, "nerf_prv_amd")
+    exe = tmp_path / "c_caller"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe), "-L", libdir,
+                           "-lprv_hip", "-lprv_host", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "table halfs" in out.stdout and "tm03 0.25" in out.stdout  # json translation = (z, x, y) of the position

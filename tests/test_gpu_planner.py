@@ -211,3 +211,48 @@ def test_flag_file_compat_server_answers_the_reference_handshake(ctx, tmp_path):
     assert got.shape == (45, 80, 4) and np.array_equal(got, want[2].cpu().numpy())
     args = compat_server.parse_command((interact / "run_with_c++.py").read_text())
     assert args["n_steps"] == "2500" and "train" in args["flags"] and args["screenshot_dir"].endswith("ensemble_1/")
+
+
+def test_compat_server_metrics_request_with_png_reference_images(ctx, tmp_path):
+    """--test_transforms J --save_metrics M (main.cpp:1670-1674 -> run.py:213-277): reference images are
+    the PNGs the json points at; the answer is the two-line metrics file"""
+    from PIL import Image
+
+    from nerf_prv_amd import compat_server
+
+    interact = tmp_path / "interact"
+    gt_dir = tmp_path / "gt"
+    (gt_dir / "5").mkdir(parents=True)
+    interact.mkdir()
+    pts = planner.hemisphere_read(os.path.join(GOLD, "hemisphere", "5.txt"), 5)
+    c = [1e-10] * 3
+    pos = planner.view_space(pts, 0.3, c)
+    k = planner.Intrinsics(width=160, height=90, ppx=80.0, ppy=45.0, fx=114.45, fy=114.45)
+    tj = gt_dir / "5.json"
+    planner.write_transforms(tj, k, pos, c, 0.1, path_prefix="5/rgbaClip_")
+    cams = ctx.cameras_from_json(tj)
+    ctx.synthetic_model(6, small_desc(), SEED + 4096)  # the "ground truth" object
+    clear = api.render_opts(160, 90, 64, 1, 1e-4, background=(0, 0, 0, 0))
+    png, _ = ctx.render_rgba8(6, cams, None, clear)  # straight-alpha sRGB bytes, as a GT screenshot would be
+    for i, img in enumerate(png.cpu().numpy()):
+        Image.fromarray(img, "RGBA").save(gt_dir / "5" / f"rgbaClip_{i}.png")
+    metrics = gt_dir / "3.txt"
+    cmd = (f"python D:/instant-ngp/scripts/run.py --train --n_steps 2500 --scene {gt_dir}/3.json "
+           f" --test_transforms {tj}  --save_metrics {metrics} ")
+    (interact / "run_with_c++.py").write_text("import os\nos.system('" + cmd + "')\n")
+    (interact / "ready_c++.txt").write_text("")
+
+    def load_model(scene, cx):
+        cx.synthetic_model(0, small_desc(), SEED)
+        return 0
+
+    srv = compat_server.CompatServer(str(interact), ctx, load_model, samples_per_ray=64)
+    assert srv.poll_once() and (interact / "ready_py.txt").exists()
+    psnr, ssim = planner.read_metrics(metrics)
+    gt = compat_server.load_reference_images(ctx, tj)
+    assert gt.shape == (5, 90, 160, 4)
+    want = ctx.evaluate(0, cams, None, api.render_opts(160, 90, 64, 1, 1e-4, background=(0, 0, 0, 1)), gt)
+    assert (psnr, ssim) == want and 5.0 < psnr < 60.0 and 0.0 < ssim < 1.0
+    # the PNG round trip loses at most the 8-bit quantisation of the linear image
+    lin, _ = ctx.render(6, cams, None, clear)
+    assert float((gt - lin).abs().max()) < 0.02
