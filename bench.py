@@ -65,7 +65,19 @@ def cpu_baseline(args, tms, scale, offset, fov_x):
         "sample": f"rows {rows[0]}-{rows[1]} of {n_views} views at {args.width}x{args.height}, "
                   f"{args.samples} samples/ray, {n_eval} samples evaluated in {dt:.1f} s "
                   f"(oracle/prv_oracle.c, pthreads over rows)",
+        "first_hit_rays_per_s": first_hit_cpu(f, cams[0], args),
     }
+
+
+def first_hit_cpu(f, cam, args):
+    """the oracle's scalar first-hit DDA on ONE core, 64 rows of one view (the reference spawns one OS
+    thread per voxel, main.cpp:124-130; a single tight loop is the kinder comparison)"""
+    from oracle import oracle as orc
+
+    rows = (args.height // 2 - 32, args.height // 2 + 32)
+    t0 = time.perf_counter()
+    orc.first_hit_image(f, cam, args.width, args.height, rows=rows)
+    return (rows[1] - rows[0]) * args.width / (time.perf_counter() - t0)
 
 
 def main():
@@ -147,6 +159,20 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_end()
 
+    # BASELINE config 1 analogue (the reference's CPU render path, main.cpp:98-284): first occupied voxel
+    # per ray over the same views; GPU (prv_first_hit) here, the oracle's scalar DDA in cpu_baseline
+    first_hit = None
+    if rank == 0:
+        cells = ctx.first_hit(0, cams, my_ids, args.width, args.height)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            cells = ctx.first_hit(0, cams, my_ids, args.width, args.height)
+        torch.cuda.synchronize()
+        dt_fh = (time.perf_counter() - t1) / 5
+        first_hit = {"gpu_rays_per_s": len(my_ids) * args.width * args.height / dt_fh,
+                     "hit_fraction": float((cells >= 0).float().mean().item())}
+
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     tot = torch.tensor([float(evaluated_per_step), float(nominal_per_step), float(rays_per_step)], dtype=torch.float64,
                        device=device)
@@ -204,7 +230,9 @@ def main():
                 "launches": launches,
                 "march_avg_launch_ms": prof["march_ms"] / max(1, prof["march_launches"]),
                 "mfma_tflops": samples_per_launch * 20480 / kernel_s / 1e12,
+                "mfma_util_frac": samples_per_launch * 20480 / kernel_s / 2.5e15,  # of the ~2.5 PFLOP/s dense f16 peak
             },
+            "first_hit": first_hit,
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, tms, scale, offset, fov_x)

@@ -86,6 +86,7 @@ def lib():
         L.orc_rank.argtypes = [vp, vp, C.c_int, vp]
         L.orc_argmax.restype, L.orc_argmax.argtypes = C.c_int, [vp, vp, C.c_int]
         L.orc_first_hit.argtypes = [C.POINTER(Field), vp, vp, C.c_float, vp]
+        L.orc_first_hit_rows.argtypes = [C.POINTER(Field), C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_float, vp]
         L.orc_precept.argtypes = [C.POINTER(Field), vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]
         _lib = L
     return _lib
@@ -239,16 +240,11 @@ def raygen(cam, w, h, spp_index=0):
     return o, d, t
 
 
-def first_hit_image(field, cam, w, h, max_range=1e30):
+def first_hit_image(field, cam, w, h, max_range=1e30, rows=None):
     """oracle: linear cell index of the first occupied voxel per pixel, or -1"""
-    out = np.full((h, w), -1, np.int32)
-    R = field.desc.occ_res
-    o, d, cell = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(3, np.int32)
-    for y in range(h):
-        for x in range(w):
-            lib().orc_raygen(C.byref(cam), x, y, C.c_float(0.5), C.c_float(0.5), _p(o), _p(d))
-            if lib().orc_first_hit(field.ptr, _p(o), _p(d), C.c_float(max_range), _p(cell)):
-                out[y, x] = cell[0] + R * (cell[1] + R * cell[2])
+    y0, y1 = rows if rows else (0, h)
+    out = np.full((y1 - y0, w), -1, np.int32)
+    lib().orc_first_hit_rows(field.ptr, C.byref(cam), w, y0, y1, C.c_float(max_range), _p(out))
     return out
 
 

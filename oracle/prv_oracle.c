@@ -941,3 +941,15 @@ void orc_precept(const orc_field* f, const float* voxels, int n, const double w2
     }
   }
 }
+
+/* first-hit cell per pixel for image rows [y0, y1): out[(y - y0) * w + x] = cell index or -1 */
+void orc_first_hit_rows(const orc_field* f, const orc_camera* cam, int w, int y0, int y1, float max_range, int32_t* out) {
+  const int R = f->desc.occ_res;
+  for (int y = y0; y < y1; y++)
+    for (int x = 0; x < w; x++) {
+      float o[3], d[3];
+      int cell[3];
+      orc_raygen(cam, x, y, 0.5f, 0.5f, o, d);
+      out[(size_t)(y - y0) * w + x] = orc_first_hit(f, o, d, max_range, cell) ? cell[0] + R * (cell[1] + R * cell[2]) : -1;
+    }
+}

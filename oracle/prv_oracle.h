@@ -137,6 +137,7 @@ int orc_argmax(const double* scores, const int* ids, int n);
 int orc_first_hit(const orc_field* f, const float o[3], const float d[3], float max_range,
                   int cell[3]);
 
+void orc_first_hit_rows(const orc_field* f, const orc_camera* cam, int w, int y0, int y1, float max_range, int32_t* out);
 /* the whole precept_thread_process per voxel (main.cpp:238-284) on the occupancy grid */
 void orc_precept(const orc_field* f, const float* voxels, int n, const double w2c[16], const double c2w[16],
                  const float intr[9], int width, int height, int model, float max_range, int32_t* out);
