@@ -552,6 +552,8 @@ void prv_destroy(prv_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  for (hipEvent_t e : c->ev_render) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_march) (void)hipEventDestroy(e);
   for (auto& m : c->models) {
     release(m.table);
     release(m.phys);
