@@ -540,7 +540,11 @@ int prv_create(prv_ctx** out, int device_id) {
   }
   c->stream = c->own_stream;
   if (const char* s = getenv("PRV_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(s));
-  if (const char* s = getenv("PRV_REFILL_MIN")) c->refill_min = std::min(32, std::max(1, atoi(s)));
+  if (const char* s = getenv("PRV_REFILL_MIN")) { // group size: power of two in [1, 32]
+    int g = std::min(32, std::max(1, atoi(s)));
+    while (g & (g - 1)) g &= g - 1;
+    c->refill_min = g;
+  }
   if (const char* s = getenv("PRV_DEHASH_MB")) c->dehash_budget = (size_t)std::max(0, atoi(s)) << 20;
   if (const char* s = getenv("PRV_DBG")) c->dbg_flags = atoi(s);
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
