@@ -147,7 +147,7 @@ const int kOff[5] = {0, 2048, 3072, 5120, 9216};
 // hidden unit held by element j of lane half h in k-step s of a 64-wide activation
 inline int hidden_k(int s, int h, int j) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
 
-void prepack_fragments(const uint16_t* mlp, std::vector<uint16_t>& frags) {
+void prepack_fragments(const uint16_t* mlp, int n_features, std::vector<uint16_t>& frags) {
   frags.assign((size_t)kNumFrags * kFragHalfs, 0);
   int f = 0;
   auto emit = [&](int layer, int mt, int s, int (*kmap)(int, int, int)) {
@@ -161,10 +161,12 @@ void prepack_fragments(const uint16_t* mlp, std::vector<uint16_t>& frags) {
     }
     f++;
   };
-  auto k_feat = [](int s, int h, int j) { return 16 * h + 8 * s + j; };               // grid features
+  // grid features: fragment s, element j of lane half h = feature (j % F) of level 2*(s*LH/2 + j/F) + h
+  auto k_feat4 = [](int s, int h, int j) { return 4 * (2 * (s * 2 + j / 4) + h) + j % 4; };
+  auto k_feat2 = [](int s, int h, int j) { return 2 * (2 * (s * 4 + j / 2) + h) + j % 2; };
   auto k_rgb_in = [](int s, int h, int j) { return s == 0 ? hidden_k(0, h, j) : 16 + 8 * h + j; }; // [dens | SH]
   for (int mt = 0; mt < 2; mt++)
-    for (int s = 0; s < 2; s++) emit(0, mt, s, k_feat);
+    for (int s = 0; s < 2; s++) emit(0, mt, s, n_features == 4 ? (int (*)(int, int, int))k_feat4 : (int (*)(int, int, int))k_feat2);
   for (int s = 0; s < 4; s++) emit(1, 0, s, hidden_k);
   for (int mt = 0; mt < 2; mt++)
     for (int s = 0; s < 2; s++) emit(2, mt, s, k_rgb_in);
@@ -267,7 +269,7 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
     HIPCHK(c, hipMemcpyAsync(m.occ_coarse.p, coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice, c->stream));
   }
   std::vector<uint16_t> frags;
-  prepack_fragments(mlp, frags);
+  prepack_fragments(mlp, d.n_features, frags);
   HIPCHK(c, hipMemcpyAsync(m.frags.p, frags.data(), frags.size() * 2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(m.mlp.p, mlp, PRV_MLP_HALFS * 2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream)); // host staging vectors go out of scope
@@ -280,14 +282,14 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   for (int l = 0; l < d.n_levels; l++) {
     order[l] = l;
     // a hashed level may be STORED densely (coherent gathers) when that fits the budget
-    const uint32_t sxl = ceil_log2(lv[l].res);
+    const uint32_t sxl = ceil_log2(lv[l].res + 1); // +1: room for the duplicated border entry
     const uint64_t dense_entries = 1ull << (3 * sxl); // >= pow2 ceiling of res << 2sx
     dehash[l] = lv[l].hashed && sxl <= 9 && dense_entries * ebytes <= c->dehash_budget;
     if (lv[l].hashed && !dehash[l]) {
       sx[l] = 0;
       psize[l] = lv[l].size;
     } else {
-      sx[l] = ceil_log2(lv[l].res);
+      sx[l] = sxl;
       psize[l] = 1u << ceil_log2(lv[l].res << (2 * sx[l]));
     }
   }
@@ -319,7 +321,13 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
     f.occ_lo[a] = m.occ_lo[a];
     f.occ_hi[a] = m.occ_hi[a];
   }
-  // Level order seen by the kernel: lane half h gathers canonical levels [h*L/2, (h+1)*L/2).
+  // gather step j = levels (2j, 2j+1) on lane halves (0, 1); leading steps whose two levels are both
+  // physically dense can use the paired loads
+  f.n_pair_steps = 0;
+  while (2 * f.n_pair_steps + 1 < d.n_levels && (!lv[2 * f.n_pair_steps].hashed || dehash[2 * f.n_pair_steps]) &&
+         (!lv[2 * f.n_pair_steps + 1].hashed || dehash[2 * f.n_pair_steps + 1]))
+    f.n_pair_steps++;
+  if (getenv("PRV_NO_PAIR")) f.n_pair_steps = 0;
   for (int l = 0; l < d.n_levels; l++) {
     LevelDev& L = f.levels[l];
     L.scale = lv[l].scale;

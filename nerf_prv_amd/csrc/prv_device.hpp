@@ -7,6 +7,7 @@
 // with -ffp-contract=off), so sample positions, grid indices and fp16 features are
 // bit-identical to the oracle.  Only the MFMA accumulation order and expf differ.
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -47,6 +48,7 @@ struct FieldDev {
   const half8* frags;     // kNumFrags * 64 half8, MFMA A fragments (prepacked weights)
   LevelDev levels[kMaxLevels];
   int n_levels, n_features, occ_res;
+  int n_pair_steps; // leading gather steps whose two levels are physically dense (paired loads)
   float density_bias;
   float occ_lo[3], occ_hi[3]; // bounding box of the occupied cells, grown by one cell (march pass clips to it)
 };
@@ -207,12 +209,36 @@ template <> struct Entry<2> {
   }
 };
 
+// the entries of vertices x and x+1 with ONE load (dense levels: contiguous in the physical layout, and
+// the entry after the last vertex of a row duplicates it, so the +1 clamp is implicit)
+template <int F> struct EntryPair;
+template <> struct EntryPair<4> {
+  uint32_t w[4];
+  __device__ __forceinline__ static EntryPair load(const char* p) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p); // 8-byte aligned 16-byte load
+    EntryPair e;
+    e.w[0] = v.x; e.w[1] = v.y; e.w[2] = v.z; e.w[3] = v.w;
+    return e;
+  }
+};
+template <> struct EntryPair<2> {
+  uint32_t w[2];
+  __device__ __forceinline__ static EntryPair load(const char* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    EntryPair e;
+    e.w[0] = v.x; e.w[1] = v.y;
+    return e;
+  }
+};
+
 // One level, one sample, one lane: 8 corner loads of F halfs and the trilinear blend in
 // packed binary16 (as tiny-cuda-nn does for fp16 tables): weights rounded to fp16,
 // w = fp16(fp16(wx*wy)*wz), acc = fp16 fma(w, v, acc), corners in order dx + 2dy + 4dz.
 // Every op is an IEEE RNE fp16 op (v_pk_mul_f16 / v_pk_fma_f16), so the result is
 // bit-identical to the oracle.  out = F/2 packed pairs.
-template <int F>
+// PAIR (compile time): the level stores x-neighbours contiguously -> 4 loads of 2 entries instead of 8
+// loads of 1: half the lane-addresses through the texture addresser.  Same values, same blend order.
+template <int F, bool PAIR>
 __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table, const LevelDev& L,
                                              float px, float py, float pz, half2v out[F / 2]) {
   constexpr int ESH = F == 4 ? 3 : 2; // log2(entry bytes)
@@ -232,11 +258,26 @@ __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table,
   // 24 bits of the multiplier, and only bits below m_b < 2^24 of the product are kept.
   const uint32_t ty[2] = {__umul24(c0[1], L.my_b) & L.m_b, __umul24(c1[1], L.my_b) & L.m_b};
   const uint32_t tz[2] = {(__umul24(c0[2], L.mz_b) & L.m_b) | L.off_b, (__umul24(c1[2], L.mz_b) & L.m_b) | L.off_b};
-  Entry<F> v[8];
+  uint32_t vw[8][F / 2]; // corner c = dx + 2dy + 4dz, F/2 packed pairs each
+  if (PAIR) {
 #pragma unroll
-  for (int c = 0; c < 8; c++) {
-    const uint32_t byte_off = tx[c & 1] ^ ty[(c >> 1) & 1] ^ tz[c >> 2];
-    v[c] = Entry<F>::load(reinterpret_cast<const char*>(table) + byte_off);
+    for (int q = 0; q < 4; q++) {
+      const uint32_t byte_off = tx[0] ^ ty[q & 1] ^ tz[q >> 1];
+      const EntryPair<F> e = EntryPair<F>::load(reinterpret_cast<const char*>(table) + byte_off);
+#pragma unroll
+      for (int k = 0; k < F / 2; k++) {
+        vw[2 * q][k] = e.w[k];
+        vw[2 * q + 1][k] = e.w[F / 2 + k];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const uint32_t byte_off = tx[c & 1] ^ ty[(c >> 1) & 1] ^ tz[c >> 2];
+      const Entry<F> e = Entry<F>::load(reinterpret_cast<const char*>(table) + byte_off);
+#pragma unroll
+      for (int k = 0; k < F / 2; k++) vw[c][k] = e.w[k];
+    }
   }
   // pair weights over x for each (dy, dz): (wx0, wx1) * wy[dy] * wz[dz]
   half2v wp[4];
@@ -252,14 +293,24 @@ __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table,
     const _Float16 w = wp[c >> 1][c & 1];
     const half2v ww = {w, w};
 #pragma unroll
-    for (int k = 0; k < F / 2; k++) out[k] = __builtin_elementwise_fma(ww, __builtin_bit_cast(half2v, v[c].w[k]), out[k]);
+    for (int k = 0; k < F / 2; k++) out[k] = __builtin_elementwise_fma(ww, __builtin_bit_cast(half2v, vw[c][k]), out[k]);
   }
 }
 
-// The 16 canonical features [16*h, 16*h+16) of one sample, as the two MFMA B fragments
-// (k-steps 0,1) of lane half h.  Lane half h gathers levels [h*L/2, (h+1)*L/2); the level
-// constants come from LDS (two broadcast ds_read_b128 per level: off the VALU path).
-template <int F>
+template <int F, int NPAIR, int... J>
+__device__ __forceinline__ void encode_steps(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv, int h,
+                                             float px, float py, float pz, half2v* out,
+                                             std::integer_sequence<int, J...>) {
+  (encode_level<F, (J < NPAIR)>(table, lv[2 * J + h], px, py, pz, out + J * (F / 2)), ...);
+}
+
+// The 16 features one lane half contributes to a sample, as its two MFMA B fragments (k-steps 0,1).
+// Levels are INTERLEAVED over the lane halves: gather step j handles level 2j on half 0 and level
+// 2j+1 on half 1, so both halves of a step are of the same kind wherever the field allows it; the first
+// NPAIR steps (compile time; both levels physically dense) use the paired loads.  Fragment s of half h
+// holds levels 2j+h for j in [s*LH/2, (s+1)*LH/2): the first-layer weights are prepacked with the same
+// map (prv_api.cpp: k_feat).
+template <int F, int NPAIR>
 __device__ __forceinline__ void encode_half(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv,
                                             int h, float px, float py, float pz, half8& b0, half8& b1) {
   constexpr int LH = 16 / F; // levels per lane half
@@ -267,11 +318,7 @@ __device__ __forceinline__ void encode_half(const uint16_t* __restrict__ table, 
   py = clamp01(py);
   pz = clamp01(pz);
   half2v out[8];
-#pragma unroll
-  for (int j = 0; j < LH; j++) {
-    const LevelDev L = lv[h * LH + j];
-    encode_level<F>(table, L, px, py, pz, out + j * (F / 2));
-  }
+  encode_steps<F, NPAIR>(table, lv, h, px, py, pz, out, std::make_integer_sequence<int, LH>{});
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     b0[2 * k] = out[k][0];

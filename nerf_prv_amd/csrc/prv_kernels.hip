@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
 
 // ------------------------------------------------------------------ K_B render from the queue
 
-template <int F>
+template <int F, int NPAIR>
 __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
   __shared__ half8 wl[kNumFrags * 64];
   __shared__ LevelDev lvl[kMaxLevels];
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
 #if PRV_ABLATE & 1
       f0[0] = (_Float16)t; f1[3] = (_Float16)dt;
 #else
-      encode_half<F>(P.field.table, lvl, h, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f0, f1);
+      encode_half<F, NPAIR>(P.field.table, lvl, h, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f0, f1);
 #endif
     }
     // ---- both MLPs on the matrix cores (whole wave)
@@ -276,8 +276,6 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
   }
 }
 
-template __global__ void render_queue_kernel<2>(RenderParams);
-template __global__ void render_queue_kernel<4>(RenderParams);
 
 // ------------------------------------------------------------------ first-hit ray cast (a13)
 // first occupied cell along (o, d) within max_range, or -1: Amanatides-Woo over the occupancy bits
@@ -642,6 +640,7 @@ __global__ __launch_bounds__(256) void repack_level_kernel(const uint16_t* __res
       const uint32_t x = i % L.res, y = (i / L.res) % L.res, z = i / (L.res * L.res);
       const uint32_t hsh = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & (L.n - 1u);
       dst[x | (y << L.sx) | (z << (2 * L.sx))] = src[hsh];
+      if (x == L.res - 1) dst[(x + 1) | (y << L.sx) | (z << (2 * L.sx))] = src[hsh]; // duplicated border (paired loads)
     }
     return;
   }
@@ -651,6 +650,7 @@ __global__ __launch_bounds__(256) void repack_level_kernel(const uint16_t* __res
       const uint32_t x = i % L.res, y = (i / L.res) % L.res, z = i / (L.res * L.res);
       if (z >= L.res) continue; // canonical padding entries
       to = x | (y << L.sx) | (z << (2 * L.sx));
+      if (x == L.res - 1) dst[to + 1] = src[i]; // duplicated border entry: the paired load at x = res-1 reads it
     }
     dst[to] = src[i];
   }
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void debug_raygen_kernel(CamDev cam, int W, in
 }
 
 // one wave = 32 points through exactly the production gather + MFMA code
-template <int F>
+template <int F, int NPAIR>
 __global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const float* __restrict__ pos,
                                                           const float* __restrict__ dir, int n,
                                                           uint16_t* __restrict__ feat,
@@ -701,14 +701,20 @@ __global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const flo
     }
   }
   half8 f0, f1;
-  encode_half<F>(fd.table, lvl, h, p[0], p[1], p[2], f0, f1);
+  encode_half<F, NPAIR>(fd.table, lvl, h, p[0], p[1], p[2], f0, f1);
   const half8 shf = sh_fragment(h, dd[0], dd[1], dd[2]);
   const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf);
   if (!ok) return;
-  if (feat) { // two 16-byte vector stores per lane (canonical features [16h, 16h+16))
-    half8* dst = reinterpret_cast<half8*>(feat + (size_t)idx * 32 + 16 * h);
-    dst[0] = f0;
-    dst[1] = f1;
+  if (feat) { // fragment s, element e of half h is canonical feature F*(2*(s*LH/2 + e/F) + h) + e%F
+    constexpr int LHd = 16 / F;
+    uint16_t* dst = feat + (size_t)idx * 32;
+    typedef uint16_t ushort8 __attribute__((ext_vector_type(8)));
+    const ushort8 u0 = __builtin_bit_cast(ushort8, f0), u1 = __builtin_bit_cast(ushort8, f1);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      dst[F * (2 * (0 * LHd / 2 + e / F) + h) + e % F] = u0[e];
+      dst[F * (2 * (1 * LHd / 2 + e / F) + h) + e % F] = u1[e];
+    }
   }
   if (out36) {
     float* q = out36 + (size_t)idx * 36;
@@ -742,11 +748,17 @@ hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_
   return hipGetLastError();
 }
 
+// instances: paired loads on the first NPAIR gather steps (host picks the largest instance <= the
+// field's count of leading dense-dense steps)
 hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s) {
-  if (P.field.n_features == 4)
-    hipLaunchKernelGGL(render_queue_kernel<4>, dim3(n_blocks), dim3(256), 0, s, P);
-  else
-    hipLaunchKernelGGL(render_queue_kernel<2>, dim3(n_blocks), dim3(256), 0, s, P);
+  const int np = P.field.n_pair_steps;
+  if (P.field.n_features == 4) {
+    if (np >= 2) hipLaunchKernelGGL((render_queue_kernel<4, 2>), dim3(n_blocks), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((render_queue_kernel<4, 0>), dim3(n_blocks), dim3(256), 0, s, P);
+  } else {
+    if (np >= 5) hipLaunchKernelGGL((render_queue_kernel<2, 5>), dim3(n_blocks), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((render_queue_kernel<2, 0>), dim3(n_blocks), dim3(256), 0, s, P);
+  }
   return hipGetLastError();
 }
 
@@ -832,10 +844,14 @@ hipError_t launch_debug_raygen(const CamDev& cam, int W, int H, int spp_k, float
 hipError_t launch_debug_field(const FieldDev& fd, const float* pos, const float* dir, int n, uint16_t* feat,
                               float* out36, int32_t* occ, hipStream_t s) {
   unsigned blocks = (unsigned)((n + 127) / 128);
-  if (fd.n_features == 4)
-    hipLaunchKernelGGL(debug_field_kernel<4>, dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
-  else
-    hipLaunchKernelGGL(debug_field_kernel<2>, dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+  const int np = fd.n_pair_steps;
+  if (fd.n_features == 4) {
+    if (np >= 2) hipLaunchKernelGGL((debug_field_kernel<4, 2>), dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+    else hipLaunchKernelGGL((debug_field_kernel<4, 0>), dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+  } else {
+    if (np >= 5) hipLaunchKernelGGL((debug_field_kernel<2, 5>), dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+    else hipLaunchKernelGGL((debug_field_kernel<2, 0>), dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+  }
   return hipGetLastError();
 }
 
