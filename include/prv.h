@@ -145,6 +145,23 @@ int prv_cameras_from_json(prv_ctx* ctx, const char* path, prv_camset** out);
 int prv_cameras_from_matrices(prv_ctx* ctx, const double* tm, int n, double camera_angle_x,
                               int width, int height, double scale, const double offset[3],
                               prv_camset** out);
+/* The cameras of a DATASET json, as the engine sees its training / test views: replaces
+ * testbed.load_training_data(--test_transforms) + set_camera_to_training_view(i) with
+ * render_with_lens_distortion (run.py:145, 238, 242) -- the per-file intrinsics the planner writes at
+ * main.cpp:1585-1602 (fl_x, fl_y, cx, cy, w, h; k1, k2, p1, p2 read BY KEY = the yaml's color_k1, color_k2,
+ * color_p1, color_p2; k3 is written too but is not a term of the engine's OpenCV lens and is ignored).  Missing fl_* fall
+ * back to camera_angle_*, missing cx, cy to the image centre, missing lens terms to 0.  Rendering at
+ * another size than (w,h) scales fl and the principal point per axis. */
+typedef struct prv_intrinsics {
+  double fl_x, fl_y, cx, cy; /* pixels, at (w,h) */
+  double k1, k2, p1, p2;     /* OpenCV radial / tangential terms on normalised coordinates */
+  int32_t w, h;
+} prv_intrinsics;
+int prv_cameras_from_dataset_json(prv_ctx* ctx, const char* path, prv_camset** out);
+int prv_cameras_from_matrices_intr(prv_ctx* ctx, const double* tm, int n, const prv_intrinsics* intr,
+                                   double scale, const double offset[3], prv_camset** out);
+/* lens terms {k1,k2,p1,p2} of camera i (all 0 for the screenshot-style sets above) */
+int prv_camset_lens(const prv_camset* cs, int i, float lens[4]);
 int prv_camset_count(const prv_camset* cs);
 int prv_camset_size(const prv_camset* cs, int* width, int* height);
 /* engine-frame camera i: c2w[12] row-major 3x4, intr = {fx, fy, cx, cy} at the json w,h */

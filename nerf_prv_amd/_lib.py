@@ -62,6 +62,10 @@ class Stats(C.Structure):
                 ("wave_rounds", C.c_uint64)]
 
 
+class Intrinsics(C.Structure):
+    _fields_ = [(n, C.c_double) for n in "fl_x fl_y cx cy k1 k2 p1 p2".split()] + [("w", C.c_int32), ("h", C.c_int32)]
+
+
 _vp = C.c_void_p
 _i = C.c_int
 _P = C.POINTER
@@ -89,6 +93,9 @@ SIGNATURES = {
     "prv_model_load_file": (_i, [_vp, _i, C.c_char_p]),
     "prv_cameras_from_json": (_i, [_vp, C.c_char_p, _P(_vp)]),
     "prv_cameras_from_matrices": (_i, [_vp, _vp, _i, C.c_double, _i, _i, C.c_double, _vp, _P(_vp)]),
+    "prv_cameras_from_dataset_json": (_i, [_vp, C.c_char_p, _P(_vp)]),
+    "prv_cameras_from_matrices_intr": (_i, [_vp, _vp, _i, _P(Intrinsics), C.c_double, _vp, _P(_vp)]),
+    "prv_camset_lens": (_i, [_vp, _i, _vp]),
     "prv_camset_count": (_i, [_vp]),
     "prv_camset_size": (_i, [_vp, _P(_i), _P(_i)]),
     "prv_camset_get": (_i, [_vp, _i, _vp, _vp]),

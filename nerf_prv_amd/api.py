@@ -87,6 +87,13 @@ class CamSet:
             raise PrvError(rc, "camera index out of range")
         return c2w.reshape(3, 4), intr
 
+    def lens(self, i):
+        """{k1, k2, p1, p2} of camera i"""
+        lens = np.zeros(4, np.float32)
+        if self.ctx.lib.prv_camset_lens(self.handle, i, _ptr(lens)) != 0:
+            raise PrvError(L.PRV_E_INVALID, "camera index out of range")
+        return lens
+
     def close(self):
         if self.handle:
             self.ctx.lib.prv_camset_destroy(self.handle)
@@ -177,6 +184,22 @@ class Context:
     def cameras_from_json(self, path):
         h = C.c_void_p()
         self._chk(self.lib.prv_cameras_from_json(self.handle, str(path).encode(), C.byref(h)))
+        return CamSet(self, h)
+
+    def cameras_from_dataset_json(self, path):
+        """the json's own intrinsics block (fl, principal point, lens): the engine's view of a dataset"""
+        h = C.c_void_p()
+        self._chk(self.lib.prv_cameras_from_dataset_json(self.handle, str(path).encode(), C.byref(h)))
+        return CamSet(self, h)
+
+    def cameras_from_matrices_intr(self, tm, intr, scale, offset):
+        """intr: dict with fl_x fl_y cx cy w h and optional k1 k2 p1 p2"""
+        tm = np.ascontiguousarray(tm, np.float64).reshape(-1, 16)
+        off = np.ascontiguousarray(offset, np.float64)
+        ci = L.Intrinsics(**{k: (int(v) if k in ("w", "h") else float(v)) for k, v in intr.items()})
+        h = C.c_void_p()
+        self._chk(self.lib.prv_cameras_from_matrices_intr(self.handle, _ptr(tm), tm.shape[0], C.byref(ci), float(scale),
+                                                          _ptr(off), C.byref(h)))
         return CamSet(self, h)
 
     def cameras_from_matrices(self, tm, camera_angle_x, width, height, scale, offset):
@@ -331,6 +354,25 @@ class _NerfSettings:
         self.render_with_lens_distortion = False
         self.sharpen = 0.0
         self.samples_per_ray = 128
+        self.training = _Training()
+
+
+class _FrameMeta:
+    def __init__(self, w, h):
+        self.resolution = (w, h)
+
+
+class _Dataset:
+    """testbed.nerf.training.dataset (run.py:240-241): n_images, metadata[i].resolution"""
+
+    def __init__(self):
+        self.n_images = 0
+        self.metadata = []
+
+
+class _Training:
+    def __init__(self):
+        self.dataset = _Dataset()
 
 
 class Testbed:
@@ -360,6 +402,10 @@ class Testbed:
         self._matrix = np.eye(4)[:3]
         self._slot = 0
         self._have_model = False
+        self.render_ground_truth = False
+        self._dataset_cams = None
+        self._dataset_path = None
+        self._training_view = None
 
     def load_training_data(self, path):
         with open(path) as f:
@@ -369,6 +415,21 @@ class Testbed:
         if "camera_angle_x" in meta:
             self.fov_axis, self.fov = 0, meta["camera_angle_x"] * 180.0 / math.pi
         self.training_meta = meta
+        if self._dataset_cams is not None:
+            self._dataset_cams.close()
+            self._dataset_cams = None
+        ds = self.nerf.training.dataset
+        ds.n_images, ds.metadata = 0, []
+        if meta.get("frames") and "w" in meta and "h" in meta:  # the dataset's own cameras (run.py:238-242)
+            self._dataset_cams = self.ctx.cameras_from_dataset_json(path)
+            self._dataset_path = str(path)
+            ds.n_images = len(self._dataset_cams)
+            ds.metadata = [_FrameMeta(int(meta["w"]), int(meta["h"])) for _ in range(ds.n_images)]
+
+    def set_camera_to_training_view(self, i):  # run.py:242
+        if self._dataset_cams is None or not 0 <= int(i) < len(self._dataset_cams):
+            raise PrvError(L.PRV_E_INVALID, "no such training view")
+        self._training_view = int(i)
 
     def load_model(self, desc, table, mlp, occ):
         self.ctx.load_model(self._slot, desc, table, mlp, occ)
@@ -390,6 +451,7 @@ class Testbed:
         if m.shape != (3, 4):
             raise ValueError("set_nerf_camera_matrix expects a 3x4 matrix")
         self._matrix = m
+        self._training_view = None
 
     def render(self, width, height, spp=1, linear=True):
         if not self._have_model:
@@ -398,13 +460,32 @@ class Testbed:
             raise NotImplementedError("only linear=True is used on the reference path (run.py:245,247,304)")
         if self.fov_axis != 0:
             raise NotImplementedError("fov_axis must be 0 (run.py:285)")
-        tm = np.vstack([self._matrix, [0, 0, 0, 1]])
-        cams = self.ctx.cameras_from_matrices(tm, self.fov * math.pi / 180.0, width, height, self.scale, self.offset)
         eff_spp = 1 if self.snap_to_pixel_centers else int(spp)
         opts = render_opts(width, height, self.nerf.samples_per_ray, eff_spp, self.nerf.render_min_transmittance)
-        img, _ = self.ctx.render(self._slot, cams, None, opts, want_stats=False)
-        img = img[0]
+        if self._training_view is not None:  # dataset camera: own intrinsics + lens (run.py:242-247)
+            if self.render_ground_truth:
+                img = self._ground_truth(self._training_view, width, height)
+            else:
+                img, _ = self.ctx.render(self._slot, self._dataset_cams, [self._training_view], opts, want_stats=False)
+                img = img[0]
+        else:
+            tm = np.vstack([self._matrix, [0, 0, 0, 1]])
+            cams = self.ctx.cameras_from_matrices(tm, self.fov * math.pi / 180.0, width, height, self.scale, self.offset)
+            img, _ = self.ctx.render(self._slot, cams, None, opts, want_stats=False)
+            img = img[0]
+            cams.close()
         bg = self.ctx.torch.tensor(self.background_color, dtype=img.dtype, device=img.device)
         img = img + (1.0 - img[..., 3:4]) * bg  # composite over the background colour
-        cams.close()
         return img.cpu().numpy()
+
+    def _ground_truth(self, i, width, height):
+        """render_ground_truth (run.py:241-244): the dataset image of view i, linear premultiplied RGBA"""
+        from .compat_server import load_reference_images
+
+        if getattr(self, "_gt_cache_path", None) != self._dataset_path:
+            self._gt_cache = load_reference_images(self.ctx, self._dataset_path)
+            self._gt_cache_path = self._dataset_path
+        img = self._gt_cache[i]
+        if tuple(img.shape[:2]) != (height, width):
+            raise NotImplementedError("ground-truth images are only served at their own resolution (run.py:240-244)")
+        return img

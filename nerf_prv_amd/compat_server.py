@@ -97,7 +97,8 @@ class CompatServer:
         elif "test_transforms" in args:
             from . import planner
 
-            cams = self.ctx.cameras_from_json(args["test_transforms"])
+            # the dataset's own cameras: fl_x/fl_y, principal point, lens (run.py:238-242)
+            cams = self.ctx.cameras_from_dataset_json(args["test_transforms"])
             w, h = cams.size
             gt = self.reference_images(args["test_transforms"])
             opts = api.render_opts(w, h, self.samples_per_ray, 1, 1e-4, background=(0.0, 0.0, 0.0, 1.0))  # run.py:226-235

@@ -44,6 +44,7 @@ struct prv_camset {
   CamDev* dev = nullptr;
   int device = 0;
   int width = 0, height = 0;
+  bool dataset = false; // intrinsics are the dataset's (own principal point, fl_y, lens), not fov-at-centre
 };
 
 struct prv_ctx {
@@ -368,9 +369,19 @@ int check_opts(prv_ctx* c, const prv_render_opts* o) {
 
 // cameras at the render resolution: focal from camera_angle_x at the json width (run.py:285-286,
 // fov_axis = 0), rescaled to the requested width; principal point at the image centre.
-CamDev cam_at(const CamDev& c, int json_w, int w, int h) {
+// Dataset sets (prv_cameras_from_dataset_json) keep their principal point and scale per axis.
+CamDev cam_at(const prv_camset* cs, int i, int w, int h) {
+  const CamDev& c = cs->cams[i];
   CamDev r = c;
-  const float s = (float)w / (float)json_w;
+  const float s = (float)w / (float)cs->width;
+  if (cs->dataset) {
+    const float sy = (float)h / (float)cs->height;
+    r.fx = c.fx * s;
+    r.fy = c.fy * sy;
+    r.cx = c.cx * s;
+    r.cy = c.cy * sy;
+    return r;
+  }
   r.fx = c.fx * s;
   r.fy = c.fy * s;
   r.cx = 0.5f * (float)w;
@@ -399,7 +410,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   for (int i = 0; i < n_views; i++) {
     const int v = view_ids ? view_ids[i] : i;
     if (v < 0 || v >= (int)cs->cams.size()) return fail(c, PRV_E_INVALID, "view id %d out of range", v);
-    cams[i] = cam_at(cs->cams[v], cs->width, W, H);
+    cams[i] = cam_at(cs, v, W, H);
     ids[i] = i;
   }
   if ((rc = ensure(c, c->view_ids, (size_t)n_views * (sizeof(CamDev) + sizeof(int)))) != PRV_OK) return rc;
@@ -777,20 +788,23 @@ int prv_model_load_file(prv_ctx* c, int slot, const char* path) {
 // transform_matrix (NeRF convention, as written at main.cpp:1626-1641) -> engine frame:
 // negate columns 1 and 2, t*scale + offset, cycle rows (y,z,x).  ASSUMED from upstream
 // instant-ngp (not in the reference tree).
-int prv_cameras_from_matrices(prv_ctx* c, const double* tm, int n, double camera_angle_x, int width, int height,
-                              double scale, const double offset[3], prv_camset** out) {
-  if (!c) return PRV_E_INVALID;
+static int build_camset(prv_ctx* c, const double* tm, int n, const prv_intrinsics& in, bool dataset, double scale,
+                        const double offset[3], prv_camset** out) {
   if (!out) return fail(c, PRV_E_INVALID, "out is NULL");
   *out = nullptr;
   if (n < 0 || (n > 0 && !tm)) return fail(c, PRV_E_INVALID, "bad matrix array");
-  if (width < 1 || height < 1) return fail(c, PRV_E_INVALID, "bad size %dx%d", width, height);
-  if (!(camera_angle_x > 0.0 && camera_angle_x < M_PI)) return fail(c, PRV_E_INVALID, "bad camera_angle_x %g", camera_angle_x);
+  if (in.w < 1 || in.h < 1) return fail(c, PRV_E_INVALID, "bad size %dx%d", in.w, in.h);
+  if (!(in.fl_x > 0.0) || !(in.fl_y > 0.0) || !std::isfinite(in.fl_x) || !std::isfinite(in.fl_y))
+    return fail(c, PRV_E_INVALID, "bad focal length %g, %g", in.fl_x, in.fl_y);
+  if (!std::isfinite(in.cx) || !std::isfinite(in.cy) || !std::isfinite(in.k1) || !std::isfinite(in.k2) ||
+      !std::isfinite(in.p1) || !std::isfinite(in.p2))
+    return fail(c, PRV_E_INVALID, "non-finite intrinsics");
   prv_camset* cs = new prv_camset();
   cs->device = c->device;
-  cs->width = width;
-  cs->height = height;
+  cs->width = in.w;
+  cs->height = in.h;
+  cs->dataset = dataset;
   const double off[3] = {offset ? offset[0] : 0.5, offset ? offset[1] : 0.5, offset ? offset[2] : 0.5};
-  const float focal = (float)(0.5 * (double)width / std::tan(0.5 * camera_angle_x));
   static const int src_row[3] = {1, 2, 0};
   cs->cams.resize(n);
   for (int i = 0; i < n; i++) {
@@ -805,15 +819,44 @@ int prv_cameras_from_matrices(prv_ctx* c, const double* tm, int n, double camera
     CamDev& cam = cs->cams[i];
     for (int r = 0; r < 3; r++)
       for (int k = 0; k < 4; k++) cam.c2w[r * 4 + k] = (float)e[src_row[r]][k];
-    cam.fx = cam.fy = focal;
-    cam.cx = 0.5f * (float)width;
-    cam.cy = 0.5f * (float)height;
+    cam.fx = (float)in.fl_x;
+    cam.fy = (float)in.fl_y;
+    cam.cx = (float)in.cx;
+    cam.cy = (float)in.cy;
+    cam.lens[0] = (float)in.k1;
+    cam.lens[1] = (float)in.k2;
+    cam.lens[2] = (float)in.p1;
+    cam.lens[3] = (float)in.p2;
   }
   *out = cs;
   return PRV_OK;
 }
 
-int prv_cameras_from_json(prv_ctx* c, const char* path, prv_camset** out) {
+int prv_cameras_from_matrices(prv_ctx* c, const double* tm, int n, double camera_angle_x, int width, int height,
+                              double scale, const double offset[3], prv_camset** out) {
+  if (!c) return PRV_E_INVALID;
+  if (out) *out = nullptr;
+  if (width < 1 || height < 1) return fail(c, PRV_E_INVALID, "bad size %dx%d", width, height);
+  if (!(camera_angle_x > 0.0 && camera_angle_x < M_PI)) return fail(c, PRV_E_INVALID, "bad camera_angle_x %g", camera_angle_x);
+  prv_intrinsics in{};
+  in.fl_x = in.fl_y = (double)(float)(0.5 * (double)width / std::tan(0.5 * camera_angle_x));
+  in.cx = 0.5 * width;
+  in.cy = 0.5 * height;
+  in.w = width;
+  in.h = height;
+  return build_camset(c, tm, n, in, false, scale, offset, out);
+}
+
+int prv_cameras_from_matrices_intr(prv_ctx* c, const double* tm, int n, const prv_intrinsics* intr, double scale,
+                                   const double offset[3], prv_camset** out) {
+  if (!c) return PRV_E_INVALID;
+  if (out) *out = nullptr;
+  if (!intr) return fail(c, PRV_E_INVALID, "intrinsics are NULL");
+  return build_camset(c, tm, n, *intr, true, scale, offset, out);
+}
+
+// header + frames of a transforms.json; dataset = use the file's own intrinsics block
+static int cameras_from_json(prv_ctx* c, const char* path, bool dataset, prv_camset** out) {
   if (!c) return PRV_E_INVALID;
   if (!out || !path) return fail(c, PRV_E_INVALID, "NULL argument");
   *out = nullptr;
@@ -821,8 +864,8 @@ int prv_cameras_from_json(prv_ctx* c, const char* path, prv_camset** out) {
   if (!prvjson::read_file(path, text)) return fail(c, PRV_E_IO, "cannot read %s", path);
   prvjson::Value root;
   if (!prvjson::Parser(text).parse(root, err)) return fail(c, PRV_E_IO, "%s: %s", path, err.c_str());
-  if (!root.has("camera_angle_x") || !root.has("frames") || !root.has("w") || !root.has("h"))
-    return fail(c, PRV_E_IO, "%s: missing camera_angle_x / w / h / frames", path);
+  if (!root.has("frames") || !root.has("w") || !root.has("h")) return fail(c, PRV_E_IO, "%s: missing w / h / frames", path);
+  if (!dataset && !root.has("camera_angle_x")) return fail(c, PRV_E_IO, "%s: missing camera_angle_x", path);
   const double scale = root.has("scale") ? root.at("scale").number() : 0.33;
   double offset[3] = {0.5, 0.5, 0.5};
   if (root.has("offset") && root.at("offset").arr.size() == 3)
@@ -830,6 +873,7 @@ int prv_cameras_from_json(prv_ctx* c, const char* path, prv_camset** out) {
   const auto& frames = root.at("frames").arr;
   std::vector<double> tm(frames.size() * 16);
   for (size_t i = 0; i < frames.size(); i++) {
+    if (!frames[i].has("transform_matrix")) return fail(c, PRV_E_IO, "%s: frame %zu has no transform_matrix", path, i);
     const auto& M = frames[i].at("transform_matrix");
     if (M.arr.size() != 4) return fail(c, PRV_E_IO, "%s: frame %zu has no 4x4 transform_matrix", path, i);
     for (int r = 0; r < 4; r++) {
@@ -837,8 +881,37 @@ int prv_cameras_from_json(prv_ctx* c, const char* path, prv_camset** out) {
       for (int k = 0; k < 4; k++) tm[i * 16 + r * 4 + k] = M.arr[r].arr[k].number();
     }
   }
-  return prv_cameras_from_matrices(c, tm.data(), (int)frames.size(), root.at("camera_angle_x").number(),
-                                   (int)root.at("w").number(), (int)root.at("h").number(), scale, offset, out);
+  const int w = (int)root.at("w").number(), h = (int)root.at("h").number();
+  if (!dataset)
+    return prv_cameras_from_matrices(c, tm.data(), (int)frames.size(), root.at("camera_angle_x").number(), w, h, scale,
+                                     offset, out);
+  auto num = [&](const char* k, double dflt) { return root.has(k) ? root.at(k).number() : dflt; };
+  prv_intrinsics in{};
+  in.w = w;
+  in.h = h;
+  if (root.has("fl_x")) in.fl_x = root.at("fl_x").number();
+  else if (root.has("camera_angle_x")) in.fl_x = 0.5 * w / std::tan(0.5 * root.at("camera_angle_x").number());
+  if (root.has("fl_y")) in.fl_y = root.at("fl_y").number();
+  else if (root.has("camera_angle_y")) in.fl_y = 0.5 * h / std::tan(0.5 * root.at("camera_angle_y").number());
+  else in.fl_y = in.fl_x;
+  if (!(in.fl_x > 0.0)) in.fl_x = in.fl_y;
+  if (!(in.fl_x > 0.0)) return fail(c, PRV_E_IO, "%s: no fl_x / fl_y / camera_angle_*", path);
+  in.cx = num("cx", 0.5 * w);
+  in.cy = num("cy", 0.5 * h);
+  in.k1 = num("k1", 0.0);
+  in.k2 = num("k2", 0.0);
+  in.p1 = num("p1", 0.0);
+  in.p2 = num("p2", 0.0);
+  return build_camset(c, tm.data(), (int)frames.size(), in, true, scale, offset, out);
+}
+
+int prv_cameras_from_json(prv_ctx* c, const char* path, prv_camset** out) { return cameras_from_json(c, path, false, out); }
+int prv_cameras_from_dataset_json(prv_ctx* c, const char* path, prv_camset** out) { return cameras_from_json(c, path, true, out); }
+
+int prv_camset_lens(const prv_camset* cs, int i, float lens[4]) {
+  if (!cs || i < 0 || i >= (int)cs->cams.size() || !lens) return PRV_E_INVALID;
+  memcpy(lens, cs->cams[i].lens, sizeof(float) * 4);
+  return PRV_OK;
 }
 
 int prv_camset_count(const prv_camset* cs) { return cs ? (int)cs->cams.size() : PRV_E_INVALID; }
@@ -900,7 +973,7 @@ int prv_first_hit(prv_ctx* c, int slot, const prv_camset* cs, const int* view_id
   for (int i = 0; i < n_views; i++) {
     const int v = view_ids ? view_ids[i] : i;
     if (v < 0 || v >= (int)cs->cams.size()) return fail(c, PRV_E_INVALID, "view id %d out of range", v);
-    cams[i] = cam_at(cs->cams[v], cs->width, W, H);
+    cams[i] = cam_at(cs, v, W, H);
   }
   if ((rc = ensure(c, c->view_ids, (size_t)n_views * (sizeof(CamDev) + sizeof(int)))) != PRV_OK) return rc;
   HIPCHK(c, hipMemcpyAsync(c->view_ids.p, cams.data(), (size_t)n_views * sizeof(CamDev), hipMemcpyHostToDevice, c->stream));
@@ -1152,7 +1225,7 @@ int prv_debug_raygen(prv_ctx* c, const prv_camset* cs, int view, int W, int H, i
   if ((rc = ensure(c, c->dbg[0], n * 12)) != PRV_OK || (rc = ensure(c, c->dbg[1], n * 12)) != PRV_OK ||
       (rc = ensure(c, c->dbg[2], n * 8)) != PRV_OK)
     return rc;
-  HIPCHK(c, launch_debug_raygen(cam_at(cs->cams[view], cs->width, W, H), W, H, spp_k, (float*)c->dbg[0].p,
+  HIPCHK(c, launch_debug_raygen(cam_at(cs, view, W, H), W, H, spp_k, (float*)c->dbg[0].p,
                                 (float*)c->dbg[1].p, (float*)c->dbg[2].p, c->stream));
   HIPCHK(c, hipMemcpyAsync(o, c->dbg[0].p, n * 12, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(d, c->dbg[1].p, n * 12, hipMemcpyDeviceToHost, c->stream));

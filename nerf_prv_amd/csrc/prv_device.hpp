@@ -56,6 +56,7 @@ struct FieldDev {
 struct CamDev {  // engine-frame camera
   float c2w[12]; // row-major 3x4
   float fx, fy, cx, cy;
+  float lens[4]; // k1, k2, p1, p2 (OpenCV model on normalised coordinates); all zero = pinhole
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -72,10 +73,50 @@ __device__ __forceinline__ void spp_offset(int k, float& ox, float& oy) {
 }
 
 // pinhole ray through pixel (px+ox, py+oy); direction normalised
+// OpenCV radial + tangential model and its Jacobian; the operation order is the oracle's (lens_eval)
+__device__ __forceinline__ void lens_eval(const float L[4], float x, float y, float& fx, float& fy, float J[4]) {
+  const float k1 = L[0], k2 = L[1], p1 = L[2], p2 = L[3];
+  const float r2 = fmaf(x, x, y * y);
+  const float kr = fmaf(k2, r2, k1);
+  const float radial = fmaf(kr, r2, 1.0f);
+  const float dk = 2.0f * fmaf(2.0f * k2, r2, k1);
+  const float xy = x * y;
+  fx = fmaf(x, radial, fmaf(2.0f * p1, xy, p2 * fmaf(2.0f * x, x, r2)));
+  fy = fmaf(y, radial, fmaf(p1, fmaf(2.0f * y, y, r2), (2.0f * p2) * xy));
+  const float a = 2.0f * fmaf(p1, x, p2 * y);
+  J[0] = fmaf(x * x, dk, fmaf(2.0f * p1, y, fmaf(6.0f * p2, x, radial)));
+  J[1] = fmaf(xy, dk, a);
+  J[2] = J[1];
+  J[3] = fmaf(y * y, dk, fmaf(6.0f * p1, y, fmaf(2.0f * p2, x, radial)));
+}
+
+constexpr int kLensIters = 8; // fixed count, no early exit: identical on every lane and in the oracle
+__device__ __forceinline__ void lens_undistort(const float L[4], float& px, float& py) {
+  const float xd = px, yd = py;
+  float x = xd, y = yd;
+  for (int it = 0; it < kLensIters; it++) {
+    float fx, fy, J[4];
+    lens_eval(L, x, y, fx, fy, J);
+    const float ex = fx - xd, ey = fy - yd;
+    const float det = fmaf(J[0], J[3], -(J[1] * J[2]));
+    const float sx = fmaf(J[3], ex, -(J[1] * ey)) / det;
+    const float sy = fmaf(J[0], ey, -(J[2] * ex)) / det;
+    x -= sx;
+    y -= sy;
+  }
+  px = x;
+  py = y;
+}
+
+__device__ __forceinline__ bool has_lens(const CamDev& cam) {
+  return cam.lens[0] != 0.0f || cam.lens[1] != 0.0f || cam.lens[2] != 0.0f || cam.lens[3] != 0.0f;
+}
+
 __device__ __forceinline__ void raygen(const CamDev& cam, int px, int py, float ox, float oy,
                                        float o[3], float d[3]) {
   float dx = (((float)px + ox) - cam.cx) / cam.fx;
   float dy = (((float)py + oy) - cam.cy) / cam.fy;
+  if (has_lens(cam)) lens_undistort(cam.lens, dx, dy); // uniform per view
   float v[3];
 #pragma unroll
   for (int r = 0; r < 3; r++) {

@@ -31,7 +31,8 @@ class Field(C.Structure):
 
 
 class Camera(C.Structure):
-    _fields_ = [("c2w", C.c_float * 12), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+    _fields_ = [("c2w", C.c_float * 12), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("lens", C.c_float * 4)]
 
 
 def build():
@@ -71,6 +72,8 @@ def lib():
         L.orc_spp_offset.argtypes = [C.c_int, f32p, f32p]
         L.orc_raygen.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]
         L.orc_ray_aabb.argtypes = [vp, vp, f32p, f32p]
+        L.orc_lens_distort.argtypes = [C.c_float * 4, C.c_float, C.c_float, f32p, f32p]
+        L.orc_lens_undistort.argtypes = [C.c_float * 4, f32p, f32p]
         L.orc_render.argtypes = [C.POINTER(Field), C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp,
                                  C.POINTER(C.c_uint64), C.c_int]
         L.orc_render_rows.argtypes = [C.POINTER(Field), C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -173,13 +176,39 @@ class OracleField:
             pass
 
 
-def camera(c2w, fx, fy, cx, cy):
+def camera(c2w, fx, fy, cx, cy, lens=(0.0, 0.0, 0.0, 0.0)):
     cam = Camera()
     flat = np.asarray(c2w, np.float32).reshape(12)
     for i in range(12):
         cam.c2w[i] = float(flat[i])
     cam.fx, cam.fy, cam.cx, cam.cy = float(fx), float(fy), float(cx), float(cy)
+    for i in range(4):
+        cam.lens[i] = float(np.float32(lens[i]))
     return cam
+
+
+def lens_distort(lens, x, y):
+    L = (C.c_float * 4)(*[float(np.float32(v)) for v in lens])
+    xd, yd = C.c_float(), C.c_float()
+    lib().orc_lens_distort(L, C.c_float(x), C.c_float(y), C.byref(xd), C.byref(yd))
+    return xd.value, yd.value
+
+
+def lens_undistort(lens, xd, yd):
+    L = (C.c_float * 4)(*[float(np.float32(v)) for v in lens])
+    x, y = C.c_float(xd), C.c_float(yd)
+    lib().orc_lens_undistort(L, C.byref(x), C.byref(y))
+    return x.value, y.value
+
+
+def cameras_from_dataset(tms, intr, scale, offset, w=None, h=None):
+    """oracle-side equivalent of prv_cameras_from_matrices_intr (+ the per-axis rescale to a render size w,h)"""
+    sx = np.float32(w) / np.float32(intr["w"]) if w else np.float32(1)
+    sy = np.float32(h) / np.float32(intr["h"]) if h else np.float32(1)
+    fx, fy = np.float32(intr["fl_x"]) * sx, np.float32(intr["fl_y"]) * sy
+    cx, cy = np.float32(intr["cx"]) * sx, np.float32(intr["cy"]) * sy
+    lens = [intr.get(k, 0.0) for k in ("k1", "k2", "p1", "p2")]
+    return [camera(nerf_to_ngp(tm, scale, offset), fx, fy, cx, cy, lens) for tm in tms]
 
 
 def view_pose(init_pos, center):

@@ -565,9 +565,50 @@ void orc_spp_offset(int k, float* ox, float* oy) {
   *oy = b - floorf(b);
 }
 
+/* forward model and its Jacobian, every operation spelled out (fmaf order is part of the contract
+ * with the device twin in prv_device.hpp) */
+static void lens_eval(const float L[4], float x, float y, float* fx, float* fy, float J[4]) {
+  const float k1 = L[0], k2 = L[1], p1 = L[2], p2 = L[3];
+  const float r2 = fmaf(x, x, y * y);
+  const float kr = fmaf(k2, r2, k1);         /* k1 + k2 r^2 */
+  const float radial = fmaf(kr, r2, 1.0f);   /* 1 + k1 r^2 + k2 r^4 */
+  const float dk = 2.0f * fmaf(2.0f * k2, r2, k1); /* d radial / d r^2, times 2 */
+  const float xy = x * y;
+  *fx = fmaf(x, radial, fmaf(2.0f * p1, xy, p2 * fmaf(2.0f * x, x, r2)));
+  *fy = fmaf(y, radial, fmaf(p1, fmaf(2.0f * y, y, r2), (2.0f * p2) * xy));
+  if (J) {
+    const float a = 2.0f * fmaf(p1, x, p2 * y); /* shared off-diagonal tangential part */
+    J[0] = fmaf(x * x, dk, fmaf(2.0f * p1, y, fmaf(6.0f * p2, x, radial)));
+    J[1] = fmaf(xy, dk, a);
+    J[2] = J[1];
+    J[3] = fmaf(y * y, dk, fmaf(6.0f * p1, y, fmaf(2.0f * p2, x, radial)));
+  }
+}
+
+void orc_lens_distort(const float lens[4], float x, float y, float* xd, float* yd) { lens_eval(lens, x, y, xd, yd, NULL); }
+
+void orc_lens_undistort(const float lens[4], float* px, float* py) {
+  const float xd = *px, yd = *py;
+  float x = xd, y = yd;
+  for (int it = 0; it < ORC_LENS_ITERS; it++) {
+    float fx, fy, J[4];
+    lens_eval(lens, x, y, &fx, &fy, J);
+    const float ex = fx - xd, ey = fy - yd;
+    const float det = fmaf(J[0], J[3], -(J[1] * J[2]));
+    const float sx = fmaf(J[3], ex, -(J[1] * ey)) / det;
+    const float sy = fmaf(J[0], ey, -(J[2] * ex)) / det;
+    x -= sx;
+    y -= sy;
+  }
+  *px = x;
+  *py = y;
+}
+
 void orc_raygen(const orc_camera* cam, int px, int py, float ox, float oy, float o[3], float d[3]) {
   float dx = (((float)px + ox) - cam->cx) / cam->fx;
   float dy = (((float)py + oy) - cam->cy) / cam->fy;
+  if (cam->lens[0] != 0.0f || cam->lens[1] != 0.0f || cam->lens[2] != 0.0f || cam->lens[3] != 0.0f)
+    orc_lens_undistort(cam->lens, &dx, &dy);
   float v[3];
   for (int r = 0; r < 3; r++) {
     const float* m = cam->c2w + r * 4;

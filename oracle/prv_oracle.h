@@ -101,7 +101,16 @@ void orc_rs2_deproject(float point[3], const float intr[9], int model, const flo
 typedef struct {
   float c2w[12]; /* ngp frame, row-major 3x4 */
   float fx, fy, cx, cy;
+  float lens[4]; /* k1, k2, p1, p2 of the OpenCV model (the keys of the dataset json); all 0 = pinhole */
 } orc_camera;
+
+/* OpenCV radial + tangential model on normalised coordinates, and its inverse by ORC_LENS_ITERS
+ * Newton steps with the analytic Jacobian (what a lens-aware marcher does for the test views of
+ * run.py:238-247, render_with_lens_distortion run.py:145; upstream's solver is not in tree: own
+ * restatement, parity unpinned) */
+#define ORC_LENS_ITERS 8
+void orc_lens_distort(const float lens[4], float x, float y, float* xd, float* yd);
+void orc_lens_undistort(const float lens[4], float* x, float* y);
 
 /* sub-pixel offset of sample k of spp (k=0 -> pixel centre) */
 void orc_spp_offset(int k, float* ox, float* oy);

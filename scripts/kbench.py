@@ -11,7 +11,12 @@ ap.add_argument("--field", default="256")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--bias", type=float, default=None)
 ap.add_argument("--tag", default="")
+ap.add_argument("--width", type=int, default=0)
+ap.add_argument("--height", type=int, default=0)
+ap.add_argument("--spp", type=int, default=1)
+ap.add_argument("--min-t", type=float, default=1e-4)
 args = ap.parse_args()
+W, H = (args.width or args.size), (args.height or args.size)
 import torch
 from nerf_prv_amd import api, planner
 ctx = api.Context(0)
@@ -21,9 +26,9 @@ ctx.synthetic_model(0, api.L.FieldDesc(**fd), 0x5EED0001)
 pts = planner.hemisphere_generate(args.views)
 fov = 2.0 * np.arctan(0.5 * 1280 / 915.60668945312500)
 tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
-cams = ctx.cameras_from_matrices(tms, fov, args.size, args.size, scale, offset)
-opts = api.render_opts(args.size, args.size, args.samples, 1, 1e-4)
-out = torch.empty((args.views, args.size, args.size, 4), dtype=torch.float32, device="cuda")
+cams = ctx.cameras_from_matrices(tms, fov, W, H, scale, offset)
+opts = api.render_opts(W, H, args.samples, args.spp, args.min_t)
+out = torch.empty((args.views, H, W, 4), dtype=torch.float32, device="cuda")
 _, st = ctx.render(0, cams, None, opts, out=out)
 ctx.profile_begin()
 t0 = time.perf_counter()

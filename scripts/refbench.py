@@ -32,4 +32,5 @@ p = ctx.profile_end()
 print(f"views={args.views} E={args.members} spp={args.spp} method={args.method}: {dt*1e3:.2f} ms per scoring round "
       f"({args.views/dt:.0f} views/s, {st.samples_evaluated/dt/1e9:.2f} Gsamp/s evaluated, {st.rays/dt/1e9:.2f} Grays/s); "
       f"kernels: render {p['render_ms']/args.reps:.2f} ms in {p['render_launches']//args.reps} launches, "
-      f"march {p['march_ms']/args.reps:.2f} ms; best view {ctx.argmax(rec, np.arange(args.views))}")
+      f"march {p['march_ms']/args.reps:.2f} ms; slot util {st.samples_evaluated/max(1,st.wave_rounds*32):.3f}, "
+      f"{st.samples_evaluated/max(1,st.rays):.1f} samples/ray; best view {ctx.argmax(rec, np.arange(args.views))}")

@@ -334,6 +334,78 @@ def raygen_np(c2w, fx, fy, cx, cy, px, py, ox=0.5, oy=0.5):
     return m[:, 3].copy(), np.array([f32(x * inv) for x in v], np.float32)
 
 
+def fma32(a, b, c):
+    """float32 fma: the product is exact in float64, so this is one rounding (up to a 2^-29 double-rounding tie)"""
+    return f32(np.float64(f32(a)) * np.float64(f32(b)) + np.float64(f32(c)))
+
+
+def lens_eval_np(L, x, y):
+    """OpenCV radial + tangential model on normalised coordinates and its Jacobian (float32, spelled out)"""
+    k1, k2, p1, p2 = (f32(v) for v in L)
+    two, six = f32(2), f32(6)
+    r2 = fma32(x, x, f32(y * y))
+    kr = fma32(k2, r2, k1)
+    radial = fma32(kr, r2, f32(1))
+    dk = f32(two * fma32(f32(two * k2), r2, k1))
+    xy = f32(x * y)
+    fx = fma32(x, radial, fma32(f32(two * p1), xy, f32(p2 * fma32(f32(two * x), x, r2))))
+    fy = fma32(y, radial, fma32(p1, fma32(f32(two * y), y, r2), f32(f32(two * p2) * xy)))
+    a = f32(two * fma32(p1, x, f32(p2 * y)))
+    j0 = fma32(f32(x * x), dk, fma32(f32(two * p1), y, fma32(f32(six * p2), x, radial)))
+    j1 = fma32(xy, dk, a)
+    j3 = fma32(f32(y * y), dk, fma32(f32(six * p1), y, fma32(f32(two * p2), x, radial)))
+    return fx, fy, (j0, j1, j1, j3)
+
+
+def lens_undistort_np(L, xd, yd, iters=8):
+    xd, yd = f32(xd), f32(yd)
+    x, y = xd, yd
+    for _ in range(iters):
+        fx, fy, J = lens_eval_np(L, x, y)
+        ex, ey = f32(fx - xd), f32(fy - yd)
+        det = fma32(J[0], J[3], f32(-f32(J[1] * J[2])))
+        sx = f32(fma32(J[3], ex, f32(-f32(J[1] * ey))) / det)
+        sy = f32(fma32(J[0], ey, f32(-f32(J[2] * ex))) / det)
+        x, y = f32(x - sx), f32(y - sy)
+    return x, y
+
+
+def raygen_lens_np(c2w, fx, fy, cx, cy, lens, px, py, ox=0.5, oy=0.5):
+    dx = f32((f32(f32(px) + f32(ox)) - f32(cx)) / f32(fx))
+    dy = f32((f32(f32(py) + f32(oy)) - f32(cy)) / f32(fy))
+    dx, dy = lens_undistort_np(lens, dx, dy)
+    m = np.asarray(c2w, np.float32).reshape(3, 4)
+    v = [fma32(m[r, 0], dx, fma32(m[r, 1], dy, m[r, 2])) for r in range(3)]
+    n2 = fma32(v[0], v[0], fma32(v[1], v[1], f32(v[2] * v[2])))
+    inv = f32(f32(1.0) / np.sqrt(n2, dtype=np.float32))
+    return m[:, 3].copy(), np.array([f32(x * inv) for x in v], np.float32)
+
+
+def gen_lens():
+    """the reference camera (DefaultConfiguration.yaml:38-49) as the dataset json carries it BY KEY
+    (Share_Data.hpp:395-399 + main.cpp:1589-1593: k1, k2, p1, p2 = color_k1, color_k2, color_p1, color_p2;
+    k3 is written too but is not a term of the engine's lens): undistortion grid + a few rays.
+    lens2 adds a non-zero p2 so every term is exercised."""
+    lens = [1.2042199820280075e-01, -2.1373499929904938e-01, -2.1210000850260258e-03, 0.0]
+    lens2 = [1.2042199820280075e-01, -2.1373499929904938e-01, -2.1210000850260258e-03, 7.5e-04]
+    intr = {"fl_x": 9.1560668945312500e+02, "fl_y": 9.1332666015625000e+02, "cx": 6.4714532470703125e+02,
+            "cy": 3.7251531982421875e+02, "w": 1280, "h": 720}
+    grid = []
+    for L in (lens, lens2):
+        for xd in (-0.7, -0.31, 0.0, 0.2, 0.69):
+            for yd in (-0.4, 0.0, 0.13, 0.39):
+                x, y = lens_undistort_np(L, xd, yd)
+                fx, fy, _ = lens_eval_np(L, x, y)
+                grid.append({"lens": L, "xd": float(f32(xd)), "yd": float(f32(yd)), "x": float(x), "y": float(y),
+                             "back_x": float(fx), "back_y": float(fy)})
+    c2w = [1, 0, 0, 0.5, 0, 1, 0, 0.5, 0, 0, -1, 2.0]
+    rays = []
+    for (px, py) in ((0, 0), (1279, 719), (640, 360), (100, 700), (1200, 15)):
+        o, d = raygen_lens_np(c2w, f32(intr["fl_x"]), f32(intr["fl_y"]), f32(intr["cx"]), f32(intr["cy"]), lens2, px, py)
+        rays.append({"px": px, "py": py, "o": o.astype(np.float64).tolist(), "d": d.astype(np.float64).tolist()})
+    return {"intr": intr, "lens_rays": lens2, "c2w": c2w, "grid": grid, "rays": rays}
+
+
 def aabb_np(o, d):
     tmin, tmax = f32(0), f32(np.inf)
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -426,7 +498,8 @@ def gen_render():
 
 def main():
     for name, fn in (("golden_cameras.json", gen_cameras), ("golden_scores.json", gen_scores),
-                     ("golden_field.json", gen_field), ("golden_render.json", gen_render)):
+                     ("golden_field.json", gen_field), ("golden_render.json", gen_render),
+                     ("golden_lens.json", gen_lens)):
         data = fn()
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(data, f)

@@ -108,6 +108,126 @@ def test_render_pixels_and_sample_counts(ctx, oracle, fields, cams, S, spp):
     assert st.rays == len(ocams) * w * h * spp and st.samples_nominal == st.rays * S
 
 
+REF_INTR = {"fl_x": 915.60668945312500, "fl_y": 913.32666015625, "cx": 647.14532470703125, "cy": 372.51531982421875,
+            "w": 1280, "h": 720, "k1": 0.12042199820280075, "k2": -0.21373499929904938, "p1": -0.0021210000850260258,
+            "p2": 7.5e-4}
+
+
+def test_dataset_cameras_lens_rays_bit_exact(ctx, oracle):
+    """the dataset's own intrinsics (run.py:238-247: off-centre principal point, fl_y, OpenCV lens solved by 8
+    Newton steps): rays bit-identical to the oracle at the json size and at a rescaled size; the golden rays
+    of the independent numpy restatement reproduced on the device"""
+    import json
+    import os
+
+    pts = util.fibonacci_hemisphere(3)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    cs = ctx.cameras_from_matrices_intr(tms, REF_INTR, scale, offset)
+    assert cs.size == (1280, 720)
+    np.testing.assert_array_equal(cs.lens(1), np.array([REF_INTR[k] for k in ("k1", "k2", "p1", "p2")], np.float32))
+    import ctypes as C
+
+    for (w, h) in ((160, 90), (100, 40)):
+        ocams = oracle.cameras_from_dataset(tms, REF_INTR, scale, offset, w, h)
+        for v in (0, 2):
+            o, d, t = ctx.debug_raygen(cs, v, w, h, 0)
+            oo, od, ot = oracle.raygen(ocams[v], w, h, 0)
+            assert np.array_equal(o, oo) and np.array_equal(d, od) and np.array_equal(t, ot)
+    # full size: 300 seeded pixels of one view, sub-sample 5
+    w, h = 1280, 720
+    ocam = oracle.cameras_from_dataset(tms, REF_INTR, scale, offset)[1]
+    o, d, t = ctx.debug_raygen(cs, 1, w, h, 5)
+    ox, oy = C.c_float(), C.c_float()
+    oracle.lib().orc_spp_offset(5, C.byref(ox), C.byref(oy))
+    rng = np.random.default_rng(11)
+    for px, py in zip(rng.integers(0, w, 300), rng.integers(0, h, 300)):
+        oo, od = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        oracle.lib().orc_raygen(C.byref(ocam), int(px), int(py), ox, oy, oracle._p(oo), oracle._p(od))
+        i = int(py) * w + int(px)
+        assert np.array_equal(o[i], oo) and np.array_equal(d[i], od), (px, py)
+    # the golden rays of the numpy restatement: transform_matrix chosen so that the engine-frame camera IS the
+    # fixture's c2w (rows cycle (y,z,x), columns 1,2 negate; scale 1, offset 0)
+    with open(os.path.join(os.path.dirname(__file__), "golden", "golden_lens.json")) as f:
+        g = json.load(f)
+    k = dict(g["intr"], **dict(zip(("k1", "k2", "p1", "p2"), g["lens_rays"])))
+    R = np.asarray(g["c2w"], np.float64).reshape(3, 4)
+    tm = np.eye(4)
+    for src, dst in ((2, 0), (0, 1), (1, 2)):
+        tm[dst, :3] = R[src, :3] * [1, -1, -1]
+        tm[dst, 3] = R[src, 3]
+    one = ctx.cameras_from_matrices_intr(tm[None], k, 1.0, [0.0, 0.0, 0.0])
+    c2w_dev, _ = one.get(0)
+    assert np.array_equal(c2w_dev, R.astype(np.float32))
+    o, d, _ = ctx.debug_raygen(one, 0, 1280, 720, 0)
+    for r in g["rays"]:
+        i = r["py"] * 1280 + r["px"]
+        np.testing.assert_array_equal(o[i].astype(np.float64), r["o"])
+        np.testing.assert_array_equal(d[i].astype(np.float64), r["d"])
+
+
+def test_dataset_cameras_render_parity(ctx, oracle, fields):
+    """pixels through the lens path against the oracle, 1e-3 (north_star)"""
+    d_o, d_p, f = fields
+    pts = util.fibonacci_hemisphere(4)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    cs = ctx.cameras_from_matrices_intr(tms, REF_INTR, scale, offset)
+    w, h = 64, 36
+    ocams = oracle.cameras_from_dataset(tms, REF_INTR, scale, offset, w, h)
+    img, st = ctx.render(0, cs, None, api.render_opts(w, h, 64, 1, 1e-4))
+    img = img.cpu().numpy()
+    n_eval = 0
+    for v, oc in enumerate(ocams):
+        want, ne = f.render(oc, w, h, 64, 1, 1e-4)
+        n_eval += ne
+        assert np.abs(img[v] - want).max() <= PIX_ATOL
+    assert abs(int(st.samples_evaluated) - n_eval) <= 2 and n_eval > 0
+    # and the lens matters: the pinhole set of the same poses renders different pixels
+    pin = ctx.cameras_from_matrices(tms, 2 * np.arctan(0.5 * 1280 / REF_INTR["fl_x"]), 1280, 720, scale, offset)
+    img_pin, _ = ctx.render(0, pin, None, api.render_opts(w, h, 64, 1, 1e-4))
+    assert float((img_pin.cpu().numpy() - img).__abs__().max()) > 0.05
+
+
+def test_dataset_json_loader(ctx, oracle, tmp_path):
+    """prv_cameras_from_dataset_json reads the intrinsics block the planner writes (main.cpp:1585-1602) by key,
+    with the documented fall-backs; prv_cameras_from_json keeps the screenshot rule (fov at the centre)"""
+    import json
+
+    pts = util.fibonacci_hemisphere(2)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    k = REF_INTR
+    root = {"camera_angle_x": 2 * np.arctan(0.5 * k["w"] / k["fl_x"]), "camera_angle_y": 2 * np.arctan(0.5 * k["h"] / k["fl_y"]),
+            "fl_x": k["fl_x"], "fl_y": k["fl_y"], "k1": k["k1"], "k2": k["k2"], "k3": 0.005386, "p1": k["p1"], "p2": k["p2"],
+            "cx": k["cx"], "cy": k["cy"], "w": k["w"], "h": k["h"], "aabb_scale": 1, "scale": scale, "offset": list(offset),
+            "frames": [{"file_path": f"2/rgbaClip_{i}.png", "transform_matrix": np.asarray(tm).tolist()} for i, tm in enumerate(tms)]}
+    path = tmp_path / "2.json"
+    path.write_text(json.dumps(root))
+    ds = ctx.cameras_from_dataset_json(path)
+    ref = ctx.cameras_from_matrices_intr(tms, k, scale, offset)
+    for v in range(2):
+        for a, b in zip(ds.get(v), ref.get(v)):
+            assert np.array_equal(a, b)
+        assert np.array_equal(ds.lens(v), ref.lens(v))
+    _, intr = ds.get(0)
+    np.testing.assert_array_equal(intr, np.array([k["fl_x"], k["fl_y"], k["cx"], k["cy"]], np.float32))
+    shot = ctx.cameras_from_json(path)  # screenshot rule: camera_angle_x, centre, no lens
+    _, intr_s = shot.get(0)
+    assert intr_s[2] == 640.0 and intr_s[3] == 360.0 and intr_s[0] == intr_s[1] and not shot.lens(0).any()
+    # fall-backs: no fl_*/cx/cy/lens keys -> camera_angle_*, image centre, pinhole
+    for key in ("fl_x", "fl_y", "cx", "cy", "k1", "k2", "p1", "p2"):
+        root.pop(key)
+    path.write_text(json.dumps(root))
+    fb = ctx.cameras_from_dataset_json(path)
+    _, intr_f = fb.get(1)
+    np.testing.assert_allclose(intr_f, [k["fl_x"], k["fl_y"], 640.0, 360.0], rtol=1e-6)
+    assert not fb.lens(1).any()
+    root.pop("camera_angle_x"), root.pop("camera_angle_y")
+    path.write_text(json.dumps(root))
+    with pytest.raises(api.PrvError):
+        ctx.cameras_from_dataset_json(path)
+    with pytest.raises(api.PrvError):
+        ctx.cameras_from_matrices_intr(tms, dict(k, fl_x=float("nan")), scale, offset)
+
+
 def test_render_view_subset_and_order(ctx, fields, cams):
     cs, ocams, w, h = cams
     opts = api.render_opts(w, h, 64, 1, 1e-4)

@@ -256,3 +256,52 @@ def test_compat_server_metrics_request_with_png_reference_images(ctx, tmp_path):
     # the PNG round trip loses at most the 8-bit quantisation of the linear image
     lin, _ = ctx.render(6, cams, None, clear)
     assert float((gt - lin).abs().max()) < 0.02
+
+
+def test_testbed_mirror_dataset_views(ctx, tmp_path):
+    """run.py:238-247 spelled with the mirror: load_training_data(test json) -> dataset.n_images /
+    metadata[i].resolution -> set_camera_to_training_view(i) -> render(..): the dataset's own intrinsics and
+    lens are used, and render_ground_truth hands back the dataset image"""
+    from PIL import Image
+
+    pts = planner.hemisphere_read(os.path.join(GOLD, "hemisphere", "5.txt"), 5)
+    c = [1e-10] * 3
+    pos = planner.view_space(pts, 0.3, c)
+    k = planner.Intrinsics(width=160, height=90, ppx=83.5, ppy=41.25, fx=114.45, fy=113.9)
+    k.coeffs[0], k.coeffs[1], k.coeffs[3], k.coeffs[4] = 0.1204, -0.2137, -0.00212, 0.0  # k1 k2 (k3) p1 p2
+    (tmp_path / "5").mkdir()
+    tj = tmp_path / "5.json"
+    planner.write_transforms(tj, k, pos, c, 0.1, path_prefix="5/rgbaClip_")
+    for i in range(5):
+        Image.fromarray(np.full((90, 160, 4), 255 if i % 2 else 0, np.uint8), "RGBA").save(tmp_path / "5" / f"rgbaClip_{i}.png")
+    tb = api.Testbed()
+    tb.synthetic_model(small_desc(), SEED)
+    tb.background_color = [0.0, 0.0, 0.0, 1.0]
+    tb.snap_to_pixel_centers = True
+    tb.nerf.render_min_transmittance = 1e-4
+    tb.nerf.samples_per_ray = 64
+    tb.load_training_data(str(tj))
+    ds = tb.nerf.training.dataset
+    assert ds.n_images == 5 and ds.metadata[3].resolution == (160, 90)
+    tb.set_camera_to_training_view(3)
+    img = tb.render(160, 90, 8, True)
+    cams = tb.ctx.cameras_from_dataset_json(tj)
+    np.testing.assert_allclose(cams.lens(3), [0.1204, -0.2137, -0.00212, 0.0], rtol=1e-6)
+    _, intr = cams.get(3)
+    np.testing.assert_allclose(intr, [114.45, 113.9, 83.5, 41.25], rtol=1e-6)
+    want, _ = tb.ctx.render(0, cams, [3], api.render_opts(160, 90, 64, 1, 1e-4), want_stats=False)
+    want = want[0] + (1.0 - want[0][..., 3:4]) * tb.ctx.torch.tensor([0, 0, 0, 1.0], device=want.device)
+    assert np.array_equal(img, want.cpu().numpy())
+    # not the screenshot camera: the same pose through set_nerf_camera_matrix renders other pixels
+    import json
+    with open(tj) as f:
+        meta = json.load(f)
+    tb.set_nerf_camera_matrix(np.asarray(meta["frames"][3]["transform_matrix"])[:-1, :])
+    shot = tb.render(160, 90, 8, True)
+    assert np.abs(shot - img).max() > 0.02
+    tb.set_camera_to_training_view(1)
+    tb.render_ground_truth = True
+    gt = tb.render(160, 90, 1, True)
+    assert gt.shape == (90, 160, 4) and np.allclose(gt, 1.0)
+    with pytest.raises(api.PrvError):
+        tb.set_camera_to_training_view(7)

@@ -118,6 +118,25 @@ def test_render_against_numpy(oracle):
         assert float(t[i, 0]) == r["t0"] and float(t[i, 1]) == r["t1"]
 
 
+def test_lens_model_against_numpy(oracle):
+    """inverse OpenCV lens (dataset cameras of run.py:238-247): the C oracle against the independent numpy
+    restatement of tests/golden/gen_golden.py -- bit-exact, and the Newton solve really inverts the model"""
+    import ctypes as C
+
+    g = load("golden_lens.json")
+    for e in g["grid"]:
+        assert oracle.lens_undistort(e["lens"], e["xd"], e["yd"]) == (e["x"], e["y"])
+        assert oracle.lens_distort(e["lens"], e["x"], e["y"]) == (e["back_x"], e["back_y"])
+        assert abs(e["back_x"] - e["xd"]) < 2e-7 and abs(e["back_y"] - e["yd"]) < 2e-7
+    k = g["intr"]
+    cam = oracle.camera(g["c2w"], k["fl_x"], k["fl_y"], k["cx"], k["cy"], g["lens_rays"])
+    for r in g["rays"]:
+        o, d = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        oracle.lib().orc_raygen(C.byref(cam), r["px"], r["py"], C.c_float(0.5), C.c_float(0.5), oracle._p(o), oracle._p(d))
+        np.testing.assert_array_equal(o.astype(np.float64), r["o"])
+        np.testing.assert_array_equal(d.astype(np.float64), r["d"])
+
+
 @pytest.mark.parametrize("n,top", [(5, 1), (64, 48), (144, 62)])
 def test_reference_view_sets_properties(n, top):
     """N rows, unit norm, z >= 0, exactly one row at (0,0,1) -- at the surveyed index"""

@@ -1,3 +1,4 @@
+import pytest
 """Hand-derivable known answers for the reference's in-tree formulas (SURVEY 8c(4)).  CPU only."""
 import math
 
@@ -121,3 +122,24 @@ def test_first_hit_dda(oracle):
     assert cell[0] == 16 and cell[1] == 16 and 4 <= cell[2] <= 5
     o2 = np.array([0.02, 0.02, -1.0], np.float32)  # corner column misses every sphere
     assert oracle.lib().orc_first_hit(f.ptr, p(o2), p(d), C.c_float(10.0), p(cell)) == 0
+
+
+def test_lens_known_answers(oracle):
+    """hand-derived: no lens terms -> identity; k1 only on the x axis -> x (1 + k1 x^2); p1 only at (0, y) ->
+    (0, y + 3 p1 y^2) (OpenCV: yd = y*radial + p1 (r^2 + 2 y^2) + 2 p2 x y)"""
+    z = (0.0, 0.0, 0.0, 0.0)
+    assert oracle.lens_distort(z, 0.3, -0.2) == (np.float32(0.3), np.float32(-0.2))
+    assert oracle.lens_undistort(z, 0.3, -0.2) == (np.float32(0.3), np.float32(-0.2))
+    xd, yd = oracle.lens_distort((0.5, 0, 0, 0), 0.5, 0.0)
+    assert xd == pytest.approx(0.5 * (1 + 0.5 * 0.25), rel=1e-7) and yd == 0.0
+    xd, yd = oracle.lens_distort((0, 0, 0.01, 0), 0.0, 0.4)
+    assert xd == 0.0 and yd == pytest.approx(0.4 + 0.01 * 3 * 0.16, rel=1e-6)
+    # p2 mirrors p1 on the other axis
+    xd, yd = oracle.lens_distort((0, 0, 0, 0.01), 0.4, 0.0)
+    assert yd == 0.0 and xd == pytest.approx(0.4 + 0.01 * 3 * 0.16, rel=1e-6)
+    # the inverse undoes the forward model well inside the field of view of the reference camera
+    lens = (0.12042199820280075, -0.21373499929904938, -0.0021210000850260258, 0.0)
+    for x, y in ((0.69, 0.39), (-0.5, 0.1), (0.0, 0.0), (0.2, -0.4)):
+        a, b = oracle.lens_distort(lens, x, y)
+        ux, uy = oracle.lens_undistort(lens, a, b)
+        assert abs(ux - x) < 3e-7 and abs(uy - y) < 3e-7
