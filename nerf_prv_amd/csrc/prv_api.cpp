@@ -61,6 +61,7 @@ struct prv_ctx {
   std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs
   int blocks_per_cu = 4;
   int refill_min = 32;
+  int queue_segments = 8; // ray-queue segments = XCDs (PRV_QUEUE_SEGMENTS: 1 = single shared head)
   int dbg_flags = 0;
   size_t stage_budget = (size_t)4 << 30; // staging bytes for multi-sample renders (spp x batch x image)
   size_t dehash_budget = 0; // bytes per hashed level allowed for a physically dense copy (0 = keep hashed)
@@ -397,9 +398,9 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   const int W = o->width, H = o->height;
   const size_t npix = (size_t)W * H;
   int rc;
-  if ((rc = ensure(c, c->counters, 64)) != PRV_OK) return rc;
+  if ((rc = ensure(c, c->counters, 64 + 8 * 64)) != PRV_OK) return rc;
   uint32_t* q_count = (uint32_t*)c->counters.p;
-  uint32_t* q_head = q_count + 1;
+  uint32_t* q_head = q_count + 16; // 8 segment heads, one 64-byte line each
   unsigned long long* stat = (unsigned long long*)((char*)c->counters.p + 16);
   if (zero_stats) HIPCHK(c, hipMemsetAsync(stat, 0, 16, c->stream));
   if (n_views == 0) return PRV_OK;
@@ -438,6 +439,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     float* dst_f32 = out_f32 + b0 * npix * 4;
     uint32_t* dst_u8 = out_u8 ? (uint32_t*)out_u8 + b0 * npix : nullptr;
     HIPCHK(c, hipMemsetAsync(q_count, 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(q_head, 0, 8 * 64, c->stream));
     MarchParams mp;
     memset(&mp, 0, sizeof(mp));
     mp.field = m.dev;
@@ -480,6 +482,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     rp.queue = c->queue.p;
     rp.queue_count = q_count;
     rp.queue_head = q_head;
+    rp.n_segments = c->queue_segments;
     rp.stat_evaluated = stat;
     rp.out_f32 = mp.out_f32;
     rp.out_u8 = mp.out_u8;
@@ -564,6 +567,7 @@ int prv_create(prv_ctx** out, int device_id) {
     while (g & (g - 1)) g &= g - 1;
     c->refill_min = g;
   }
+  if (const char* s = getenv("PRV_QUEUE_SEGMENTS")) c->queue_segments = std::min(8, std::max(1, atoi(s)));
   if (const char* s = getenv("PRV_DEHASH_MB")) c->dehash_budget = (size_t)std::max(0, atoi(s)) << 20;
   if (const char* s = getenv("PRV_DBG")) c->dbg_flags = atoi(s);
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;

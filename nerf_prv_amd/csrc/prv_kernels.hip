@@ -154,6 +154,11 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
   bool drained = false;
   unsigned long long n_eval = 0ull, n_rounds = 0ull;
   uint32_t q_cur = 0, q_end = 0; // this wave's claimed range of queue records (wave-uniform)
+  const uint32_t n_seg = (uint32_t)P.n_segments; // 8 = one per XCD, 1 = a single shared head
+  const uint32_t seg_len = ((n_rec + n_seg * kClaim - 1u) / (n_seg * kClaim)) * kClaim;
+  // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this workgroup runs on
+  uint32_t seg = n_seg > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % n_seg : 0u;
+  uint32_t seg_tried = 0;
 
   for (;;) {
     // ---- refill idle slots from the wave's claimed range: ballot + prefix sum hand-out;
@@ -171,13 +176,23 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
     }
     const uint32_t cnt = (uint32_t)__popc(need);
     if (!drained && cnt != 0u) {
-      if (q_cur == q_end) {
+      // The queue is cut into n_seg contiguous segments, one per XCD (queue order is tile order, so a
+      // segment is a compact set of views / image regions): a wave drains its own XCD's segment first and
+      // then steals from the next ones.  Each XCD's private L2 then serves one region's table lines
+      // instead of a share of everybody's.  Placement changes speed only, never results.
+      while (q_cur == q_end && !drained) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(P.queue_head, kClaim);
+        if (lane == 0) base = atomicAdd(P.queue_head + 16u * seg, kClaim);
         base = __builtin_amdgcn_readfirstlane(base);
-        q_cur = min(base, n_rec);
-        q_end = min(base + kClaim, n_rec);
-        if (q_cur == q_end) drained = true;
+        const uint32_t s_lo = min(seg * seg_len, n_rec), s_hi = min(s_lo + seg_len, n_rec);
+        if (base < s_hi - s_lo) {
+          q_cur = s_lo + base;
+          q_end = min(q_cur + kClaim, s_hi);
+        } else if (++seg_tried >= n_seg) {
+          drained = true;
+        } else {
+          seg = seg + 1u == n_seg ? 0u : seg + 1u;
+        }
       }
       const uint32_t avail = min(cnt, q_end - q_cur);
       const uint32_t prefix = (uint32_t)__popc(need & lt_mask);

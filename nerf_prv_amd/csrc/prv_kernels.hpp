@@ -33,7 +33,8 @@ struct RenderParams {
   FieldDev field;
   const void* queue;
   const uint32_t* queue_count;
-  uint32_t* queue_head;
+  uint32_t* queue_head; // n_segments heads, 64 bytes apart (segment-relative record counts)
+  int n_segments;
   unsigned long long* stat_evaluated;
   float* out_f32;
   uint32_t* out_u8;
