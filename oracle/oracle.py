@@ -35,6 +35,22 @@ class Camera(C.Structure):
                 ("lens", C.c_float * 4)]
 
 
+class TrainOpts(C.Structure):
+    _fields_ = [("n_rays", C.c_int32), ("n_samples", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("l2_reg", C.c_float), ("min_T", C.c_float),
+                ("seed", C.c_uint64), ("random_bg", C.c_int32), ("occ_every", C.c_int32), ("occ_decay", C.c_float),
+                ("occ_sigma_thresh", C.c_float)]
+
+
+TRAIN_DEFAULTS = dict(n_rays=4096, n_samples=128, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, l2_reg=1e-6, min_T=1e-4,
+                      seed=0x7EA10001, random_bg=1, occ_every=16, occ_decay=0.95,
+                      occ_sigma_thresh=0.01 * 128 / 3 ** 0.5)
+
+
+def train_opts(**kw):
+    return TrainOpts(**dict(TRAIN_DEFAULTS, **kw))
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
@@ -72,6 +88,20 @@ def lib():
         L.orc_spp_offset.argtypes = [C.c_int, f32p, f32p]
         L.orc_raygen.argtypes = [C.POINTER(Camera), C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]
         L.orc_ray_aabb.argtypes = [vp, vp, f32p, f32p]
+        L.orc_rng_u24.restype, L.orc_rng_u24.argtypes = C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.orc_train_create.restype = vp
+        L.orc_train_create.argtypes = [C.POINTER(Field), C.POINTER(TrainOpts), vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orc_train_free.argtypes = [vp]
+        for n in ("orc_train_step", "orc_train_loss_only"):
+            getattr(L, n).restype, getattr(L, n).argtypes = C.c_double, [vp]
+        L.orc_train_gradients.restype, L.orc_train_gradients.argtypes = C.c_double, [vp, vp, vp]
+        L.orc_train_refresh_occupancy.argtypes = [vp]
+        L.orc_train_field.restype, L.orc_train_field.argtypes = C.POINTER(Field), [vp]
+        L.orc_train_steps_done.restype, L.orc_train_steps_done.argtypes = C.c_uint32, [vp]
+        L.orc_train_samples_last.restype, L.orc_train_samples_last.argtypes = C.c_uint64, [vp]
+        L.orc_train_master_table.restype, L.orc_train_master_table.argtypes = C.POINTER(C.c_float), [vp]
+        L.orc_train_master_mlp.restype, L.orc_train_master_mlp.argtypes = C.POINTER(C.c_float), [vp]
+        L.orc_train_table_size.restype, L.orc_train_table_size.argtypes = C.c_size_t, [vp]
         L.orc_lens_distort.argtypes = [C.c_float * 4, C.c_float, C.c_float, f32p, f32p]
         L.orc_lens_undistort.argtypes = [C.c_float * 4, f32p, f32p]
         L.orc_render.argtypes = [C.POINTER(Field), C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp,
@@ -335,3 +365,60 @@ def rank(scores, ids):
 def argmax(scores, ids):
     s, i = np.ascontiguousarray(scores, np.float64), np.ascontiguousarray(ids, np.int32)
     return lib().orc_argmax(_p(s), _p(i), len(i))
+
+
+class OracleTrainer:
+    """the CPU oracle of the training step (oracle/prv_train.c)"""
+
+    def __init__(self, field, opts, cams, images_rgba8, exact=False):
+        self.images = np.ascontiguousarray(images_rgba8, np.uint8)
+        n, h, w, _ = self.images.shape
+        assert n == len(cams)
+        self.cams = (Camera * n)(*cams)
+        self.opts = opts
+        self.desc = field.desc
+        self.ptr = lib().orc_train_create(field.ptr, C.byref(opts), self.cams, n, w, h, _p(self.images), int(exact))
+        if not self.ptr:
+            raise ValueError("oracle trainer creation failed")
+        self.n_table = lib().orc_train_table_size(self.ptr)
+
+    def step(self):
+        return lib().orc_train_step(self.ptr)
+
+    def loss_only(self):
+        return lib().orc_train_loss_only(self.ptr)
+
+    def gradients(self):
+        tg, mg = np.zeros(self.n_table, np.float64), np.zeros(MLP_HALFS, np.float64)
+        loss = lib().orc_train_gradients(self.ptr, _p(tg), _p(mg))
+        return loss, tg, mg
+
+    def master(self):
+        """views (not copies) of the fp32 master weights"""
+        t = np.ctypeslib.as_array(lib().orc_train_master_table(self.ptr), shape=(self.n_table,))
+        m = np.ctypeslib.as_array(lib().orc_train_master_mlp(self.ptr), shape=(MLP_HALFS,))
+        return t, m
+
+    def params(self):
+        f = lib().orc_train_field(self.ptr).contents
+        table = np.ctypeslib.as_array(f.table, shape=(self.n_table,)).copy()
+        mlp = np.frombuffer(f.mlp, dtype=np.uint16).copy()
+        R = self.desc.occ_res
+        occ = np.ctypeslib.as_array(f.occ, shape=((R ** 3 + 31) // 32,)).copy()
+        return table, mlp, occ
+
+    def field(self):
+        return OracleField(self.desc, params=self.params())
+
+    @property
+    def samples_last(self):
+        return lib().orc_train_samples_last(self.ptr)
+
+    def refresh_occupancy(self):
+        lib().orc_train_refresh_occupancy(self.ptr)
+
+    def __del__(self):
+        try:
+            lib().orc_train_free(self.ptr)
+        except Exception:
+            pass

@@ -151,6 +151,35 @@ void orc_first_hit_rows(const orc_field* f, const orc_camera* cam, int w, int y0
 void orc_precept(const orc_field* f, const float* voxels, int n, const double w2c[16], const double c2w[16],
                  const float intr[9], int width, int height, int model, float max_range, int32_t* out);
 
+/* ---- training step (prv_train.c; published instant-ngp optimiser restated, parity unpinned) ---- */
+typedef struct {
+  int32_t n_rays;    /* rays per step */
+  int32_t n_samples; /* S samples per ray between the AABB hits, <= 128 */
+  float lr, beta1, beta2, eps, l2_reg; /* Adam; l2_reg on the MLP weights only */
+  float min_T;       /* early termination of a training ray */
+  uint64_t seed;
+  int32_t random_bg; /* 1: a random background colour per ray blends target and prediction */
+  int32_t occ_every; /* refresh the density grid every N steps (0: never) */
+  float occ_decay, occ_sigma_thresh; /* ema = max(ema*decay, sigma); occupied iff ema > thresh */
+} orc_train_opts;
+typedef struct orc_trainer orc_trainer;
+uint32_t orc_rng_u24(uint64_t seed, uint64_t stream, uint64_t i);
+/* cams[n_img] are dataset cameras at (w,h); rgba8 = n_img*h*w*4 straight-alpha sRGB bytes.  exact = 1:
+ * no fp16 rounding (differentiable forward, for the finite-difference check of the backward pass) */
+orc_trainer* orc_train_create(const orc_field* init, const orc_train_opts* o, const orc_camera* cams, int n_img,
+                              int w, int h, const uint8_t* rgba8, int exact);
+void orc_train_free(orc_trainer* t);
+double orc_train_step(orc_trainer* t);       /* returns the batch loss before the update */
+double orc_train_loss_only(orc_trainer* t);  /* loss of the next batch, nothing changes */
+double orc_train_gradients(orc_trainer* t, double* table_grad, double* mlp_grad); /* next batch, no update */
+void orc_train_refresh_occupancy(orc_trainer* t);
+const orc_field* orc_train_field(const orc_trainer* t);
+uint32_t orc_train_steps_done(const orc_trainer* t);
+uint64_t orc_train_samples_last(const orc_trainer* t);
+float* orc_train_master_table(orc_trainer* t);
+float* orc_train_master_mlp(orc_trainer* t);
+size_t orc_train_table_size(const orc_trainer* t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,131 @@
+"""The training-step oracle (oracle/prv_train.c) checked against itself: the analytic backward pass against
+central finite differences of the (exact-mode, rounding-free) forward pass, optimiser bookkeeping, and that
+a short run actually fits images of a known field.  CPU only."""
+import numpy as np
+import pytest
+
+from tests import util
+
+TINY = dict(n_levels=8, n_features=4, log2_hashmap=10, base_res=4, finest_res=24, occ_res=16, density_bias=1.0, table_amp=0.5)
+
+
+@pytest.fixture(scope="module")
+def scene(oracle):
+    """8 views of a 'ground truth' field rendered by the oracle marcher, as straight-alpha sRGB bytes"""
+    d = oracle.desc(**TINY)
+    gt = oracle.OracleField(oracle.desc(**dict(TINY, density_bias=3.0, table_amp=2.0)), seed=util.SEED_B)
+    pts = util.fibonacci_hemisphere(8)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    w, h = 24, 16
+    intr = {"fl_x": 20.0, "fl_y": 19.5, "cx": 12.3, "cy": 7.8, "w": w, "h": h, "k1": 0.05, "k2": -0.02, "p1": 0.001, "p2": -0.002}
+    cams = oracle.cameras_from_dataset(tms, intr, scale, offset)
+    imgs = []
+    for c in cams:
+        rgba, _ = gt.render(c, w, h, 32, 1, 1e-4)
+        imgs.append(oracle.quantize_rgba8(rgba, (0, 0, 0, 0)))
+    return d, cams, np.stack(imgs), (w, h)
+
+
+def all_occupied(oracle, field):
+    t, m, o = field.params()
+    return oracle.OracleField(field.desc, params=(t, m, np.full_like(o, 0xFFFFFFFF)))
+
+
+def test_backward_matches_finite_differences(oracle, scene):
+    d, cams, imgs, _ = scene
+    init = all_occupied(oracle, oracle.OracleField(d, seed=util.SEED_A))
+    opts = oracle.train_opts(n_rays=96, n_samples=24, occ_every=0)
+    tr = oracle.OracleTrainer(init, opts, cams, imgs, exact=True)
+    loss, tg, mg = tr.gradients()
+    assert loss > 1e-3 and tr.samples_last > 500
+    assert loss == pytest.approx(tr.loss_only(), rel=1e-12)
+    table, mlp = tr.master()
+    rng = np.random.default_rng(5)
+
+    def fd(arr, i, h):
+        keep = arr[i]
+        arr[i] = keep + h
+        up = tr.loss_only()
+        arr[i] = keep - h
+        dn = tr.loss_only()
+        arr[i] = keep
+        return (up - dn) / (2 * h)
+
+    # MLP weights: a few of every layer, the largest-gradient ones included
+    for lo, hi in ((0, 2048), (2048, 3072), (3072, 5120), (5120, 9216), (9216, 10240)):
+        idx = list(lo + np.argsort(-np.abs(mg[lo:hi]))[:3]) + list(rng.integers(lo, hi, 3))
+        for i in idx:
+            if abs(mg[i]) < 2e-5:
+                continue
+            assert fd(mlp, i, 4e-3) == pytest.approx(mg[i], rel=3e-2, abs=1e-6), i
+    # hash-table entries with the largest gradients and some random touched ones
+    touched = np.flatnonzero(tg)
+    assert len(touched) > 100
+    idx = list(np.argsort(-np.abs(tg))[:12]) + list(rng.choice(touched, 8))
+    n_checked = 0
+    for i in idx:
+        if abs(tg[i]) < 2e-5:
+            continue
+        n_checked += 1
+        assert fd(table, i, 1e-2) == pytest.approx(tg[i], rel=3e-2, abs=1e-6), i
+    assert n_checked >= 8
+
+
+def test_adam_step_bookkeeping(oracle, scene):
+    d, cams, imgs, _ = scene
+    init = all_occupied(oracle, oracle.OracleField(d, seed=util.SEED_A))
+    opts = oracle.train_opts(n_rays=64, n_samples=24, occ_every=0, l2_reg=0.0)
+    tr = oracle.OracleTrainer(init, opts, cams, imgs)
+    t0, m0 = (a.copy() for a in tr.master())
+    loss, tg, mg = tr.gradients()
+    assert tr.step() == pytest.approx(loss, rel=1e-12)
+    t1, m1 = tr.master()
+    # first Adam step moves every touched weight by lr against the sign of its gradient (|m|/sqrt(v) = 1
+    # after bias correction), untouched table entries do not move at all
+    g32 = tg.astype(np.float32)
+    moved = t1 != t0
+    assert np.array_equal(moved, g32 != 0)
+    big = np.abs(g32) > 1e-10  # below that sqrt(v) is no longer >> eps = 1e-15 and the step shrinks
+    np.testing.assert_allclose((t1 - t0)[big], -opts.lr * np.sign(g32[big]), rtol=2e-3)
+    nz = np.abs(mg.astype(np.float32)) > 1e-10
+    np.testing.assert_allclose((m1 - m0)[nz], -opts.lr * np.sign(mg[nz]), rtol=2e-3)
+    # the fp16 working copy is the rounded master
+    tab16, mlp16, _ = tr.params()
+    assert np.array_equal(tab16, t1.astype(np.float16).view(np.uint16))
+    assert np.array_equal(mlp16, m1.astype(np.float16).view(np.uint16))
+
+
+def test_rng_and_batch_are_reproducible(oracle, scene):
+    d, cams, imgs, _ = scene
+    init = all_occupied(oracle, oracle.OracleField(d, seed=util.SEED_A))
+    opts = oracle.train_opts(n_rays=64, n_samples=24, occ_every=4)
+    a = oracle.OracleTrainer(init, opts, cams, imgs)
+    b = oracle.OracleTrainer(init, opts, cams, imgs)
+    la = [a.step() for _ in range(5)]
+    lb = [b.step() for _ in range(5)]
+    assert la == lb and all(np.array_equal(x, y) for x, y in zip(a.params(), b.params()))
+    assert oracle.lib().orc_rng_u24(1, 2, 3) == oracle.lib().orc_rng_u24(1, 2, 3) < (1 << 24)
+    assert len({oracle.lib().orc_rng_u24(1, 2, i) for i in range(64)}) > 60
+
+
+def test_training_fits_the_images(oracle, scene):
+    """a few hundred steps on 8 views of a known field: loss falls by an order of magnitude and a training
+    view renders closer to its image than the initial model did"""
+    d, cams, imgs, (w, h) = scene
+    init = all_occupied(oracle, oracle.OracleField(oracle.desc(**dict(TINY, table_amp=1e-4)), seed=util.SEED_A))
+    opts = oracle.train_opts(n_rays=256, n_samples=24, occ_every=16, occ_sigma_thresh=0.01 * 24 / 3 ** 0.5)
+    tr = oracle.OracleTrainer(init, opts, cams, imgs)
+    losses = [tr.step() for _ in range(160)]
+    assert np.mean(losses[-10:]) < 0.2 * np.mean(losses[:5])
+
+    def view_mse(field):
+        rgba, _ = field.render(cams[2], w, h, 24, 1, 1e-4)
+        got = oracle.quantize_rgba8(rgba, (0, 0, 0, 1)).astype(np.float64)[..., :3]
+        a = imgs[2].astype(np.float64)
+        want = a[..., :3] * a[..., 3:4] / 255.0  # the image over black
+        return np.mean((got - want) ** 2)
+
+    assert view_mse(tr.field()) < 0.35 * view_mse(init)
+    _, _, occ = tr.params()
+    bits = np.unpackbits(occ.view(np.uint8)).sum()
+    assert 0 < bits < d.occ_res ** 3  # the density grid has carved some empty space and kept some
