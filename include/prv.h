@@ -243,6 +243,41 @@ int prv_score_views(prv_ctx* ctx, int method, const int* model_slots, int n_mode
 int prv_rank(const prv_score_record* records, const int* view_ids, int n, int* order);
 int prv_argmax(const prv_score_record* records, const int* view_ids, int n);
 
+/* ---- training ------------------------------------------------------------- */
+/* replaces: the `while testbed.frame()` loop run.py:185-208 drives for `--train --n_steps 2500`
+ * (main.cpp:1668) on the dataset of testbed.load_training_data (run.py:109): random rays over the dataset
+ * images, L2 loss on linear colours over a random background, backward through both MLPs and the hash
+ * grid, Adam with sparse table updates, periodic density-grid refresh -- the published instant-ngp
+ * optimiser restated (the optimiser itself is inside pyngp, not in the reference tree).
+ * The model slot is trained IN PLACE: after every prv_train_steps call the slot renders / scores with the
+ * trained weights and occupancy. */
+typedef struct prv_train_opts {
+  int32_t n_rays;    /* rays per step */
+  int32_t n_samples; /* samples per ray between the AABB hits, <= 128 */
+  float lr, beta1, beta2, eps, l2_reg; /* Adam; l2_reg on the MLP weights only */
+  float min_T;       /* early termination of a training ray */
+  uint64_t seed;
+  int32_t random_bg; /* 1: random background colour per ray */
+  int32_t occ_every; /* refresh the density grid every N steps (0 = never) */
+  float occ_decay, occ_sigma_thresh; /* ema = max(ema*decay, sigma); occupied iff ema > thresh */
+} prv_train_opts;
+typedef struct prv_trainer prv_trainer;
+int prv_train_default_opts(prv_train_opts* opts);
+/* dataset = cameras of prv_cameras_from_dataset_json (own intrinsics + lens) and their images,
+ * n * h * w * 4 straight-alpha sRGB bytes in device memory (caller keeps them alive) */
+int prv_train_create(prv_ctx* ctx, int model_slot, const prv_camset* dataset, const uint8_t* images_rgba8_dev,
+                     const prv_train_opts* opts, prv_trainer** out);
+/* n optimiser steps; losses_host (n floats, may be NULL) = the batch loss of each step before its update */
+int prv_train_steps(prv_trainer* t, int n_steps, float* losses_host);
+int prv_train_info(const prv_trainer* t, uint32_t* steps_done, uint64_t* samples_last_batch,
+                   uint64_t* table_scalars);
+void prv_train_destroy(prv_trainer* t);
+/* parity hooks: gradients of the NEXT batch without an update (host arrays: table_scalars and
+ * PRV_MLP_HALFS floats), the fp32 master weights, one density-grid refresh */
+int prv_train_gradients(prv_trainer* t, float* table_grad_host, float* mlp_grad_host, float* loss);
+int prv_train_master(prv_trainer* t, float* table_host, float* mlp_host);
+int prv_train_refresh_occupancy(prv_trainer* t);
+
 /* ---- stage hooks for parity tests (host in / host out, small n) ---------- */
 /* rays of view i at (w,h): o,d = n*3, t = n*2 (AABB entry/exit; exit<=entry => miss) */
 int prv_debug_raygen(prv_ctx* ctx, const prv_camset* cs, int view, int width, int height,

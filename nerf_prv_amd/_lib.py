@@ -66,6 +66,13 @@ class Intrinsics(C.Structure):
     _fields_ = [(n, C.c_double) for n in "fl_x fl_y cx cy k1 k2 p1 p2".split()] + [("w", C.c_int32), ("h", C.c_int32)]
 
 
+class TrainOpts(C.Structure):
+    _fields_ = [("n_rays", C.c_int32), ("n_samples", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("l2_reg", C.c_float), ("min_T", C.c_float),
+                ("seed", C.c_uint64), ("random_bg", C.c_int32), ("occ_every", C.c_int32), ("occ_decay", C.c_float),
+                ("occ_sigma_thresh", C.c_float)]
+
+
 _vp = C.c_void_p
 _i = C.c_int
 _P = C.POINTER
@@ -112,6 +119,14 @@ SIGNATURES = {
     "prv_score_views": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _P(RenderOpts), _vp, _vp, _vp, _P(Stats)]),
     "prv_rank": (_i, [_vp, _vp, _i, _vp]),
     "prv_argmax": (_i, [_vp, _vp, _i]),
+    "prv_train_default_opts": (_i, [_P(TrainOpts)]),
+    "prv_train_create": (_i, [_vp, _i, _vp, _vp, _P(TrainOpts), _P(_vp)]),
+    "prv_train_steps": (_i, [_vp, _i, _vp]),
+    "prv_train_info": (_i, [_vp, _P(C.c_uint32), _P(C.c_uint64), _P(C.c_uint64)]),
+    "prv_train_destroy": (None, [_vp]),
+    "prv_train_gradients": (_i, [_vp, _vp, _vp, _P(C.c_float)]),
+    "prv_train_master": (_i, [_vp, _vp, _vp]),
+    "prv_train_refresh_occupancy": (_i, [_vp]),
     "prv_debug_raygen": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "prv_debug_encode": (_i, [_vp, _i, _vp, _i, _vp]),
     "prv_debug_field": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),

@@ -346,6 +346,71 @@ def rank_host(records, view_ids):
     return order
 
 
+def train_opts(**kw):
+    """prv_train_default_opts with overrides"""
+    o = L.TrainOpts()
+    rc = L.load().prv_train_default_opts(C.byref(o))
+    if rc != 0:
+        raise PrvError(rc, "prv_train_default_opts")
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown training option {k}")
+        setattr(o, k, v)
+    return o
+
+
+class Trainer:
+    """the in-process training step on one model slot (include/prv.h, training section)"""
+
+    def __init__(self, ctx, slot, camset, images_u8, opts=None):
+        t = ctx.torch
+        self.ctx, self.slot, self.camset = ctx, slot, camset
+        self.images = images_u8.to(device=ctx.device, dtype=t.uint8).contiguous()  # kept alive here
+        n, h, w, ch = self.images.shape
+        if ch != 4 or n != len(camset) or (w, h) != camset.size:
+            raise ValueError("images must be [n_views, h, w, 4] at the dataset resolution")
+        self.opts = opts if opts is not None else train_opts()
+        self.handle = C.c_void_p()
+        ctx._chk(ctx.lib.prv_train_create(ctx.handle, slot, camset.handle, _ptr(self.images), C.byref(self.opts),
+                                          C.byref(self.handle)))
+
+    def steps(self, n):
+        losses = np.zeros(int(n), np.float32)
+        self.ctx._chk(self.ctx.lib.prv_train_steps(self.handle, int(n), _ptr(losses)))
+        return losses
+
+    def info(self):
+        s, u, n = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        self.ctx.lib.prv_train_info(self.handle, C.byref(s), C.byref(u), C.byref(n))
+        return {"steps": s.value, "samples_last": u.value, "table_scalars": n.value}
+
+    def gradients(self):
+        n = self.info()["table_scalars"]
+        tg, mg, loss = np.zeros(n, np.float32), np.zeros(L.MLP_HALFS, np.float32), C.c_float()
+        self.ctx._chk(self.ctx.lib.prv_train_gradients(self.handle, _ptr(tg), _ptr(mg), C.byref(loss)))
+        return loss.value, tg, mg
+
+    def master(self):
+        n = self.info()["table_scalars"]
+        tw, mw = np.zeros(n, np.float32), np.zeros(L.MLP_HALFS, np.float32)
+        self.ctx._chk(self.ctx.lib.prv_train_master(self.handle, _ptr(tw), _ptr(mw)))
+        return tw, mw
+
+    def refresh_occupancy(self):
+        self.ctx._chk(self.ctx.lib.prv_train_refresh_occupancy(self.handle))
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.prv_train_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _NerfSettings:
     """stands in for testbed.nerf (run.py:140,145,235)"""
 

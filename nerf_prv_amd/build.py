@@ -45,8 +45,9 @@ def hipcc():
 
 def build_hip(force=False):
     out = os.path.join(HERE, "libprv_hip.so")
-    srcs = [os.path.join(CSRC, f) for f in ("prv_kernels.hip", "prv_api.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("prv_device.hpp", "prv_kernels.hpp", "prv_json.hpp")] + [
+    srcs = [os.path.join(CSRC, f) for f in ("prv_kernels.hip", "prv_train.hip", "prv_api.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("prv_device.hpp", "prv_kernels.hpp", "prv_json.hpp", "prv_train.hpp",
+                                                   "prv_train_api.inc")] + [
         os.path.join(ROOT, "include", "prv.h")]
     if force or _newer(out, deps):
         _run([hipcc()] + HIP_FLAGS + ["-o", out] + srcs)

@@ -14,6 +14,7 @@
 
 #include "prv_json.hpp"
 #include "prv_kernels.hpp"
+#include "prv_train.hpp"
 
 using namespace prv;
 
@@ -1274,3 +1275,5 @@ int prv_debug_field(prv_ctx* c, int slot, const float* pos, const float* dir, in
 }
 
 } // extern "C"
+
+#include "prv_train_api.inc"

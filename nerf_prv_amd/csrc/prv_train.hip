@@ -1,0 +1,619 @@
+// prv_train.hip -- in-process training step of the field (gfx950), replaces the `while testbed.frame()`
+// loop that run.py:185-208 drives for --n_steps 2500 (main.cpp:1668).  The algorithm is the one
+// oracle/prv_train.c states (published instant-ngp optimiser, parity unpinned); this file is its HIP form.
+//
+//   train_rays_kernel      one lane = one training ray: counter RNG -> image / pixel / jitter / background,
+//                          target colour, dataset camera (lens solve), unit-cube slab test, 128-bit occupancy
+//                          mask at the jittered sample positions, live samples appended to the sample list
+//   train_tile_kernel<FWD> one 256-thread block = 32 samples at a time, persistent.  8 threads per sample
+//                          encode (one or two levels each, binary16 blend as in inference); the five layers run
+//                          as f32 MFMAs (v_mfma_f32_32x32x2_f32) with BOTH operands read from plain
+//                          [neuron][sample] / [in][out] LDS arrays, so every layout is trivial:
+//                            FWD : logits out.   BWD : activations recomputed, dX chain, dW accumulated in
+//                          registers over all tiles of the block (3 weight tiles per wave), feature gradients
+//                          scattered into the canonical table gradient with f32 atomics
+//   train_composite_kernel one lane = one ray: compositing, loss, and the per-sample gradient seeds
+//   adam_*_kernel          sparse Adam on the table, dense Adam (+L2) on the MLP, fp16 working copies refreshed
+//   density_refresh_kernel density at every occupancy cell centre -> EMA -> bitfield
+#include <hip/hip_runtime.h>
+#include "prv_train.hpp"
+
+namespace prv {
+
+namespace {
+
+__device__ __forceinline__ uint64_t t_mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t rng_u24(uint64_t seed, uint64_t stream, uint64_t i) {
+  return (uint32_t)(t_mix64(seed + (stream + 1) * 0xD1B54A32D192ED03ull + i * 0x9E3779B97F4A7C15ull) >> 40);
+}
+
+__device__ __forceinline__ float srgb_to_linear(float c) {
+  return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f);
+}
+
+__device__ __forceinline__ bool occ_bit(const uint32_t* __restrict__ occ, int R, float px, float py, float pz) {
+  const float fr = (float)R;
+  int cx = min((int)(clamp01(px) * fr), R - 1), cy = min((int)(clamp01(py) * fr), R - 1),
+      cz = min((int)(clamp01(pz) * fr), R - 1);
+  const uint32_t bit = (uint32_t)cx + (uint32_t)R * ((uint32_t)cy + (uint32_t)R * (uint32_t)cz);
+  return (occ[bit >> 5] >> (bit & 31u)) & 1u;
+}
+
+// ------------------------------------------------------------------ rays of one step
+
+__global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= (uint32_t)P.n_rays) return;
+  const uint64_t st = (uint64_t)P.step * 8u;
+  const uint32_t img = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 0, j) * (uint64_t)P.n_img) >> 24);
+  const uint32_t px = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 1, j) * (uint64_t)P.W) >> 24);
+  const uint32_t py = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 2, j) * (uint64_t)P.H) >> 24);
+  const float jitter = (float)rng_u24(P.seed, st + 3, j) * (1.0f / 16777216.0f);
+  float bg[3] = {0.f, 0.f, 0.f};
+  if (P.random_bg)
+    for (int k = 0; k < 3; k++) bg[k] = (float)rng_u24(P.seed, st + 4 + k, j) * (1.0f / 16777216.0f);
+  const uint8_t* gp = P.images + (((size_t)img * P.H + py) * P.W + px) * 4;
+  const float ga = (float)gp[3] * (1.0f / 255.0f);
+  TrainRay r;
+  for (int k = 0; k < 3; k++) {
+    r.target[k] = fmaf(srgb_to_linear((float)gp[k] * (1.0f / 255.0f)), ga, (1.0f - ga) * bg[k]);
+    r.bg[k] = bg[k];
+  }
+  const CamDev cam = P.cams[img];
+  raygen(cam, (int)px, (int)py, 0.5f, 0.5f, r.o, r.d);
+  float t0, t1;
+  uint32_t m[4] = {0u, 0u, 0u, 0u};
+  r.t0 = 0.f;
+  r.dt = 0.f;
+  if (ray_aabb(r.o, r.d, t0, t1)) {
+    r.t0 = t0;
+    r.dt = (t1 - t0) / (float)P.S;
+    for (int i = 0; i < P.S; i++) {
+      const float t = fmaf((float)i + jitter, r.dt, t0);
+      if (occ_bit(P.occ, P.occ_res, fmaf(t, r.d[0], r.o[0]), fmaf(t, r.d[1], r.o[1]), fmaf(t, r.d[2], r.o[2])))
+        m[i >> 5] |= 1u << (i & 31);
+    }
+  }
+  r.jitter = jitter;
+  r.n_live = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
+  r.offset = r.n_live ? atomicAdd(P.sample_count, r.n_live) : 0u;
+  r.n_used = 0u;
+  P.rays[j] = r;
+  uint32_t k = r.offset;
+  for (int w = 0; w < 4; w++) {
+    uint32_t mm = m[w];
+    while (mm) {
+      const int b = __builtin_ctz(mm);
+      mm &= mm - 1u;
+      P.samples[k++] = make_uint2(j, (uint32_t)(w * 32 + b));
+    }
+  }
+}
+
+// ------------------------------------------------------------------ one level of the encoder, canonical table
+
+// features of one level (binary16 blend, bit for bit encode_level / orc_encode) + the corner entries and
+// weights the backward pass scatters into
+template <int F>
+__device__ __forceinline__ void train_encode_level(const uint16_t* __restrict__ table, const LevelCanon& L, float px,
+                                                   float py, float pz, float feat[F], uint32_t cidx[8], float cw[8]) {
+  const float p[3] = {clamp01(px), clamp01(py), clamp01(pz)};
+  uint32_t c0[3];
+  _Float16 wh[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float pos = fmaf(L.scale, p[a], 0.5f);
+    const float fl = floorf(pos);
+    const float w = pos - fl;
+    c0[a] = (uint32_t)(int)fl;
+    wh[a][0] = (_Float16)(1.0f - w);
+    wh[a][1] = (_Float16)w;
+  }
+  _Float16 acc[F];
+#pragma unroll
+  for (int k = 0; k < F; k++) acc[k] = (_Float16)0.0f;
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    uint32_t cc[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) cc[a] = min(c0[a] + ((c >> a) & 1u), L.res - 1u);
+    const uint32_t idx = L.hashed ? ((cc[0] ^ (cc[1] * 2654435761u) ^ (cc[2] * 805459861u)) & (L.size - 1u))
+                                  : (cc[0] + L.res * (cc[1] + L.res * cc[2]));
+    const _Float16 wxy = wh[0][c & 1] * wh[1][(c >> 1) & 1];
+    const _Float16 w = wxy * wh[2][c >> 2];
+    cidx[c] = L.offset + idx;
+    cw[c] = (float)w;
+    const uint16_t* e = table + (size_t)(L.offset + idx) * F;
+#pragma unroll
+    for (int k = 0; k < F; k++) acc[k] = __builtin_fmaf16(w, __builtin_bit_cast(_Float16, e[k]), acc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < F; k++) feat[k] = (float)acc[k];
+}
+
+// ------------------------------------------------------------------ tile kernel
+
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16v mfma32(float a, float b, f32x16v c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// accumulator register i of lane half h holds row rho(i, h) of the 32x32 tile
+__device__ __forceinline__ int rho(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+constexpr int kTS = 33; // sample stride of the [row][sample] LDS arrays (conflict-free in both read directions)
+// layer l: n_in, n_out, canonical offset, padded LDS row stride and LDS offset of the weights
+__device__ constexpr int kLIn[5] = {32, 64, 32, 64, 64}, kLOut[5] = {64, 16, 64, 64, 16};
+__device__ constexpr int kLOff[5] = {0, 2048, 3072, 5120, 9216};
+__device__ constexpr int kLStr[5] = {65, 17, 65, 65, 17};
+__device__ constexpr int kLLds[5] = {0, 2080, 3168, 5248, 9408}; // prefix of n_in * stride
+constexpr int kWLds = 10496;
+// activation rows: feat 0..31 | h1 32..95 | in2 96..127 | h2 128..191 | h3 192..255
+constexpr int kAFeat = 0, kAH1 = 32, kAIn2 = 96, kAH2 = 128, kAH3 = 192, kARows = 256;
+// gradient rows: dOrr 0..15 | dH3 16..79 | dH2 80..143 | dOd 144..175 | dH1 176..239 | dFeat 240..271
+constexpr int kGOrr = 0, kGH3 = 16, kGH2 = 80, kGOd = 144, kGH1 = 176, kGFeat = 240, kGRows = 272;
+
+// OUT[32*mt + row][s] = sum_k A(row, k) * IN[k][s]  over k in [0, K): forward (A = W[k][o]) or transposed
+// (A = W[row][k]) -- one wave, one 32-row tile, K/2 MFMAs
+template <bool TRANSPOSED>
+__device__ __forceinline__ f32x16v layer_tile(const float* __restrict__ Wl, int stride, int n_rows_valid, int mt,
+                                              const float* __restrict__ in, int K, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int row = 32 * mt + r;
+  const bool valid = row < n_rows_valid;
+  f32x16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = h; k < K; k += 2) {
+    float a = 0.0f;
+    if (valid) a = TRANSPOSED ? Wl[row * stride + k] : Wl[k * stride + row];
+    acc = mfma32(a, in[k * kTS + r], acc);
+  }
+  return acc;
+}
+
+template <int F, bool FWD>
+__global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
+  extern __shared__ float lds[];
+  float* W = lds;                 // kWLds
+  float* A = W + kWLds;           // kARows * kTS
+  float* G = A + kARows * kTS;    // kGRows * kTS (backward only)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  for (int l = 0; l < 5; l++)
+    for (int i = tid; i < kLIn[l] * kLOut[l]; i += 256)
+      W[kLLds[l] + (i / kLOut[l]) * kLStr[l] + (i % kLOut[l])] = P.mlp[kLOff[l] + i];
+  __syncthreads();
+
+  const uint32_t n_samples = *P.sample_count;
+  const uint32_t n_tiles = (n_samples + 31u) / 32u;
+  constexpr int LPT = (32 / F) / 8; // levels per thread (8 threads per sample)
+  f32x16v dw[3];
+  for (int q = 0; q < 3; q++) dw[q] = f32x16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // ---- phase E: encode (8 threads per sample), SH inputs, gradient seeds
+    const int s = tid & 31, g = tid >> 5;
+    const uint32_t sid = tile * 32u + (uint32_t)s;
+    const bool live = sid < n_samples;
+    uint32_t cidx[LPT][8];
+    float cw[LPT][8];
+    float4 seed = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      float pos[3] = {0.5f, 0.5f, 0.5f}, dir[3] = {0.f, 0.f, 1.f};
+      if (live) {
+        const uint2 sr = P.samples[sid];
+        const TrainRay* ray = P.rays + sr.x;
+        const float t = fmaf((float)sr.y + ray->jitter, ray->dt, ray->t0);
+        for (int a = 0; a < 3; a++) {
+          dir[a] = ray->d[a];
+          pos[a] = fmaf(t, dir[a], ray->o[a]);
+        }
+        if (!FWD) seed = P.seeds[sid];
+      }
+#pragma unroll
+      for (int q = 0; q < LPT; q++) {
+        const int l = g * LPT + q;
+        float f[F];
+        train_encode_level<F>(P.table, P.levels[l], pos[0], pos[1], pos[2], f, cidx[q], cw[q]);
+#pragma unroll
+        for (int k = 0; k < F; k++) A[(kAFeat + l * F + k) * kTS + s] = live ? f[k] : 0.0f;
+      }
+      if (g == 0) {
+        float sh[16];
+        sh4(dir[0], dir[1], dir[2], sh);
+#pragma unroll
+        for (int k = 0; k < 16; k++) A[(kAIn2 + 16 + k) * kTS + s] = live ? (float)(_Float16)sh[k] : 0.0f;
+      }
+      if (!FWD && g == 1) {
+        G[(kGOrr + 0) * kTS + s] = seed.y;
+        G[(kGOrr + 1) * kTS + s] = seed.z;
+        G[(kGOrr + 2) * kTS + s] = seed.w;
+#pragma unroll
+        for (int k = 3; k < 16; k++) G[(kGOrr + k) * kTS + s] = 0.0f;
+      }
+    }
+    __syncthreads();
+    // ---- forward: relu + fp16 rounding of the hidden activations as in inference
+    if (wave < 2) { // D1: 32 -> 64
+      const f32x16v a = layer_tile<false>(W + kLLds[0], kLStr[0], 64, wave, A + kAFeat * kTS, 32, lane);
+#pragma unroll
+      for (int i = 0; i < 16; i++) A[(kAH1 + 32 * wave + rho(i, h)) * kTS + r] = (float)(_Float16)fmaxf(a[i], 0.0f);
+    }
+    __syncthreads();
+    float od0 = 0.0f;
+    if (wave == 0) { // D2: 64 -> 16
+      const f32x16v a = layer_tile<false>(W + kLLds[1], kLStr[1], 16, 0, A + kAH1 * kTS, 64, lane);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int row = rho(i, h);
+        if (row < 16) A[(kAIn2 + row) * kTS + r] = (float)(_Float16)a[i];
+      }
+      od0 = a[0]; // row 0 lives in register 0 of lane half 0
+    }
+    __syncthreads();
+    if (wave < 2) { // R1: 32 -> 64
+      const f32x16v a = layer_tile<false>(W + kLLds[2], kLStr[2], 64, wave, A + kAIn2 * kTS, 32, lane);
+#pragma unroll
+      for (int i = 0; i < 16; i++) A[(kAH2 + 32 * wave + rho(i, h)) * kTS + r] = (float)(_Float16)fmaxf(a[i], 0.0f);
+    }
+    __syncthreads();
+    if (wave < 2) { // R2: 64 -> 64
+      const f32x16v a = layer_tile<false>(W + kLLds[3], kLStr[3], 64, wave, A + kAH2 * kTS, 64, lane);
+#pragma unroll
+      for (int i = 0; i < 16; i++) A[(kAH3 + 32 * wave + rho(i, h)) * kTS + r] = (float)(_Float16)fmaxf(a[i], 0.0f);
+    }
+    __syncthreads();
+    if (FWD) {
+      if (wave == 0) { // R3: 64 -> 16, logits out
+        const f32x16v a = layer_tile<false>(W + kLLds[4], kLStr[4], 16, 0, A + kAH3 * kTS, 64, lane);
+        const uint32_t o = tile * 32u + (uint32_t)r;
+        if (h == 0 && o < n_samples) P.logits[o] = make_float4(od0, a[0], a[1], a[2]);
+      }
+      __syncthreads();
+      continue;
+    }
+    // ---- backward: dX chain (straight through the fp16 roundings, ReLU masks from the activations)
+    if (wave < 2) { // dH3 = W_r3 dOrr
+      const f32x16v a = layer_tile<true>(W + kLLds[4], kLStr[4], 64, wave, G + kGOrr * kTS, 16, lane);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int row = 32 * wave + rho(i, h);
+        G[(kGH3 + row) * kTS + r] = A[(kAH3 + row) * kTS + r] > 0.0f ? a[i] : 0.0f;
+      }
+    }
+    __syncthreads();
+    if (wave < 2) { // dH2 = W_r2 dH3
+      const f32x16v a = layer_tile<true>(W + kLLds[3], kLStr[3], 64, wave, G + kGH3 * kTS, 64, lane);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int row = 32 * wave + rho(i, h);
+        G[(kGH2 + row) * kTS + r] = A[(kAH2 + row) * kTS + r] > 0.0f ? a[i] : 0.0f;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) { // dOd = (W_r1 dH2)[0..15] (+ the density seed on row 0); the SH rows carry no parameters
+      const f32x16v a = layer_tile<true>(W + kLLds[2], kLStr[2], 32, 0, G + kGH2 * kTS, 64, lane);
+      const float sd = seed.x; // every thread of sample s = tid & 31 holds its seed; in wave 0, s == r
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int row = rho(i, h);
+        if (row < 16) G[(kGOd + row) * kTS + r] = a[i] + (row == 0 ? sd : 0.0f);
+      }
+    }
+    __syncthreads();
+    if (wave < 2) { // dH1 = W_d2 dOd
+      const f32x16v a = layer_tile<true>(W + kLLds[1], kLStr[1], 64, wave, G + kGOd * kTS, 16, lane);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int row = 32 * wave + rho(i, h);
+        G[(kGH1 + row) * kTS + r] = A[(kAH1 + row) * kTS + r] > 0.0f ? a[i] : 0.0f;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) { // dFeat = W_d1 dH1
+      const f32x16v a = layer_tile<true>(W + kLLds[0], kLStr[0], 32, 0, G + kGH1 * kTS, 64, lane);
+#pragma unroll
+      for (int i = 0; i < 16; i++) G[(kGFeat + rho(i, h)) * kTS + r] = a[i];
+    }
+    __syncthreads();
+    // ---- dW[k][o] += sum_s X[k][s] dOut[o][s]: three 32x32 weight tiles per wave, K = the 32 samples
+    {
+      // tile q of wave w: {activation row base, gradient row base, valid gradient rows}
+      int xa[3], ga[3], gv[3];
+      if (wave == 0) { xa[0] = kAH2; ga[0] = kGH3; gv[0] = 32; xa[1] = kAH2; ga[1] = kGH3 + 32; gv[1] = 32; xa[2] = kAH3; ga[2] = kGOrr; gv[2] = 16; }
+      else if (wave == 1) { xa[0] = kAH2 + 32; ga[0] = kGH3; gv[0] = 32; xa[1] = kAH2 + 32; ga[1] = kGH3 + 32; gv[1] = 32; xa[2] = kAH3 + 32; ga[2] = kGOrr; gv[2] = 16; }
+      else if (wave == 2) { xa[0] = kAIn2; ga[0] = kGH2; gv[0] = 32; xa[1] = kAIn2; ga[1] = kGH2 + 32; gv[1] = 32; xa[2] = kAH1; ga[2] = kGOd; gv[2] = 16; }
+      else { xa[0] = kAFeat; ga[0] = kGH1; gv[0] = 32; xa[1] = kAFeat; ga[1] = kGH1 + 32; gv[1] = 32; xa[2] = kAH1 + 32; ga[2] = kGOd; gv[2] = 16; }
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const bool bv = r < gv[q];
+        for (int k = h; k < 32; k += 2) {
+          const float a = A[(xa[q] + r) * kTS + k];
+          const float b = bv ? G[(ga[q] + r) * kTS + k] : 0.0f;
+          dw[q] = mfma32(a, b, dw[q]);
+        }
+      }
+    }
+    // ---- scatter the feature gradients into the canonical table gradient
+    if (live && (seed.x != 0.0f || seed.y != 0.0f || seed.z != 0.0f || seed.w != 0.0f)) {
+#pragma unroll
+      for (int q = 0; q < LPT; q++) {
+        const int l = g * LPT + q;
+        float df[F];
+#pragma unroll
+        for (int k = 0; k < F; k++) df[k] = G[(kGFeat + l * F + k) * kTS + s];
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+#pragma unroll
+          for (int k = 0; k < F; k++) atomicAdd(P.table_grad + (size_t)cidx[q][c] * F + k, cw[q][c] * df[k]);
+      }
+    }
+    __syncthreads();
+  }
+  if (!FWD) { // flush this block's weight-gradient tiles: accumulator i of lane (r, h) = dW[k = rho(i,h)][o = r]
+    // {layer, k base, o base, valid o columns}
+    int ly[3], kb[3], ob[3], ov[3];
+    if (wave == 0) { ly[0] = 3; kb[0] = 0; ob[0] = 0; ov[0] = 32; ly[1] = 3; kb[1] = 0; ob[1] = 32; ov[1] = 32; ly[2] = 4; kb[2] = 0; ob[2] = 0; ov[2] = 16; }
+    else if (wave == 1) { ly[0] = 3; kb[0] = 32; ob[0] = 0; ov[0] = 32; ly[1] = 3; kb[1] = 32; ob[1] = 32; ov[1] = 32; ly[2] = 4; kb[2] = 32; ob[2] = 0; ov[2] = 16; }
+    else if (wave == 2) { ly[0] = 2; kb[0] = 0; ob[0] = 0; ov[0] = 32; ly[1] = 2; kb[1] = 0; ob[1] = 32; ov[1] = 32; ly[2] = 1; kb[2] = 0; ob[2] = 0; ov[2] = 16; }
+    else { ly[0] = 0; kb[0] = 0; ob[0] = 0; ov[0] = 32; ly[1] = 0; kb[1] = 0; ob[1] = 32; ov[1] = 32; ly[2] = 1; kb[2] = 32; ob[2] = 0; ov[2] = 16; }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      if (r >= ov[q]) continue;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const float v = dw[q][i];
+        if (v != 0.0f) atomicAdd(P.mlp_grad + kLOff[ly[q]] + (kb[q] + rho(i, h)) * kLOut[ly[q]] + ob[q] + r, v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ compositing, loss, gradient seeds
+
+__global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositeParams P) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= (uint32_t)P.n_rays) return;
+  TrainRay* ray = P.rays + j;
+  const uint32_t n = ray->n_live, off = ray->offset;
+  const float dt = ray->dt;
+  float T = 1.0f, C[3] = {0.f, 0.f, 0.f};
+  uint32_t used = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    const float4 lg = P.logits[off + k];
+    const float sigma = expf(lg.x + P.density_bias);
+    const float alpha = 1.0f - expf(-(sigma * dt));
+    const float wgt = alpha * T;
+    C[0] = fmaf(wgt, 1.0f / (1.0f + expf(-lg.y)), C[0]);
+    C[1] = fmaf(wgt, 1.0f / (1.0f + expf(-lg.z)), C[1]);
+    C[2] = fmaf(wgt, 1.0f / (1.0f + expf(-lg.w)), C[2]);
+    T = T * (1.0f - alpha);
+    used = k + 1;
+    if (T < P.min_T) break;
+  }
+  ray->n_used = used;
+  float dC[3], loss = 0.0f, suffix[3];
+  const float inv = 1.0f / (3.0f * (float)P.n_rays);
+  for (int k = 0; k < 3; k++) {
+    const float e = fmaf(T, ray->bg[k], C[k]) - ray->target[k];
+    loss = fmaf(e, e, loss);
+    dC[k] = 2.0f * e * inv;
+    suffix[k] = T * ray->bg[k];
+  }
+  P.ray_loss[j] = loss * inv;
+  P.ray_used[j] = used;
+  // second forward walk keeps (alpha, T_before) of the used samples, then the seeds are emitted back to front
+  float Tb = 1.0f;
+  float al[kMaxTrainSamples], tb[kMaxTrainSamples];
+  for (uint32_t k = 0; k < used; k++) {
+    const float4 lg = P.logits[off + k];
+    const float sigma = expf(lg.x + P.density_bias);
+    al[k] = 1.0f - expf(-(sigma * dt));
+    tb[k] = Tb;
+    Tb = Tb * (1.0f - al[k]);
+  }
+  for (int k = (int)used - 1; k >= 0; k--) {
+    const float4 lg = P.logits[off + k];
+    const float sigma = expf(lg.x + P.density_bias);
+    const float rgb[3] = {1.0f / (1.0f + expf(-lg.y)), 1.0f / (1.0f + expf(-lg.z)), 1.0f / (1.0f + expf(-lg.w))};
+    const float wgt = al[k] * tb[k], T_after = tb[k] * (1.0f - al[k]);
+    float d_sigma = 0.0f, d_orr[3];
+    for (int c = 0; c < 3; c++) {
+      d_sigma += dC[c] * dt * (T_after * rgb[c] - suffix[c]);
+      d_orr[c] = dC[c] * wgt * rgb[c] * (1.0f - rgb[c]);
+      suffix[c] += wgt * rgb[c];
+    }
+    P.seeds[off + k] = make_float4(d_sigma * sigma, d_orr[0], d_orr[1], d_orr[2]);
+  }
+  for (uint32_t k = used; k < n; k++) P.seeds[off + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// fixed-order sum of the per-ray losses and used-sample counts (one block)
+__global__ __launch_bounds__(256) void train_loss_kernel(const float* __restrict__ ray_loss,
+                                                         const uint32_t* __restrict__ ray_used, int n, float* out_loss,
+                                                         unsigned long long* out_used) {
+  __shared__ double sl[256];
+  __shared__ unsigned long long su[256];
+  double a = 0.0;
+  unsigned long long u = 0ull;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    a += (double)ray_loss[i];
+    u += ray_used[i];
+  }
+  sl[threadIdx.x] = a;
+  su[threadIdx.x] = u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    unsigned long long tu = 0ull;
+    for (int i = 0; i < 256; i++) {
+      t += sl[i];
+      tu += su[i];
+    }
+    *out_loss = (float)t;
+    *out_used = tu;
+  }
+}
+
+// ------------------------------------------------------------------ optimiser
+
+__device__ __forceinline__ void adam_update(const AdamParams& P, float g, float& w, float& m, float& v) {
+  m = fmaf(P.beta1, m, (1.0f - P.beta1) * g);
+  v = fmaf(P.beta2, v, ((1.0f - P.beta2) * g) * g);
+  w = w - (P.lr_t * m) / (sqrtf(v) + P.eps);
+}
+
+__global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n, float* __restrict__ grad,
+                                                         float* __restrict__ w, float* __restrict__ m,
+                                                         float* __restrict__ v, uint16_t* __restrict__ w16) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float g = grad[i];
+  if (g == 0.0f) return; // sparse: untouched entries keep their moments
+  grad[i] = 0.0f;
+  float ww = w[i], mm = m[i], vv = v[i];
+  adam_update(P, g, ww, mm, vv);
+  w[i] = ww;
+  m[i] = mm;
+  v[i] = vv;
+  w16[i] = __builtin_bit_cast(uint16_t, (_Float16)ww);
+}
+
+__global__ __launch_bounds__(256) void adam_mlp_kernel(AdamParams P, float l2_reg, float* __restrict__ grad,
+                                                       float* __restrict__ w, float* __restrict__ m,
+                                                       float* __restrict__ v, uint16_t* __restrict__ w16,
+                                                       float* __restrict__ w16_as_f32) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= PRV_MLP_HALFS) return;
+  const float g = fmaf(l2_reg, w[i], grad[i]);
+  grad[i] = 0.0f;
+  float ww = w[i], mm = m[i], vv = v[i];
+  adam_update(P, g, ww, mm, vv);
+  w[i] = ww;
+  m[i] = mm;
+  v[i] = vv;
+  const _Float16 hh = (_Float16)ww;
+  w16[i] = __builtin_bit_cast(uint16_t, hh);
+  w16_as_f32[i] = (float)hh;
+}
+
+__global__ __launch_bounds__(256) void widen_kernel(const uint16_t* __restrict__ in, size_t n, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (float)__builtin_bit_cast(_Float16, in[i]);
+}
+
+// ------------------------------------------------------------------ density grid
+
+// one thread = one occupancy cell: density at the cell centre (encoder + density MLP, fp16 semantics of
+// inference, f32 accumulation), EMA, threshold.  32 consecutive cells = one word of the bitfield.
+template <int F>
+__global__ __launch_bounds__(256) void density_refresh_kernel(DensityParams P) {
+  __shared__ float W1[32 * 64], W2[64];
+  for (int i = threadIdx.x; i < 32 * 64; i += 256) W1[i] = P.mlp[i];
+  for (int i = threadIdx.x; i < 64; i += 256) W2[i] = P.mlp[2048 + i * 16]; // output 0 of layer D2
+  __syncthreads();
+  const int R = P.occ_res;
+  const uint32_t n_cells = (uint32_t)R * R * R;
+  const uint32_t cell = blockIdx.x * 256u + threadIdx.x;
+  bool on = false;
+  if (cell < n_cells) {
+    const uint32_t x = cell % R, y = (cell / R) % R, z = cell / (R * R);
+    const float invR = 1.0f / (float)R;
+    const float px = ((float)x + 0.5f) * invR, py = ((float)y + 0.5f) * invR, pz = ((float)z + 0.5f) * invR;
+    float h1[64];
+#pragma unroll
+    for (int o = 0; o < 64; o++) h1[o] = 0.0f;
+    for (int l = 0; l < 32 / F; l++) {
+      float f[F], cw[8];
+      uint32_t ci[8];
+      train_encode_level<F>(P.table, P.levels[l], px, py, pz, f, ci, cw);
+#pragma unroll
+      for (int k = 0; k < F; k++) {
+        const float* wr = W1 + (l * F + k) * 64;
+#pragma unroll
+        for (int o = 0; o < 64; o++) h1[o] = fmaf(f[k], wr[o], h1[o]);
+      }
+    }
+    float od0 = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 64; o++) od0 = fmaf((float)(_Float16)fmaxf(h1[o], 0.0f), W2[o], od0);
+    const float sigma = expf(od0 + P.density_bias);
+    const float e = fmaxf(P.ema[cell] * P.decay, sigma);
+    P.ema[cell] = e;
+    on = e > P.thresh;
+  }
+  const unsigned long long b = __ballot(on);
+  if ((threadIdx.x & 31) == 0 && cell < n_cells) P.occ[cell >> 5] = (uint32_t)(b >> (threadIdx.x & 32));
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ launchers
+
+size_t train_tile_lds_bytes(bool fwd) { return sizeof(float) * (size_t)(kWLds + kARows * kTS + (fwd ? 0 : kGRows * kTS)); }
+
+hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s) {
+  hipLaunchKernelGGL(train_rays_kernel, dim3((P.n_rays + 255) / 256), dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+template <int F, bool FWD>
+static hipError_t launch_tile(const TrainTileParams& P, int n_blocks, hipStream_t s) {
+  const size_t lds = train_tile_lds_bytes(FWD);
+  static bool attr_set = false; // one attribute call per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_tile_kernel<F, FWD>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((train_tile_kernel<F, FWD>), dim3(n_blocks), dim3(256), lds, s, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s) {
+  if (P.n_features == 4) return forward ? launch_tile<4, true>(P, n_blocks, s) : launch_tile<4, false>(P, n_blocks, s);
+  return forward ? launch_tile<2, true>(P, n_blocks, s) : launch_tile<2, false>(P, n_blocks, s);
+}
+
+hipError_t launch_train_composite(const TrainCompositeParams& P, hipStream_t s) {
+  hipLaunchKernelGGL(train_composite_kernel, dim3((P.n_rays + 255) / 256), dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, float* out_loss,
+                             unsigned long long* out_used, hipStream_t s) {
+  hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(256), 0, s, ray_loss, ray_used, n, out_loss, out_used);
+  return hipGetLastError();
+}
+
+hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* w, float* m, float* v, uint16_t* w16,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(adam_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P, n, grad, w, m, v, w16);
+  return hipGetLastError();
+}
+
+hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float* w, float* m, float* v, uint16_t* w16,
+                           float* w16_as_f32, hipStream_t s) {
+  hipLaunchKernelGGL(adam_mlp_kernel, dim3((PRV_MLP_HALFS + 255) / 256), dim3(256), 0, s, P, l2_reg, grad, w, m, v, w16,
+                     w16_as_f32);
+  return hipGetLastError();
+}
+
+hipError_t launch_widen(const uint16_t* in, size_t n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_density_refresh(const DensityParams& P, int n_features, hipStream_t s) {
+  const uint32_t n = (uint32_t)P.occ_res * P.occ_res * P.occ_res;
+  if (n_features == 4)
+    hipLaunchKernelGGL(density_refresh_kernel<4>, dim3((n + 255) / 256), dim3(256), 0, s, P);
+  else
+    hipLaunchKernelGGL(density_refresh_kernel<2>, dim3((n + 255) / 256), dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+} // namespace prv

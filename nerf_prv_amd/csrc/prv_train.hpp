@@ -1,0 +1,85 @@
+// prv_train.hpp -- parameter blocks and launchers of the training step (prv_train.hip)
+#pragma once
+#include "../../include/prv.h"
+#include "prv_device.hpp"
+
+namespace prv {
+
+constexpr int kMaxTrainSamples = 128;
+
+struct LevelCanon { // canonical (ABI) table layout of one level
+  float scale;
+  uint32_t res, offset, size, hashed;
+};
+
+struct TrainRay {
+  float o[3], d[3], t0, dt, jitter;
+  float target[3], bg[3];
+  uint32_t offset, n_live, n_used;
+  uint32_t pad[2];
+};
+
+struct TrainRaysParams {
+  const CamDev* cams;    // n_img dataset cameras at (W, H)
+  const uint8_t* images; // n_img * H * W * 4 straight-alpha sRGB bytes
+  const uint32_t* occ;
+  int n_img, W, H, S, n_rays, occ_res, random_bg;
+  uint32_t step;
+  uint64_t seed;
+  TrainRay* rays;
+  uint2* samples; // (ray, sample index) of every live sample, grouped by ray
+  uint32_t* sample_count;
+};
+
+struct TrainTileParams {
+  const uint16_t* table; // canonical fp16
+  const float* mlp;      // canonical [in][out], the fp16 working weights widened to f32
+  LevelCanon levels[16];
+  int n_levels, n_features;
+  const TrainRay* rays;
+  const uint2* samples;
+  const uint32_t* sample_count;
+  float4* logits;        // forward: {density logit, r, g, b logits} per sample
+  const float4* seeds;   // backward: {dL/d od0 via sigma, dL/d rgb logits}
+  float* table_grad;     // canonical, f32
+  float* mlp_grad;       // canonical, f32
+};
+
+struct TrainCompositeParams {
+  TrainRay* rays;
+  int n_rays;
+  const float4* logits;
+  float4* seeds;
+  float density_bias, min_T;
+  float* ray_loss;
+  uint32_t* ray_used;
+};
+
+struct AdamParams {
+  float lr_t, beta1, beta2, eps;
+};
+
+struct DensityParams {
+  const uint16_t* table;
+  const float* mlp;
+  LevelCanon levels[16];
+  int occ_res;
+  float density_bias, decay, thresh;
+  float* ema;
+  uint32_t* occ;
+};
+
+size_t train_tile_lds_bytes(bool fwd);
+hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s);
+hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s);
+hipError_t launch_train_composite(const TrainCompositeParams& P, hipStream_t s);
+hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, float* out_loss,
+                             unsigned long long* out_used, hipStream_t s);
+hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* w, float* m, float* v, uint16_t* w16,
+                             hipStream_t s);
+hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float* w, float* m, float* v, uint16_t* w16,
+                           float* w16_as_f32, hipStream_t s);
+hipError_t launch_widen(const uint16_t* in, size_t n, float* out, hipStream_t s);
+hipError_t launch_density_refresh(const DensityParams& P, int n_features, hipStream_t s);
+
+} // namespace prv

@@ -1,0 +1,131 @@
+"""GPU parity of the training step (nerf_prv_amd/csrc/prv_train.hip through the C ABI) against the CPU oracle
+(oracle/prv_train.c) on the same seeded batch.  Bars: identical ray batch (same RNG, same live samples);
+loss and gradients within 1e-3 relative (north_star; f32 atomics reorder the sums, the oracle accumulates in
+double); after optimiser steps the fp16 weights agree except for rare one-ulp roundings; a short run fits."""
+import numpy as np
+import pytest
+
+from nerf_prv_amd import api
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(n_levels=8, n_features=4, log2_hashmap=10, base_res=4, finest_res=24, occ_res=16, density_bias=1.0, table_amp=0.5)
+TINY_F2 = dict(n_levels=16, n_features=2, log2_hashmap=10, base_res=4, finest_res=24, occ_res=16, density_bias=1.0, table_amp=0.5)
+INTR = {"fl_x": 20.0, "fl_y": 19.5, "cx": 12.3, "cy": 7.8, "w": 24, "h": 16, "k1": 0.05, "k2": -0.02, "p1": 0.001, "p2": -0.002}
+
+
+@pytest.fixture(scope="module", params=["F4", "F2"])
+def scene(request, ctx, oracle):
+    kw = TINY if request.param == "F4" else TINY_F2
+    gt = oracle.OracleField(oracle.desc(**dict(kw, density_bias=3.0, table_amp=2.0)), seed=util.SEED_B)
+    pts = util.fibonacci_hemisphere(8)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    ocams = oracle.cameras_from_dataset(tms, INTR, scale, offset)
+    imgs = np.stack([oracle.quantize_rgba8(gt.render(c, 24, 16, 32, 1, 1e-4)[0], (0, 0, 0, 0)) for c in ocams])
+    cams = ctx.cameras_from_matrices_intr(tms, INTR, scale, offset)
+    return kw, ocams, cams, imgs
+
+
+def start(ctx, oracle, scene, seed=util.SEED_A, table_amp=None, **opts):
+    """the same initial field (all cells occupied) and the same options on both sides"""
+    kw, ocams, cams, imgs = scene
+    if table_amp is not None:
+        kw = dict(kw, table_amp=table_amp)
+    f = oracle.OracleField(oracle.desc(**kw), seed=seed)
+    t, m, o = f.params()
+    o = np.full_like(o, 0xFFFFFFFF)
+    f = oracle.OracleField(f.desc, params=(t, m, o))
+    ctx.load_model(3, api.field_desc(**kw), t, m, o)
+    base = dict(n_rays=192, n_samples=24, occ_every=0)
+    base.update(opts)
+    otr = oracle.OracleTrainer(f, oracle.train_opts(**base), ocams, imgs)
+    gtr = api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(**base))
+    return f, otr, gtr
+
+
+def rel_l2(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def test_batch_loss_and_gradients(ctx, oracle, scene):
+    f, otr, gtr = start(ctx, oracle, scene)
+    want_loss, want_tg, want_mg = otr.gradients()
+    loss, tg, mg = gtr.gradients()
+    assert gtr.info()["samples_last"] == otr.samples_last > 1000  # same rays, same live + used samples
+    assert loss == pytest.approx(want_loss, rel=1e-3)
+    assert np.array_equal(tg != 0, want_tg.astype(np.float32) != 0) or rel_l2(tg, want_tg) < 1e-3  # same entries touched
+    assert rel_l2(mg, want_mg) < 1e-3 and rel_l2(tg, want_tg) < 1e-3
+    # element-wise on everything that is not tiny
+    for got, want in ((mg, want_mg), (tg, want_tg)):
+        big = np.abs(want) > 1e-3 * np.abs(want).max()
+        assert big.sum() > 50
+        np.testing.assert_allclose(got[big], want[big], rtol=5e-3)
+    # a second call gives the same batch again (nothing was updated, gradients were cleared)
+    loss2, tg2, mg2 = gtr.gradients()
+    assert loss2 == pytest.approx(loss, rel=1e-6) and rel_l2(tg2, tg) < 1e-5 and rel_l2(mg2, mg) < 1e-5
+
+
+def test_optimiser_steps_track_the_oracle(ctx, oracle, scene):
+    f, otr, gtr = start(ctx, oracle, scene, occ_every=4, n_samples=24, occ_sigma_thresh=0.3)
+    want = np.array([otr.step() for _ in range(6)])
+    got = gtr.steps(6)
+    np.testing.assert_allclose(got, want, rtol=2e-3)
+    assert gtr.info()["steps"] == 6
+    wt, wm = otr.master()
+    gt_, gm = gtr.master()
+    # Adam's first steps are sign-like (+-lr): a gradient that is ~0 on one side and exactly 0 on the other, or
+    # whose sign flips inside the f32 noise, moves by lr on one side only -- tolerate a small fraction
+    assert np.mean(np.abs(gm - wm) > 2e-3) < 0.01 and np.mean(np.abs(gt_ - wt) > 2e-3) < 0.01
+    assert rel_l2(gm, wm) < 2e-2 and rel_l2(gt_, wt) < 2e-2
+    # the slot now holds the trained field: fp16 copies of the masters, refreshed occupancy
+    d_p = api.field_desc(**scene[0])
+    t16, m16, occ = ctx.export_model(3, d_p)
+    assert np.array_equal(m16, gm.astype(np.float16).view(np.uint16)) and np.array_equal(t16, gt_.astype(np.float16).view(np.uint16))
+    _, _, want_occ = otr.params()
+    diff = np.unpackbits((occ ^ want_occ).view(np.uint8)).sum()
+    assert diff <= 0.02 * d_p.occ_res ** 3  # cells whose EMA sits at the threshold may flip
+    assert 0 < np.unpackbits(occ.view(np.uint8)).sum()
+
+
+def test_density_refresh_matches_the_oracle(ctx, oracle, scene):
+    f, otr, gtr = start(ctx, oracle, scene, occ_sigma_thresh=2.5)
+    otr.refresh_occupancy()
+    gtr.refresh_occupancy()
+    d_p = api.field_desc(**scene[0])
+    _, _, occ = ctx.export_model(3, d_p)
+    _, _, want = otr.params()
+    n_on = np.unpackbits(want.view(np.uint8)).sum()
+    assert 0 < n_on < d_p.occ_res ** 3
+    assert np.unpackbits((occ ^ want).view(np.uint8)).sum() <= 4  # sigma within 1e-6 of the threshold
+
+
+def test_training_fits_and_the_slot_renders_the_result(ctx, oracle, scene):
+    kw, ocams, cams, imgs = scene
+    f, otr, gtr = start(ctx, oracle, scene, table_amp=1e-4, n_rays=1024, occ_every=16, occ_sigma_thresh=0.01 * 24 / 3 ** 0.5)
+    opts = api.render_opts(24, 16, 24, 1, 1e-4, background=(0, 0, 0, 1))
+    gt_img = ctx.torch.from_numpy(imgs.astype(np.float32) / 255.0).to(ctx.device)
+    lin = ctx.torch.where(gt_img[..., :3] <= 0.04045, gt_img[..., :3] / 12.92, ((gt_img[..., :3] + 0.055) / 1.055) ** 2.4)
+    gt_lin = ctx.torch.cat([lin * gt_img[..., 3:4], gt_img[..., 3:4]], dim=-1).contiguous()
+    psnr0, _ = ctx.evaluate(3, cams, None, opts, gt_lin)
+    losses = gtr.steps(300)
+    assert np.mean(losses[-20:]) < 0.15 * np.mean(losses[:5])
+    psnr1, _ = ctx.evaluate(3, cams, None, opts, gt_lin)  # the slot renders with the trained weights
+    assert psnr1 > psnr0 + 6.0
+    # trainer follows a reloaded slot only if the field is the same
+    ctx.synthetic_model(3, api.field_desc(**dict(kw, finest_res=32)), 1)
+    with pytest.raises(api.PrvError):
+        gtr.steps(1)
+
+
+def test_error_behaviour(ctx, oracle, scene):
+    kw, ocams, cams, imgs = scene
+    ctx.synthetic_model(3, api.field_desc(**kw), 5)
+    with pytest.raises(api.PrvError):
+        api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(n_samples=129))
+    with pytest.raises(api.PrvError):
+        api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(n_rays=0))
+    with pytest.raises(api.PrvError):
+        api.Trainer(ctx, 7, cams, ctx.torch.from_numpy(imgs))  # empty slot
+    with pytest.raises(ValueError):
+        api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs[:3]))
