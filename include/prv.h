@@ -129,6 +129,10 @@ int prv_model_load(prv_ctx* ctx, int slot, const prv_field_desc* desc, const uin
                    const uint16_t* mlp, const uint32_t* occ);
 /* deterministic synthetic field (counter-based RNG), generated on the device */
 int prv_model_synthetic(prv_ctx* ctx, int slot, const prv_field_desc* desc, uint64_t seed);
+/* a field to start training from (replaces the network reset of a new Testbed, run.py:90): the same
+ * counter-RNG parameters as prv_model_synthetic -- table ~ U(-table_amp, table_amp), use 1e-4 as upstream
+ * does; Xavier-uniform MLP -- with EVERY occupancy cell set */
+int prv_model_fresh(prv_ctx* ctx, int slot, const prv_field_desc* desc, uint64_t seed);
 int prv_model_export(prv_ctx* ctx, int slot, uint16_t* table, uint16_t* mlp, uint32_t* occ);
 /* replaces: testbed.save_snapshot / load_snapshot (run.py:123-127, 210-211).  File = "PRVF" magic,
  * ABI version, prv_field_desc, then table / mlp / occupancy arrays in the canonical layout. */

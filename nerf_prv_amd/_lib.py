@@ -95,6 +95,7 @@ SIGNATURES = {
     "prv_model_sizes": (_i, [_P(FieldDesc), _P(C.c_uint64), _P(C.c_uint64), _P(C.c_uint64)]),
     "prv_model_load": (_i, [_vp, _i, _P(FieldDesc), _vp, _vp, _vp]),
     "prv_model_synthetic": (_i, [_vp, _i, _P(FieldDesc), C.c_uint64]),
+    "prv_model_fresh": (_i, [_vp, _i, _P(FieldDesc), C.c_uint64]),
     "prv_model_export": (_i, [_vp, _i, _vp, _vp, _vp]),
     "prv_model_save_file": (_i, [_vp, _i, C.c_char_p]),
     "prv_model_load_file": (_i, [_vp, _i, C.c_char_p]),

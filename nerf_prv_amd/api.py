@@ -168,6 +168,10 @@ class Context:
     def synthetic_model(self, slot, desc, seed):
         self._chk(self.lib.prv_model_synthetic(self.handle, slot, C.byref(desc), C.c_uint64(seed)))
 
+    def fresh_model(self, slot, desc, seed):
+        """training start: small random table, Xavier MLP, all cells occupied"""
+        self._chk(self.lib.prv_model_fresh(self.handle, slot, C.byref(desc), C.c_uint64(seed)))
+
     def export_model(self, slot, desc):
         t, m, o = model_sizes(desc)
         table, mlp, occ = np.empty(t, np.uint16), np.empty(m, np.uint16), np.empty(o, np.uint32)
@@ -468,6 +472,10 @@ class Testbed:
         self._slot = 0
         self._have_model = False
         self.render_ground_truth = False
+        self.steps_per_frame = 16  # ASSUMED: upstream trains a batch of steps per frame() call
+        self.train_options = None  # TrainOpts override
+        self._trainer = None
+        self._last_loss = 0.0
         self._dataset_cams = None
         self._dataset_path = None
         self._training_view = None
@@ -480,6 +488,7 @@ class Testbed:
         if "camera_angle_x" in meta:
             self.fov_axis, self.fov = 0, meta["camera_angle_x"] * 180.0 / math.pi
         self.training_meta = meta
+        self._drop_trainer()
         if self._dataset_cams is not None:
             self._dataset_cams.close()
             self._dataset_cams = None
@@ -491,6 +500,40 @@ class Testbed:
             ds.n_images = len(self._dataset_cams)
             ds.metadata = [_FrameMeta(int(meta["w"]), int(meta["h"])) for _ in range(ds.n_images)]
 
+    def reset_network(self, desc, seed=0x1234):
+        """a new network to train (what a fresh pyngp.Testbed holds, run.py:90)"""
+        self.ctx.fresh_model(self._slot, desc, seed)
+        self._have_model = True
+        self._drop_trainer()
+
+    def _drop_trainer(self):
+        if self._trainer is not None:
+            self._trainer.close()
+            self._trainer = None
+
+    @property
+    def training_step(self):  # run.py:191
+        return self._trainer.info()["steps"] if self._trainer is not None else 0
+
+    @property
+    def loss(self):  # run.py:206
+        return self._last_loss
+
+    def frame(self):
+        """one iteration of `while testbed.frame()` (run.py:187): a batch of optimiser steps when shall_train"""
+        if self.shall_train:
+            if not self._have_model:
+                raise PrvError(L.PRV_E_STATE, "no network: call reset_network(desc) or load a snapshot first")
+            if self._dataset_cams is None:
+                raise PrvError(L.PRV_E_STATE, "no training data loaded")
+            if self._trainer is None:
+                from .compat_server import load_dataset_bytes
+
+                self._trainer = Trainer(self.ctx, self._slot, self._dataset_cams,
+                                        load_dataset_bytes(self.ctx, self._dataset_path), self.train_options)
+            self._last_loss = float(self._trainer.steps(self.steps_per_frame)[-1])
+        return True
+
     def set_camera_to_training_view(self, i):  # run.py:242
         if self._dataset_cams is None or not 0 <= int(i) < len(self._dataset_cams):
             raise PrvError(L.PRV_E_INVALID, "no such training view")
@@ -499,14 +542,17 @@ class Testbed:
     def load_model(self, desc, table, mlp, occ):
         self.ctx.load_model(self._slot, desc, table, mlp, occ)
         self._have_model = True
+        self._drop_trainer()
 
     def synthetic_model(self, desc, seed):
         self.ctx.synthetic_model(self._slot, desc, seed)
         self._have_model = True
+        self._drop_trainer()
 
     def load_snapshot(self, path):  # run.py:127
         self.ctx.load_model_file(self._slot, path)
         self._have_model = True
+        self._drop_trainer()
 
     def save_snapshot(self, path, include_optimizer_state=False):  # run.py:211
         self.ctx.save_model(self._slot, path)

@@ -68,15 +68,58 @@ def load_reference_images(ctx, test_json):
     return ctx.torch.from_numpy(np.stack(imgs)).to(ctx.device)
 
 
+def load_dataset_bytes(ctx, scene_json):
+    """the images of a dataset json as the trainer takes them: [n, h, w, 4] straight-alpha sRGB bytes on the
+    device (what testbed.load_training_data uploads, run.py:109)"""
+    from PIL import Image
+
+    with open(scene_json) as f:
+        meta = json.load(f)
+    base = os.path.dirname(os.path.abspath(scene_json))
+    imgs = []
+    for frame in meta["frames"]:
+        path = os.path.join(base, frame["file_path"])
+        if not os.path.splitext(path)[1]:
+            path += ".png"
+        imgs.append(np.asarray(Image.open(path).convert("RGBA"), np.uint8))
+    return ctx.torch.from_numpy(np.stack(imgs)).to(ctx.device)
+
+
+def train_scene(ctx, slot, scene_json, n_steps, desc, seed=0x1234, opts=None):
+    """`--train --n_steps N --scene J` in process (run.py:109, 185-208): fresh field, N optimiser steps on the
+    dataset's own cameras and images; returns the per-step losses"""
+    ctx.fresh_model(slot, desc, seed)
+    cams = ctx.cameras_from_dataset_json(scene_json)
+    tr = api.Trainer(ctx, slot, cams, load_dataset_bytes(ctx, scene_json), opts)
+    losses = tr.steps(int(n_steps))
+    tr.close()
+    cams.close()
+    return losses
+
+
 class CompatServer:
-    def __init__(self, interact_dir, ctx, load_model, samples_per_ray=128, screenshot_spp=16, reference_images=None):
-        self.dir, self.ctx, self.load_model = interact_dir, ctx, load_model
+    def __init__(self, interact_dir, ctx, load_model=None, samples_per_ray=128, screenshot_spp=16, reference_images=None,
+                 train_desc=None, train_opts=None, train_seed=0x1234):
+        self.dir, self.ctx = interact_dir, ctx
+        # load_model(scene_json, ctx) -> slot supplies weights from elsewhere; without it the request's
+        # `--train --n_steps N --scene J` is carried out in process on slot 0
+        self.load_model = load_model or self._train
+        self.train_desc, self.train_opts, self.train_seed = train_desc, train_opts, train_seed
+        self.last_losses = None
         self.samples_per_ray, self.spp = samples_per_ray, screenshot_spp  # run.py:48 default spp 16
         # callable(test_json) -> device tensor, for --test_transforms; default: the PNGs the json points at
         self.reference_images = reference_images or (lambda test_json: load_reference_images(ctx, test_json))
 
+    def _train(self, scene, ctx):
+        if self.train_desc is None:
+            raise api.PrvError(api.L.PRV_E_STATE, "no load_model callback and no train_desc: nothing to render with")
+        n_steps = int(self._args.get("n_steps", 35000))  # run.py:177-178 default when --n_steps is absent
+        self.last_losses = train_scene(ctx, 0, scene, n_steps, self.train_desc, self.train_seed, self.train_opts)
+        return 0
+
     def serve_one(self, args):
-        slot = self.load_model(args.get("scene"), self.ctx)  # stands in for load_training_data + training
+        self._args = args
+        slot = self.load_model(args.get("scene"), self.ctx)  # load_training_data + training, or supplied weights
         if "screenshot_transforms" in args:
             from PIL import Image
 

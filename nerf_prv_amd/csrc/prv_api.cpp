@@ -695,7 +695,14 @@ int prv_model_load(prv_ctx* c, int slot, const prv_field_desc* d, const uint16_t
   return install_model(c, slot, *d, mlp, occ, table);
 }
 
+static int model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed, bool all_occupied);
 int prv_model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed) {
+  return model_synthetic(c, slot, d, seed, false);
+}
+int prv_model_fresh(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed) {
+  return model_synthetic(c, slot, d, seed, true);
+}
+static int model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed, bool all_occupied) {
   if (!c) return PRV_E_INVALID;
   if (slot < 0 || slot >= PRV_MAX_MODELS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
   if (!d) return fail(c, PRV_E_INVALID, "NULL descriptor");
@@ -718,7 +725,7 @@ int prv_model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t 
     for (int y = 0; y < R; y++)
       for (int x = 0; x < R; x++) {
         const float cx = ((float)x + 0.5f) * invR, cy = ((float)y + 0.5f) * invR, cz = ((float)z + 0.5f) * invR;
-        bool in = false;
+        bool in = all_occupied;
         for (int b = 0; b < 4 && !in; b++) {
           const float dx = cx - kSynthSpheres[b][0], dy = cy - kSynthSpheres[b][1], dz = cz - kSynthSpheres[b][2];
           const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));

@@ -305,3 +305,133 @@ def test_testbed_mirror_dataset_views(ctx, tmp_path):
     assert gt.shape == (90, 160, 4) and np.allclose(gt, 1.0)
     with pytest.raises(api.PrvError):
         tb.set_camera_to_training_view(7)
+
+
+TRAIN_FIELD = dict(n_levels=8, n_features=4, log2_hashmap=12, base_res=4, finest_res=32, occ_res=16, density_bias=0.0,
+                   table_amp=1e-4)
+
+
+def write_dataset(ctx, root, n_views=10, w=32, h=24):
+    """a dataset as the planner + GT renderer leave it (main.cpp:1581-1656): json with the camera block and
+    straight-alpha PNGs, here rendered from a synthetic ground-truth field"""
+    from PIL import Image
+
+    gt_desc = api.field_desc(**dict(TRAIN_FIELD, density_bias=3.0, table_amp=2.0))
+    ctx.synthetic_model(6, gt_desc, SEED + 99)
+    pts = util.fibonacci_hemisphere(n_views)
+    c = [1e-10] * 3
+    pos = planner.view_space(pts, 0.3, c)
+    k = planner.Intrinsics(width=w, height=h, ppx=w / 2 + 0.7, ppy=h / 2 - 0.4, fx=0.8 * w, fy=0.79 * w)
+    k.coeffs[0], k.coeffs[1], k.coeffs[3] = 0.05, -0.02, 0.001
+    (root / str(n_views)).mkdir(parents=True, exist_ok=True)
+    tj = root / f"{n_views}.json"
+    planner.write_transforms(tj, k, pos, c, 0.1, path_prefix=f"{n_views}/rgbaClip_")
+    cams = ctx.cameras_from_dataset_json(tj)
+    png, _ = ctx.render_rgba8(6, cams, None, api.render_opts(w, h, 48, 1, 1e-4, background=(0, 0, 0, 0)))
+    for i, img in enumerate(png.cpu().numpy()):
+        Image.fromarray(img, "RGBA").save(root / str(n_views) / f"rgbaClip_{i}.png")
+    cams.close()
+    return tj, pos, k, c
+
+
+def test_testbed_training_loop_reads_like_run_py(ctx, tmp_path):
+    """run.py:109 + 185-208 + 226-277 with the mirror: load_training_data, `while testbed.frame()` until
+    n_steps, then the evaluation block on the same json -- PSNR far above the untrained network's"""
+    tj, _, _, _ = write_dataset(ctx, tmp_path)
+    testbed = api.Testbed()
+    testbed.reset_network(api.field_desc(**TRAIN_FIELD), seed=SEED)
+    testbed.nerf.samples_per_ray = 48
+    testbed.train_options = api.train_opts(n_rays=1024, n_samples=48, occ_sigma_thresh=0.01 * 48 / 3 ** 0.5)
+    testbed.load_training_data(str(tj))
+    testbed.shall_train = True
+    n_steps, first = 320, None
+    while testbed.frame():
+        first = testbed.loss if first is None else first
+        if testbed.training_step >= n_steps:
+            break
+    assert testbed.training_step == n_steps and testbed.loss < 0.25 * first
+    # evaluation block
+    testbed.background_color = [0.0, 0.0, 0.0, 1.0]
+    testbed.snap_to_pixel_centers = True
+    testbed.nerf.render_min_transmittance = 1e-4
+    testbed.shall_train = False
+    testbed.load_training_data(str(tj))
+    tot = 0.0
+    n = testbed.nerf.training.dataset.n_images
+    for i in range(n):
+        res = testbed.nerf.training.dataset.metadata[i].resolution
+        testbed.render_ground_truth = True
+        testbed.set_camera_to_training_view(i)
+        ref = testbed.render(res[0], res[1], 1, True)
+        testbed.render_ground_truth = False
+        img = testbed.render(res[0], res[1], 8, True)
+        mse = float(np.mean((np.clip(img[..., :3], 0, 1) - np.clip(ref[..., :3], 0, 1)) ** 2))
+        tot += -10.0 * np.log10(max(mse, 1e-12))
+    assert tot / n > 22.0
+    snap = tmp_path / "trained.prvf"
+    testbed.save_snapshot(str(snap))
+    again = api.Testbed()
+    again.load_snapshot(str(snap))
+    again.nerf.samples_per_ray, again.snap_to_pixel_centers, again.nerf.render_min_transmittance = 48, True, 1e-4
+    again.load_training_data(str(tj))
+    again.set_camera_to_training_view(n - 1)
+    assert np.array_equal(again.render(res[0], res[1], 8, True), img)
+
+
+def test_compat_server_trains_in_process(ctx, tmp_path):
+    """the whole request of main.cpp:1663-1689 -- `--train --n_steps N --scene J --screenshot_transforms ...` --
+    served without any external weights: the server trains, then renders the candidates"""
+    from PIL import Image
+
+    from nerf_prv_amd import compat_server
+
+    tj, pos, k, c = write_dataset(ctx, tmp_path / "Coverage_images")
+    interact = tmp_path / "interact"
+    interact.mkdir()
+    rj = tmp_path / "render_json" / "0.json"
+    rj.parent.mkdir()
+    planner.write_transforms(rj, planner.Intrinsics(width=512, height=384, ppx=256, ppy=192, fx=410.0, fy=410.0), pos[3:7], c, 0.1,
+                             ids=[3, 4, 5, 6], candidate=True, path_prefix="x/rgbaClip_")
+    out_dir = tmp_path / "render" / "0" / "ensemble_0"
+    cmd = (f"python D:/instant-ngp/scripts/run.py --train --n_steps 96 --scene {tj} "
+           f" --screenshot_transforms {rj}  --screenshot_dir {out_dir}/")
+    (interact / "run_with_c++.py").write_text("import os\nos.system('" + cmd + "')\n")
+    (interact / "ready_c++.txt").write_text("")
+    srv = compat_server.CompatServer(str(interact), ctx, samples_per_ray=48, screenshot_spp=2,
+                                     train_desc=api.field_desc(**TRAIN_FIELD),
+                                     train_opts=api.train_opts(n_rays=1024, n_samples=48, occ_sigma_thresh=0.01 * 48 / 3 ** 0.5))
+    assert srv.poll_once() and (interact / "ready_py.txt").exists()
+    assert len(srv.last_losses) == 96 and np.mean(srv.last_losses[-8:]) < 0.5 * np.mean(srv.last_losses[:4])
+    names = sorted(os.listdir(out_dir))
+    assert names == [f"rgbaClip_{i}.png" for i in (3, 4, 5, 6)]
+    shot = np.array(Image.open(out_dir / "rgbaClip_4.png"))
+    assert shot.shape == (24, 32, 4) and shot[..., :3].max() > 40  # the trained object is visible
+
+
+def test_nbv_iteration_with_in_process_training(ctx, tmp_path):
+    """one iteration of nbv_loop case 2 (main.cpp:2041-2097) end to end on the device: train an ensemble on the
+    views chosen so far, render every unchosen candidate with each member, EnsembleRGB, arg-max"""
+    from nerf_prv_amd import compat_server
+
+    tj, pos, k, c = write_dataset(ctx, tmp_path, n_views=12)
+    with open(tj) as f:
+        meta = json.load(f)
+    chosen, rest = [0, 5], [i for i in range(12) if i not in (0, 5)]
+    sub = dict(meta, frames=[meta["frames"][i] for i in chosen])
+    cur = tmp_path / "cur.json"
+    cur.write_text(json.dumps(sub))
+    desc = api.field_desc(**TRAIN_FIELD)
+    opts = dict(n_rays=1024, n_samples=48, occ_sigma_thresh=0.01 * 48 / 3 ** 0.5)
+    for e in range(2):  # ensemble members differ by their seeds (network init and ray batches)
+        losses = compat_server.train_scene(ctx, e, cur, 64, desc, seed=1000 + e, opts=api.train_opts(seed=77 + e, **opts))
+        assert losses[-1] < losses[0]
+    rj = tmp_path / "cand.json"
+    planner.write_transforms(rj, planner.Intrinsics(width=512, height=384, ppx=256, ppy=192, fx=410.0, fy=410.0), pos[rest], c, 0.1,
+                             ids=rest, candidate=True, path_prefix="x/rgbaClip_")
+    cams = ctx.cameras_from_json(rj)
+    rec, _ = ctx.score_views(api.L.SCORE_ENSEMBLE_RGB, [0, 1], cams, None,
+                             api.render_opts(32, 24, 48, 4, 0.01, background=(0, 0, 0, 1)))
+    scores = np.array([r["score"] for r in rec])
+    assert np.isfinite(scores).all() and np.ptp(scores) > 0  # the members disagree, differently per view
+    best = ctx.argmax(rec, np.asarray(rest, np.int32))
+    assert best in rest

@@ -126,6 +126,6 @@ def test_error_behaviour(ctx, oracle, scene):
     with pytest.raises(api.PrvError):
         api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(n_rays=0))
     with pytest.raises(api.PrvError):
-        api.Trainer(ctx, 7, cams, ctx.torch.from_numpy(imgs))  # empty slot
+        api.Trainer(ctx, 99, cams, ctx.torch.from_numpy(imgs))  # no such slot
     with pytest.raises(ValueError):
         api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs[:3]))
