@@ -268,9 +268,10 @@ typedef struct prv_train_opts {
 typedef struct prv_trainer prv_trainer;
 int prv_train_default_opts(prv_train_opts* opts);
 /* dataset = cameras of prv_cameras_from_dataset_json (own intrinsics + lens) and their images,
- * n * h * w * 4 straight-alpha sRGB bytes in device memory (caller keeps them alive) */
+ * n * height * width * 4 straight-alpha sRGB bytes in device memory (caller keeps them alive); when
+ * (width, height) differs from the dataset's size the intrinsics are scaled per axis */
 int prv_train_create(prv_ctx* ctx, int model_slot, const prv_camset* dataset, const uint8_t* images_rgba8_dev,
-                     const prv_train_opts* opts, prv_trainer** out);
+                     int width, int height, const prv_train_opts* opts, prv_trainer** out);
 /* n optimiser steps; losses_host (n floats, may be NULL) = the batch loss of each step before its update */
 int prv_train_steps(prv_trainer* t, int n_steps, float* losses_host);
 int prv_train_info(const prv_trainer* t, uint32_t* steps_done, uint64_t* samples_last_batch,

@@ -371,11 +371,11 @@ class Trainer:
         self.ctx, self.slot, self.camset = ctx, slot, camset
         self.images = images_u8.to(device=ctx.device, dtype=t.uint8).contiguous()  # kept alive here
         n, h, w, ch = self.images.shape
-        if ch != 4 or n != len(camset) or (w, h) != camset.size:
-            raise ValueError("images must be [n_views, h, w, 4] at the dataset resolution")
+        if ch != 4 or n != len(camset):
+            raise ValueError("images must be [n_views, h, w, 4], one per dataset camera")
         self.opts = opts if opts is not None else train_opts()
         self.handle = C.c_void_p()
-        ctx._chk(ctx.lib.prv_train_create(ctx.handle, slot, camset.handle, _ptr(self.images), C.byref(self.opts),
+        ctx._chk(ctx.lib.prv_train_create(ctx.handle, slot, camset.handle, _ptr(self.images), w, h, C.byref(self.opts),
                                           C.byref(self.handle)))
 
     def steps(self, n):

@@ -8,7 +8,11 @@
 // Ensemble members / the field under test come from model files
 //   <model_path>/<object>/member_<e>.prvf  (prv_model_save_file format)
 // or, when the config carries `synthetic_seed`, from the deterministic synthetic generator
-// (member e = seed + e; reference images for method 5 from seed + 4096).
+// (member e = seed + e; reference images for method 5 from seed + 4096),
+// or -- `train_steps: N` -- they are TRAINED in process every iteration, as the reference does through
+// train_by_instantNGP (main.cpp:1658-1715, 2041-2043): a fresh field per member, N optimiser steps on the
+// views chosen so far; the training images are rendered from the ground-truth field
+// (`ground_truth_seed`, slot 6) with the dataset cameras of the iteration's json.
 #include <cstdio>
 #include <iostream>
 #include <string>
@@ -31,9 +35,50 @@ struct HipScorer {
   int n_members = 1;
   float* gt_dev = nullptr; // method 5: reference images of ALL views at the candidate size
   int gt_w = 0, gt_h = 0;
+  // training in the loop
+  int train_steps = 0, train_rays = 4096, train_w = 0, train_h = 0;
+  prv_field_desc train_desc{};
+  uint64_t train_seed = 0x1234;
 
-  int operator()(int method, int /*iteration*/, const std::string& /*scene_json*/, const std::string& render_json,
+  // train_by_instantNGP(json/<it>.json, ..., ensemble_id = e) for every member, in process
+  int train_members(const std::string& scene_json) {
+    prv_camset* ds = nullptr;
+    if (prv_cameras_from_dataset_json(ctx, scene_json.c_str(), &ds) != PRV_OK) return -30;
+    int w = 0, h = 0;
+    prv_camset_size(ds, &w, &h);
+    prv_render_opts o{};
+    o.width = train_w > 0 ? train_w : w; // training images at the dataset size unless the config shrinks them
+    o.height = train_h > 0 ? train_h : h;
+    o.samples_per_ray = 128;
+    o.spp = 1;
+    o.min_transmittance = 1e-4f;
+    const int n = prv_camset_count(ds);
+    uint8_t* imgs = nullptr;
+    int rc = prv_malloc(ctx, (void**)&imgs, (size_t)n * o.width * o.height * 4);
+    if (rc == PRV_OK) rc = prv_render_rgba8(ctx, 6, ds, nullptr, n, &o, imgs, nullptr); // straight alpha over nothing
+    for (int e = 0; rc == PRV_OK && e < n_members; e++) {
+      rc = prv_model_fresh(ctx, e, &train_desc, train_seed + (uint64_t)e);
+      prv_train_opts to;
+      prv_train_default_opts(&to);
+      to.n_rays = train_rays;
+      to.seed += (uint64_t)e;
+      prv_trainer* tr = nullptr;
+      if (rc == PRV_OK) rc = prv_train_create(ctx, e, ds, imgs, o.width, o.height, &to, &tr);
+      if (rc == PRV_OK) rc = prv_train_steps(tr, train_steps, nullptr);
+      prv_train_destroy(tr);
+    }
+    if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+    prv_camset_destroy(ds);
+    if (imgs) prv_free(ctx, imgs);
+    return rc;
+  }
+
+  int operator()(int method, int /*iteration*/, const std::string& scene_json, const std::string& render_json,
                  const std::vector<int>& ids, std::vector<double>& scores) {
+    if (train_steps > 0) {
+      const int trc = train_members(scene_json);
+      if (trc != PRV_OK) return trc;
+    }
     prv_camset* cams = nullptr;
     if (prv_cameras_from_json(ctx, render_json.c_str(), &cams) != PRV_OK) {
       std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
@@ -104,7 +149,8 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   fs.open(cfg);
   const prv_field_desc desc = field_from_config(fs);
   const int members = (method == EnsembleRGB || method == EnsembleRGBDensity) ? sd->ensemble_num : 1;
-  for (int e = 0; e < members; e++) {
+  const int train_steps = fs.has("train_steps") ? (int)fs.num("train_steps") : 0;
+  for (int e = 0; e < members && train_steps == 0; e++) {
     int rc;
     if (fs.has("synthetic_seed")) rc = prv_model_synthetic(ctx, e, &desc, (uint64_t)fs.num("synthetic_seed") + (uint64_t)e);
     else rc = prv_model_load_file(ctx, e, (sd->model_path + name + "/member_" + std::to_string(e) + ".prvf").c_str());
@@ -120,6 +166,22 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   scorer.ctx = ctx;
   scorer.sd = sd;
   scorer.n_members = members;
+  if (train_steps > 0) { // ground truth = a synthetic field in slot 6; members are trained from scratch every iteration
+    prv_field_desc gt = desc;
+    const int rc = prv_model_synthetic(ctx, 6, &gt, fs.has("ground_truth_seed") ? (uint64_t)fs.num("ground_truth_seed") : 0x5EED0002ull);
+    if (rc != PRV_OK) {
+      std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+      return rc;
+    }
+    scorer.train_steps = train_steps;
+    scorer.train_rays = fs.has("train_rays") ? (int)fs.num("train_rays") : 4096;
+    scorer.train_w = fs.has("train_width") ? (int)fs.num("train_width") : 0;
+    scorer.train_h = fs.has("train_height") ? (int)fs.num("train_height") : 0;
+    scorer.train_desc = desc;
+    scorer.train_desc.density_bias = fs.has("train_density_bias") ? (float)fs.num("train_density_bias") : 0.0f;
+    scorer.train_desc.table_amp = 1e-4f;
+    if (fs.has("train_seed")) scorer.train_seed = (uint64_t)fs.num("train_seed");
+  }
   NBV_Net_Labeler labeler(sd, center, size, scorer);
   labeler.get_coverage(); // <gt_path>/<N>.json (main.cpp:3882-3978, json part)
   if (method == PSNRCoverage) { // reference images of every view, rendered once from the reference field

@@ -435,3 +435,25 @@ def test_nbv_iteration_with_in_process_training(ctx, tmp_path):
     assert np.isfinite(scores).all() and np.ptp(scores) > 0  # the members disagree, differently per view
     best = ctx.argmax(rec, np.asarray(rest, np.int32))
     assert best in rest
+
+
+def test_planner_executable_trains_its_ensemble_every_iteration(ctx, tmp_path):
+    """mode 21 with `train_steps`: the whole loop of main.cpp:1730-2170 case 2 in one process -- train a fresh
+    ensemble on the views chosen so far, render + score the rest, move on -- no weights supplied from outside"""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    pre = tmp_path / "train_loop"
+    pre.mkdir()
+    cfg = pre / "cfg.yaml"
+    text = YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=2,
+                       model_source="train_steps: 40\ntrain_rays: 1024\ntrain_width: 64\ntrain_height: 36\nground_truth_seed: 4242")
+    cfg.write_text(text.replace("ensemble_num: 5", "ensemble_num: 2"))
+    out = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("chosen_nbvs:")][-1]
+    chosen = [int(x) for x in line.split(":")[1].split()]
+    assert len(chosen) == 4 and len(set(chosen)) == 4 and chosen[0] == 1
+    save = pre / "Compare" / "ShapeNet" / "objA_m2_v1_t0"
+    assert (save / "json" / "3.json").exists() and (save / "train_time" / "2.txt").exists()
+    # a finished run is not repeated (the reference skips objects whose run_time.txt exists, main.cpp:3878-3881)
+    out2 = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
+    assert out2.returncode == 0 and "chosen_nbvs:\n" in out2.stdout

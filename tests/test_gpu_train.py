@@ -129,3 +129,25 @@ def test_error_behaviour(ctx, oracle, scene):
         api.Trainer(ctx, 99, cams, ctx.torch.from_numpy(imgs))  # no such slot
     with pytest.raises(ValueError):
         api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs[:3]))
+
+
+def test_training_images_at_another_size_than_the_dataset(ctx, oracle, scene):
+    """images half the dataset size: the trainer scales the intrinsics per axis; same batch as an oracle
+    given the rescaled cameras"""
+    kw, ocams, cams, imgs = scene
+    half = np.ascontiguousarray(imgs[:, ::2, ::2])
+    pts = util.fibonacci_hemisphere(8)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    ocams_half = oracle.cameras_from_dataset(tms, INTR, scale, offset, 12, 8)
+    f = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
+    t, m, o = f.params()
+    o = np.full_like(o, 0xFFFFFFFF)
+    f = oracle.OracleField(f.desc, params=(t, m, o))
+    ctx.load_model(3, api.field_desc(**kw), t, m, o)
+    base = dict(n_rays=128, n_samples=24, occ_every=0)
+    otr = oracle.OracleTrainer(f, oracle.train_opts(**base), ocams_half, half)
+    gtr = api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(half), api.train_opts(**base))
+    want_loss, want_tg, want_mg = otr.gradients()
+    loss, tg, mg = gtr.gradients()
+    assert gtr.info()["samples_last"] == otr.samples_last
+    assert loss == pytest.approx(want_loss, rel=1e-3) and rel_l2(mg, want_mg) < 1e-3 and rel_l2(tg, want_tg) < 1e-3
