@@ -274,6 +274,9 @@ int prv_train_create(prv_ctx* ctx, int model_slot, const prv_camset* dataset, co
                      int width, int height, const prv_train_opts* opts, prv_trainer** out);
 /* n optimiser steps; losses_host (n floats, may be NULL) = the batch loss of each step before its update */
 int prv_train_steps(prv_trainer* t, int n_steps, float* losses_host);
+/* the members of an ensemble side by side: step i of every trainer (each on its own HIP stream) before step
+ * i+1 of any; one slot per trainer, one context; losses_host = n_trainers rows of n_steps, may be NULL */
+int prv_train_steps_multi(prv_trainer** trainers, int n_trainers, int n_steps, float* losses_host);
 int prv_train_info(const prv_trainer* t, uint32_t* steps_done, uint64_t* samples_last_batch,
                    uint64_t* table_scalars);
 void prv_train_destroy(prv_trainer* t);

@@ -415,6 +415,15 @@ class Trainer:
             pass
 
 
+def train_many(trainers, n):
+    """n steps of every trainer side by side (prv_train_steps_multi) -> losses [n_trainers, n]"""
+    ctx = trainers[0].ctx
+    arr = (C.c_void_p * len(trainers))(*[t.handle for t in trainers])
+    losses = np.zeros((len(trainers), int(n)), np.float32)
+    ctx._chk(ctx.lib.prv_train_steps_multi(arr, len(trainers), int(n), _ptr(losses)))
+    return losses
+
+
 class _NerfSettings:
     """stands in for testbed.nerf (run.py:140,145,235)"""
 

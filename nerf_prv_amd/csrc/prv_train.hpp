@@ -43,6 +43,7 @@ struct TrainTileParams {
   const float4* seeds;   // backward: {dL/d od0 via sigma, dL/d rgb logits}
   float* table_grad;     // canonical, f32
   float* mlp_grad;       // canonical, f32
+  float* mlp_grad_partial; // n_blocks slots of PRV_MLP_HALFS floats (backward)
 };
 
 struct TrainCompositeParams {

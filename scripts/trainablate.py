@@ -1,0 +1,39 @@
+"""time one training batch (forward + composite + backward, no update) on a FIXED trained state (dev tool):
+   --save P : train 500 steps with the current build, store the field;   --load P : time gradients() on it"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from nerf_prv_amd import api, planner
+ap = argparse.ArgumentParser()
+ap.add_argument("--save"); ap.add_argument("--load"); ap.add_argument("--rays", type=int, default=4096); ap.add_argument("--tag", default="")
+args = ap.parse_args()
+ctx = api.Context(0)
+fd = dict(api.FIELD_256)
+ctx.synthetic_model(1, api.L.FieldDesc(**fd), 0x5EED0002)
+pts = planner.hemisphere_generate(64)
+fov = 2.0 * np.arctan(0.5 * 1280 / 915.60668945312500)
+tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
+W = H = 400
+fl = 0.5 * W / np.tan(0.5 * fov)
+cams = ctx.cameras_from_matrices_intr(tms, dict(fl_x=fl, fl_y=fl, cx=W / 2, cy=H / 2, w=W, h=H), scale, offset)
+u8, _ = ctx.render_rgba8(1, cams, None, api.render_opts(W, H, 128, 1, 1e-4, background=(0, 0, 0, 0)))
+d = api.L.FieldDesc(**dict(fd, table_amp=1e-4, density_bias=0.0))
+if args.save:
+    ctx.fresh_model(0, d, 0x1234)
+    tr = api.Trainer(ctx, 0, cams, u8, api.train_opts(n_rays=args.rays))
+    tr.steps(500)
+    ctx.save_model(0, args.save)
+    print("saved; samples/batch", tr.info()["samples_last"])
+else:
+    ctx.load_model_file(0, args.load)
+    tr = api.Trainer(ctx, 0, cams, u8, api.train_opts(n_rays=args.rays))
+    tr.gradients()
+    torch.cuda.synchronize()
+    ctx.lib.prv_train_gradients.argtypes  # keep
+    n = 30
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ctx._chk(ctx.lib.prv_train_gradients(tr.handle, None, None, None))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"{args.tag}: {dt*1e3:.3f} ms per batch (fwd + composite + bwd + grad clear), samples/batch {tr.info()['samples_last']}")

@@ -10,6 +10,7 @@ ap.add_argument("--steps", type=int, default=500)
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--samples", type=int, default=128)
 ap.add_argument("--chunk", type=int, default=100)
+ap.add_argument("--members", type=int, default=0, help="also time an ensemble of this many members stepping side by side")
 args = ap.parse_args()
 import torch
 from nerf_prv_amd import api, planner
@@ -57,3 +58,23 @@ tr.steps(args.chunk)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"pure training: {args.chunk/dt:.1f} steps/s ({dt/args.chunk*1e3:.2f} ms/step, {args.rays} rays x {args.samples} samples)")
+
+if args.members > 1:
+    trs = []
+    for e in range(args.members):
+        ctx.fresh_model(e, d, 0x1234 + e)
+        trs.append(api.Trainer(ctx, e, train_cams, u8[train_ids].contiguous(), api.train_opts(n_rays=args.rays, n_samples=args.samples, seed=0x7EA10001 + e)))
+    api.train_many(trs, 300)  # past the all-occupied start
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    api.train_many(trs, args.chunk)
+    torch.cuda.synchronize()
+    dt_many = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for t in trs:
+        t.steps(args.chunk)
+    torch.cuda.synchronize()
+    dt_seq = time.perf_counter() - t0
+    print(f"ensemble of {args.members}: side by side {dt_many/args.chunk*1e3:.2f} ms per round of {args.members} member-steps "
+          f"({args.members*args.chunk/dt_many:.0f} member-steps/s); one after another {dt_seq/args.chunk*1e3:.2f} ms "
+          f"({args.members*args.chunk/dt_seq:.0f} member-steps/s)")

@@ -151,3 +151,27 @@ def test_training_images_at_another_size_than_the_dataset(ctx, oracle, scene):
     loss, tg, mg = gtr.gradients()
     assert gtr.info()["samples_last"] == otr.samples_last
     assert loss == pytest.approx(want_loss, rel=1e-3) and rel_l2(mg, want_mg) < 1e-3 and rel_l2(tg, want_tg) < 1e-3
+
+
+def test_ensemble_members_step_side_by_side(ctx, oracle, scene):
+    """prv_train_steps_multi: members on their own streams give what each gives alone (up to atomics order)"""
+    kw, ocams, cams, imgs = scene
+    d = api.field_desc(**dict(kw, table_amp=1e-4))
+    u8 = ctx.torch.from_numpy(imgs)
+    alone = []
+    for e in range(3):
+        ctx.fresh_model(e, d, 500 + e)
+        tr = api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=256, n_samples=24, seed=900 + e, occ_every=8, occ_sigma_thresh=0.1))
+        alone.append(tr.steps(24))
+        tr.close()
+    trs = []
+    for e in range(3):
+        ctx.fresh_model(e, d, 500 + e)
+        trs.append(api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=256, n_samples=24, seed=900 + e, occ_every=8, occ_sigma_thresh=0.1)))
+    together = api.train_many(trs, 24)
+    assert together.shape == (3, 24) and all(t.info()["steps"] == 24 for t in trs)
+    np.testing.assert_allclose(together, np.stack(alone), rtol=2e-2)
+    np.testing.assert_allclose(together[:, :4], np.stack(alone)[:, :4], rtol=1e-4)  # before the noise compounds
+    assert not np.allclose(together[0], together[1])  # members differ (seeds)
+    with pytest.raises(api.PrvError):
+        api.train_many([trs[0], trs[0]], 1)  # the same slot twice
