@@ -285,6 +285,8 @@ void prv_train_destroy(prv_trainer* t);
 int prv_train_gradients(prv_trainer* t, float* table_grad_host, float* mlp_grad_host, float* loss);
 int prv_train_master(prv_trainer* t, float* table_host, float* mlp_host);
 int prv_train_refresh_occupancy(prv_trainer* t);
+/* dev only: 64 phase time stamps of the tile kernels' block 0 (zeros unless built with PRV_TRAIN_ABLATE=16) */
+int prv_train_debug_stamps(prv_trainer* t, unsigned long long* out64);
 
 /* ---- stage hooks for parity tests (host in / host out, small n) ---------- */
 /* rays of view i at (w,h): o,d = n*3, t = n*2 (AABB entry/exit; exit<=entry => miss) */

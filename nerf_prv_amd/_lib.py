@@ -124,6 +124,7 @@ SIGNATURES = {
     "prv_train_create": (_i, [_vp, _i, _vp, _vp, _i, _i, _P(TrainOpts), _P(_vp)]),
     "prv_train_steps": (_i, [_vp, _i, _vp]),
     "prv_train_steps_multi": (_i, [_vp, _i, _i, _vp]),
+    "prv_train_debug_stamps": (_i, [_vp, _vp]),
     "prv_train_info": (_i, [_vp, _P(C.c_uint32), _P(C.c_uint64), _P(C.c_uint64)]),
     "prv_train_destroy": (None, [_vp]),
     "prv_train_gradients": (_i, [_vp, _vp, _vp, _P(C.c_float)]),

@@ -19,7 +19,12 @@
 #include "prv_train.hpp"
 
 #ifndef PRV_TRAIN_ABLATE
-#define PRV_TRAIN_ABLATE 0 // dev only: 1 no table scatter, 2 no dW MFMAs, 4 no dX chain, 8 no encode gathers
+#define PRV_TRAIN_ABLATE 0 // dev only: 1 no table scatter, 2 no dW MFMAs, 16 phase time stamps of block 0
+#endif
+#if PRV_TRAIN_ABLATE & 16
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && P.stamps) P.stamps[(FWD ? 0 : 32) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
 #endif
 
 namespace prv {
@@ -49,52 +54,60 @@ __device__ __forceinline__ bool occ_bit(const uint32_t* __restrict__ occ, int R,
 
 // ------------------------------------------------------------------ rays of one step
 
+// one WAVE = one ray: the lanes test the occupancy of the S <= 128 sample positions (two per lane), ballots
+// give the live mask, each lane appends its own live samples at (offset + rank)
 __global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) {
-  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (j >= (uint32_t)P.n_rays) return;
   const uint64_t st = (uint64_t)P.step * 8u;
   const uint32_t img = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 0, j) * (uint64_t)P.n_img) >> 24);
   const uint32_t px = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 1, j) * (uint64_t)P.W) >> 24);
   const uint32_t py = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 2, j) * (uint64_t)P.H) >> 24);
   const float jitter = (float)rng_u24(P.seed, st + 3, j) * (1.0f / 16777216.0f);
-  float bg[3] = {0.f, 0.f, 0.f};
-  if (P.random_bg)
-    for (int k = 0; k < 3; k++) bg[k] = (float)rng_u24(P.seed, st + 4 + k, j) * (1.0f / 16777216.0f);
-  const uint8_t* gp = P.images + (((size_t)img * P.H + py) * P.W + px) * 4;
-  const float ga = (float)gp[3] * (1.0f / 255.0f);
   TrainRay r;
-  for (int k = 0; k < 3; k++) {
-    r.target[k] = fmaf(srgb_to_linear((float)gp[k] * (1.0f / 255.0f)), ga, (1.0f - ga) * bg[k]);
-    r.bg[k] = bg[k];
-  }
   const CamDev cam = P.cams[img];
   raygen(cam, (int)px, (int)py, 0.5f, 0.5f, r.o, r.d);
   float t0, t1;
-  uint32_t m[4] = {0u, 0u, 0u, 0u};
   r.t0 = 0.f;
   r.dt = 0.f;
+  unsigned long long m0 = 0ull, m1 = 0ull;
   if (ray_aabb(r.o, r.d, t0, t1)) {
     r.t0 = t0;
     r.dt = (t1 - t0) / (float)P.S;
-    for (int i = 0; i < P.S; i++) {
+    bool on[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int i = q * 64 + lane;
       const float t = fmaf((float)i + jitter, r.dt, t0);
-      if (occ_bit(P.occ, P.occ_res, fmaf(t, r.d[0], r.o[0]), fmaf(t, r.d[1], r.o[1]), fmaf(t, r.d[2], r.o[2])))
-        m[i >> 5] |= 1u << (i & 31);
+      on[q] = i < P.S && occ_bit(P.occ, P.occ_res, fmaf(t, r.d[0], r.o[0]), fmaf(t, r.d[1], r.o[1]), fmaf(t, r.d[2], r.o[2]));
     }
+    m0 = __ballot(on[0]);
+    m1 = __ballot(on[1]);
   }
-  r.jitter = jitter;
-  r.n_live = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
-  r.offset = r.n_live ? atomicAdd(P.sample_count, r.n_live) : 0u;
-  r.n_used = 0u;
-  P.rays[j] = r;
-  uint32_t k = r.offset;
-  for (int w = 0; w < 4; w++) {
-    uint32_t mm = m[w];
-    while (mm) {
-      const int b = __builtin_ctz(mm);
-      mm &= mm - 1u;
-      P.samples[k++] = make_uint2(j, (uint32_t)(w * 32 + b));
+  const uint32_t n0 = (uint32_t)__popcll(m0), n_live = n0 + (uint32_t)__popcll(m1);
+  uint32_t offset = 0;
+  if (lane == 0 && n_live) offset = atomicAdd(P.sample_count, n_live);
+  offset = __shfl(offset, 0);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if ((m0 >> lane) & 1ull) P.samples[offset + (uint32_t)__popcll(m0 & below)] = make_uint2(j, (uint32_t)lane);
+  if ((m1 >> lane) & 1ull) P.samples[offset + n0 + (uint32_t)__popcll(m1 & below)] = make_uint2(j, 64u + (uint32_t)lane);
+  if (lane == 0) {
+    float bg[3] = {0.f, 0.f, 0.f};
+    if (P.random_bg)
+      for (int k = 0; k < 3; k++) bg[k] = (float)rng_u24(P.seed, st + 4 + k, j) * (1.0f / 16777216.0f);
+    const uint8_t* gp = P.images + (((size_t)img * P.H + py) * P.W + px) * 4;
+    const float ga = (float)gp[3] * (1.0f / 255.0f);
+    for (int k = 0; k < 3; k++) {
+      r.target[k] = fmaf(srgb_to_linear((float)gp[k] * (1.0f / 255.0f)), ga, (1.0f - ga) * bg[k]);
+      r.bg[k] = bg[k];
     }
+    r.jitter = jitter;
+    r.n_live = n_live;
+    r.offset = offset;
+    r.n_used = 0u;
+    r.pad[0] = r.pad[1] = 0u;
+    P.rays[j] = r;
   }
 }
 
@@ -131,9 +144,10 @@ __device__ __forceinline__ void train_encode_level(const uint16_t* __restrict__ 
     const _Float16 w = wxy * wh[2][c >> 2];
     cidx[c] = L.offset + idx;
     cw[c] = (float)w;
-    const uint16_t* e = table + (size_t)(L.offset + idx) * F;
+    typedef _Float16 entry_t __attribute__((ext_vector_type(F)));
+    const entry_t e = *reinterpret_cast<const entry_t*>(table + (size_t)(L.offset + idx) * F); // one 4- or 8-byte load
 #pragma unroll
-    for (int k = 0; k < F; k++) acc[k] = __builtin_fmaf16(w, __builtin_bit_cast(_Float16, e[k]), acc[k]);
+    for (int k = 0; k < F; k++) acc[k] = __builtin_fmaf16(w, e[k], acc[k]);
   }
 #pragma unroll
   for (int k = 0; k < F; k++) feat[k] = (float)acc[k];
@@ -200,6 +214,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
   float* W = lds;                 // kWLds
   float* A = W + kWLds;           // kARows * kTS
   float* G = A + kARows * kTS;    // kGRows * kTS (backward only)
+  STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const uint32_t n_samples = *P.sample_count;
@@ -209,10 +224,20 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
       for (int i = tid; i < PRV_MLP_HALFS; i += 256) P.mlp_grad_partial[(size_t)blockIdx.x * PRV_MLP_HALFS + i] = 0.0f;
     return;
   }
-  for (int l = 0; l < 5; l++)
-    for (int i = tid; i < kLIn[l] * kLOut[l]; i += 256)
-      W[kLLds[l] + (i / kLOut[l]) * kLStr[l] + (i % kLOut[l])] = P.mlp[kLOff[l] + i];
-  __syncthreads();
+  // level constants: kernel arguments indexed by a per-lane level would be re-fetched from the kernarg
+  // segment through the vector memory path before every corner (measured: 37 us per tile) -> LDS copy
+  __shared__ LevelCanon lv[16];
+  if (tid < 16 * (int)(sizeof(LevelCanon) / 4))
+    reinterpret_cast<uint32_t*>(lv)[tid] = reinterpret_cast<const uint32_t*>(P.levels)[tid];
+#pragma unroll
+  for (int l = 0; l < 5; l++) { // n_out is a power of two per layer: shifts, no divisions; loads independent
+    constexpr int kSh[5] = {6, 4, 6, 6, 4};
+    const int n = kLIn[l] * kLOut[l];
+#pragma unroll 4
+    for (int i = tid; i < n; i += 256)
+      W[kLLds[l] + (i >> kSh[l]) * kLStr[l] + (i & (kLOut[l] - 1))] = P.mlp[kLOff[l] + i];
+  }
+  __syncthreads(); STAMP(1);
 
   constexpr int LPT = (32 / F) / 8; // levels per thread (8 threads per sample)
   f32x16v dw[3];
@@ -242,7 +267,8 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
       for (int q = 0; q < LPT; q++) {
         const int l = g * LPT + q;
         float f[F];
-        train_encode_level<F>(P.table, P.levels[l], pos[0], pos[1], pos[2], f, cidx[q], cw[q]);
+        const LevelCanon L = lv[l];
+        train_encode_level<F>(P.table, L, pos[0], pos[1], pos[2], f, cidx[q], cw[q]);
 #pragma unroll
         for (int k = 0; k < F; k++) A[(kAFeat + l * F + k) * kTS + s] = live ? f[k] : 0.0f;
       }
@@ -260,14 +286,14 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
         for (int k = 3; k < 16; k++) G[(kGOrr + k) * kTS + s] = 0.0f;
       }
     }
-    __syncthreads();
+    __syncthreads(); STAMP(2);
     // ---- forward: relu + fp16 rounding of the hidden activations as in inference
     if (wave < 2) { // D1: 32 -> 64
       const f32x16v a = layer_tile<false>(W + kLLds[0], kLStr[0], 64, wave, A + kAFeat * kTS, 32, lane);
 #pragma unroll
       for (int i = 0; i < 16; i++) A[(kAH1 + 32 * wave + rho(i, h)) * kTS + r] = (float)(_Float16)fmaxf(a[i], 0.0f);
     }
-    __syncthreads();
+    __syncthreads(); STAMP(3);
     float od0 = 0.0f;
     if (wave == 0) { // D2: 64 -> 16
       const f32x16v a = layer_tile<false>(W + kLLds[1], kLStr[1], 16, 0, A + kAH1 * kTS, 64, lane);
@@ -278,26 +304,26 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
       }
       od0 = a[0]; // row 0 lives in register 0 of lane half 0
     }
-    __syncthreads();
+    __syncthreads(); STAMP(4);
     if (wave < 2) { // R1: 32 -> 64
       const f32x16v a = layer_tile<false>(W + kLLds[2], kLStr[2], 64, wave, A + kAIn2 * kTS, 32, lane);
 #pragma unroll
       for (int i = 0; i < 16; i++) A[(kAH2 + 32 * wave + rho(i, h)) * kTS + r] = (float)(_Float16)fmaxf(a[i], 0.0f);
     }
-    __syncthreads();
+    __syncthreads(); STAMP(5);
     if (wave < 2) { // R2: 64 -> 64
       const f32x16v a = layer_tile<false>(W + kLLds[3], kLStr[3], 64, wave, A + kAH2 * kTS, 64, lane);
 #pragma unroll
       for (int i = 0; i < 16; i++) A[(kAH3 + 32 * wave + rho(i, h)) * kTS + r] = (float)(_Float16)fmaxf(a[i], 0.0f);
     }
-    __syncthreads();
+    __syncthreads(); STAMP(6);
     if (FWD) {
       if (wave == 0) { // R3: 64 -> 16, logits out
         const f32x16v a = layer_tile<false>(W + kLLds[4], kLStr[4], 16, 0, A + kAH3 * kTS, 64, lane);
         const uint32_t o = tile * 32u + (uint32_t)r;
         if (h == 0 && o < n_samples) P.logits[o] = make_float4(od0, a[0], a[1], a[2]);
       }
-      __syncthreads();
+      __syncthreads(); STAMP(7);
       continue;
     }
     // ---- backward: dX chain (straight through the fp16 roundings, ReLU masks from the activations)
@@ -309,7 +335,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
         G[(kGH3 + row) * kTS + r] = A[(kAH3 + row) * kTS + r] > 0.0f ? a[i] : 0.0f;
       }
     }
-    __syncthreads();
+    __syncthreads(); STAMP(8);
     if (wave < 2) { // dH2 = W_r2 dH3
       const f32x16v a = layer_tile<true>(W + kLLds[3], kLStr[3], 64, wave, G + kGH3 * kTS, 64, lane);
 #pragma unroll
@@ -318,7 +344,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
         G[(kGH2 + row) * kTS + r] = A[(kAH2 + row) * kTS + r] > 0.0f ? a[i] : 0.0f;
       }
     }
-    __syncthreads();
+    __syncthreads(); STAMP(9);
     if (wave == 0) { // dOd = (W_r1 dH2)[0..15] (+ the density seed on row 0); the SH rows carry no parameters
       const f32x16v a = layer_tile<true>(W + kLLds[2], kLStr[2], 32, 0, G + kGH2 * kTS, 64, lane);
       const float sd = seed.x; // every thread of sample s = tid & 31 holds its seed; in wave 0, s == r
@@ -328,7 +354,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
         if (row < 16) G[(kGOd + row) * kTS + r] = a[i] + (row == 0 ? sd : 0.0f);
       }
     }
-    __syncthreads();
+    __syncthreads(); STAMP(10);
     if (wave < 2) { // dH1 = W_d2 dOd
       const f32x16v a = layer_tile<true>(W + kLLds[1], kLStr[1], 64, wave, G + kGOd * kTS, 16, lane);
 #pragma unroll
@@ -337,13 +363,13 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
         G[(kGH1 + row) * kTS + r] = A[(kAH1 + row) * kTS + r] > 0.0f ? a[i] : 0.0f;
       }
     }
-    __syncthreads();
+    __syncthreads(); STAMP(11);
     if (wave == 0) { // dFeat = W_d1 dH1
       const f32x16v a = layer_tile<true>(W + kLLds[0], kLStr[0], 32, 0, G + kGH1 * kTS, 64, lane);
 #pragma unroll
       for (int i = 0; i < 16; i++) G[(kGFeat + rho(i, h)) * kTS + r] = a[i];
     }
-    __syncthreads();
+    __syncthreads(); STAMP(12);
     // ---- dW[k][o] += sum_s X[k][s] dOut[o][s]: three 32x32 weight tiles per wave, K = the 32 samples
     if (!(PRV_TRAIN_ABLATE & 2)) {
       // tile q of wave w: {activation row base, gradient row base, valid gradient rows}
@@ -374,7 +400,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
     // slow shape.  The (entry, weight) pairs are re-dealt through LDS so that F consecutive lanes add the F
     // features of ONE entry (one request carries the whole entry; x-neighbour corners sit on adjacent lane
     // groups and usually share the line too).
-    __syncthreads(); // the activation rows are dead: their LDS becomes the staging array
+    __syncthreads(); STAMP(13); // the activation rows are dead: their LDS becomes the staging array
     {
       uint2* stage = reinterpret_cast<uint2*>(A);
       constexpr int NL = 32 / F;
@@ -384,7 +410,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
 #pragma unroll
         for (int c = 0; c < 8; c++)
           stage[(s * NL + g * LPT + q) * 8 + c] = make_uint2(contributes ? cidx[q][c] : 0xffffffffu, __float_as_uint(cw[q][c]));
-      __syncthreads();
+      __syncthreads(); STAMP(14);
       if (!(PRV_TRAIN_ABLATE & 1)) {
         const int k = tid % F;
         constexpr int kItems = 32 * NL * 8, kPerPass = 256 / F;
@@ -396,7 +422,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
         }
       }
     }
-    __syncthreads();
+    __syncthreads(); STAMP(15);
   }
   if (!FWD) { // this block's weight-gradient tiles -> its own slot of the partials (plain stores; a second
     // kernel sums the slots in block order: no same-address atomics, and a reproducible sum)
@@ -416,14 +442,27 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
   }
 }
 
-// mlp_grad[i] += sum over the blocks' partial slots, in block order
+// mlp_grad[i] += sum over the blocks' partial slots: 64 weights x 4 slot groups per block, every thread's
+// loads independent of each other, the four group sums combined in a fixed order
 __global__ __launch_bounds__(256) void train_reduce_dw_kernel(const float* __restrict__ partial, int n_blocks,
                                                               float* __restrict__ mlp_grad) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= PRV_MLP_HALFS) return;
+  __shared__ float part[4][64];
+  const int w = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + w;
   float a = 0.0f;
-  for (int b = 0; b < n_blocks; b++) a += partial[(size_t)b * PRV_MLP_HALFS + i];
-  mlp_grad[i] += a;
+  if (i < PRV_MLP_HALFS) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int b = grp;
+    for (; b + 12 < n_blocks; b += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc[u] += partial[(size_t)(b + 4 * u) * PRV_MLP_HALFS + i];
+    }
+    for (; b < n_blocks; b += 4) acc[0] += partial[(size_t)b * PRV_MLP_HALFS + i];
+    a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  }
+  part[grp][w] = a;
+  __syncthreads();
+  if (grp == 0 && i < PRV_MLP_HALFS) mlp_grad[i] += (part[0][w] + part[1][w]) + (part[2][w] + part[3][w]);
 }
 
 // ------------------------------------------------------------------ compositing, loss, gradient seeds
@@ -610,6 +649,9 @@ __global__ __launch_bounds__(256) void widen_kernel(const uint16_t* __restrict__
 template <int F>
 __global__ __launch_bounds__(256) void density_refresh_kernel(DensityParams P) {
   __shared__ float W1[32 * 64], W2[64];
+  __shared__ LevelCanon lv[16];
+  if (threadIdx.x < 16 * (int)(sizeof(LevelCanon) / 4))
+    reinterpret_cast<uint32_t*>(lv)[threadIdx.x] = reinterpret_cast<const uint32_t*>(P.levels)[threadIdx.x];
   for (int i = threadIdx.x; i < 32 * 64; i += 256) W1[i] = P.mlp[i];
   for (int i = threadIdx.x; i < 64; i += 256) W2[i] = P.mlp[2048 + i * 16]; // output 0 of layer D2
   __syncthreads();
@@ -627,7 +669,8 @@ __global__ __launch_bounds__(256) void density_refresh_kernel(DensityParams P) {
     for (int l = 0; l < 32 / F; l++) {
       float f[F], cw[8];
       uint32_t ci[8];
-      train_encode_level<F>(P.table, P.levels[l], px, py, pz, f, ci, cw);
+      const LevelCanon L = lv[l];
+      train_encode_level<F>(P.table, L, px, py, pz, f, ci, cw);
 #pragma unroll
       for (int k = 0; k < F; k++) {
         const float* wr = W1 + (l * F + k) * 64;
@@ -654,7 +697,7 @@ __global__ __launch_bounds__(256) void density_refresh_kernel(DensityParams P) {
 size_t train_tile_lds_bytes(bool fwd) { return sizeof(float) * (size_t)(kWLds + kARows * kTS + (fwd ? 0 : kGRows * kTS)); }
 
 hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s) {
-  hipLaunchKernelGGL(train_rays_kernel, dim3((P.n_rays + 255) / 256), dim3(256), 0, s, P);
+  hipLaunchKernelGGL(train_rays_kernel, dim3((P.n_rays + 3) / 4), dim3(256), 0, s, P);
   return hipGetLastError();
 }
 
@@ -677,7 +720,7 @@ hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_bloc
   if (P.n_features == 4) e = forward ? launch_tile<4, true>(P, n_blocks, s) : launch_tile<4, false>(P, n_blocks, s);
   else e = forward ? launch_tile<2, true>(P, n_blocks, s) : launch_tile<2, false>(P, n_blocks, s);
   if (e != hipSuccess || forward) return e;
-  hipLaunchKernelGGL(train_reduce_dw_kernel, dim3((PRV_MLP_HALFS + 255) / 256), dim3(256), 0, s, P.mlp_grad_partial, n_blocks,
+  hipLaunchKernelGGL(train_reduce_dw_kernel, dim3((PRV_MLP_HALFS + 63) / 64), dim3(256), 0, s, P.mlp_grad_partial, n_blocks,
                      P.mlp_grad);
   return hipGetLastError();
 }

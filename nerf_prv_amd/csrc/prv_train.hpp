@@ -44,6 +44,7 @@ struct TrainTileParams {
   float* table_grad;     // canonical, f32
   float* mlp_grad;       // canonical, f32
   float* mlp_grad_partial; // n_blocks slots of PRV_MLP_HALFS floats (backward)
+  unsigned long long* stamps; // dev only (PRV_TRAIN_ABLATE & 16)
 };
 
 struct TrainCompositeParams {

@@ -11,9 +11,10 @@ S[3]="SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_THREAD_CYCLES_VALU 
 S[4]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
 S[5]="FETCH_SIZE"
 S[6]="WRITE_SIZE"
+S[8]="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_WAVES SQ_BUSY_CYCLES"
 S[7]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum"
 for i in ${SETS//,/ }; do
-  timeout 150 rocprofv3 --kernel-trace --pmc ${S[$i]} --output-format csv -d $OUT/p$i -- python3 scripts/kbench.py --reps 1 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed/timeout"
+  timeout 150 rocprofv3 --kernel-trace --pmc ${S[$i]} --output-format csv -d $OUT/p$i -- python3 ${PMC_SCRIPT:-scripts/kbench.py} ${PMC_SCRIPT:+} $( [ -z "$PMC_SCRIPT" ] && echo --reps 1 ) "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed/timeout"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
@@ -21,11 +22,11 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-32:]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-40:]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
 with open(out + "/summary.txt", "w") as w:
     for k in agg:
-        if "render_queue" not in k and "march" not in k: continue
+        if "render_queue" not in k and "march" not in k and "train_" not in k: continue
         w.write(f"== {k}\n")
         for c in sorted(agg[k]):
             w.write(f"{c:32s} total={agg[k][c]:.6g} dispatches={cnt[k][c]} per_dispatch={agg[k][c]/cnt[k][c]:.6g}\n")

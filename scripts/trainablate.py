@@ -37,3 +37,12 @@ else:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print(f"{args.tag}: {dt*1e3:.3f} ms per batch (fwd + composite + bwd + grad clear), samples/batch {tr.info()['samples_last']}")
+    st = np.zeros(64, np.uint64)
+    ctx.lib.prv_train_debug_stamps(tr.handle, st.ctypes.data_as(__import__("ctypes").c_void_p))
+    if st.any():
+        for name, base in (("fwd", 0), ("bwd", 32)):
+            v = st[base:base + 32].astype(np.int64)
+            nz = np.flatnonzero(v)
+            if len(nz) > 1:
+                d = np.diff(v[nz]) / 100.0  # s_memtime ticks at 100 MHz -> microseconds
+                print(name, "stamps", list(nz), "deltas us:", " ".join(f"{x:.1f}" for x in d))
