@@ -176,9 +176,9 @@ constexpr int kGOrr = 0, kGH3 = 16, kGH2 = 80, kGOd = 144, kGH1 = 176, kGFeat = 
 
 // OUT[32*mt + row][s] = sum_k A(row, k) * IN[k][s]  over k in [0, K): forward (A = W[k][o]) or transposed
 // (A = W[row][k]) -- one wave, one 32-row tile, K/2 MFMAs
-template <bool TRANSPOSED>
-__device__ __forceinline__ f32x16v layer_tile(const float* __restrict__ Wl, int stride, int n_rows_valid, int mt,
-                                              const float* __restrict__ in, int K, int lane) {
+template <bool TRANSPOSED, typename TIN>
+__device__ __forceinline__ f32x16v layer_tile(const _Float16* __restrict__ Wl, int stride, int n_rows_valid, int mt,
+                                              const TIN* __restrict__ in, int K, int lane) {
   const int r = lane & 31, h = lane >> 5;
   const int row = 32 * mt + r;
   const bool valid = row < n_rows_valid;
@@ -190,8 +190,8 @@ __device__ __forceinline__ f32x16v layer_tile(const float* __restrict__ Wl, int 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int k = k0 + 2 * j;
-      pa[j] = valid ? (TRANSPOSED ? Wl[row * stride + k] : Wl[k * stride + row]) : 0.0f;
-      pb[j] = in[k * kTS + r];
+      pa[j] = valid ? (float)(TRANSPOSED ? Wl[row * stride + k] : Wl[k * stride + row]) : 0.0f;
+      pb[j] = (float)in[k * kTS + r];
     }
   };
   load(h, an, bn);
@@ -210,10 +210,12 @@ __device__ __forceinline__ f32x16v layer_tile(const float* __restrict__ Wl, int 
 
 template <int F, bool FWD>
 __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
+  // weights and activations are fp16 VALUES (working weights, rounded activations): stored as fp16, widened
+  // at the operand read; 21 + 17 KB (+ 36 KB of f32 gradients backward) -> 2 backward / 4 forward blocks per CU
   extern __shared__ float lds[];
-  float* W = lds;                 // kWLds
-  float* A = W + kWLds;           // kARows * kTS
-  float* G = A + kARows * kTS;    // kGRows * kTS (backward only)
+  float* G = lds;                                                  // kGRows * kTS floats (backward only)
+  _Float16* W = reinterpret_cast<_Float16*>(lds + (FWD ? 0 : kGRows * kTS)); // kWLds halfs
+  _Float16* A = W + kWLds;                                         // kARows * kTS halfs
   STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
     const int n = kLIn[l] * kLOut[l];
 #pragma unroll 4
     for (int i = tid; i < n; i += 256)
-      W[kLLds[l] + (i >> kSh[l]) * kLStr[l] + (i & (kLOut[l] - 1))] = P.mlp[kLOff[l] + i];
+      W[kLLds[l] + (i >> kSh[l]) * kLStr[l] + (i & (kLOut[l] - 1))] = (_Float16)P.mlp[kLOff[l] + i];
   }
   __syncthreads(); STAMP(1);
 
@@ -270,13 +272,13 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
         const LevelCanon L = lv[l];
         train_encode_level<F>(P.table, L, pos[0], pos[1], pos[2], f, cidx[q], cw[q]);
 #pragma unroll
-        for (int k = 0; k < F; k++) A[(kAFeat + l * F + k) * kTS + s] = live ? f[k] : 0.0f;
+        for (int k = 0; k < F; k++) A[(kAFeat + l * F + k) * kTS + s] = (_Float16)(live ? f[k] : 0.0f);
       }
       if (g == 0) {
         float sh[16];
         sh4(dir[0], dir[1], dir[2], sh);
 #pragma unroll
-        for (int k = 0; k < 16; k++) A[(kAIn2 + 16 + k) * kTS + s] = live ? (float)(_Float16)sh[k] : 0.0f;
+        for (int k = 0; k < 16; k++) A[(kAIn2 + 16 + k) * kTS + s] = live ? (_Float16)sh[k] : (_Float16)0.0f;
       }
       if (!FWD && g == 1) {
         G[(kGOrr + 0) * kTS + s] = seed.y;
@@ -289,37 +291,37 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
     __syncthreads(); STAMP(2);
     // ---- forward: relu + fp16 rounding of the hidden activations as in inference
     if (wave < 2) { // D1: 32 -> 64
-      const f32x16v a = layer_tile<false>(W + kLLds[0], kLStr[0], 64, wave, A + kAFeat * kTS, 32, lane);
+      const f32x16v a = layer_tile<false, _Float16>(W + kLLds[0], kLStr[0], 64, wave, A + kAFeat * kTS, 32, lane);
 #pragma unroll
-      for (int i = 0; i < 16; i++) A[(kAH1 + 32 * wave + rho(i, h)) * kTS + r] = (float)(_Float16)fmaxf(a[i], 0.0f);
+      for (int i = 0; i < 16; i++) A[(kAH1 + 32 * wave + rho(i, h)) * kTS + r] = (_Float16)fmaxf(a[i], 0.0f);
     }
     __syncthreads(); STAMP(3);
     float od0 = 0.0f;
     if (wave == 0) { // D2: 64 -> 16
-      const f32x16v a = layer_tile<false>(W + kLLds[1], kLStr[1], 16, 0, A + kAH1 * kTS, 64, lane);
+      const f32x16v a = layer_tile<false, _Float16>(W + kLLds[1], kLStr[1], 16, 0, A + kAH1 * kTS, 64, lane);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int row = rho(i, h);
-        if (row < 16) A[(kAIn2 + row) * kTS + r] = (float)(_Float16)a[i];
+        if (row < 16) A[(kAIn2 + row) * kTS + r] = (_Float16)a[i];
       }
       od0 = a[0]; // row 0 lives in register 0 of lane half 0
     }
     __syncthreads(); STAMP(4);
     if (wave < 2) { // R1: 32 -> 64
-      const f32x16v a = layer_tile<false>(W + kLLds[2], kLStr[2], 64, wave, A + kAIn2 * kTS, 32, lane);
+      const f32x16v a = layer_tile<false, _Float16>(W + kLLds[2], kLStr[2], 64, wave, A + kAIn2 * kTS, 32, lane);
 #pragma unroll
-      for (int i = 0; i < 16; i++) A[(kAH2 + 32 * wave + rho(i, h)) * kTS + r] = (float)(_Float16)fmaxf(a[i], 0.0f);
+      for (int i = 0; i < 16; i++) A[(kAH2 + 32 * wave + rho(i, h)) * kTS + r] = (_Float16)fmaxf(a[i], 0.0f);
     }
     __syncthreads(); STAMP(5);
     if (wave < 2) { // R2: 64 -> 64
-      const f32x16v a = layer_tile<false>(W + kLLds[3], kLStr[3], 64, wave, A + kAH2 * kTS, 64, lane);
+      const f32x16v a = layer_tile<false, _Float16>(W + kLLds[3], kLStr[3], 64, wave, A + kAH2 * kTS, 64, lane);
 #pragma unroll
-      for (int i = 0; i < 16; i++) A[(kAH3 + 32 * wave + rho(i, h)) * kTS + r] = (float)(_Float16)fmaxf(a[i], 0.0f);
+      for (int i = 0; i < 16; i++) A[(kAH3 + 32 * wave + rho(i, h)) * kTS + r] = (_Float16)fmaxf(a[i], 0.0f);
     }
     __syncthreads(); STAMP(6);
     if (FWD) {
       if (wave == 0) { // R3: 64 -> 16, logits out
-        const f32x16v a = layer_tile<false>(W + kLLds[4], kLStr[4], 16, 0, A + kAH3 * kTS, 64, lane);
+        const f32x16v a = layer_tile<false, _Float16>(W + kLLds[4], kLStr[4], 16, 0, A + kAH3 * kTS, 64, lane);
         const uint32_t o = tile * 32u + (uint32_t)r;
         if (h == 0 && o < n_samples) P.logits[o] = make_float4(od0, a[0], a[1], a[2]);
       }
@@ -328,25 +330,25 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
     }
     // ---- backward: dX chain (straight through the fp16 roundings, ReLU masks from the activations)
     if (wave < 2) { // dH3 = W_r3 dOrr
-      const f32x16v a = layer_tile<true>(W + kLLds[4], kLStr[4], 64, wave, G + kGOrr * kTS, 16, lane);
+      const f32x16v a = layer_tile<true, float>(W + kLLds[4], kLStr[4], 64, wave, G + kGOrr * kTS, 16, lane);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int row = 32 * wave + rho(i, h);
-        G[(kGH3 + row) * kTS + r] = A[(kAH3 + row) * kTS + r] > 0.0f ? a[i] : 0.0f;
+        G[(kGH3 + row) * kTS + r] = A[(kAH3 + row) * kTS + r] > (_Float16)0.0f ? a[i] : 0.0f;
       }
     }
     __syncthreads(); STAMP(8);
     if (wave < 2) { // dH2 = W_r2 dH3
-      const f32x16v a = layer_tile<true>(W + kLLds[3], kLStr[3], 64, wave, G + kGH3 * kTS, 64, lane);
+      const f32x16v a = layer_tile<true, float>(W + kLLds[3], kLStr[3], 64, wave, G + kGH3 * kTS, 64, lane);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int row = 32 * wave + rho(i, h);
-        G[(kGH2 + row) * kTS + r] = A[(kAH2 + row) * kTS + r] > 0.0f ? a[i] : 0.0f;
+        G[(kGH2 + row) * kTS + r] = A[(kAH2 + row) * kTS + r] > (_Float16)0.0f ? a[i] : 0.0f;
       }
     }
     __syncthreads(); STAMP(9);
     if (wave == 0) { // dOd = (W_r1 dH2)[0..15] (+ the density seed on row 0); the SH rows carry no parameters
-      const f32x16v a = layer_tile<true>(W + kLLds[2], kLStr[2], 32, 0, G + kGH2 * kTS, 64, lane);
+      const f32x16v a = layer_tile<true, float>(W + kLLds[2], kLStr[2], 32, 0, G + kGH2 * kTS, 64, lane);
       const float sd = seed.x; // every thread of sample s = tid & 31 holds its seed; in wave 0, s == r
 #pragma unroll
       for (int i = 0; i < 16; i++) {
@@ -356,16 +358,16 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
     }
     __syncthreads(); STAMP(10);
     if (wave < 2) { // dH1 = W_d2 dOd
-      const f32x16v a = layer_tile<true>(W + kLLds[1], kLStr[1], 64, wave, G + kGOd * kTS, 16, lane);
+      const f32x16v a = layer_tile<true, float>(W + kLLds[1], kLStr[1], 64, wave, G + kGOd * kTS, 16, lane);
 #pragma unroll
       for (int i = 0; i < 16; i++) {
         const int row = 32 * wave + rho(i, h);
-        G[(kGH1 + row) * kTS + r] = A[(kAH1 + row) * kTS + r] > 0.0f ? a[i] : 0.0f;
+        G[(kGH1 + row) * kTS + r] = A[(kAH1 + row) * kTS + r] > (_Float16)0.0f ? a[i] : 0.0f;
       }
     }
     __syncthreads(); STAMP(11);
     if (wave == 0) { // dFeat = W_d1 dH1
-      const f32x16v a = layer_tile<true>(W + kLLds[0], kLStr[0], 32, 0, G + kGH1 * kTS, 64, lane);
+      const f32x16v a = layer_tile<true, float>(W + kLLds[0], kLStr[0], 32, 0, G + kGH1 * kTS, 64, lane);
 #pragma unroll
       for (int i = 0; i < 16; i++) G[(kGFeat + rho(i, h)) * kTS + r] = a[i];
     }
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const int k = k0 + 2 * j;
-            a[q][j] = A[(xa[q] + r) * kTS + k];
+            a[q][j] = (float)A[(xa[q] + r) * kTS + k];
             b[q][j] = r < gv[q] ? G[(ga[q] + r) * kTS + k] : 0.0f;
           }
 #pragma unroll
@@ -402,23 +404,31 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
     // groups and usually share the line too).
     __syncthreads(); STAMP(13); // the activation rows are dead: their LDS becomes the staging array
     {
+      // staging = the (dead) activation region: 256 rows x 33 halfs = 2112 uint2 -> 8 levels of 32 samples at a time
       uint2* stage = reinterpret_cast<uint2*>(A);
-      constexpr int NL = 32 / F;
+      constexpr int NL = 32 / F, NPASS = NL / 8;
       const bool contributes = live && (seed.x != 0.0f || seed.y != 0.0f || seed.z != 0.0f || seed.w != 0.0f);
 #pragma unroll
-      for (int q = 0; q < LPT; q++)
+      for (int pass = 0; pass < NPASS; pass++) {
+        if (pass) __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 8; c++)
-          stage[(s * NL + g * LPT + q) * 8 + c] = make_uint2(contributes ? cidx[q][c] : 0xffffffffu, __float_as_uint(cw[q][c]));
-      __syncthreads(); STAMP(14);
-      if (!(PRV_TRAIN_ABLATE & 1)) {
-        const int k = tid % F;
-        constexpr int kItems = 32 * NL * 8, kPerPass = 256 / F;
-        for (int it = tid / F; it < kItems; it += kPerPass) {
-          const uint2 e = stage[it];
-          if (e.x == 0xffffffffu) continue;
-          const int ss = it / (NL * 8), l = (it >> 3) % NL;
-          atomicAdd(P.table_grad + (size_t)e.x * F + k, __uint_as_float(e.y) * G[(kGFeat + l * F + k) * kTS + ss]);
+        for (int q = 0; q < LPT; q++) {
+          const int l = g * LPT + q;
+          if (l / 8 != pass) continue;
+#pragma unroll
+          for (int c = 0; c < 8; c++)
+            stage[(s * 8 + (l & 7)) * 8 + c] = make_uint2(contributes ? cidx[q][c] : 0xffffffffu, __float_as_uint(cw[q][c]));
+        }
+        __syncthreads();
+        if (!(PRV_TRAIN_ABLATE & 1)) {
+          const int k = tid % F;
+          constexpr int kItems = 32 * 8 * 8, kPerPass = 256 / F;
+          for (int it = tid / F; it < kItems; it += kPerPass) {
+            const uint2 e = stage[it];
+            if (e.x == 0xffffffffu) continue;
+            const int ss = it >> 6, l = pass * 8 + ((it >> 3) & 7);
+            atomicAdd(P.table_grad + (size_t)e.x * F + k, __uint_as_float(e.y) * G[(kGFeat + l * F + k) * kTS + ss]);
+          }
         }
       }
     }
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(256) void density_refresh_kernel(DensityParams P) {
 
 // ------------------------------------------------------------------ launchers
 
-size_t train_tile_lds_bytes(bool fwd) { return sizeof(float) * (size_t)(kWLds + kARows * kTS + (fwd ? 0 : kGRows * kTS)); }
+size_t train_tile_lds_bytes(bool fwd) { return 2u * (size_t)(kWLds + kARows * kTS) + (fwd ? 0u : 4u * (size_t)(kGRows * kTS)); }
 
 hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s) {
   hipLaunchKernelGGL(train_rays_kernel, dim3((P.n_rays + 3) / 4), dim3(256), 0, s, P);
