@@ -247,6 +247,16 @@ int prv_score_views(prv_ctx* ctx, int method, const int* model_slots, int n_mode
 int prv_rank(const prv_score_record* records, const int* view_ids, int n, int* order);
 int prv_argmax(const prv_score_record* records, const int* view_ids, int n);
 
+/* replaces: Perception_3D::render (the PCL screenshot of the coloured ground-truth cloud with
+ * points_size_cloud-pixel points on white, main.cpp:68-96) + convertToAlpha (Share_Data.hpp:771-784) +
+ * cv::flip(-1) (main.cpp:1616) = the rgbaClip_<i>.png training images of get_coverage (main.cpp:1604-1618),
+ * as a z-buffered square-splat rasteriser.  xyz_dev n*3 floats in world units, rgb_dev n*3 bytes; scale /
+ * offset = the json's (the cloud goes where the cameras go); cameras = the dataset's.  out: n_views*h*w*4
+ * RGBA bytes (device): nearest point's colour, alpha 255; background and exactly-white points 255,255,255,0. */
+int prv_splat_points(prv_ctx* ctx, const float* xyz_dev, const uint8_t* rgb_dev, size_t n_points, double scale,
+                     const double offset[3], const prv_camset* cs, const int* view_ids, int n_views, int width,
+                     int height, int point_size, int flip180, uint8_t* out_rgba8_dev);
+
 /* ---- training ------------------------------------------------------------- */
 /* replaces: the `while testbed.frame()` loop run.py:185-208 drives for `--train --n_steps 2500`
  * (main.cpp:1668) on the dataset of testbed.load_training_data (run.py:109): random rays over the dataset

@@ -120,6 +120,7 @@ SIGNATURES = {
     "prv_score_views": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _P(RenderOpts), _vp, _vp, _vp, _P(Stats)]),
     "prv_rank": (_i, [_vp, _vp, _i, _vp]),
     "prv_argmax": (_i, [_vp, _vp, _i]),
+    "prv_splat_points": (_i, [_vp, _vp, _vp, C.c_size_t, C.c_double, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "prv_train_default_opts": (_i, [_P(TrainOpts)]),
     "prv_train_create": (_i, [_vp, _i, _vp, _vp, _i, _i, _P(TrainOpts), _P(_vp)]),
     "prv_train_steps": (_i, [_vp, _i, _vp]),

@@ -214,6 +214,19 @@ class Context:
                                                      int(width), int(height), float(scale), _ptr(off), C.byref(h)))
         return CamSet(self, h)
 
+    def splat_points(self, xyz, rgb, scale, offset, camset, view_ids, width, height, point_size=5, flip180=True):
+        """ground-truth images of a coloured cloud (get_coverage's rgbaClip images) -> uint8 [n, h, w, 4] on the device"""
+        t = self.torch
+        xyz = t.as_tensor(np.ascontiguousarray(xyz, np.float32)).to(self.device).contiguous().reshape(-1, 3)
+        rgb = t.as_tensor(np.ascontiguousarray(rgb, np.uint8)).to(self.device).contiguous().reshape(-1, 3)
+        ids = self._ids(camset, view_ids)
+        off = np.ascontiguousarray(offset, np.float64)
+        out = t.empty((len(ids), height, width, 4), dtype=t.uint8, device=self.device)
+        self._chk(self.lib.prv_splat_points(self.handle, _ptr(xyz), _ptr(rgb), xyz.shape[0], float(scale), _ptr(off),
+                                            camset.handle, _ptr(ids), len(ids), int(width), int(height), int(point_size),
+                                            int(flip180), _ptr(out)))
+        return out
+
     # -- render
     def _ids(self, camset, view_ids):
         if view_ids is None:

@@ -994,6 +994,32 @@ int prv_first_hit(prv_ctx* c, int slot, const prv_camset* cs, const int* view_id
   return PRV_OK;
 }
 
+int prv_splat_points(prv_ctx* c, const float* xyz, const uint8_t* rgb, size_t n, double scale, const double offset[3],
+                     const prv_camset* cs, const int* view_ids, int n_views, int W, int H, int point_size, int flip180,
+                     uint8_t* out) {
+  if (!c) return PRV_E_INVALID;
+  if (!cs || n_views < 0 || W < 1 || H < 1 || W > 16384 || H > 16384 || (!out && n_views > 0) || (n > 0 && (!xyz || !rgb)))
+    return fail(c, PRV_E_INVALID, "bad argument");
+  if (point_size < 1 || point_size > 64) return fail(c, PRV_E_INVALID, "point_size must be in [1,64], got %d", point_size);
+  if (n_views == 0) return PRV_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<CamDev> cams(n_views);
+  for (int i = 0; i < n_views; i++) {
+    const int v = view_ids ? view_ids[i] : i;
+    if (v < 0 || v >= (int)cs->cams.size()) return fail(c, PRV_E_INVALID, "view id %d out of range", v);
+    cams[i] = cam_at(cs, v, W, H);
+  }
+  int rc;
+  if ((rc = ensure(c, c->view_ids, (size_t)n_views * (sizeof(CamDev) + sizeof(int)))) != PRV_OK) return rc;
+  if ((rc = ensure(c, c->stage, (size_t)n_views * W * H * 8)) != PRV_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->view_ids.p, cams.data(), (size_t)n_views * sizeof(CamDev), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const float off[3] = {(float)(offset ? offset[0] : 0.5), (float)(offset ? offset[1] : 0.5), (float)(offset ? offset[2] : 0.5)};
+  HIPCHK(c, launch_splat_points(xyz, rgb, n, (float)scale, off, (const CamDev*)c->view_ids.p, n_views, W, H, point_size,
+                                flip180, (unsigned long long*)c->stage.p, (uint32_t*)out, c->stream));
+  return PRV_OK;
+}
+
 int prv_precept(prv_ctx* c, int slot, const float* voxels, int n, const double c2w[16], const prv_rs2_intrinsics* k,
                 float max_range, int32_t* out) {
   if (!c) return PRV_E_INVALID;

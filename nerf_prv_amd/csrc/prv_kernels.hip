@@ -747,7 +747,86 @@ __global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const flo
   if (occ_out && h == 0) occ_out[idx] = occupied(fd, p[0], p[1], p[2]) ? 1 : 0;
 }
 
+// ------------------------------------------------------------------ ground-truth splats
+// the PCL screenshot of the coloured cloud + convertToAlpha + 180-degree flip (main.cpp:68-96, 1610-1618;
+// Share_Data.hpp:771-784) as a z-buffered square-splat rasteriser: one lane = one point of one view, the
+// depth test is a 64-bit atomicMin on (depth bits << 32 | colour), so the result does not depend on order
+
+__device__ __forceinline__ bool splat_project(const CamDev& cam, float scale, const float off[3], const float* p,
+                                              float& u, float& v, float& z) {
+  const float q[3] = {fmaf(p[0], scale, off[0]), fmaf(p[1], scale, off[1]), fmaf(p[2], scale, off[2])};
+  const float e[3] = {q[1], q[2], q[0]};
+  const float d[3] = {e[0] - cam.c2w[3], e[1] - cam.c2w[7], e[2] - cam.c2w[11]};
+  float c[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) c[a] = fmaf(cam.c2w[a], d[0], fmaf(cam.c2w[4 + a], d[1], cam.c2w[8 + a] * d[2]));
+  if (!(c[2] > 1e-6f)) return false;
+  float x = c[0] / c[2], y = c[1] / c[2];
+  if (has_lens(cam)) {
+    float xd, yd, J[4];
+    lens_eval(cam.lens, x, y, xd, yd, J);
+    x = xd;
+    y = yd;
+  }
+  u = fmaf(cam.fx, x, cam.cx);
+  v = fmaf(cam.fy, y, cam.cy);
+  z = c[2];
+  return true;
+}
+
+__global__ __launch_bounds__(256) void splat_points_kernel(const float* __restrict__ xyz, const uint8_t* __restrict__ rgb,
+                                                           size_t n, float scale, float ox, float oy, float oz,
+                                                           const CamDev* __restrict__ cams, int W, int H, int point_size,
+                                                           unsigned long long* __restrict__ zbuf) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const CamDev cam = cams[blockIdx.y];
+  const float off[3] = {ox, oy, oz};
+  const float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+  float u, v, z;
+  if (!splat_project(cam, scale, off, p, u, v, z)) return;
+  const uint32_t col = (uint32_t)rgb[3 * i] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i + 2] << 16);
+  const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | col;
+  const int x0 = (int)floorf(u - 0.5f * (float)point_size + 0.5f), y0 = (int)floorf(v - 0.5f * (float)point_size + 0.5f);
+  unsigned long long* zb = zbuf + (size_t)blockIdx.y * W * H;
+  for (int dy = 0; dy < point_size; dy++)
+    for (int dx = 0; dx < point_size; dx++) {
+      const int x = x0 + dx, y = y0 + dy;
+      if (x < 0 || y < 0 || x >= W || y >= H) continue;
+      atomicMin(zb + (size_t)y * W + x, key);
+    }
+}
+
+__global__ __launch_bounds__(256) void splat_resolve_kernel(const unsigned long long* __restrict__ zbuf, int W, int H,
+                                                            int flip180, uint32_t* __restrict__ out) {
+  const size_t npix = (size_t)W * H;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npix) return;
+  const unsigned long long k = zbuf[(size_t)blockIdx.y * npix + i];
+  uint32_t px = 0x00ffffffu; // white, alpha 0
+  if (k != ~0ull) {
+    const uint32_t col = (uint32_t)k & 0x00ffffffu;
+    px = col | (col == 0x00ffffffu ? 0u : 0xff000000u);
+  }
+  const int x = (int)(i % W), y = (int)(i / W);
+  const size_t o = flip180 ? ((size_t)(H - 1 - y) * W + (size_t)(W - 1 - x)) : i;
+  out[(size_t)blockIdx.y * npix + o] = px;
+}
+
 // ------------------------------------------------------------------ host-callable launchers
+
+hipError_t launch_splat_points(const float* xyz, const uint8_t* rgb, size_t n, float scale, const float off[3],
+                               const CamDev* cams, int n_views, int W, int H, int point_size, int flip180,
+                               unsigned long long* zbuf, uint32_t* out, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(zbuf, 0xff, (size_t)n_views * W * H * 8, s);
+  if (e != hipSuccess) return e;
+  if (n > 0)
+    hipLaunchKernelGGL(splat_points_kernel, dim3((unsigned)((n + 255) / 256), n_views), dim3(256), 0, s, xyz, rgb, n, scale,
+                       off[0], off[1], off[2], cams, W, H, point_size, zbuf);
+  hipLaunchKernelGGL(splat_resolve_kernel, dim3((unsigned)(((size_t)W * H + 255) / 256), n_views), dim3(256), 0, s, zbuf, W, H,
+                     flip180, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_spp_reduce(const float* stage, size_t n_pixels, int spp, const float bg[4], float* out, uint32_t* out_u8,
                              hipStream_t s) {

@@ -78,6 +78,9 @@ hipError_t launch_precept(const FieldDev& fd, const float* voxels, int n, const 
                           float max_range, int32_t* out, hipStream_t s);
 hipError_t launch_first_hit(const FieldDev& fd, const CamDev* cams, int n_views, int W, int H, float max_range,
                             int32_t* out, hipStream_t s);
+hipError_t launch_splat_points(const float* xyz, const uint8_t* rgb, size_t n, float scale, const float off[3],
+                               const CamDev* cams, int n_views, int W, int H, int point_size, int flip180,
+                               unsigned long long* zbuf, uint32_t* out, hipStream_t s);
 hipError_t launch_quantize(const float* in, size_t n, const float bg[4], uint8_t* out, hipStream_t s);
 hipError_t launch_score_ensemble(const EnsembleParams& P, int method, int n_views, int n_blocks, hipStream_t s);
 hipError_t launch_score_psnr(const PsnrParams& P, int n_views, int n_blocks, hipStream_t s);

@@ -102,6 +102,7 @@ def lib():
         L.orc_train_master_table.restype, L.orc_train_master_table.argtypes = C.POINTER(C.c_float), [vp]
         L.orc_train_master_mlp.restype, L.orc_train_master_mlp.argtypes = C.POINTER(C.c_float), [vp]
         L.orc_train_table_size.restype, L.orc_train_table_size.argtypes = C.c_size_t, [vp]
+        L.orc_splat_points.argtypes = [vp, vp, C.c_size_t, C.c_float, vp, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, vp]
         L.orc_lens_distort.argtypes = [C.c_float * 4, C.c_float, C.c_float, f32p, f32p]
         L.orc_lens_undistort.argtypes = [C.c_float * 4, f32p, f32p]
         L.orc_render.argtypes = [C.POINTER(Field), C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp,
@@ -365,6 +366,16 @@ def rank(scores, ids):
 def argmax(scores, ids):
     s, i = np.ascontiguousarray(scores, np.float64), np.ascontiguousarray(ids, np.int32)
     return lib().orc_argmax(_p(s), _p(i), len(i))
+
+
+def splat_points(xyz, rgb, scale, offset, cam, w, h, point_size=5, flip180=True):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    rgb = np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
+    off = np.ascontiguousarray(offset, np.float32)
+    out = np.zeros((h, w, 4), np.uint8)
+    lib().orc_splat_points(_p(xyz), _p(rgb), len(xyz), C.c_float(scale), _p(off), C.byref(cam), w, h, point_size,
+                           int(flip180), _p(out))
+    return out
 
 
 class OracleTrainer:

@@ -994,3 +994,62 @@ void orc_first_hit_rows(const orc_field* f, const orc_camera* cam, int w, int y0
       out[(size_t)(y - y0) * w + x] = orc_first_hit(f, o, d, max_range, cell) ? cell[0] + R * (cell[1] + R * cell[2]) : -1;
     }
 }
+
+/* ------------------------------------------------------------------ ground-truth splats */
+
+/* shared with the device twin (prv_kernels.hip: splat_project): engine-frame point -> pixel centre + depth */
+static int splat_project(const orc_camera* cam, float scale, const float off[3], const float* p, float* u, float* v,
+                         float* z) {
+  const float q[3] = {fmaf(p[0], scale, off[0]), fmaf(p[1], scale, off[1]), fmaf(p[2], scale, off[2])};
+  const float e[3] = {q[1], q[2], q[0]}; /* axes cycled as nerf_to_ngp cycles camera positions */
+  const float d[3] = {e[0] - cam->c2w[3], e[1] - cam->c2w[7], e[2] - cam->c2w[11]};
+  float c[3];
+  for (int a = 0; a < 3; a++) c[a] = fmaf(cam->c2w[a], d[0], fmaf(cam->c2w[4 + a], d[1], cam->c2w[8 + a] * d[2]));
+  if (!(c[2] > 1e-6f)) return 0;
+  float x = c[0] / c[2], y = c[1] / c[2];
+  if (cam->lens[0] != 0.0f || cam->lens[1] != 0.0f || cam->lens[2] != 0.0f || cam->lens[3] != 0.0f) {
+    float xd, yd;
+    orc_lens_distort(cam->lens, x, y, &xd, &yd);
+    x = xd;
+    y = yd;
+  }
+  *u = fmaf(cam->fx, x, cam->cx);
+  *v = fmaf(cam->fy, y, cam->cy);
+  *z = c[2];
+  return 1;
+}
+
+void orc_splat_points(const float* xyz, const uint8_t* rgb, size_t n, float scale, const float offset[3],
+                      const orc_camera* cam, int w, int h, int point_size, int flip180, uint8_t* out) {
+  uint64_t* zb = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)w * h);
+  for (size_t i = 0; i < (size_t)w * h; i++) zb[i] = ~0ull;
+  for (size_t i = 0; i < n; i++) {
+    float u, v, z;
+    if (!splat_project(cam, scale, offset, xyz + 3 * i, &u, &v, &z)) continue;
+    uint32_t zbits;
+    memcpy(&zbits, &z, 4);
+    const uint32_t col = (uint32_t)rgb[3 * i] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i + 2] << 16);
+    const uint64_t key = ((uint64_t)zbits << 32) | col;
+    const int x0 = (int)floorf(u - 0.5f * (float)point_size + 0.5f), y0 = (int)floorf(v - 0.5f * (float)point_size + 0.5f);
+    for (int dy = 0; dy < point_size; dy++)
+      for (int dx = 0; dx < point_size; dx++) {
+        const int x = x0 + dx, y = y0 + dy;
+        if (x < 0 || y < 0 || x >= w || y >= h) continue;
+        if (key < zb[(size_t)y * w + x]) zb[(size_t)y * w + x] = key;
+      }
+  }
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      const uint64_t k = zb[(size_t)y * w + x];
+      uint8_t px[4] = {255, 255, 255, 0}; /* white background, made transparent by convertToAlpha */
+      if (k != ~0ull) {
+        px[0] = (uint8_t)(k & 255);
+        px[1] = (uint8_t)((k >> 8) & 255);
+        px[2] = (uint8_t)((k >> 16) & 255);
+        px[3] = (px[0] == 255 && px[1] == 255 && px[2] == 255) ? 0 : 255; /* a white POINT turns transparent too */
+      }
+      const size_t o = flip180 ? ((size_t)(h - 1 - y) * w + (size_t)(w - 1 - x)) : ((size_t)y * w + x);
+      memcpy(out + 4 * o, px, 4);
+    }
+  free(zb);
+}

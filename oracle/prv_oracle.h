@@ -151,6 +151,17 @@ void orc_first_hit_rows(const orc_field* f, const orc_camera* cam, int w, int y0
 void orc_precept(const orc_field* f, const float* voxels, int n, const double w2c[16], const double c2w[16],
                  const float intr[9], int width, int height, int model, float max_range, int32_t* out);
 
+/* ---- ground-truth image synthesis: the PCL screenshot of the coloured ground-truth cloud
+ * (Perception_3D::render main.cpp:68-96, points of points_size_cloud pixels on a white background),
+ * convertToAlpha (Share_Data.hpp:771-784: exactly-white pixels -> alpha 0, everything else 255) and the 180
+ * degree flip of main.cpp:1616, restated as a z-buffered square-splat rasteriser.  OpenGL's own point
+ * rasterisation rules are not reproducible from the tree: parity unpinned.
+ * xyz in world units (n*3), rgb n*3 bytes; points go to the engine frame as the json's scale/offset do with
+ * camera positions (p*scale + offset, axes cycled y,z,x).  Nearest point wins; equal depths -> smaller packed
+ * colour.  out: h*w*4 RGBA bytes. */
+void orc_splat_points(const float* xyz, const uint8_t* rgb, size_t n, float scale, const float offset[3],
+                      const orc_camera* cam, int w, int h, int point_size, int flip180, uint8_t* out);
+
 /* ---- training step (prv_train.c; published instant-ngp optimiser restated, parity unpinned) ---- */
 typedef struct {
   int32_t n_rays;    /* rays per step */

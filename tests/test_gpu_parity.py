@@ -389,3 +389,34 @@ def test_error_behaviour(ctx, fields, cams):
         ctx.cameras_from_json("/nonexistent/transforms.json")
     img, st = ctx.render(0, cs, [], api.render_opts(w, h))  # empty view list is fine
     assert img.shape[0] == 0 and st.rays == 0
+
+
+def test_ground_truth_splats_byte_exact(ctx, oracle):
+    """prv_splat_points (the rgbaClip images of get_coverage, main.cpp:1604-1618) against the oracle: a coloured
+    sphere-shell cloud seen by lens cameras, 5-pixel points (yaml:18) -- identical bytes"""
+    rng = np.random.default_rng(3)
+    n = 20000
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    xyz = (0.04 * d + 1e-10).astype(np.float32)  # a 4 cm sphere at the origin, world units
+    rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
+    rgb[:50] = 255  # some exactly-white points
+    pts = util.fibonacci_hemisphere(3)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    cs = ctx.cameras_from_matrices_intr(tms, REF_INTR, scale, offset)
+    for (w, h, size) in ((160, 90, 5), (64, 36, 1)):
+        ocams = oracle.cameras_from_dataset(tms, REF_INTR, scale, offset, w, h)
+        got = ctx.splat_points(xyz, rgb, scale, offset, cs, None, w, h, point_size=size).cpu().numpy()
+        assert got.shape == (3, h, w, 4)
+        for v in range(3):
+            want = oracle.splat_points(xyz, rgb, scale, offset, ocams[v], w, h, point_size=size)
+            assert np.array_equal(got[v], want), v
+        cover = (got[..., 3] == 255).mean()
+        assert 0.005 < cover < 0.6
+    one = ctx.splat_points(xyz, rgb, scale, offset, cs, [2], 160, 90, 5, flip180=False).cpu().numpy()[0]
+    assert np.array_equal(one[::-1, ::-1], got_last := ctx.splat_points(xyz, rgb, scale, offset, cs, [2], 160, 90, 5).cpu().numpy()[0])
+    empty = ctx.splat_points(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8), scale, offset, cs, [0], 32, 18).cpu().numpy()
+    assert (empty == np.array([255, 255, 255, 0], np.uint8)).all()
+    with pytest.raises(api.PrvError):
+        ctx.splat_points(xyz, rgb, scale, offset, cs, [0], 32, 18, point_size=0)
+    del got_last

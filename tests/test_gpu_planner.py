@@ -457,3 +457,41 @@ def test_planner_executable_trains_its_ensemble_every_iteration(ctx, tmp_path):
     # a finished run is not repeated (the reference skips objects whose run_time.txt exists, main.cpp:3878-3881)
     out2 = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
     assert out2.returncode == 0 and "chosen_nbvs:\n" in out2.stdout
+
+
+def test_coverage_images_from_a_point_cloud_train_a_field(ctx, tmp_path):
+    """get_coverage without PCL (main.cpp:1581-1656): splat the coloured ground-truth cloud into the rgbaClip
+    images of every view, write the json, train on them, and the trained field shows the object where the
+    cloud is"""
+    from PIL import Image
+
+    rng = np.random.default_rng(8)
+    n = 60000
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    xyz = (0.035 * d).astype(np.float32) + np.float32(1e-10)
+    rgb = np.clip(128 + 120 * d, 0, 254).astype(np.uint8)  # colour = normal direction, never exactly white
+    pts = util.fibonacci_hemisphere(16)
+    c = [1e-10] * 3
+    pos = planner.view_space(pts, 0.3, c)
+    w, h = 64, 48
+    k = planner.Intrinsics(width=w, height=h, ppx=w / 2, ppy=h / 2, fx=0.9 * w, fy=0.9 * w)
+    (tmp_path / "16").mkdir()
+    tj = tmp_path / "16.json"
+    planner.write_transforms(tj, k, pos, c, 0.1, path_prefix="16/rgbaClip_")
+    with open(tj) as f:
+        meta = json.load(f)
+    cams = ctx.cameras_from_dataset_json(tj)
+    imgs = ctx.splat_points(xyz, rgb, meta["scale"], meta["offset"], cams, None, w, h, point_size=2, flip180=False)
+    for i, img in enumerate(imgs.cpu().numpy()):
+        Image.fromarray(img, "RGBA").save(tmp_path / "16" / f"rgbaClip_{i}.png")
+    cover = float((imgs[..., 3] == 255).float().mean())
+    assert 0.02 < cover < 0.5
+    from nerf_prv_amd import compat_server
+    losses = compat_server.train_scene(ctx, 0, tj, 300, api.field_desc(**TRAIN_FIELD), seed=SEED,
+                                       opts=api.train_opts(n_rays=2048, n_samples=48, occ_sigma_thresh=0.01 * 48 / 3 ** 0.5))
+    assert np.mean(losses[-20:]) < 0.3 * np.mean(losses[:5])
+    out, _ = ctx.render(0, cams, [3], api.render_opts(w, h, 48, 1, 1e-4))
+    alpha = out[0, ..., 3]
+    gt_a = (imgs[3, ..., 3] == 255)
+    assert float(alpha[gt_a].mean()) > 0.6 and float(alpha[~gt_a].mean()) < 0.1

@@ -143,3 +143,37 @@ def test_lens_known_answers(oracle):
         a, b = oracle.lens_distort(lens, x, y)
         ux, uy = oracle.lens_undistort(lens, a, b)
         assert abs(ux - x) < 3e-7 and abs(uy - y) < 3e-7
+
+
+def test_ground_truth_splat_known_answers(oracle):
+    """hand-placed points in front of an axis-aligned camera: projection, square splat footprint, nearest
+    wins, white -> transparent (convertToAlpha, Share_Data.hpp:771-784), 180-degree flip (main.cpp:1616)"""
+    # engine-frame camera at (0.5, 0.5, 2) looking down -z with x right, y down in the image: c2w columns
+    c2w = [1, 0, 0, 0.5, 0, -1, 0, 0.5, 0, 0, -1, 2.0]
+    cam = oracle.camera(c2w, 10.0, 10.0, 8.0, 6.0)
+    w, h = 16, 12
+
+    def world(e):  # engine (x,y,z) -> world point for scale 1, offset 0 (engine = (wy, wz, wx))
+        return [e[2], e[0], e[1]]
+
+    red, green, white = (200, 10, 20), (5, 220, 30), (255, 255, 255)
+    pts = [world((0.5, 0.5, 1.0)),          # on the axis, depth 1 -> pixel centre (8, 6)
+           world((0.5, 0.5, 0.5)),          # behind it on the same ray, depth 1.5: hidden
+           world((0.5 + 0.3, 0.5, 1.0)),    # depth 1, x/z = 0.3 -> u = 11
+           world((0.5, 0.5 - 0.2, 1.0))]    # y axis of the camera points to -engine y: v = 6 + 2 = 8
+    cols = [red, green, green, white]
+    img = oracle.splat_points(pts, cols, 1.0, (0, 0, 0), cam, w, h, point_size=1, flip180=False)
+    assert tuple(img[6, 8]) == red + (255,)
+    assert tuple(img[6, 11]) == green + (255,)
+    assert tuple(img[8, 8]) == white + (0,)  # a white point is as transparent as the background
+    assert tuple(img[0, 0]) == (255, 255, 255, 0)
+    assert (img[..., 3] == 255).sum() == 2
+    # point size 3: a 3x3 footprint centred on the pixel
+    img3 = oracle.splat_points(pts[:1], cols[:1], 1.0, (0, 0, 0), cam, w, h, point_size=3, flip180=False)
+    ys, xs = np.nonzero(img3[..., 3])
+    assert sorted(set(ys)) == [5, 6, 7] and sorted(set(xs)) == [7, 8, 9] and len(ys) == 9
+    # flip: rotate by 180 degrees
+    f = oracle.splat_points(pts, cols, 1.0, (0, 0, 0), cam, w, h, point_size=1, flip180=True)
+    assert np.array_equal(f, img[::-1, ::-1])
+    # behind the camera: nothing
+    assert oracle.splat_points([world((0.5, 0.5, 3.0))], [red], 1.0, (0, 0, 0), cam, w, h, 1, False)[..., 3].sum() == 0
