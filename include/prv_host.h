@@ -92,6 +92,10 @@ typedef struct prvh_loop_result {
 } prvh_loop_result;
 int prvh_nbv_loop(prvh_share_data* sd, const double center[3], double predicted_size, int first_view_id,
                   int test_id, prvh_score_fn score, void* user, prvh_loop_result* out);
+/* the same with the view budget of method 4 (PVBCoverage, main.cpp:2163-2242) supplied by the caller -- what
+ * PRVNet's server answers through <pvb_path>/data/view_budget.txt; <= 0: read that file */
+int prvh_nbv_loop_budget(prvh_share_data* sd, const double center[3], double predicted_size, int first_view_id,
+                         int test_id, prvh_score_fn score, void* user, int view_budget, prvh_loop_result* out);
 
 #ifdef __cplusplus
 }

@@ -237,6 +237,11 @@ void prvh_share_data_intrinsics(const prvh_share_data* h, prvh_intrinsics* o) {
 
 int prvh_nbv_loop(prvh_share_data* h, const double center[3], double predicted_size, int first_view_id, int test_id,
                   prvh_score_fn score, void* user, prvh_loop_result* out) {
+  return prvh_nbv_loop_budget(h, center, predicted_size, first_view_id, test_id, score, user, 0, out);
+}
+
+int prvh_nbv_loop_budget(prvh_share_data* h, const double center[3], double predicted_size, int first_view_id, int test_id,
+                         prvh_score_fn score, void* user, int view_budget, prvh_loop_result* out) {
   if (!h || !center || !out) return -1;
   Scorer s = [score, user](int method, int iteration, const std::string& scene, const std::string& render,
                            const std::vector<int>& ids, std::vector<double>& scores) -> int {
@@ -244,6 +249,7 @@ int prvh_nbv_loop(prvh_share_data* h, const double center[3], double predicted_s
     return score(user, method, iteration, scene.c_str(), render.c_str(), ids.data(), (int)ids.size(), scores.data());
   };
   NBV_Net_Labeler labeler(h->sd, Vec3(center[0], center[1], center[2]), predicted_size, s);
+  if (view_budget > 0) labeler.budget_fn = [view_budget](const std::vector<int>&) { return view_budget; };
   const int rc = labeler.nbv_loop(first_view_id, test_id);
   out->n_chosen = (int)std::min<size_t>(labeler.chosen_nbvs.size(), 1024);
   for (int i = 0; i < out->n_chosen; i++) out->chosen[i] = labeler.chosen_nbvs[i];

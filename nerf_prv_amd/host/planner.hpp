@@ -3,7 +3,8 @@
 // nbv_loop's per-iteration json/render_json), the boundary call (train_by_instantNGP, now an
 // in-process call through a scorer callback instead of the file-flag handshake), the
 // per-iteration bookkeeping files, arg-max selection.  Not kept (out of scope):
-// point-cloud / OctoMap asset preparation, PCL rendering, Gurobi path planning, methods 1 and 4.
+// point-cloud / OctoMap asset preparation, PCL rendering, PRVNet itself (method 4 takes its view budget
+// from a callback or from the file PRVNet's server would have written).
 #pragma once
 #include <cstdio>
 #include <ctime>
@@ -93,11 +94,16 @@ using Scorer = std::function<int(int method, int iteration, const std::string& s
                                  const std::string& render_json, const std::vector<int>& candidate_ids,
                                  std::vector<double>& scores)>;
 
+// method 4: the number of views PRVNet predicts from the initial images (main.cpp:2165-2192 hands the images to a
+// Python server through <pvb_path>/data and reads view_budget.txt back); <= 0 = no answer
+using BudgetFn = std::function<int(const std::vector<int>& init_view_ids)>;
+
 class NBV_Net_Labeler {
 public:
   std::shared_ptr<Share_Data> share_data;
   std::shared_ptr<View_Space> view_space;
   Scorer scorer;
+  BudgetFn budget_fn; // empty: read <pvb_path>/data/view_budget.txt
   std::vector<int> chosen_nbvs;
   std::vector<double> last_scores;
   double total_movement_cost = 0.0;
@@ -140,10 +146,15 @@ public:
     return rc;
   }
 
-  // main.cpp:1718-2277, methods 0 (random), 2, 3 and 5; chosen views in `chosen_nbvs`
+  // main.cpp:1718-2277, methods 0-5; chosen views in `chosen_nbvs`
   int nbv_loop(int first_view_id = -1, int test_id = 0) {
     if (first_view_id == -1) first_view_id = 0; // :1725-1728
     Share_Data& sd = *share_data;
+    if (sd.method_of_IG != PVBCoverage) { // :1735-1747: the other methods run with the budget method 4 found
+      std::ifstream fin(sd.pre_path + "Compare/ShapeNet/" + sd.name_of_pcd + "_m4_v1_t" + std::to_string(test_id) + "/view_budget.txt");
+      int view_budget = 0;
+      if (fin.is_open() && (fin >> view_budget) && view_budget > 0) sd.num_of_max_iteration = view_budget - 1;
+    }
     sd.save_path += "_v1";                     // one initial view (init_view_ids.size() == 1, :1751)
     sd.save_path += "_t" + std::to_string(test_id);
     for (const char* sub : {"/json", "/render_json", "/metrics", "/render", "/train_time", "/infer_time", "/movement"})
@@ -163,10 +174,12 @@ public:
     std::set<int> chosen_nbvs_set{first_view_id};
     std::mt19937 rng(12345); // the reference seeds rand() with clock() (Share_Data.hpp:514): unreproducible by design
     const std::clock_t loop_t0 = std::clock();
-    const int n_views = (int)view_space->views.size();
-    const std::string prefix = "../../../../Coverage_images/ShapeNet/" + sd.name_of_pcd + "/" + std::to_string(sd.num_of_views) + "/rgbaClip_";
     int iteration = 0;
+    std::vector<int> oneshot_views; // methods 1 and 4: the planned tour, consumed front to back
+    bool oneshot_planned = false;
     while (true) {
+      const int n_views = (int)view_space->views.size(); // method 4 swaps the view space
+      const std::string prefix = "../../../../Coverage_images/ShapeNet/" + sd.name_of_pcd + "/" + std::to_string(sd.num_of_views) + "/rgbaClip_";
       Value now_nbvs_json(root_nbvs), now_render_json(root_render);
       std::vector<int> candidates;
       for (int i = 0; i < n_views; i++) { // :1887-1916
@@ -213,8 +226,89 @@ public:
           next_view_id = best_view_id;
           break;
         }
+        case RandomOneshot: { // :1981-2037: 50 random view sets, keep the most spread one, visit it along the shortest tour
+          if (!oneshot_planned) {
+            std::set<int> best;
+            double largest_pair_dis = -1e100;
+            for (int check = 0; check < 50; check++) {
+              std::set<int> pick{first_view_id};
+              for (int i = 0; i < sd.num_of_max_iteration && (int)pick.size() < n_views; i++) {
+                int v = (int)(rng() % (unsigned)n_views);
+                while (pick.count(v)) v = (int)(rng() % (unsigned)n_views);
+                pick.insert(v);
+              }
+              double dis = 0;
+              for (auto a = pick.begin(); a != pick.end(); ++a)
+                for (auto b = std::next(a); b != pick.end(); ++b)
+                  dis += (view_space->views[*a].init_pos - view_space->views[*b].init_pos).norm();
+              if (dis > largest_pair_dis) {
+                largest_pair_dis = dis;
+                best = pick;
+              }
+            }
+            oneshot_views.assign(best.begin(), best.end());
+            Global_Path_Planner gpp(view_space->views, oneshot_views, first_view_id,
+                                    view_space->object_center_world + Vec3(1e-10, 1e-10, 1e-10), view_space->predicted_size);
+            gpp.solve();
+            oneshot_views = gpp.get_path_id_set();
+            if (oneshot_views.empty()) return -13;
+            oneshot_views.erase(oneshot_views.begin()); // the initial view
+            sd.num_of_max_iteration = (int)oneshot_views.size();
+            oneshot_planned = true;
+          }
+          if (oneshot_views.empty()) return -13;
+          next_view_id = oneshot_views.front();
+          oneshot_views.erase(oneshot_views.begin());
+          break;
+        }
+        case PVBCoverage: { // :2163-2242: PRVNet's view budget N -> the N-view coverage set, visited along the shortest tour
+          if (!oneshot_planned) {
+            int view_budget = -1;
+            if (budget_fn) view_budget = budget_fn(chosen_nbvs);
+            else {
+              std::ifstream fin(sd.pvb_path + "data/view_budget.txt");
+              if (fin.is_open()) fin >> view_budget;
+            }
+            if (view_budget < 2) return -12; // no budget: PRVNet (or its stand-in) has not answered
+            sd.num_of_views = view_budget;
+            std::ifstream fin_sphere(sd.viewspace_path + std::to_string(view_budget) + ".txt");
+            if (!fin_sphere.is_open()) return -14;
+            sd.pt_sphere.assign(view_budget, std::vector<double>(3, 0.0));
+            for (int i = 0; i < view_budget; i++)
+              for (int j = 0; j < 3; j++) fin_sphere >> sd.pt_sphere[i][j];
+            sd.pt_norm = std::sqrt(sd.pt_sphere[0][0] * sd.pt_sphere[0][0] + sd.pt_sphere[0][1] * sd.pt_sphere[0][1] +
+                                   sd.pt_sphere[0][2] * sd.pt_sphere[0][2]);
+            const Vec3 center = view_space->object_center_world;
+            const double size = view_space->predicted_size;
+            view_space = std::make_shared<View_Space>(share_data);
+            view_space->set_view_space(center, size);
+            int now_first_view_id = -1;
+            const int nv = (int)view_space->views.size();
+            for (int i = 0; i < nv; i++) {
+              const Vec3 p = view_space->views[i].init_pos - center;
+              if (std::fabs(p.x) < 1e-6 && std::fabs(p.y) < 1e-6 && std::fabs(p.z - sd.view_space_radius) < 1e-6) now_first_view_id = i;
+              oneshot_views.push_back(i);
+            }
+            if (now_first_view_id == -1) return -15; // "can not find now view id" (:2221)
+            chosen_nbvs.assign(1, now_first_view_id);
+            chosen_nbvs_set = {now_first_view_id};
+            Global_Path_Planner gpp(view_space->views, oneshot_views, now_first_view_id,
+                                    center + Vec3(1e-10, 1e-10, 1e-10), size);
+            gpp.solve();
+            oneshot_views = gpp.get_path_id_set();
+            write_text(sd.save_path + "/view_budget.txt", std::to_string(oneshot_views.size()) + "\n"); // :2233-2234
+            if (oneshot_views.empty()) return -13;
+            oneshot_views.erase(oneshot_views.begin());
+            sd.num_of_max_iteration = (int)oneshot_views.size();
+            oneshot_planned = true;
+          }
+          if (oneshot_views.empty()) return -13;
+          next_view_id = oneshot_views.front();
+          oneshot_views.erase(oneshot_views.begin());
+          break;
+        }
         default:
-          return -10; // RandomOneshot / PVBCoverage need the TSP planner / PRVNet: out of scope
+          return -10;
       }
       if (next_view_id < 0) return -11;
       chosen_nbvs.push_back(next_view_id); // :2246-2247

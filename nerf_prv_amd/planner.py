@@ -54,6 +54,7 @@ HOST_SIGNATURES = {
     "prvh_share_data_views": (_i, [_vp, _vp]),
     "prvh_share_data_intrinsics": (None, [_vp, C.POINTER(Intrinsics)]),
     "prvh_nbv_loop": (_i, [_vp, _vp, _d, _i, _i, SCORE_FN, _vp, C.POINTER(LoopResult)]),
+    "prvh_nbv_loop_budget": (_i, [_vp, _vp, _d, _i, _i, SCORE_FN, _vp, _i, C.POINTER(LoopResult)]),
 }
 
 _host = None
@@ -224,8 +225,9 @@ class ShareData:
         host().prvh_share_data_intrinsics(self.h, C.byref(k))
         return k
 
-    def nbv_loop(self, center, predicted_size, score_fn, first_view_id=-1, test_id=0):
-        """run NBV_Net_Labeler::nbv_loop; score_fn(method, iteration, scene_json, render_json, ids) -> scores"""
+    def nbv_loop(self, center, predicted_size, score_fn, first_view_id=-1, test_id=0, view_budget=0):
+        """run NBV_Net_Labeler::nbv_loop; score_fn(method, iteration, scene_json, render_json, ids) -> scores;
+        view_budget: method 4's PRVNet answer (0: read <pvb_path>/data/view_budget.txt)"""
         def cb(user, method, iteration, scene, render, ids, n, scores):
             try:
                 vals = score_fn(method, iteration, scene.decode(), render.decode(), [ids[i] for i in range(n)])
@@ -239,7 +241,8 @@ class ShareData:
         c = np.ascontiguousarray(center, np.float64)
         res = LoopResult()
         keep = SCORE_FN(cb)
-        rc = host().prvh_nbv_loop(self.h, _p(c), float(predicted_size), first_view_id, test_id, keep, None, C.byref(res))
+        rc = host().prvh_nbv_loop_budget(self.h, _p(c), float(predicted_size), first_view_id, test_id, keep, None,
+                                         int(view_budget), C.byref(res))
         if rc != 0:
             raise RuntimeError(f"nbv_loop failed rc={rc}: {getattr(self, 'last_error', '')}")
         return [res.chosen[i] for i in range(res.n_chosen)]

@@ -166,9 +166,73 @@ def test_nbv_loop_random_method_and_error_path(config):
     sd2 = planner.ShareData(config, "boom", -1, -1, 2)
     with pytest.raises(RuntimeError):
         sd2.nbv_loop([1e-10] * 3, 0.1, lambda *a: 1 / 0)  # scorer failure surfaces as an error code, no hang
-    sd3 = planner.ShareData(config, "oneshot", -1, -1, 1)
+
+
+def tour_length(pos, order, center, size):
+    return sum(planner.local_path(pos[a], pos[b], center, size)[1] for a, b in zip(order[:-1], order[1:]))
+
+
+def test_nbv_loop_random_oneshot(config):
+    """method 1 (main.cpp:1981-2037): a spread-out random view set, visited along the shortest open tour from
+    the first view; never calls the render boundary"""
+    import itertools
+
+    sd = planner.ShareData(config, "oneshot", -1, -1, 1)
+    chosen = sd.nbv_loop([1e-10] * 3, 0.1, lambda *a: 1 / 0, first_view_id=1)
+    assert len(chosen) == 4 and len(set(chosen)) == 4 and chosen[0] == 1
+    pos = planner.view_space(sd.views(), 0.3, [1e-10] * 3)
+    c = [2e-10] * 3  # object centre + 1e-10, as the planner passes it
+    got = tour_length(pos, chosen, c, 0.1)
+    best = min(tour_length(pos, [1] + list(p), c, 0.1) for p in itertools.permutations(chosen[1:]))
+    assert got == pytest.approx(best, rel=1e-9)  # the visiting order is the optimal one for the picked set
+    save = sd.string("save_path")
+    assert save.endswith("_m1_v1_t0") and sorted(os.listdir(os.path.join(save, "movement"))) == ["-1.txt", "0.txt", "1.txt", "2.txt"]
+
+
+@pytest.fixture()
+def config9(tmp_path):
+    """a view-space directory holding the reference's 5.txt and a generated 9-view set"""
+    import shutil
+
+    vs = tmp_path / "vs"
+    vs.mkdir()
+    shutil.copy(os.path.join(GOLD, "hemisphere", "5.txt"), vs / "5.txt")
+    pts = planner.hemisphere_generate(9)
+    (vs / "9.txt").write_text("".join(f"{a:.17g} {b:.17g} {c:.17g}\n" for a, b, c in pts))
+    p = tmp_path / "DefaultConfiguration.yaml"
+    p.write_text(YAML.format(pre=tmp_path, vs=vs))
+    return p, pts
+
+
+def test_nbv_loop_pvb_coverage(config9, tmp_path):
+    """method 4 (main.cpp:2163-2242) with PRVNet's answer supplied: the budget's coverage set (N.txt) replaces the
+    view space, all of it is visited along the shortest tour from its top view, view_budget.txt is left for the
+    other methods, which then run with budget - 1 iterations (main.cpp:1735-1747)"""
+    config, pts9 = config9
+    sd = planner.ShareData(config, "pvb", -1, -1, 4)
+    chosen = sd.nbv_loop([1e-10] * 3, 0.1, lambda *a: 1 / 0, first_view_id=1, view_budget=9)
+    top = int(np.argmax(np.asarray(pts9)[:, 2]))
+    assert sorted(chosen) == list(range(9)) and chosen[0] == top
+    pos = planner.view_space(pts9, 0.3, [1e-10] * 3)
+    order, length, exact = planner.global_path(pos, top, -1, [2e-10] * 3, 0.1)
+    assert exact and tour_length(pos, chosen, [2e-10] * 3, 0.1) == pytest.approx(length, rel=1e-9)
+    save = sd.string("save_path")
+    assert open(os.path.join(save, "view_budget.txt")).read().split() == ["9"]
+    frames = json.load(open(os.path.join(save, "json", "8.json")))["frames"]
+    assert len(frames) == 9 and "/9/rgbaClip_" in frames[0]["file_path"]
+    # the budget file written to <pvb_path>/data is read when no budget is passed
+    sd_b = planner.ShareData(config, "pvb", -1, -1, 2)  # same object name, another method: picks the budget up
+    seen = []
+
+    def scorer(method, iteration, scene_json, render_json, ids):
+        seen.append(iteration)
+        return [float(i) for i in ids]
+
+    chosen_b = sd_b.nbv_loop([1e-10] * 3, 0.1, scorer, first_view_id=1)
+    assert len(chosen_b) == 5 and seen == [0, 1, 2, 3]  # 5 views in the set cap the loop below budget - 1 = 8
+    sd_c = planner.ShareData(config, "nobudget", -1, -1, 4)
     with pytest.raises(RuntimeError):
-        sd3.nbv_loop([1e-10] * 3, 0.1, lambda *a: [0])  # RandomOneshot needs the TSP planner: out of scope
+        sd_c.nbv_loop([1e-10] * 3, 0.1, lambda *a: [0])  # PRVNet has not answered and no file exists
 
 
 def test_metrics_file_format_and_roundtrip(tmp_path):
