@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--field", choices=["256", "512"], default="256")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-training", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=500)
     args = ap.parse_args()
 
     import torch
@@ -173,6 +175,29 @@ def main():
         first_hit = {"gpu_rays_per_s": len(my_ids) * args.width * args.height / dt_fh,
                      "hit_fraction": float((cells >= 0).float().mean().item())}
 
+    # the other half of an NBV iteration: in-process training of the field (run.py:185-208), outside the timed
+    # region and not part of `value`: a fresh 256^3 field trained on this rank's reference images
+    training = None
+    if rank == 0 and not args.no_training:
+        tcams = ctx.cameras_from_matrices(np.asarray(tms)[my_ids], fov_x, args.width, args.height, scale, offset)
+        u8, _ = ctx.render_rgba8(1, tcams, None, api.render_opts(args.width, args.height, args.samples, 1, 1e-4,
+                                                                background=(0, 0, 0, 0)))
+        tdesc = api.L.FieldDesc(**dict(fdict, table_amp=1e-4, density_bias=0.0))
+        ctx.fresh_model(2, tdesc, 0x1234)
+        tr = api.Trainer(ctx, 2, tcams, u8, api.train_opts())
+        tr.steps(300)  # past the all-occupied start
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        losses = tr.steps(args.train_steps)
+        torch.cuda.synchronize()
+        dt_tr = time.perf_counter() - t2
+        training = {"steps_per_s": args.train_steps / dt_tr, "ms_per_step": dt_tr / args.train_steps * 1e3,
+                    "rays_per_step": int(tr.opts.n_rays), "samples_per_ray": int(tr.opts.n_samples),
+                    "used_samples_last_batch": tr.info()["samples_last"], "loss_last": float(losses[-1]),
+                    "note": "fresh field, 300 warm-up steps untimed; f32 MFMA forward/backward, sparse Adam"}
+        tr.close()
+        tcams.close()
+
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     tot = torch.tensor([float(evaluated_per_step), float(nominal_per_step), float(rays_per_step)], dtype=torch.float64,
                        device=device)
@@ -233,6 +258,7 @@ def main():
                 "mfma_util_frac": samples_per_launch * 20480 / kernel_s / 2.5e15,  # of the ~2.5 PFLOP/s dense f16 peak
             },
             "first_hit": first_hit,
+            "training": training,
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, tms, scale, offset, fov_x)
