@@ -309,3 +309,92 @@ def scoring_round(n_views, score_shard, group=None, device=None):
     records = gather_records(local, per, n_views, group, device)
     order = rank_host(records, np.arange(n_views, dtype=np.int32))
     return records, order
+
+
+# ---------------------------------------------------------------- the ensemble across GPUs
+
+def member_owner(e, world):
+    """rank that trains ensemble member e (round-robin)"""
+    return e % world
+
+
+def exchange_members(local, n_members, sizes, group=None, device=None):
+    """the real exchange step of a multi-GPU NBV iteration: rank r has trained the members e with
+    e % world == r; every rank needs every member to score its shard of the candidate views.
+    ONE all-gather of the packed fields (fp16 table | fp16 MLP | occupancy words per member, padded to
+    ceil(E / world) members per rank).
+
+    local: {e: (table_u16, mlp_u16, occ_u32)} for this rank's members; sizes = (n_table, n_mlp, n_occ).
+    Returns {e: (table, mlp, occ)} for all e, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_t, n_m, n_o = (int(x) for x in sizes)
+    per_member = 2 * n_t + 2 * n_m + 4 * n_o
+    per_rank = -(-n_members // world)
+    mine = [e for e in range(n_members) if member_owner(e, world) == rank]
+    if sorted(local) != mine:
+        raise ValueError(f"rank {rank} must bring members {mine}, got {sorted(local)}")
+    buf = np.zeros(per_rank * per_member, np.uint8)
+    for k, e in enumerate(mine):
+        t, m, o = local[e]
+        if (t.size, m.size, o.size) != (n_t, n_m, n_o):
+            raise ValueError("member arrays do not match the field's sizes")
+        off = k * per_member
+        buf[off: off + 2 * n_t] = np.ascontiguousarray(t, np.uint16).view(np.uint8)
+        buf[off + 2 * n_t: off + 2 * n_t + 2 * n_m] = np.ascontiguousarray(m, np.uint16).view(np.uint8)
+        buf[off + 2 * n_t + 2 * n_m: off + per_member] = np.ascontiguousarray(o, np.uint32).view(np.uint8)
+    send = torch.from_numpy(buf)
+    if device is not None:
+        send = send.to(device)
+    if dist.is_initialized():
+        out = torch.empty(world * per_rank * per_member, dtype=torch.uint8, device=send.device)
+        dist.all_gather_into_tensor(out, send, group=group)
+    else:
+        out = send
+    host = out.cpu().numpy()
+    result = {}
+    for e in range(n_members):
+        r, k = member_owner(e, world), e // world
+        off = (r * per_rank + k) * per_member
+        t = host[off: off + 2 * n_t].view(np.uint16).copy()
+        m = host[off + 2 * n_t: off + 2 * n_t + 2 * n_m].view(np.uint16).copy()
+        o = host[off + 2 * n_t + 2 * n_m: off + per_member].view(np.uint32).copy()
+        result[e] = (t, m, o)
+    return result
+
+
+def train_ensemble(ctx, n_members, scene_json, n_steps, desc, seed=0x1234, opts=None, group=None, device=None):
+    """one NBV iteration's training (main.cpp:2041-2043: train_by_instantNGP once per ensemble member) over the
+    GPUs of the job: this rank trains its members side by side on the scene json's views, the fields are
+    exchanged with ONE all-gather, and slots 0..E-1 of `ctx` hold the whole ensemble on every rank."""
+    import torch.distributed as dist
+
+    from . import api
+    from .compat_server import load_dataset_bytes
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = [e for e in range(n_members) if member_owner(e, world) == rank]
+    cams = ctx.cameras_from_dataset_json(scene_json)
+    images = load_dataset_bytes(ctx, scene_json)
+    trainers = []
+    for e in mine:
+        ctx.fresh_model(e, desc, seed + e)
+        o = api.train_opts() if opts is None else opts
+        member_opts = api.L.TrainOpts.from_buffer_copy(o)
+        member_opts.seed = o.seed + e
+        trainers.append(api.Trainer(ctx, e, cams, images, member_opts))
+    losses = api.train_many(trainers, n_steps) if trainers else np.zeros((0, n_steps), np.float32)
+    for t in trainers:
+        t.close()
+    cams.close()
+    if world > 1:
+        local = {e: ctx.export_model(e, desc) for e in mine}
+        everyone = exchange_members(local, n_members, api.model_sizes(desc), group, device)
+        for e in range(n_members):
+            if e not in local:
+                ctx.load_model(e, desc, *everyone[e])
+    return dict(zip(mine, losses))

@@ -80,3 +80,44 @@ def test_shard_layout():
     assert per == 1 and len(ids) == 0  # more ranks than views: empty shard is legal
     cover = np.concatenate([planner.shard_views(1000, r, 8)[0] for r in range(8)])
     assert cover.tolist() == list(range(1000))
+
+
+def _member(e, sizes):
+    """a recognisable fake field for member e"""
+    rng = np.random.default_rng(100 + e)
+    return (rng.integers(0, 65536, sizes[0], dtype=np.uint16), rng.integers(0, 65536, sizes[1], dtype=np.uint16),
+            rng.integers(0, 2 ** 32, sizes[2], dtype=np.uint32))
+
+
+def _exchange_worker(rank, world, port, n_members, sizes, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        local = {e: _member(e, sizes) for e in range(n_members) if planner.member_owner(e, world) == rank}
+        got = planner.exchange_members(local, n_members, sizes)
+        q.put((rank, {e: [a.tobytes() for a in got[e]] for e in got}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_members", [5, 2, 1])  # uneven shares, one each, fewer members than ranks
+def test_two_rank_ensemble_exchange(n_members):
+    """the exchange step of a multi-GPU NBV iteration: every rank ends up with every member, bit for bit"""
+    sizes = (4096 + 8, 10240, 129)
+    want = {e: [a.tobytes() for a in _member(e, sizes)] for e in range(n_members)}
+    single = planner.exchange_members({e: _member(e, sizes) for e in range(n_members)}, n_members, sizes)  # world = 1
+    assert {e: [a.tobytes() for a in single[e]] for e in single} == want
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, n_members, sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, fields in got:
+        assert fields == want
+    with pytest.raises(ValueError):
+        planner.exchange_members({0: _member(0, sizes)}, 2, sizes)  # world 1 must bring both members

@@ -495,3 +495,14 @@ def test_coverage_images_from_a_point_cloud_train_a_field(ctx, tmp_path):
     alpha = out[0, ..., 3]
     gt_a = (imgs[3, ..., 3] == 255)
     assert float(alpha[gt_a].mean()) > 0.6 and float(alpha[~gt_a].mean()) < 0.1
+
+
+def test_train_ensemble_single_rank(ctx, tmp_path):
+    """planner.train_ensemble on one GPU (world 1: no exchange): members train side by side from their own seeds"""
+    tj, pos, k, c = write_dataset(ctx, tmp_path, n_views=8)
+    desc = api.field_desc(**TRAIN_FIELD)
+    losses = planner.train_ensemble(ctx, 3, tj, 64, desc, seed=50,
+                                    opts=api.train_opts(n_rays=1024, n_samples=48, occ_sigma_thresh=0.01 * 48 / 3 ** 0.5))
+    assert sorted(losses) == [0, 1, 2] and all(len(v) == 64 and v[-1] < v[0] for v in losses.values())
+    tabs = [ctx.export_model(e, desc)[0] for e in range(3)]
+    assert not np.array_equal(tabs[0], tabs[1]) and not np.array_equal(tabs[1], tabs[2])
