@@ -273,7 +273,8 @@ typedef struct prv_train_opts {
   uint64_t seed;
   int32_t random_bg; /* 1: random background colour per ray */
   int32_t occ_every; /* refresh the density grid every N steps (0 = never) */
-  float occ_decay, occ_sigma_thresh; /* ema = max(ema*decay, sigma); occupied iff ema > thresh */
+  float occ_decay, occ_sigma_thresh; /* ema = max(ema*decay, sigma); occupied iff ema > thresh (default 5.9 =
+                                        upstream's optical thickness 0.01 over a sqrt(3)/1024 step) */
 } prv_train_opts;
 typedef struct prv_trainer prv_trainer;
 int prv_train_default_opts(prv_train_opts* opts);

@@ -44,7 +44,7 @@ class TrainOpts(C.Structure):
 
 TRAIN_DEFAULTS = dict(n_rays=4096, n_samples=128, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, l2_reg=1e-6, min_T=1e-4,
                       seed=0x7EA10001, random_bg=1, occ_every=16, occ_decay=0.95,
-                      occ_sigma_thresh=0.01 * 128 / 3 ** 0.5)
+                      occ_sigma_thresh=0.01 * 1024 / 3 ** 0.5)
 
 
 def train_opts(**kw):

@@ -5,6 +5,7 @@ import numpy as np, torch
 from nerf_prv_amd import api, planner
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 rays = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+thresh = float(sys.argv[3]) if len(sys.argv) > 3 else 0.01 * 128 / 3 ** 0.5
 ctx = api.Context(0)
 fd = dict(api.FIELD_256)
 ctx.synthetic_model(1, api.L.FieldDesc(**fd), 0x5EED0002)
@@ -21,7 +22,7 @@ gt, _ = ctx.render(1, cams, None, ropts)
 train_cams = ctx.cameras_from_matrices_intr(np.asarray(tms)[8:], intr, scale, offset)
 d = api.L.FieldDesc(**dict(fd, table_amp=1e-4, density_bias=0.0))
 ctx.fresh_model(0, d, 0x1234)
-tr = api.Trainer(ctx, 0, train_cams, u8[8:].contiguous(), api.train_opts(n_rays=rays))
+tr = api.Trainer(ctx, 0, train_cams, u8[8:].contiguous(), api.train_opts(n_rays=rays, occ_sigma_thresh=thresh))
 for chunk in range(steps // 500):
     tr.steps(500)
     img, st = ctx.render(0, cams, [0, 1], ropts)
