@@ -114,3 +114,39 @@ def test_evaluation_path_psnr_ssim_and_metrics_file(ctx, oracle, scene, tmp_path
     path = tmp_path / "64.txt"
     planner.write_metrics(path, mp, ms)
     assert planner.read_metrics(path) == (mp, ms)
+
+
+@pytest.mark.parametrize("which", ["256", "512"])
+def test_training_gradients_on_the_full_size_fields(ctx, oracle, which):
+    """one training batch on the BASELINE fields (256^3: L=8 F=4 T=2^19; 512^3: L=16 F=2 T=2^21) at 128 samples
+    per ray: same ray batch, loss and gradients within 1e-3 of the oracle -- covers the full-size level tables
+    (dense up to 79^3 / 215^3 vertices, 2^19 / 2^21-entry hashed levels) in the encoder's backward scatter"""
+    fd = dict(api.FIELD_256 if which == "256" else api.FIELD_512)
+    fd.update(density_bias=1.0, table_amp=0.5)  # moderate density: rays go several samples deep
+    d_p = api.L.FieldDesc(**fd)
+    d_o = oracle.desc(**fd)
+    f = oracle.OracleField(d_o, seed=util.SEED_A)
+    t, m, o = f.params()
+    ctx.load_model(3, d_p, t, m, o)
+    ctx.synthetic_model(1, api.L.FieldDesc(**dict(fd, density_bias=3.0, table_amp=4.0)), util.SEED_B)
+    pts = planner.hemisphere_generate(6)
+    tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
+    intr = {"fl_x": 70.0, "fl_y": 69.0, "cx": 47.5, "cy": 36.2, "w": 96, "h": 72, "k1": 0.05, "k2": -0.02, "p1": 0.001, "p2": -0.002}
+    cams = ctx.cameras_from_matrices_intr(tms, intr, scale, offset)
+    u8, _ = ctx.render_rgba8(1, cams, None, api.render_opts(96, 72, S, 1, 1e-4, background=(0, 0, 0, 0)))
+    imgs = u8.cpu().numpy()
+    ocams = oracle.cameras_from_dataset(tms, intr, scale, offset)
+    base = dict(n_rays=192, n_samples=S, occ_every=0)
+    otr = oracle.OracleTrainer(f, oracle.train_opts(**base), ocams, imgs)
+    gtr = api.Trainer(ctx, 3, cams, u8, api.train_opts(**base))
+    want_loss, want_tg, want_mg = otr.gradients()
+    loss, tg, mg = gtr.gradients()
+    assert gtr.info()["samples_last"] == otr.samples_last > 300
+    assert loss == pytest.approx(want_loss, rel=1e-3)
+    for got, want in ((mg, want_mg), (tg, want_tg)):
+        assert np.linalg.norm(got - want) <= 1e-3 * np.linalg.norm(want)
+        big = np.abs(want) > 1e-3 * np.abs(want).max()
+        assert big.sum() > 50
+        np.testing.assert_allclose(got[big], want[big], rtol=5e-3)
+    assert np.array_equal(np.flatnonzero(tg), np.flatnonzero(want_tg.astype(np.float32))) or \
+        np.linalg.norm(tg - want_tg) <= 1e-3 * np.linalg.norm(want_tg)
