@@ -48,6 +48,8 @@ struct prv_camset {
   bool dataset = false; // intrinsics are the dataset's (own principal point, fl_y, lens), not fov-at-centre
 };
 
+static void train_detach_all(struct prv_ctx* c);
+
 struct prv_ctx {
   int device = 0;
   int n_cu = 256;
@@ -62,6 +64,7 @@ struct prv_ctx {
   std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs
   int blocks_per_cu = 4;
   int refill_min = 32;
+  std::vector<struct prv_trainer*> trainers; // live trainers of this context (detached by prv_destroy)
   int queue_segments = 8; // ray-queue segments = XCDs (PRV_QUEUE_SEGMENTS: 1 = single shared head)
   int dbg_flags = 0;
   size_t stage_budget = (size_t)4 << 30; // staging bytes for multi-sample renders (spp x batch x image)
@@ -580,6 +583,7 @@ void prv_destroy(prv_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  train_detach_all(c); // trainers outliving their context become inert handles
   for (hipEvent_t e : c->ev_render) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_march) (void)hipEventDestroy(e);
   for (auto& m : c->models) {

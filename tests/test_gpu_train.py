@@ -175,3 +175,21 @@ def test_ensemble_members_step_side_by_side(ctx, oracle, scene):
     assert not np.allclose(together[0], together[1])  # members differ (seeds)
     with pytest.raises(api.PrvError):
         api.train_many([trs[0], trs[0]], 1)  # the same slot twice
+
+
+def test_trainer_outliving_its_context_is_inert(oracle, scene):
+    """destroying the context first must not leave a dangling trainer (interpreter shutdown order)"""
+    kw, ocams, cams_unused, imgs = scene
+    c2 = api.Context(0)
+    pts = util.fibonacci_hemisphere(8)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    cams = c2.cameras_from_matrices_intr(tms, INTR, scale, offset)
+    c2.fresh_model(0, api.field_desc(**kw), 3)
+    tr = api.Trainer(c2, 0, cams, c2.torch.from_numpy(imgs), api.train_opts(n_rays=64, n_samples=24))
+    tr.steps(2)
+    cams.close()
+    lib, handle = c2.lib, tr.handle
+    c2.close()  # context goes first
+    assert lib.prv_train_steps(handle, 1, None) != 0  # inert: an error code, no crash
+    lib.prv_train_destroy(handle)
+    tr.handle = None
