@@ -301,9 +301,14 @@ __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table,
   const uint32_t tz[2] = {(__umul24(c0[2], L.mz_b) & L.m_b) | L.off_b, (__umul24(c1[2], L.mz_b) & L.m_b) | L.off_b};
   uint32_t vw[8][F / 2]; // corner c = dx + 2dy + 4dz, F/2 packed pairs each
   if (PAIR) {
+    // physically dense level: nothing wraps (no masks) and the level offset folds into the z term
+    // (v_mad_u32_u24); the three terms occupy disjoint bits, so XOR and + agree with the generic form
+    const uint32_t dx0 = c0[0] << ESH;
+    const uint32_t dy[2] = {(uint32_t)__umul24(c0[1], L.my_b), (uint32_t)__umul24(c1[1], L.my_b)};
+    const uint32_t dz[2] = {(uint32_t)__umul24(c0[2], L.mz_b) + L.off_b, (uint32_t)__umul24(c1[2], L.mz_b) + L.off_b};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const uint32_t byte_off = tx[0] ^ ty[q & 1] ^ tz[q >> 1];
+      const uint32_t byte_off = dx0 ^ dy[q & 1] ^ dz[q >> 1];
       const EntryPair<F> e = EntryPair<F>::load(reinterpret_cast<const char*>(table) + byte_off);
 #pragma unroll
       for (int k = 0; k < F / 2; k++) {
