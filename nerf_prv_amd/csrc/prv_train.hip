@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) {
   const int lane = threadIdx.x & 63;
   const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (j >= (uint32_t)P.n_rays) return;
-  const uint64_t st = (uint64_t)P.step * 8u;
+  const uint64_t st = (uint64_t)P.state->step * 8u;
   const uint32_t img = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 0, j) * (uint64_t)P.n_img) >> 24);
   const uint32_t px = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 1, j) * (uint64_t)P.W) >> 24);
   const uint32_t py = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 2, j) * (uint64_t)P.H) >> 24);
@@ -579,8 +579,16 @@ __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositePara
 }
 
 // fixed-order sum of the per-ray losses and used-sample counts (one block)
+// first node of a step: the bias-corrected learning rate of step n = state->step + 1, the sample counter reset
+__global__ void train_begin_kernel(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2) {
+  const double n = (double)(state->step + 1u);
+  state->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, n)) / (1.0 - pow((double)beta1, n)));
+  *sample_count = 0u;
+}
+
 __global__ __launch_bounds__(256) void train_loss_kernel(const float* __restrict__ ray_loss,
-                                                         const uint32_t* __restrict__ ray_used, int n, float* out_loss,
+                                                         const uint32_t* __restrict__ ray_used, int n,
+                                                         const TrainState* __restrict__ state,
                                                          unsigned long long* out_used) {
   __shared__ double sl[256];
   __shared__ unsigned long long su[256];
@@ -600,17 +608,17 @@ __global__ __launch_bounds__(256) void train_loss_kernel(const float* __restrict
       t += sl[i];
       tu += su[i];
     }
-    *out_loss = (float)t;
+    state->losses[state->step - state->step0] = (float)t;
     *out_used = tu;
   }
 }
 
 // ------------------------------------------------------------------ optimiser
 
-__device__ __forceinline__ void adam_update(const AdamParams& P, float g, float& w, float& m, float& v) {
+__device__ __forceinline__ void adam_update(const AdamParams& P, float lr_t, float g, float& w, float& m, float& v) {
   m = fmaf(P.beta1, m, (1.0f - P.beta1) * g);
   v = fmaf(P.beta2, v, ((1.0f - P.beta2) * g) * g);
-  w = w - (P.lr_t * m) / (sqrtf(v) + P.eps);
+  w = w - (lr_t * m) / (sqrtf(v) + P.eps);
 }
 
 __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n, float* __restrict__ grad,
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n,
   if (g == 0.0f) return; // sparse: untouched entries keep their moments
   grad[i] = 0.0f;
   float ww = w[i], mm = m[i], vv = v[i];
-  adam_update(P, g, ww, mm, vv);
+  adam_update(P, P.state->lr_t, g, ww, mm, vv);
   w[i] = ww;
   m[i] = mm;
   v[i] = vv;
@@ -638,13 +646,14 @@ __global__ __launch_bounds__(256) void adam_mlp_kernel(AdamParams P, float l2_re
   const float g = fmaf(l2_reg, w[i], grad[i]);
   grad[i] = 0.0f;
   float ww = w[i], mm = m[i], vv = v[i];
-  adam_update(P, g, ww, mm, vv);
+  adam_update(P, P.state->lr_t, g, ww, mm, vv);
   w[i] = ww;
   m[i] = mm;
   v[i] = vv;
   const _Float16 hh = (_Float16)ww;
   w16[i] = __builtin_bit_cast(uint16_t, hh);
   w16_as_f32[i] = (float)hh;
+  if (i == 0) P.state->step = P.state->step + 1u; // last node of a step; nobody else reads `step` in this kernel
 }
 
 __global__ __launch_bounds__(256) void widen_kernel(const uint16_t* __restrict__ in, size_t n, float* __restrict__ out) {
@@ -713,16 +722,23 @@ hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s) {
 
 template <int F, bool FWD>
 static hipError_t launch_tile(const TrainTileParams& P, int n_blocks, hipStream_t s) {
-  const size_t lds = train_tile_lds_bytes(FWD);
-  static bool attr_set = false; // one attribute call per instantiation
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_tile_kernel<F, FWD>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((train_tile_kernel<F, FWD>), dim3(n_blocks), dim3(256), lds, s, P);
+  hipLaunchKernelGGL((train_tile_kernel<F, FWD>), dim3(n_blocks), dim3(256), train_tile_lds_bytes(FWD), s, P);
   return hipGetLastError();
+}
+
+// dynamic LDS above 64 KB has to be allowed per kernel, once, outside any stream capture
+hipError_t train_prepare_kernels() {
+  hipError_t e;
+#define PRV_ALLOW_LDS(F, FWD)                                                                                         \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_tile_kernel<F, FWD>),                               \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)train_tile_lds_bytes(FWD))) != hipSuccess) \
+    return e;
+  PRV_ALLOW_LDS(4, true)
+  PRV_ALLOW_LDS(4, false)
+  PRV_ALLOW_LDS(2, true)
+  PRV_ALLOW_LDS(2, false)
+#undef PRV_ALLOW_LDS
+  return hipSuccess;
 }
 
 hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s) {
@@ -740,9 +756,14 @@ hipError_t launch_train_composite(const TrainCompositeParams& P, hipStream_t s) 
   return hipGetLastError();
 }
 
-hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, float* out_loss,
+hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2, hipStream_t s) {
+  hipLaunchKernelGGL(train_begin_kernel, dim3(1), dim3(1), 0, s, state, sample_count, lr, beta1, beta2);
+  return hipGetLastError();
+}
+
+hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, const TrainState* state,
                              unsigned long long* out_used, hipStream_t s) {
-  hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(256), 0, s, ray_loss, ray_used, n, out_loss, out_used);
+  hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(256), 0, s, ray_loss, ray_used, n, state, out_used);
   return hipGetLastError();
 }
 

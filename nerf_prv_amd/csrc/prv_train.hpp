@@ -19,12 +19,21 @@ struct TrainRay {
   uint32_t pad[2];
 };
 
+// the per-step scalars live in device memory so that one captured HIP graph replays every step
+struct TrainState {
+  uint32_t step;  // completed steps
+  uint32_t step0; // first step of the current prv_train_steps call (loss slot = step - step0)
+  float lr_t;     // bias-corrected learning rate of the step in flight
+  uint32_t pad;
+  float* losses;  // where the call's per-step losses go
+};
+
 struct TrainRaysParams {
   const CamDev* cams;    // n_img dataset cameras at (W, H)
   const uint8_t* images; // n_img * H * W * 4 straight-alpha sRGB bytes
   const uint32_t* occ;
   int n_img, W, H, S, n_rays, occ_res, random_bg;
-  uint32_t step;
+  const TrainState* state; // step number = state->step
   uint64_t seed;
   TrainRay* rays;
   uint2* samples; // (ray, sample index) of every live sample, grouped by ray
@@ -58,7 +67,8 @@ struct TrainCompositeParams {
 };
 
 struct AdamParams {
-  float lr_t, beta1, beta2, eps;
+  TrainState* state; // lr_t read from it; adam_mlp_kernel advances state->step
+  float beta1, beta2, eps;
 };
 
 struct DensityParams {
@@ -72,10 +82,12 @@ struct DensityParams {
 };
 
 size_t train_tile_lds_bytes(bool fwd);
+hipError_t train_prepare_kernels();
 hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s);
 hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s);
 hipError_t launch_train_composite(const TrainCompositeParams& P, hipStream_t s);
-hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, float* out_loss,
+hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2, hipStream_t s);
+hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, const TrainState* state,
                              unsigned long long* out_used, hipStream_t s);
 hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* w, float* m, float* v, uint16_t* w16,
                              hipStream_t s);
