@@ -193,3 +193,39 @@ def test_trainer_outliving_its_context_is_inert(oracle, scene):
     assert lib.prv_train_steps(handle, 1, None) != 0  # inert: an error code, no crash
     lib.prv_train_destroy(handle)
     tr.handle = None
+
+
+@pytest.mark.parametrize("n_rays,n_samples", [(37, 5), (1, 1), (130, 128)])
+def test_ragged_batch_sizes(ctx, oracle, scene, n_rays, n_samples):
+    """ray counts that do not fill a block / a wave, one sample per ray, the full 128: same batch, same loss"""
+    f, otr, gtr = start(ctx, oracle, scene, n_rays=n_rays, n_samples=n_samples)
+    want_loss, want_tg, want_mg = otr.gradients()
+    loss, tg, mg = gtr.gradients()
+    assert gtr.info()["samples_last"] == otr.samples_last
+    assert loss == pytest.approx(want_loss, rel=1e-3, abs=1e-9)
+    if otr.samples_last:
+        assert rel_l2(mg, want_mg) < 2e-3 and rel_l2(tg, want_tg) < 2e-3
+    else:
+        assert not tg.any() and not mg.any()
+    got, want = gtr.steps(3), [otr.step() for _ in range(3)]
+    np.testing.assert_allclose(got, want, rtol=5e-3, atol=1e-9)
+
+
+def test_rays_that_miss_everything(ctx, oracle, scene):
+    """an empty density grid: no sample is live, the loss is the background mismatch alone, nothing moves"""
+    kw, ocams, cams, imgs = scene
+    f = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
+    t, m, o = f.params()
+    o = np.zeros_like(o)
+    f = oracle.OracleField(f.desc, params=(t, m, o))
+    ctx.load_model(3, api.field_desc(**kw), t, m, o)
+    base = dict(n_rays=200, n_samples=24, occ_every=0, l2_reg=0.0)
+    otr = oracle.OracleTrainer(f, oracle.train_opts(**base), ocams, imgs)
+    gtr = api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(**base))
+    loss, tg, mg = gtr.gradients()
+    assert gtr.info()["samples_last"] == otr.samples_last == 0
+    assert loss == pytest.approx(otr.gradients()[0], rel=1e-5) and loss > 0 and not tg.any() and not mg.any()
+    before = gtr.master()
+    gtr.steps(2)
+    after = gtr.master()
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
