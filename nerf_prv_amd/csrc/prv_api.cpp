@@ -31,6 +31,7 @@ struct Buffer {
 
 struct Model {
   bool loaded = false;
+  bool dirty = false; // a trainer changed the canonical arrays: the derived render state is rebuilt on first use
   prv_field_desc desc{};
   FieldDev dev{};
   uint64_t table_halfs = 0, occ_words = 0;
@@ -353,12 +354,37 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
     L.pad0 = L.pad1 = 0;
   }
   m.loaded = true;
+  m.dirty = false;
   return PRV_OK;
 }
 
-int check_model(prv_ctx* c, int slot) {
+// derived state from the canonical arrays that already sit in the model's device buffers
+int republish_model(prv_ctx* c, int slot) {
+  Model& m = c->models[slot];
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<uint16_t> mlp(PRV_MLP_HALFS);
+  std::vector<uint32_t> occ(m.occ_words);
+  HIPCHK(c, hipMemcpyAsync(mlp.data(), m.mlp.p, PRV_MLP_HALFS * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(occ.data(), m.occ.p, m.occ_words * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const prv_field_desc d = m.desc;
+  return install_model(c, slot, d, mlp.data(), occ.data(), nullptr);
+}
+
+int model_present(prv_ctx* c, int slot) {
   if (slot < 0 || slot >= PRV_MAX_MODELS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
   if (!c->models[slot].loaded) return fail(c, PRV_E_STATE, "model slot %d is empty", slot);
+  return PRV_OK;
+}
+
+int republish_model(prv_ctx* c, int slot);
+
+// every render / score / export entry point comes through here: a slot a trainer has stepped since its last
+// use gets its derived state (physical table, MFMA fragments, coarse occupancy, bounding box) rebuilt first
+int check_model(prv_ctx* c, int slot) {
+  int rc = model_present(c, slot);
+  if (rc != PRV_OK) return rc;
+  if (c->models[slot].dirty) return republish_model(c, slot);
   return PRV_OK;
 }
 

@@ -42,6 +42,9 @@ struct HipScorer {
 
   // train_by_instantNGP(json/<it>.json, ..., ensemble_id = e) for every member, in process
   int train_members(const std::string& scene_json) {
+    const bool timing = getenv("PRV_PLANNER_TIMING") != nullptr; // dev: where an iteration's seconds go
+    const double t_start = now_seconds();
+    double t_gt = 0, t_fresh = 0, t_create = 0, t_steps = 0;
     prv_camset* ds = nullptr;
     if (prv_cameras_from_dataset_json(ctx, scene_json.c_str(), &ds) != PRV_OK) return -30;
     int w = 0, h = 0;
@@ -56,17 +59,33 @@ struct HipScorer {
     uint8_t* imgs = nullptr;
     int rc = prv_malloc(ctx, (void**)&imgs, (size_t)n * o.width * o.height * 4);
     if (rc == PRV_OK) rc = prv_render_rgba8(ctx, 6, ds, nullptr, n, &o, imgs, nullptr); // straight alpha over nothing
+    if (timing) {
+      prv_synchronize(ctx);
+      t_gt = now_seconds() - t_start;
+    }
+    // the members train side by side (prv_train_steps_multi), each from its own seeds
+    std::vector<prv_trainer*> trs;
     for (int e = 0; rc == PRV_OK && e < n_members; e++) {
+      double t0 = now_seconds();
       rc = prv_model_fresh(ctx, e, &train_desc, train_seed + (uint64_t)e);
+      t_fresh += now_seconds() - t0;
       prv_train_opts to;
       prv_train_default_opts(&to);
       to.n_rays = train_rays;
       to.seed += (uint64_t)e;
       prv_trainer* tr = nullptr;
+      t0 = now_seconds();
       if (rc == PRV_OK) rc = prv_train_create(ctx, e, ds, imgs, o.width, o.height, &to, &tr);
-      if (rc == PRV_OK) rc = prv_train_steps(tr, train_steps, nullptr);
-      prv_train_destroy(tr);
+      t_create += now_seconds() - t0;
+      if (tr) trs.push_back(tr);
     }
+    double t0 = now_seconds();
+    if (rc == PRV_OK && !trs.empty()) rc = prv_train_steps_multi(trs.data(), (int)trs.size(), train_steps, nullptr);
+    t_steps = now_seconds() - t0;
+    for (prv_trainer* tr : trs) prv_train_destroy(tr);
+    if (timing)
+      std::cerr << "train_members: views " << n << " gt " << t_gt << " s, fresh " << t_fresh << " s, create " << t_create
+                << " s, steps " << t_steps << " s, total " << now_seconds() - t_start << " s" << std::endl;
     if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
     prv_camset_destroy(ds);
     if (imgs) prv_free(ctx, imgs);

@@ -6,6 +6,7 @@
 // point-cloud / OctoMap asset preparation, PCL rendering, PRVNet itself (method 4 takes its view budget
 // from a callback or from the file PRVNet's server would have written).
 #pragma once
+#include <chrono>
 #include <cstdio>
 #include <ctime>
 #include <functional>
@@ -81,6 +82,13 @@ inline Value transforms_header(const rs2_intrinsics& K, int aabb_scale, double p
   return root;
 }
 
+// elapsed seconds.  The reference divides clock() by CLOCKS_PER_SEC (main.cpp:1660, 1703): on its platform
+// (MSVC) clock() is wall time; on Linux it is the process CPU time (every HIP runtime thread counted), so
+// the meaning -- elapsed seconds -- is kept, not the call
+inline double now_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 inline bool write_text(const std::string& path, const std::string& text) {
   FILE* f = fopen(path.c_str(), "wb");
   if (!f) return false;
@@ -136,11 +144,11 @@ public:
   // Only the nbv_test / ensemble branch (the candidate-scoring use, :1676-1684) is on the path.
   int train_by_instantNGP(const std::string& trian_json_file, const std::vector<int>& candidate_ids,
                           std::vector<double>& scores) {
-    const std::clock_t t0 = std::clock();
+    const double t0 = now_seconds();
     const std::string scene = share_data->save_path + "/json/" + trian_json_file + ".json";
     const std::string render = share_data->save_path + "/render_json/" + trian_json_file + ".json";
     const int rc = scorer(share_data->method_of_IG, std::atoi(trian_json_file.c_str()), scene, render, candidate_ids, scores);
-    const double cost_time = double(std::clock() - t0) / CLOCKS_PER_SEC;
+    const double cost_time = now_seconds() - t0;
     std::string t = std::to_string(cost_time) + "\n";
     write_text(share_data->save_path + "/train_time/" + trian_json_file + ".txt", t); // :1708-1710
     return rc;
@@ -173,7 +181,7 @@ public:
     total_movement_cost = 0.0; // :1867
     std::set<int> chosen_nbvs_set{first_view_id};
     std::mt19937 rng(12345); // the reference seeds rand() with clock() (Share_Data.hpp:514): unreproducible by design
-    const std::clock_t loop_t0 = std::clock();
+    const double loop_t0 = now_seconds();
     int iteration = 0;
     std::vector<int> oneshot_views; // methods 1 and 4: the planned tour, consumed front to back
     bool oneshot_planned = false;
@@ -197,11 +205,11 @@ public:
       write_text(sd.save_path + "/json/" + it + ".json", prvjson::to_styled_string(now_nbvs_json));          // :1918-1920
       write_text(sd.save_path + "/render_json/" + it + ".json", prvjson::to_styled_string(now_render_json)); // :1922-1924
       if (iteration == sd.num_of_max_iteration || candidates.empty()) { // :1946-1966
-        const double loops_time = double(std::clock() - loop_t0) / CLOCKS_PER_SEC;
+        const double loops_time = now_seconds() - loop_t0;
         write_text(sd.save_path + "/run_time.txt", std::to_string(loops_time) + "\n");
         break;
       }
-      const std::clock_t infer_t0 = std::clock();
+      const double infer_t0 = now_seconds();
       int next_view_id = -1;
       switch (sd.method_of_IG) {
         case RandomIterative: { // :1974-1979
@@ -314,7 +322,7 @@ public:
       chosen_nbvs.push_back(next_view_id); // :2246-2247
       chosen_nbvs_set.insert(next_view_id);
       write_text(sd.save_path + "/infer_time/" + it + ".txt",
-                 std::to_string(double(std::clock() - infer_t0) / CLOCKS_PER_SEC) + "\n"); // :2250-2253
+                 std::to_string(now_seconds() - infer_t0) + "\n"); // :2250-2253
       // movement cost: view id \t local path \t running total (:2256-2264)
       const auto local_path = get_local_path(view_space->views[chosen_nbvs[iteration]].init_pos,
                                              view_space->views[next_view_id].init_pos,
