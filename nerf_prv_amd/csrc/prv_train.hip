@@ -589,14 +589,22 @@ __global__ void train_begin_kernel(TrainState* state, uint32_t* sample_count, fl
 __global__ __launch_bounds__(256) void train_loss_kernel(const float* __restrict__ ray_loss,
                                                          const uint32_t* __restrict__ ray_used, int n,
                                                          const TrainState* __restrict__ state,
-                                                         unsigned long long* out_used) {
+                                                         unsigned long long* out_used, double* __restrict__ part,
+                                                         uint32_t* __restrict__ ticket) {
+  // stage 1: every block sums its 1024-ray slice in a fixed order; stage 2: the block that arrives last adds
+  // the slices in slice order -- the result does not depend on which block that is
   __shared__ double sl[256];
   __shared__ unsigned long long su[256];
+  __shared__ bool last;
   double a = 0.0;
   unsigned long long u = 0ull;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    a += (double)ray_loss[i];
-    u += ray_used[i];
+  const int base = blockIdx.x * 1024;
+  for (int k = 0; k < 4; k++) {
+    const int i = base + k * 256 + threadIdx.x;
+    if (i < n) {
+      a += (double)ray_loss[i];
+      u += ray_used[i];
+    }
   }
   sl[threadIdx.x] = a;
   su[threadIdx.x] = u;
@@ -608,8 +616,23 @@ __global__ __launch_bounds__(256) void train_loss_kernel(const float* __restrict
       t += sl[i];
       tu += su[i];
     }
+    part[2 * blockIdx.x] = t;
+    part[2 * blockIdx.x + 1] = __longlong_as_double((long long)tu);
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    double t = 0.0;
+    unsigned long long tu = 0ull;
+    for (unsigned i = 0; i < gridDim.x; i++) {
+      t += __hip_atomic_load(part + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tu += (unsigned long long)__double_as_longlong(__hip_atomic_load(part + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
     state->losses[state->step - state->step0] = (float)t;
     *out_used = tu;
+    *ticket = 0u; // ready for the next step
   }
 }
 
@@ -762,8 +785,9 @@ hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float l
 }
 
 hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, const TrainState* state,
-                             unsigned long long* out_used, hipStream_t s) {
-  hipLaunchKernelGGL(train_loss_kernel, dim3(1), dim3(256), 0, s, ray_loss, ray_used, n, state, out_used);
+                             unsigned long long* out_used, double* part, uint32_t* ticket, hipStream_t s) {
+  hipLaunchKernelGGL(train_loss_kernel, dim3((n + 1023) / 1024), dim3(256), 0, s, ray_loss, ray_used, n, state, out_used, part,
+                     ticket);
   return hipGetLastError();
 }
 

@@ -88,7 +88,7 @@ hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_bloc
 hipError_t launch_train_composite(const TrainCompositeParams& P, hipStream_t s);
 hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2, hipStream_t s);
 hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, const TrainState* state,
-                             unsigned long long* out_used, hipStream_t s);
+                             unsigned long long* out_used, double* part, uint32_t* ticket, hipStream_t s);
 hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* w, float* m, float* v, uint16_t* w16,
                              hipStream_t s);
 hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float* w, float* m, float* v, uint16_t* w16,
