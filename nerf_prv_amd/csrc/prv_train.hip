@@ -475,6 +475,81 @@ __global__ __launch_bounds__(256) void train_reduce_dw_kernel(const float* __res
   if (grp == 0 && i < PRV_MLP_HALFS) mlp_grad[i] += (part[0][w] + part[1][w]) + (part[2][w] + part[3][w]);
 }
 
+// ------------------------------------------------------------------ forward at inference speed
+
+// the 24 MFMA A-fragments of the current fp16 weights (the layout prv_api.cpp: prepack_fragments gives the
+// render kernel), rebuilt on the device after every optimiser step: one thread per fragment element
+__device__ __forceinline__ int frag_hidden_k(int s, int h, int j) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+__global__ __launch_bounds__(256) void prepack_frags_kernel(const uint16_t* __restrict__ mlp, int n_features,
+                                                            uint16_t* __restrict__ frags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kNumFrags * kFragHalfs) return;
+  const int f = i / kFragHalfs, lane = (i % kFragHalfs) >> 3, j = i & 7;
+  const int r = lane & 31, h = lane >> 5;
+  int layer, mt, st;
+  if (f < 4) { layer = 0; mt = f >> 1; st = f & 1; }
+  else if (f < 8) { layer = 1; mt = 0; st = f - 4; }
+  else if (f < 12) { layer = 2; mt = (f - 8) >> 1; st = (f - 8) & 1; }
+  else if (f < 20) { layer = 3; mt = (f - 12) >> 2; st = (f - 12) & 3; }
+  else { layer = 4; mt = 0; st = f - 20; }
+  int k;
+  if (layer == 0) k = n_features == 4 ? 4 * (2 * (st * 2 + j / 4) + h) + j % 4 : 2 * (2 * (st * 4 + j / 2) + h) + j % 2;
+  else if (layer == 2) k = st == 0 ? frag_hidden_k(0, h, j) : 16 + 8 * h + j;
+  else k = frag_hidden_k(st, h, j);
+  const int out = 32 * mt + r;
+  frags[i] = out < kLOut[layer] ? mlp[kLOff[layer] + k * kLOut[layer] + out] : (uint16_t)0;
+}
+
+// logits of every live sample with the render kernel's machinery: a lane pair per sample, each lane encodes
+// every other level from the CANONICAL table (what the optimiser updates), both MLPs as 24
+// v_mfma_f32_32x32x16_f16 on the prepacked fragments -- 32 samples per wave and round, no LDS round trips
+template <int F>
+__global__ __launch_bounds__(256) void train_forward_fast_kernel(TrainTileParams P, const half8* __restrict__ frags) {
+  __shared__ half8 wl[kNumFrags * 64];
+  __shared__ LevelCanon lv[16];
+  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = frags[i];
+  if (threadIdx.x < 16 * (int)(sizeof(LevelCanon) / 4))
+    reinterpret_cast<uint32_t*>(lv)[threadIdx.x] = reinterpret_cast<const uint32_t*>(P.levels)[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const uint32_t n_samples = *P.sample_count;
+  const uint32_t n_tiles = (n_samples + 31u) / 32u;
+  constexpr int LH = 16 / F;
+  for (uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * 4u) {
+    const uint32_t sid = tile * 32u + (uint32_t)r;
+    const bool live = sid < n_samples;
+    float pos[3] = {0.5f, 0.5f, 0.5f}, dir[3] = {0.f, 0.f, 1.f};
+    if (live) {
+      const uint2 sr = P.samples[sid];
+      const TrainRay* ray = P.rays + sr.x;
+      const float t = fmaf((float)sr.y + ray->jitter, ray->dt, ray->t0);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        dir[a] = ray->d[a];
+        pos[a] = fmaf(t, dir[a], ray->o[a]);
+      }
+    }
+    half8 f0, f1;
+#pragma unroll
+    for (int j = 0; j < LH; j++) {
+      const LevelCanon L = lv[2 * j + h];
+      float f[F], cw[8];
+      uint32_t ci[8];
+      train_encode_level<F>(P.table, L, pos[0], pos[1], pos[2], f, ci, cw);
+#pragma unroll
+      for (int k = 0; k < F; k++) {
+        const int e = j * F + k;
+        if (e < 8) f0[e] = (_Float16)f[k];
+        else f1[e - 8] = (_Float16)f[k];
+      }
+    }
+    const half8 shf = sh_fragment(h, dir[0], dir[1], dir[2]);
+    const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf);
+    if (live && h == 0) P.logits[sid] = make_float4(mo.dens[0], mo.rgb[0], mo.rgb[1], mo.rgb[2]);
+  }
+}
+
 // ------------------------------------------------------------------ compositing, loss, gradient seeds
 
 // one WAVE = one ray, one lane = one sample (two chunks of 64 for up to 128 samples): transmittance by a
@@ -771,6 +846,17 @@ hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_bloc
   if (e != hipSuccess || forward) return e;
   hipLaunchKernelGGL(train_reduce_dw_kernel, dim3((PRV_MLP_HALFS + 63) / 64), dim3(256), 0, s, P.mlp_grad_partial, n_blocks,
                      P.mlp_grad);
+  return hipGetLastError();
+}
+
+hipError_t launch_prepack_frags(const uint16_t* mlp, int n_features, uint16_t* frags, hipStream_t s) {
+  hipLaunchKernelGGL(prepack_frags_kernel, dim3((kNumFrags * kFragHalfs + 255) / 256), dim3(256), 0, s, mlp, n_features, frags);
+  return hipGetLastError();
+}
+
+hipError_t launch_train_forward_fast(const TrainTileParams& P, const half8* frags, int n_blocks, hipStream_t s) {
+  if (P.n_features == 4) hipLaunchKernelGGL(train_forward_fast_kernel<4>, dim3(n_blocks), dim3(256), 0, s, P, frags);
+  else hipLaunchKernelGGL(train_forward_fast_kernel<2>, dim3(n_blocks), dim3(256), 0, s, P, frags);
   return hipGetLastError();
 }
 

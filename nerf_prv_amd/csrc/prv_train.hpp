@@ -85,6 +85,8 @@ size_t train_tile_lds_bytes(bool fwd);
 hipError_t train_prepare_kernels();
 hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s);
 hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s);
+hipError_t launch_prepack_frags(const uint16_t* mlp, int n_features, uint16_t* frags, hipStream_t s);
+hipError_t launch_train_forward_fast(const TrainTileParams& P, const half8* frags, int n_blocks, hipStream_t s);
 hipError_t launch_train_composite(const TrainCompositeParams& P, hipStream_t s);
 hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2, hipStream_t s);
 hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, const TrainState* state,
