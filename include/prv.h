@@ -275,6 +275,10 @@ typedef struct prv_train_opts {
   int32_t occ_every; /* refresh the density grid every N steps (0 = never) */
   float occ_decay, occ_sigma_thresh; /* ema = max(ema*decay, sigma); occupied iff ema > thresh (default 5.9 =
                                         upstream's optical thickness 0.01 over a sqrt(3)/1024 step) */
+  int32_t target_samples; /* > 0: the ray count of a step adapts so that about this many samples are composited
+                             (upstream keeps 2^18 samples per batch): after every step active = clamp(target *
+                             active / used, active/2, 2*active) within [1, n_rays]; first step min(n_rays,
+                             target / n_samples).  0: always n_rays */
 } prv_train_opts;
 typedef struct prv_trainer prv_trainer;
 int prv_train_default_opts(prv_train_opts* opts);
@@ -290,6 +294,8 @@ int prv_train_steps(prv_trainer* t, int n_steps, float* losses_host);
 int prv_train_steps_multi(prv_trainer** trainers, int n_trainers, int n_steps, float* losses_host);
 int prv_train_info(const prv_trainer* t, uint32_t* steps_done, uint64_t* samples_last_batch,
                    uint64_t* table_scalars);
+/* rays the next step will cast (= n_rays unless target_samples is set) */
+int prv_train_active_rays(const prv_trainer* t);
 void prv_train_destroy(prv_trainer* t);
 /* parity hooks: gradients of the NEXT batch without an update (host arrays: table_scalars and
  * PRV_MLP_HALFS floats), the fp32 master weights, one density-grid refresh */

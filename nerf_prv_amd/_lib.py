@@ -70,7 +70,7 @@ class TrainOpts(C.Structure):
     _fields_ = [("n_rays", C.c_int32), ("n_samples", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("eps", C.c_float), ("l2_reg", C.c_float), ("min_T", C.c_float),
                 ("seed", C.c_uint64), ("random_bg", C.c_int32), ("occ_every", C.c_int32), ("occ_decay", C.c_float),
-                ("occ_sigma_thresh", C.c_float)]
+                ("occ_sigma_thresh", C.c_float), ("target_samples", C.c_int32)]
 
 
 _vp = C.c_void_p
@@ -127,6 +127,7 @@ SIGNATURES = {
     "prv_train_steps_multi": (_i, [_vp, _i, _i, _vp]),
     "prv_train_debug_stamps": (_i, [_vp, _vp]),
     "prv_train_info": (_i, [_vp, _P(C.c_uint32), _P(C.c_uint64), _P(C.c_uint64)]),
+    "prv_train_active_rays": (_i, [_vp]),
     "prv_train_destroy": (None, [_vp]),
     "prv_train_gradients": (_i, [_vp, _vp, _vp, _P(C.c_float)]),
     "prv_train_master": (_i, [_vp, _vp, _vp]),

@@ -399,7 +399,8 @@ class Trainer:
     def info(self):
         s, u, n = C.c_uint32(), C.c_uint64(), C.c_uint64()
         self.ctx.lib.prv_train_info(self.handle, C.byref(s), C.byref(u), C.byref(n))
-        return {"steps": s.value, "samples_last": u.value, "table_scalars": n.value}
+        return {"steps": s.value, "samples_last": u.value, "table_scalars": n.value,
+                "active_rays": self.ctx.lib.prv_train_active_rays(self.handle)}
 
     def gradients(self):
         n = self.info()["table_scalars"]

@@ -59,7 +59,7 @@ __device__ __forceinline__ bool occ_bit(const uint32_t* __restrict__ occ, int R,
 __global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) {
   const int lane = threadIdx.x & 63;
   const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (j >= (uint32_t)P.n_rays) return;
+  if (j >= P.state->n_active) return;
   const uint64_t st = (uint64_t)P.state->step * 8u;
   const uint32_t img = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 0, j) * (uint64_t)P.n_img) >> 24);
   const uint32_t px = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 1, j) * (uint64_t)P.W) >> 24);
@@ -580,7 +580,14 @@ __device__ __forceinline__ float scan_add_rev_incl(float v, int lane) {
 __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositeParams P) {
   const int lane = threadIdx.x & 63;
   const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (j >= (uint32_t)P.n_rays) return;
+  const uint32_t n_active = P.state->n_active;
+  if (j >= n_active) {
+    if (j < (uint32_t)P.n_rays && (threadIdx.x & 63) == 0) { // rays outside this step's budget count for nothing
+      P.ray_loss[j] = 0.0f;
+      P.ray_used[j] = 0u;
+    }
+    return;
+  }
   TrainRay* ray = P.rays + j;
   const uint32_t n = ray->n_live, off = ray->offset;
   const float dt = ray->dt;
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositePara
     if (n <= 64u) break;
   }
   float dC[3], loss = 0.0f, tail[3];
-  const float inv = 1.0f / (3.0f * (float)P.n_rays);
+  const float inv = 1.0f / (3.0f * (float)n_active);
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     const float e = fmaf(T, ray->bg[c], C[c]) - ray->target[c];
@@ -751,7 +758,19 @@ __global__ __launch_bounds__(256) void adam_mlp_kernel(AdamParams P, float l2_re
   const _Float16 hh = (_Float16)ww;
   w16[i] = __builtin_bit_cast(uint16_t, hh);
   w16_as_f32[i] = (float)hh;
-  if (i == 0) P.state->step = P.state->step + 1u; // last node of a step; nobody else reads `step` in this kernel
+  if (i == 0) { // last node of a step; nobody else reads these in this kernel
+    P.state->step = P.state->step + 1u;
+    if (P.target_samples > 0) { // the sample budget (integer rule, mirrored by oracle/prv_train.c)
+      const unsigned long long used = *P.used ? *P.used : 1ull;
+      const unsigned long long act = P.state->n_active;
+      unsigned long long a = (unsigned long long)P.target_samples * act / used;
+      a = max(a, act / 2ull);
+      a = min(a, act * 2ull);
+      a = max(a, 1ull);
+      a = min(a, (unsigned long long)P.n_rays);
+      P.state->n_active = (uint32_t)a;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void widen_kernel(const uint16_t* __restrict__ in, size_t n, float* __restrict__ out) {

@@ -24,7 +24,7 @@ struct TrainState {
   uint32_t step;  // completed steps
   uint32_t step0; // first step of the current prv_train_steps call (loss slot = step - step0)
   float lr_t;     // bias-corrected learning rate of the step in flight
-  uint32_t pad;
+  uint32_t n_active; // rays of the step in flight (<= n_rays; adapts to the sample budget)
   float* losses;  // where the call's per-step losses go
 };
 
@@ -58,6 +58,7 @@ struct TrainTileParams {
 
 struct TrainCompositeParams {
   TrainRay* rays;
+  const TrainState* state; // n_active rays take part
   int n_rays;
   const float4* logits;
   float4* seeds;
@@ -67,8 +68,10 @@ struct TrainCompositeParams {
 };
 
 struct AdamParams {
-  TrainState* state; // lr_t read from it; adam_mlp_kernel advances state->step
+  TrainState* state; // lr_t read from it; adam_mlp_kernel advances state->step and adapts state->n_active
   float beta1, beta2, eps;
+  const unsigned long long* used; // samples composited by the step (sample budget rule)
+  int target_samples, n_rays;
 };
 
 struct DensityParams {

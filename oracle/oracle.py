@@ -39,12 +39,12 @@ class TrainOpts(C.Structure):
     _fields_ = [("n_rays", C.c_int32), ("n_samples", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("eps", C.c_float), ("l2_reg", C.c_float), ("min_T", C.c_float),
                 ("seed", C.c_uint64), ("random_bg", C.c_int32), ("occ_every", C.c_int32), ("occ_decay", C.c_float),
-                ("occ_sigma_thresh", C.c_float)]
+                ("occ_sigma_thresh", C.c_float), ("target_samples", C.c_int32)]
 
 
 TRAIN_DEFAULTS = dict(n_rays=4096, n_samples=128, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, l2_reg=1e-6, min_T=1e-4,
                       seed=0x7EA10001, random_bg=1, occ_every=16, occ_decay=0.95,
-                      occ_sigma_thresh=0.01 * 1024 / 3 ** 0.5)
+                      occ_sigma_thresh=0.01 * 1024 / 3 ** 0.5, target_samples=1 << 18)
 
 
 def train_opts(**kw):
@@ -99,6 +99,7 @@ def lib():
         L.orc_train_field.restype, L.orc_train_field.argtypes = C.POINTER(Field), [vp]
         L.orc_train_steps_done.restype, L.orc_train_steps_done.argtypes = C.c_uint32, [vp]
         L.orc_train_samples_last.restype, L.orc_train_samples_last.argtypes = C.c_uint64, [vp]
+        L.orc_train_active_rays.restype, L.orc_train_active_rays.argtypes = C.c_uint32, [vp]
         L.orc_train_master_table.restype, L.orc_train_master_table.argtypes = C.POINTER(C.c_float), [vp]
         L.orc_train_master_mlp.restype, L.orc_train_master_mlp.argtypes = C.POINTER(C.c_float), [vp]
         L.orc_train_table_size.restype, L.orc_train_table_size.argtypes = C.c_size_t, [vp]
@@ -424,6 +425,10 @@ class OracleTrainer:
     @property
     def samples_last(self):
         return lib().orc_train_samples_last(self.ptr)
+
+    @property
+    def active_rays(self):
+        return lib().orc_train_active_rays(self.ptr)
 
     def refresh_occupancy(self):
         lib().orc_train_refresh_occupancy(self.ptr)

@@ -172,6 +172,7 @@ typedef struct {
   int32_t random_bg; /* 1: a random background colour per ray blends target and prediction */
   int32_t occ_every; /* refresh the density grid every N steps (0: never) */
   float occ_decay, occ_sigma_thresh; /* ema = max(ema*decay, sigma); occupied iff ema > thresh */
+  int32_t target_samples; /* > 0: adaptive ray count, see include/prv.h */
 } orc_train_opts;
 typedef struct orc_trainer orc_trainer;
 uint32_t orc_rng_u24(uint64_t seed, uint64_t stream, uint64_t i);
@@ -187,6 +188,7 @@ void orc_train_refresh_occupancy(orc_trainer* t);
 const orc_field* orc_train_field(const orc_trainer* t);
 uint32_t orc_train_steps_done(const orc_trainer* t);
 uint64_t orc_train_samples_last(const orc_trainer* t);
+uint32_t orc_train_active_rays(const orc_trainer* t); /* ray count of the next step */
 float* orc_train_master_table(orc_trainer* t);
 float* orc_train_master_mlp(orc_trainer* t);
 size_t orc_train_table_size(const orc_trainer* t);

@@ -12,8 +12,9 @@
  * pass in `exact` mode (no fp16 rounding), and the HIP trainer against this file.
  *
  * Deliberate simplifications against upstream, stated: fixed S uniform samples between the AABB hits
- * (the marcher of this build) with one random offset per ray instead of exponential stepping; fixed
- * ray count per step instead of a fixed sample budget; fp32 gradients and master weights (upstream:
+ * (the marcher of this build) with one random offset per ray instead of exponential stepping; the sample
+ * budget of a step is kept by a simple integer rule on the ray count (upstream smooths its own estimate);
+ * fp32 gradients and master weights (upstream:
  * fp16 gradients with loss scaling); the density grid is refreshed over ALL cells at their centres.
  */
 #include "prv_oracle.h"
@@ -50,6 +51,7 @@ struct orc_trainer {
   int n_img, w, h;
   const uint8_t* rgba8;
   uint32_t step; /* completed steps */
+  uint32_t n_active; /* rays of the next step */
   uint64_t n_samples_last;
 };
 
@@ -208,9 +210,9 @@ static double tr_ray(orc_trainer* t, uint32_t step, uint32_t j, int grad, tr_sam
     pred[k] = fmaf(T, bg[k], C[k]);
     const double e = (double)pred[k] - (double)target[k];
     loss += e * e;
-    dC[k] = 2.0 * e / (3.0 * (double)o->n_rays);
+    dC[k] = 2.0 * e / (3.0 * (double)t->n_active);
   }
-  loss /= 3.0 * (double)o->n_rays;
+  loss /= 3.0 * (double)t->n_active;
   if (!grad) return loss;
 
   /* suffix[k] = sum_{j>i} w_j c_j + T_final bg: walk the samples back to front */
@@ -273,6 +275,12 @@ orc_trainer* orc_train_create(const orc_field* init, const orc_train_opts* o, co
   t->ema = (float*)calloc(R * R * R, sizeof(float));
   for (size_t i = 0; i < t->n_table; i++) t->tab_w[i] = orc_h2f(init->table[i]);
   for (int i = 0; i < ORC_MLP_HALFS; i++) t->mlp_w[i] = orc_h2f(init->mlp[i]);
+  t->n_active = (uint32_t)o->n_rays;
+  if (o->target_samples > 0) {
+    uint32_t a = (uint32_t)o->target_samples / (uint32_t)o->n_samples;
+    if (a < 1u) a = 1u;
+    if (a < t->n_active) t->n_active = a;
+  }
   t->cams = cams;
   t->n_img = n_img;
   t->w = w;
@@ -295,13 +303,14 @@ void orc_train_free(orc_trainer* t) {
 const orc_field* orc_train_field(const orc_trainer* t) { return t->f; }
 uint32_t orc_train_steps_done(const orc_trainer* t) { return t->step; }
 uint64_t orc_train_samples_last(const orc_trainer* t) { return t->n_samples_last; }
+uint32_t orc_train_active_rays(const orc_trainer* t) { return t->n_active; }
 
 /* loss of the NEXT step's ray batch under the current parameters, no gradient, no update */
 double orc_train_loss_only(orc_trainer* t) {
   tr_sample* S = (tr_sample*)malloc(sizeof(tr_sample) * TR_MAX_S);
   double loss = 0.0;
   t->n_samples_last = 0;
-  for (uint32_t j = 0; j < (uint32_t)t->o.n_rays; j++) loss += tr_ray(t, t->step, j, 0, S);
+  for (uint32_t j = 0; j < t->n_active; j++) loss += tr_ray(t, t->step, j, 0, S);
   free(S);
   return loss;
 }
@@ -313,7 +322,7 @@ double orc_train_gradients(orc_trainer* t, double* table_grad, double* mlp_grad)
   memset(t->mlp_g, 0, sizeof(t->mlp_g));
   double loss = 0.0;
   t->n_samples_last = 0;
-  for (uint32_t j = 0; j < (uint32_t)t->o.n_rays; j++) loss += tr_ray(t, t->step, j, 1, S);
+  for (uint32_t j = 0; j < t->n_active; j++) loss += tr_ray(t, t->step, j, 1, S);
   free(S);
   if (table_grad) memcpy(table_grad, t->tab_g, t->n_table * sizeof(double));
   if (mlp_grad) memcpy(mlp_grad, t->mlp_g, sizeof(t->mlp_g));
@@ -366,6 +375,16 @@ double orc_train_step(orc_trainer* t) {
   }
   if (!t->exact) tr_refresh_fp16(t);
   t->step = n;
+  if (o->target_samples > 0) { /* the sample budget: integer arithmetic, mirrored by adam_mlp_kernel */
+    const uint64_t used = t->n_samples_last ? t->n_samples_last : 1u;
+    uint64_t a = (uint64_t)o->target_samples * (uint64_t)t->n_active / used;
+    const uint64_t lo = t->n_active / 2u, hi = (uint64_t)t->n_active * 2u;
+    if (a < lo) a = lo;
+    if (a > hi) a = hi;
+    if (a < 1u) a = 1u;
+    if (a > (uint64_t)o->n_rays) a = (uint64_t)o->n_rays;
+    t->n_active = (uint32_t)a;
+  }
   if (o->occ_every > 0 && n % (uint32_t)o->occ_every == 0) orc_train_refresh_occupancy(t);
   return loss;
 }

@@ -229,3 +229,28 @@ def test_rays_that_miss_everything(ctx, oracle, scene):
     gtr.steps(2)
     after = gtr.master()
     assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+
+
+def test_sample_budget_adapts_the_ray_count(ctx, oracle, scene):
+    """target_samples: the first step casts target / n_samples rays, afterwards the count follows
+    clamp(target * active / used, active/2, 2*active) within [1, n_rays] -- same schedule as the oracle"""
+    f, otr, gtr = start(ctx, oracle, scene, n_rays=700, n_samples=24, target_samples=2400, occ_every=0)
+    assert otr.active_rays == gtr.info()["active_rays"] == 100  # 2400 / 24
+    want_loss, _, want_mg = otr.gradients()
+    loss, _, mg = gtr.gradients()
+    assert gtr.info()["samples_last"] == otr.samples_last and loss == pytest.approx(want_loss, rel=1e-3)
+    assert rel_l2(mg, want_mg) < 1e-3  # the loss is normalised by the ACTIVE ray count
+    sched_o, sched_g = [], []
+    for _ in range(8):
+        otr.step()
+        gtr.steps(1)
+        sched_o.append(otr.active_rays)
+        sched_g.append(gtr.info()["active_rays"])
+    assert sched_o[0] in (200, sched_g[0]) and max(sched_o) <= 700 and sched_o[-1] > 100  # grows towards the budget
+    np.testing.assert_allclose(sched_g, sched_o, rtol=0.03)  # +-1 sample at a termination threshold moves it a little
+    used = gtr.info()["samples_last"]
+    assert 0.4 * 2400 < used < 2.5 * 2400 or gtr.info()["active_rays"] == 700
+    # without a budget the count never moves
+    f, otr, gtr = start(ctx, oracle, scene, n_rays=300, n_samples=24, target_samples=0, occ_every=0)
+    gtr.steps(3)
+    assert gtr.info()["active_rays"] == 300 == otr.active_rays
