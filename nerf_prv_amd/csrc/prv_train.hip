@@ -826,6 +826,69 @@ __global__ __launch_bounds__(256) void density_refresh_kernel(DensityParams P) {
   if ((threadIdx.x & 31) == 0 && cell < n_cells) P.occ[cell >> 5] = (uint32_t)(b >> (threadIdx.x & 32));
 }
 
+// the same refresh on the matrix cores: a wave = 32 cells (lane pair per cell, every other level each), the
+// density MLP alone (fragments 0..7: 8 v_mfma_f32_32x32x16_f16), EMA + threshold, one ballot = one bitfield word
+template <int F>
+__global__ __launch_bounds__(256) void density_refresh_fast_kernel(DensityParams P, const half8* __restrict__ frags) {
+  __shared__ half8 wl[8 * 64];
+  __shared__ LevelCanon lv[16];
+  for (int i = threadIdx.x; i < 8 * 64; i += 256) wl[i] = frags[i];
+  if (threadIdx.x < 16 * (int)(sizeof(LevelCanon) / 4))
+    reinterpret_cast<uint32_t*>(lv)[threadIdx.x] = reinterpret_cast<const uint32_t*>(P.levels)[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int R = P.occ_res;
+  const uint32_t n_cells = (uint32_t)R * R * R, n_words = (n_cells + 31u) / 32u;
+  const float invR = 1.0f / (float)R;
+  constexpr int LH = 16 / F;
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t word = blockIdx.x * 4u + (threadIdx.x >> 6); word < n_words; word += gridDim.x * 4u) {
+    const uint32_t cell = word * 32u + (uint32_t)r;
+    const bool have = cell < n_cells;
+    const uint32_t cc = have ? cell : 0u;
+    const uint32_t x = cc % R, y = (cc / R) % R, z = cc / (R * R);
+    const float px = ((float)x + 0.5f) * invR, py = ((float)y + 0.5f) * invR, pz = ((float)z + 0.5f) * invR;
+    half8 f0, f1;
+#pragma unroll
+    for (int j = 0; j < LH; j++) {
+      const LevelCanon L = lv[2 * j + h];
+      float f[F], cw[8];
+      uint32_t ci[8];
+      train_encode_level<F>(P.table, L, px, py, pz, f, ci, cw);
+#pragma unroll
+      for (int k = 0; k < F; k++) {
+        const int e = j * F + k;
+        if (e < 8) f0[e] = (_Float16)f[k];
+        else f1[e - 8] = (_Float16)f[k];
+      }
+    }
+    half8 hf[4];
+    { // density layer 1: 32 -> 64 (as mlp_forward)
+      f32x16 a0 = mfma(wl[0 * 64 + lane], f0, zero);
+      f32x16 a1 = mfma(wl[2 * 64 + lane], f0, zero);
+      a0 = mfma(wl[1 * 64 + lane], f1, a0);
+      a1 = mfma(wl[3 * 64 + lane], f1, a1);
+      hf[0] = pack8<true>(a0, 0);
+      hf[1] = pack8<true>(a0, 8);
+      hf[2] = pack8<true>(a1, 0);
+      hf[3] = pack8<true>(a1, 8);
+    }
+    f32x16 a = mfma(wl[4 * 64 + lane], hf[0], zero); // density layer 2, row 0 = the density logit
+    a = mfma(wl[5 * 64 + lane], hf[1], a);
+    a = mfma(wl[6 * 64 + lane], hf[2], a);
+    a = mfma(wl[7 * 64 + lane], hf[3], a);
+    bool on = false;
+    if (have && h == 0) {
+      const float sigma = expf(a[0] + P.density_bias);
+      const float e = fmaxf(P.ema[cell] * P.decay, sigma);
+      P.ema[cell] = e;
+      on = e > P.thresh;
+    }
+    const unsigned long long b = __ballot(on);
+    if (lane == 0) P.occ[word] = (uint32_t)b; // lanes 0..31 = lane half 0 = the 32 cells of the word
+  }
+}
+
 } // namespace
 
 // ------------------------------------------------------------------ launchers
@@ -911,6 +974,12 @@ hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float
 
 hipError_t launch_widen(const uint16_t* in, size_t n, float* out, hipStream_t s) {
   hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_density_refresh_fast(const DensityParams& P, int n_features, const half8* frags, int n_blocks, hipStream_t s) {
+  if (n_features == 4) hipLaunchKernelGGL(density_refresh_fast_kernel<4>, dim3(n_blocks), dim3(256), 0, s, P, frags);
+  else hipLaunchKernelGGL(density_refresh_fast_kernel<2>, dim3(n_blocks), dim3(256), 0, s, P, frags);
   return hipGetLastError();
 }
 

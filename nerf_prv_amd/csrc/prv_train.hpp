@@ -100,5 +100,6 @@ hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float
                            float* w16_as_f32, hipStream_t s);
 hipError_t launch_widen(const uint16_t* in, size_t n, float* out, hipStream_t s);
 hipError_t launch_density_refresh(const DensityParams& P, int n_features, hipStream_t s);
+hipError_t launch_density_refresh_fast(const DensityParams& P, int n_features, const half8* frags, int n_blocks, hipStream_t s);
 
 } // namespace prv
