@@ -194,7 +194,7 @@ def main():
         training = {"steps_per_s": args.train_steps / dt_tr, "ms_per_step": dt_tr / args.train_steps * 1e3,
                     "rays_per_step": int(tr.opts.n_rays), "samples_per_ray": int(tr.opts.n_samples),
                     "used_samples_last_batch": tr.info()["samples_last"], "loss_last": float(losses[-1]),
-                    "note": "fresh field, 300 warm-up steps untimed; f32 MFMA forward/backward, sparse Adam"}
+                    "note": "fresh field, 300 warm-up steps untimed; f16-MFMA forward, f32-MFMA backward, sparse Adam"}
         tr.close()
         tcams.close()
 
