@@ -12,8 +12,10 @@ out of the script and answers it in-process through the C ABI:
                                                     (run.py:284-309)
   --test_transforms J --save_metrics M           -> evaluate against reference images, write M
                                                     (run.py:213-277)
-Training (`--train --n_steps`) is out of scope: the field comes from `load_model`, a callable the
-embedding application provides (e.g. loading `.prvf` files); `--scene` is passed to it.
+  --train --n_steps N --scene J                  -> a fresh field trained N steps in process on J's views
+                                                    (run.py:109, 185-208; `train_desc=` names the field),
+                                                    unless a `load_model(scene, ctx) -> slot` callable supplies
+                                                    weights from elsewhere (e.g. `.prvf` files)
 PNG encoding uses PIL (present in the image); the byte rule is the library's (prv_render_rgba8).
 """
 import json

@@ -123,7 +123,7 @@ public:
   }
 
   // scene json of the full candidate set, as get_coverage writes <gt_path>/<N>.json (main.cpp:1581-1651)
-  // minus the PCL/OpenGL ground-truth screenshots (out of scope)
+  // (the rgbaClip images themselves: prv_splat_points on the coloured cloud, or renders of a ground-truth field)
   int get_coverage() {
     Value root = transforms_header(share_data->color_intrinsics, share_data->ray_casting_aabb_scale,
                                    view_space->predicted_size, view_space->object_center_world, 0);
