@@ -398,6 +398,20 @@ int check_opts(prv_ctx* c, const prv_render_opts* o) {
   return PRV_OK;
 }
 
+// "device pointer" arguments are validated instead of trusted: a host pointer handed to a kernel is a GPU page
+// fault that takes the process down; here it is an error code and a message
+int check_device_ptr(prv_ctx* c, const void* p, const char* what) {
+  if (!p) return PRV_OK; // NULL-ness is each entry point's own business
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(c, PRV_E_INVALID, "%s is not a device pointer", what);
+  }
+  if (a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeManaged && a.type != hipMemoryTypeUnified)
+    return fail(c, PRV_E_INVALID, "%s is not a device pointer", what);
+  return PRV_OK;
+}
+
 // cameras at the render resolution: focal from camera_angle_x at the json width (run.py:285-286,
 // fov_axis = 0), rescaled to the requested width; principal point at the image centre.
 // Dataset sets (prv_cameras_from_dataset_json) keep their principal point and scale per axis.
@@ -985,6 +999,7 @@ int prv_render(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, 
   if ((rc = check_model(c, slot)) != PRV_OK || (rc = check_opts(c, o)) != PRV_OK) return rc;
   if (!cs || n_views < 0 || (!out && n_views > 0)) return fail(c, PRV_E_INVALID, "bad camset / view count / output");
   HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = check_device_ptr(c, out, "out_rgba_dev")) != PRV_OK) return rc;
   if ((rc = render_views(c, slot, cs, view_ids, n_views, o, out, nullptr, true)) != PRV_OK) return rc;
   return fetch_stats(c, o, n_views, 1, st);
 }
@@ -996,6 +1011,7 @@ int prv_render_rgba8(prv_ctx* c, int slot, const prv_camset* cs, const int* view
   if ((rc = check_model(c, slot)) != PRV_OK || (rc = check_opts(c, o)) != PRV_OK) return rc;
   if (!cs || n_views < 0 || (!out && n_views > 0)) return fail(c, PRV_E_INVALID, "bad camset / view count / output");
   HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = check_device_ptr(c, out, "out_rgba8_dev")) != PRV_OK) return rc;
   const size_t npix = (size_t)o->width * o->height;
   if ((rc = ensure(c, c->img_f32, std::max<size_t>(16, (size_t)n_views * npix * 16))) != PRV_OK) return rc;
   if ((rc = render_views(c, slot, cs, view_ids, n_views, o, (float*)c->img_f32.p, out, true)) != PRV_OK) return rc;
@@ -1033,13 +1049,16 @@ int prv_splat_points(prv_ctx* c, const float* xyz, const uint8_t* rgb, size_t n,
   if (point_size < 1 || point_size > 64) return fail(c, PRV_E_INVALID, "point_size must be in [1,64], got %d", point_size);
   if (n_views == 0) return PRV_OK;
   HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = check_device_ptr(c, xyz, "xyz_dev")) != PRV_OK || (rc = check_device_ptr(c, rgb, "rgb_dev")) != PRV_OK ||
+      (rc = check_device_ptr(c, out, "out_rgba8_dev")) != PRV_OK)
+    return rc;
   std::vector<CamDev> cams(n_views);
   for (int i = 0; i < n_views; i++) {
     const int v = view_ids ? view_ids[i] : i;
     if (v < 0 || v >= (int)cs->cams.size()) return fail(c, PRV_E_INVALID, "view id %d out of range", v);
     cams[i] = cam_at(cs, v, W, H);
   }
-  int rc;
   if ((rc = ensure(c, c->view_ids, (size_t)n_views * (sizeof(CamDev) + sizeof(int)))) != PRV_OK) return rc;
   if ((rc = ensure(c, c->stage, (size_t)n_views * W * H * 8)) != PRV_OK) return rc;
   HIPCHK(c, hipMemcpyAsync(c->view_ids.p, cams.data(), (size_t)n_views * sizeof(CamDev), hipMemcpyHostToDevice, c->stream));
@@ -1227,6 +1246,7 @@ int prv_score_views(prv_ctx* c, int method, const int* model_slots, int n_models
   for (int e = 0; e < n_models; e++)
     if ((rc = check_model(c, model_slots[e])) != PRV_OK) return rc;
   HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = check_device_ptr(c, gt, "gt_rgba_dev")) != PRV_OK || (rc = check_device_ptr(c, rec_dev, "records_dev")) != PRV_OK) return rc;
   const size_t npix = (size_t)o->width * o->height;
   if ((rc = ensure(c, c->records, std::max<size_t>(16, (size_t)n_views * sizeof(prv_score_record)))) != PRV_OK) return rc;
   prv_score_record* rec = (prv_score_record*)c->records.p;

@@ -420,3 +420,22 @@ def test_ground_truth_splats_byte_exact(ctx, oracle):
     with pytest.raises(api.PrvError):
         ctx.splat_points(xyz, rgb, scale, offset, cs, [0], 32, 18, point_size=0)
     del got_last
+
+
+def test_host_pointers_are_refused_not_dereferenced(ctx, fields, cams):
+    """a host buffer where the ABI wants device memory is an error code (PRV_E_INVALID), not a GPU page fault"""
+    import ctypes as C
+
+    cs, ocams, w, h = cams
+    opts = api.render_opts(w, h, 16, 1, 1e-4)
+    ids = np.arange(1, dtype=np.int32)
+    host_out = np.zeros((1, h, w, 4), np.float32)
+    rc = ctx.lib.prv_render(ctx.handle, 0, cs.handle, ids.ctypes.data_as(C.c_void_p), 1, C.byref(opts),
+                            host_out.ctypes.data_as(C.c_void_p), None)
+    assert rc == api.L.PRV_E_INVALID and b"device pointer" in ctx.lib.prv_last_error(ctx.handle)
+    host_u8 = np.zeros((1, h, w, 4), np.uint8)
+    rc = ctx.lib.prv_render_rgba8(ctx.handle, 0, cs.handle, ids.ctypes.data_as(C.c_void_p), 1, C.byref(opts),
+                                  host_u8.ctypes.data_as(C.c_void_p), None)
+    assert rc == api.L.PRV_E_INVALID
+    img, _ = ctx.render(0, cs, [0], opts)  # the context is still healthy
+    assert img.shape == (1, h, w, 4)
