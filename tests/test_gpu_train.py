@@ -254,3 +254,26 @@ def test_sample_budget_adapts_the_ray_count(ctx, oracle, scene):
     f, otr, gtr = start(ctx, oracle, scene, n_rays=300, n_samples=24, target_samples=0, occ_every=0)
     gtr.steps(3)
     assert gtr.info()["active_rays"] == 300 == otr.active_rays
+
+
+def test_trainer_lifecycle_returns_its_memory(ctx, oracle, scene):
+    """an NBV loop creates and destroys a trainer per member and iteration: device memory must come back"""
+    kw, ocams, cams, imgs = scene
+    t = ctx.torch
+    u8 = t.from_numpy(imgs).to(ctx.device)
+    d = api.field_desc(**kw)
+
+    def cycle():
+        ctx.fresh_model(2, d, 9)
+        tr = api.Trainer(ctx, 2, cams, u8, api.train_opts(n_rays=2048, n_samples=64))
+        tr.steps(3)
+        tr.close()
+
+    cycle()
+    t.cuda.synchronize()
+    free0, _ = t.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    t.cuda.synchronize()
+    free1, _ = t.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20  # nothing accumulates (a trainer of this size holds ~60 MB)
