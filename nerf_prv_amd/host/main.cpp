@@ -92,6 +92,57 @@ struct HipScorer {
     return rc;
   }
 
+  // `evaluate: 1`: train ONE field on the final view set and score it on the test view set
+  // (<viewspace_path>/<evaluate_views>.txt, default 100 as in main.cpp:1956) against renders of the ground truth
+  int evaluate(const std::string& scene_json, const Vec3& center, double size, double* psnr, double* ssim) {
+    const int keep = n_members;
+    n_members = 1;
+    int rc = train_steps > 0 ? train_members(scene_json) : PRV_OK; // without training: member 0 as loaded
+    n_members = keep;
+    if (rc != PRV_OK) return rc;
+    // test cameras: the test view set placed like the candidates, full-size dataset header
+    auto sd_test = std::make_shared<Share_Data>(sd->yaml_file_path, sd->name_of_pcd, eval_views, -1, sd->method_of_IG);
+    if (!sd_test->ok) {
+      std::cerr << sd_test->error << std::endl;
+      return -40;
+    }
+    View_Space vs(sd_test);
+    vs.set_view_space(center, size);
+    Value root = transforms_header(sd->color_intrinsics, sd->ray_casting_aabb_scale, size, center, 0);
+    for (size_t i = 0; i < vs.views.size(); i++) {
+      Value v;
+      v["file_path"] = Value(std::to_string(eval_views) + "/rgbaClip_" + std::to_string(i) + ".png");
+      v["transform_matrix"] = matrix_json(view_transform_matrix(vs.views[i], Mat4::Identity(), center));
+      root["frames"].append(v);
+    }
+    const std::string test_json = sd->gt_path + "/" + std::to_string(eval_views) + ".json";
+    sd->access_directory(sd->gt_path);
+    write_text(test_json, prvjson::to_styled_string(root));
+    prv_camset* cams = nullptr;
+    if (prv_cameras_from_dataset_json(ctx, test_json.c_str(), &cams) != PRV_OK) return -41;
+    int w = 0, h = 0;
+    prv_camset_size(cams, &w, &h);
+    prv_render_opts o{};
+    o.width = train_w > 0 ? train_w : w;
+    o.height = train_h > 0 ? train_h : h;
+    o.samples_per_ray = 128;
+    o.spp = 1; // snap_to_pixel_centers (run.py:231)
+    o.min_transmittance = 1e-4f; // run.py:235
+    o.background[3] = 1.f;       // black, opaque (run.py:226)
+    const int n = prv_camset_count(cams);
+    float* gt = nullptr;
+    rc = prv_malloc(ctx, (void**)&gt, (size_t)n * o.width * o.height * 16);
+    prv_render_opts og = o;
+    og.background[3] = 0.f;
+    if (rc == PRV_OK) rc = prv_render(ctx, 6, cams, nullptr, n, &og, gt, nullptr); // the reference images
+    if (rc == PRV_OK) rc = prv_evaluate(ctx, 0, cams, nullptr, n, &o, gt, psnr, ssim);
+    if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+    if (gt) prv_free(ctx, gt);
+    prv_camset_destroy(cams);
+    return rc;
+  }
+  int eval_views = 100;
+
   int operator()(int method, int /*iteration*/, const std::string& scene_json, const std::string& render_json,
                  const std::vector<int>& ids, std::vector<double>& scores) {
     if (train_steps > 0) {
@@ -201,6 +252,7 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
     scorer.train_desc.table_amp = 1e-4f;
     if (fs.has("train_seed")) scorer.train_seed = (uint64_t)fs.num("train_seed");
   }
+  if (fs.has("evaluate_views")) scorer.eval_views = (int)fs.num("evaluate_views");
   NBV_Net_Labeler labeler(sd, center, size, scorer);
   labeler.get_coverage(); // <gt_path>/<N>.json (main.cpp:3882-3978, json part)
   if (method == PSNRCoverage) { // reference images of every view, rendered once from the reference field
@@ -247,8 +299,20 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
     if (std::fabs(p.x) < 1e-6 && std::fabs(p.y) < 1e-6 && std::fabs(p.z - sd->view_space_radius) < 1e-6) first_view_id = (int)i;
   }
   if (first_view_id == -1) std::cout << "can not find now view id" << std::endl; // main.cpp:3993-3995
+  // (after every assignment to labeler.scorer: the evaluator reaches into the scorer the loop will use)
+  if (sd->evaluate) {
+    if (train_steps == 0) { // evaluation needs a ground truth to compare with
+      const int rc = prv_model_synthetic(ctx, 6, &desc, fs.has("ground_truth_seed") ? (uint64_t)fs.num("ground_truth_seed") : 0x5EED0002ull);
+      if (rc != PRV_OK) return rc;
+    }
+    HipScorer* sc = labeler.scorer.target<HipScorer>();
+    labeler.evaluator = [sc, center, size](const std::string& scene, double* p, double* q) {
+      return sc ? sc->evaluate(scene, center, size, p, q) : -42;
+    };
+  }
   const int rc = labeler.nbv_loop(first_view_id, 0);
   if (scorer.gt_dev) prv_free(ctx, scorer.gt_dev);
+  if (labeler.final_psnr >= 0) std::cout << "final PSNR " << labeler.final_psnr << " SSIM " << labeler.final_ssim << std::endl;
   std::cout << "chosen_nbvs:";
   for (int v : labeler.chosen_nbvs) std::cout << ' ' << v;
   std::cout << std::endl;

@@ -105,6 +105,9 @@ using Scorer = std::function<int(int method, int iteration, const std::string& s
 // method 4: the number of views PRVNet predicts from the initial images (main.cpp:2165-2192 hands the images to a
 // Python server through <pvb_path>/data and reads view_budget.txt back); <= 0 = no answer
 using BudgetFn = std::function<int(const std::vector<int>& init_view_ids)>;
+// the final evaluation of `evaluate: 1` (main.cpp:1954-1965: train_by_instantNGP(<it>, "100", true) -> run.py's
+// --test_transforms / --save_metrics): train on the scene json's views, score against the test view set
+using EvalFn = std::function<int(const std::string& scene_json, double* mean_psnr, double* mean_ssim)>;
 
 class NBV_Net_Labeler {
 public:
@@ -112,9 +115,11 @@ public:
   std::shared_ptr<View_Space> view_space;
   Scorer scorer;
   BudgetFn budget_fn; // empty: read <pvb_path>/data/view_budget.txt
+  EvalFn evaluator;   // empty: `evaluate: 1` is ignored
   std::vector<int> chosen_nbvs;
   std::vector<double> last_scores;
   double total_movement_cost = 0.0;
+  double final_psnr = -1.0, final_ssim = -1.0; // the final evaluation's metrics, when it ran
 
   NBV_Net_Labeler(const std::shared_ptr<Share_Data>& sd, const Vec3& center, double predicted_size, Scorer s)
       : share_data(sd), scorer(std::move(s)) {
@@ -207,6 +212,16 @@ public:
       if (iteration == sd.num_of_max_iteration || candidates.empty()) { // :1946-1966
         const double loops_time = now_seconds() - loop_t0;
         write_text(sd.save_path + "/run_time.txt", std::to_string(loops_time) + "\n");
+        if (sd.evaluate && evaluator) { // "final evaluating..." (:1954-1965): metrics/<it>.txt in run.py's format
+          double psnr = 0, ssim = 0;
+          const int rc = evaluator(sd.save_path + "/json/" + it + ".json", &psnr, &ssim);
+          if (rc != 0) return rc;
+          char buf[128];
+          snprintf(buf, sizeof(buf), "PSNR\t%.17g\nSSIM\t%.17g", psnr, ssim);
+          write_text(sd.save_path + "/metrics/" + it + ".txt", buf);
+          final_psnr = psnr;
+          final_ssim = ssim;
+        }
         break;
       }
       const double infer_t0 = now_seconds();

@@ -506,3 +506,23 @@ def test_train_ensemble_single_rank(ctx, tmp_path):
     assert sorted(losses) == [0, 1, 2] and all(len(v) == 64 and v[-1] < v[0] for v in losses.values())
     tabs = [ctx.export_model(e, desc)[0] for e in range(3)]
     assert not np.array_equal(tabs[0], tabs[1]) and not np.array_equal(tabs[1], tabs[2])
+
+
+def test_planner_executable_final_evaluation(ctx, tmp_path):
+    """`evaluate: 1` (main.cpp:1954-1965): after the last iteration a field is trained on the chosen views and
+    scored on the test view set; metrics/<it>.txt carries run.py's two-line format"""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    pre = tmp_path / "eval_loop"
+    pre.mkdir()
+    cfg = pre / "cfg.yaml"
+    text = YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=0,
+                       model_source="train_steps: 150\ntrain_rays: 2048\ntrain_width: 64\ntrain_height: 36\n"
+                                    "ground_truth_seed: 4242\nevaluate: 1\nevaluate_views: 64")
+    cfg.write_text(text)
+    out = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    save = pre / "Compare" / "ShapeNet" / "objA_m0_v1_t0"
+    psnr, ssim = planner.read_metrics(save / "metrics" / "3.txt")
+    assert 12.0 < psnr < 60.0 and 0.0 < ssim <= 1.0
+    assert f"final PSNR" in out.stdout
+    assert (pre / "Coverage_images" / "ShapeNet" / "objA" / "64.json").exists()
