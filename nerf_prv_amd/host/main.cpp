@@ -4,6 +4,7 @@
 // the hot path; every render/score goes through the C ABI of include/prv.h in-process.
 //
 //   prv_planner [config.yaml]      (default "../DefaultConfiguration.yaml", main.cpp:2312)
+// Mode 4 (InstantNGP, main.cpp:2463-2487) is here too: the PSNR-vs-#views curve files of an object.
 //
 // Ensemble members / the field under test come from model files
 //   <model_path>/<object>/member_<e>.prvf  (prv_model_save_file format)
@@ -20,6 +21,7 @@
 
 extern "C" {
 #include "../../include/prv.h"
+#include "../../include/prv_host.h"
 }
 #include "planner.hpp"
 
@@ -27,7 +29,7 @@ using namespace prvhost;
 
 namespace {
 
-enum { ViewPlanning = 21 };
+enum { InstantNGP = 4, ViewPlanning = 21 }; // main.cpp:2284-2292
 
 struct HipScorer {
   prv_ctx* ctx = nullptr;
@@ -195,6 +197,9 @@ struct HipScorer {
   }
 };
 
+// `train_steps` and friends -> the scorer's in-process training settings; the ground truth goes to slot 6
+int configure_training(prv_ctx* ctx, const FileStorage& fs, const prv_field_desc& desc, HipScorer& scorer);
+
 prv_field_desc field_from_config(const FileStorage& fs) {
   prv_field_desc d{};
   auto get = [&](const char* k, double dflt) { return fs.has(k) ? fs.num(k) : dflt; };
@@ -236,21 +241,9 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   scorer.ctx = ctx;
   scorer.sd = sd;
   scorer.n_members = members;
-  if (train_steps > 0) { // ground truth = a synthetic field in slot 6; members are trained from scratch every iteration
-    prv_field_desc gt = desc;
-    const int rc = prv_model_synthetic(ctx, 6, &gt, fs.has("ground_truth_seed") ? (uint64_t)fs.num("ground_truth_seed") : 0x5EED0002ull);
-    if (rc != PRV_OK) {
-      std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
-      return rc;
-    }
-    scorer.train_steps = train_steps;
-    scorer.train_rays = fs.has("train_rays") ? (int)fs.num("train_rays") : 4096;
-    scorer.train_w = fs.has("train_width") ? (int)fs.num("train_width") : 0;
-    scorer.train_h = fs.has("train_height") ? (int)fs.num("train_height") : 0;
-    scorer.train_desc = desc;
-    scorer.train_desc.density_bias = fs.has("train_density_bias") ? (float)fs.num("train_density_bias") : 0.0f;
-    scorer.train_desc.table_amp = 1e-4f;
-    if (fs.has("train_seed")) scorer.train_seed = (uint64_t)fs.num("train_seed");
+  if (train_steps > 0) { // members are trained from scratch every iteration
+    const int rc = configure_training(ctx, fs, desc, scorer);
+    if (rc != PRV_OK) return rc;
   }
   if (fs.has("evaluate_views")) scorer.eval_views = (int)fs.num("evaluate_views");
   NBV_Net_Labeler labeler(sd, center, size, scorer);
@@ -319,6 +312,89 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   return rc;
 }
 
+int configure_training(prv_ctx* ctx, const FileStorage& fs, const prv_field_desc& desc, HipScorer& scorer) {
+  const int rc = prv_model_synthetic(ctx, 6, &desc, fs.has("ground_truth_seed") ? (uint64_t)fs.num("ground_truth_seed") : 0x5EED0002ull);
+  if (rc != PRV_OK) {
+    std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+    return rc;
+  }
+  scorer.train_steps = (int)fs.num("train_steps");
+  scorer.train_rays = fs.has("train_rays") ? (int)fs.num("train_rays") : 4096;
+  scorer.train_w = fs.has("train_width") ? (int)fs.num("train_width") : 0;
+  scorer.train_h = fs.has("train_height") ? (int)fs.num("train_height") : 0;
+  scorer.train_desc = desc;
+  scorer.train_desc.density_bias = fs.has("train_density_bias") ? (float)fs.num("train_density_bias") : 0.0f;
+  scorer.train_desc.table_amp = 1e-4f;
+  if (fs.has("train_seed")) scorer.train_seed = (uint64_t)fs.num("train_seed");
+  return PRV_OK;
+}
+
+// mode 4 (main.cpp:2463-2487): the PSNR-vs-#views curve of an object.  For n = 3, 3 + add, ... <= max: a field is
+// trained on the n-view coverage set (<gt_path>/<n>.json, written here; view set <viewspace_path>/<n>.txt or, when
+// that file does not exist, a generated n-point hemisphere) and evaluated on the test set; <gt_path>/<n>.txt gets
+// run.py's two metrics lines -- the files NeRF_fit_curve.cpp:103-115 reads.  Existing files are kept (:2473).
+int instant_ngp_curves(prv_ctx* ctx, const std::string& cfg, const std::string& name) {
+  FileStorage fs;
+  fs.open(cfg);
+  if (!fs.has("train_steps") || fs.num("train_steps") <= 0) {
+    std::cerr << "mode 4 trains: set train_steps in the configuration" << std::endl;
+    return -50;
+  }
+  const prv_field_desc desc = field_from_config(fs);
+  const double size = fs.has("object_size") ? fs.num("object_size") : 0.1;
+  const Vec3 center(1e-10, 1e-10, 1e-10);
+  auto sd0 = std::make_shared<Share_Data>(cfg, name, -1, -1, 0);
+  if (!sd0->ok) {
+    std::cerr << sd0->error << std::endl;
+    return -1;
+  }
+  HipScorer scorer;
+  scorer.ctx = ctx;
+  scorer.sd = sd0;
+  scorer.n_members = 1;
+  int rc = configure_training(ctx, fs, desc, scorer);
+  if (rc != PRV_OK) return rc;
+  if (fs.has("evaluate_views")) scorer.eval_views = (int)fs.num("evaluate_views");
+  const int n_max = sd0->coverage_view_num_max > 0 ? sd0->coverage_view_num_max : 90;
+  const int n_add = sd0->coverage_view_num_add > 0 ? sd0->coverage_view_num_add : 1;
+  sd0->access_directory(sd0->gt_path);
+  for (int n = 3; n <= n_max; n += n_add) {
+    const std::string metrics = sd0->gt_path + "/" + std::to_string(n) + ".txt";
+    if (std::ifstream(metrics).is_open()) continue;
+    // the n-view coverage set
+    std::vector<std::vector<double>> pts((size_t)n, std::vector<double>(3, 0.0));
+    std::ifstream fin(sd0->viewspace_path + std::to_string(n) + ".txt");
+    if (fin.is_open()) {
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) fin >> pts[i][j];
+    } else {
+      std::vector<double> flat((size_t)n * 3);
+      prvh_hemisphere_generate(n, flat.data());
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) pts[i][j] = flat[(size_t)i * 3 + j];
+    }
+    sd0->num_of_views = n;
+    sd0->pt_sphere = pts;
+    sd0->pt_norm = std::sqrt(pts[0][0] * pts[0][0] + pts[0][1] * pts[0][1] + pts[0][2] * pts[0][2]);
+    View_Space vs(sd0);
+    vs.set_view_space(center, size);
+    Value root = transforms_header(sd0->color_intrinsics, sd0->ray_casting_aabb_scale, size, center, 0);
+    for (size_t i = 0; i < vs.views.size(); i++) {
+      Value v;
+      v["file_path"] = Value(std::to_string(n) + "/rgbaClip_" + std::to_string(i) + ".png");
+      v["transform_matrix"] = matrix_json(view_transform_matrix(vs.views[i], Mat4::Identity(), center));
+      root["frames"].append(v);
+    }
+    const std::string scene = sd0->gt_path + "/" + std::to_string(n) + ".json";
+    write_text(scene, prvjson::to_styled_string(root));
+    double psnr = 0, ssim = 0;
+    if ((rc = scorer.evaluate(scene, center, size, &psnr, &ssim)) != PRV_OK) return rc;
+    prvh_write_metrics(metrics.c_str(), psnr, ssim);
+    std::cout << "views " << n << " PSNR " << psnr << " SSIM " << ssim << std::endl;
+  }
+  return 0;
+}
+
 } // namespace
 
 int main(int argc, char** argv) {
@@ -330,8 +406,8 @@ int main(int argc, char** argv) {
   std::cout << "input object names (-1 to stop):" << std::endl; // main.cpp:2299-2309
   std::string name;
   while (std::cin >> name && name != "-1") names.push_back(name);
-  if (mode != ViewPlanning) {
-    std::cerr << "mode " << mode << " is outside the render/score path this build covers (only 21 = ViewPlanning)" << std::endl;
+  if (mode != ViewPlanning && mode != InstantNGP) {
+    std::cerr << "mode " << mode << " is outside the render/score path this build covers (21 = ViewPlanning, 4 = InstantNGP)" << std::endl;
     return 3;
   }
   prv_ctx* ctx = nullptr;
@@ -343,6 +419,15 @@ int main(int argc, char** argv) {
   if (!fs.open(cfg)) {
     std::cerr << "cannot open " << cfg << std::endl;
     return 5;
+  }
+  if (mode == InstantNGP) {
+    int worst = 0;
+    for (const auto& n : names) {
+      const int rc = instant_ngp_curves(ctx, cfg, n);
+      if (rc != 0) worst = rc;
+    }
+    prv_destroy(ctx);
+    return worst == 0 ? 0 : 1;
   }
   // main.cpp:3838-3840 runs methods {4,0,1,2,3}; here: the configured one, or all that are in scope
   std::vector<int> methods;

@@ -526,3 +526,29 @@ def test_planner_executable_final_evaluation(ctx, tmp_path):
     assert 12.0 < psnr < 60.0 and 0.0 < ssim <= 1.0
     assert f"final PSNR" in out.stdout
     assert (pre / "Coverage_images" / "ShapeNet" / "objA" / "64.json").exists()
+
+
+def test_planner_executable_mode4_curve_files_and_stop_label(ctx, tmp_path):
+    """mode 4 (main.cpp:2463-2487): one trained + evaluated field per coverage-set size, <gt_path>/<n>.txt in run.py's
+    format -- then the stopping criterion (NeRF_fit_curve.cpp:119-206) fits the curve those files describe"""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    pre = tmp_path / "curves"
+    pre.mkdir()
+    cfg = pre / "cfg.yaml"
+    text = YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=0,
+                       model_source="train_steps: 120\ntrain_rays: 2048\ntrain_width: 64\ntrain_height: 36\nground_truth_seed: 4242\n"
+                                    "evaluate_views: 64\ncoverage_view_num_max: 15\ncoverage_view_num_add: 3")
+    cfg.write_text(text)
+    out = subprocess.run([exe, str(cfg)], input="4\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    gt = pre / "Coverage_images" / "ShapeNet" / "objA"
+    ns = [3, 6, 9, 12, 15]
+    psnr = [planner.read_metrics(gt / f"{n}.txt")[0] for n in ns]
+    assert all(10.0 < p < 60.0 for p in psnr) and psnr[-1] > psnr[0]  # more views, better reconstruction
+    assert json.load(open(gt / "9.json"))["frames"][8]["file_path"] == "9/rgbaClip_8.png"
+    # a second run keeps the existing files (main.cpp:2473)
+    before = (gt / "6.txt").read_text()
+    out = subprocess.run([exe, str(cfg)], input="4\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
+    assert out.returncode == 0 and (gt / "6.txt").read_text() == before and "views 6" not in out.stdout
+    params, converged = planner.fit_curve(ns, psnr, max(psnr))
+    assert len(params) == 4 and np.isfinite(params).all()
