@@ -29,7 +29,7 @@ using namespace prvhost;
 
 namespace {
 
-enum { InstantNGP = 4, ViewPlanning = 21 }; // main.cpp:2284-2292
+enum { InstantNGP = 4, GetPathPlan = 20, ViewPlanning = 21 }; // main.cpp:2284-2292
 
 struct HipScorer {
   prv_ctx* ctx = nullptr;
@@ -395,6 +395,46 @@ int instant_ngp_curves(prv_ctx* ctx, const std::string& cfg, const std::string& 
   return 0;
 }
 
+// mode 20 (main.cpp:3622-3832): for every view set <viewspace_path>/<N>.txt, N = 3..100, the shortest open tour
+// over the unit view sphere from the (0,0,1) view, written to <N>_path.txt, one id per line (:3826-3830).
+// No GPU involved.  Sets without a (0,0,1) view are reported and skipped ("can not find now view id", :3648).
+int get_path_plan(const std::string& cfg) {
+  FileStorage fs;
+  if (!fs.open(cfg)) {
+    std::cerr << "cannot open " << cfg << std::endl;
+    return 5;
+  }
+  const std::string vs = fs.str("viewspace_path");
+  const std::string out_dir = fs.has("path_plan_out") ? fs.str("path_plan_out") : vs; // the reference writes next to the inputs
+  int written = 0;
+  for (int n = 3; n <= 100; n++) {
+    std::ifstream fin(vs + std::to_string(n) + ".txt");
+    if (!fin.is_open()) continue;
+    std::vector<View> views;
+    std::vector<int> labels;
+    int now_view_id = -1;
+    for (int i = 0; i < n; i++) {
+      double x = 0, y = 0, z = 0;
+      fin >> x >> y >> z;
+      views.emplace_back(Vec3(x, y, z));
+      if (std::fabs(x) < 1e-6 && std::fabs(y) < 1e-6 && std::fabs(z - 1) < 1e-6) now_view_id = i;
+      labels.push_back(i);
+    }
+    if (now_view_id == -1) {
+      std::cout << "can not find now view id (" << n << ".txt)" << std::endl;
+      continue;
+    }
+    Global_Path_Planner gpp(views, labels, now_view_id, Vec3(1e-10, 1e-10, 1e-10), 0.0);
+    const double total_dis = gpp.solve();
+    std::string text;
+    for (int id : gpp.get_path_id_set()) text += std::to_string(id) + "\n";
+    if (!write_text(out_dir + std::to_string(n) + "_path.txt", text)) return -3;
+    std::cout << "view space " << n << " total dis is: " << total_dis << (gpp.exact ? "" : " (heuristic)") << std::endl;
+    written++;
+  }
+  return written > 0 ? 0 : -1;
+}
+
 } // namespace
 
 int main(int argc, char** argv) {
@@ -406,8 +446,10 @@ int main(int argc, char** argv) {
   std::cout << "input object names (-1 to stop):" << std::endl; // main.cpp:2299-2309
   std::string name;
   while (std::cin >> name && name != "-1") names.push_back(name);
+  if (mode == GetPathPlan) return get_path_plan(cfg) == 0 ? 0 : 1; // host only: before any GPU context exists
   if (mode != ViewPlanning && mode != InstantNGP) {
-    std::cerr << "mode " << mode << " is outside the render/score path this build covers (21 = ViewPlanning, 4 = InstantNGP)" << std::endl;
+    std::cerr << "mode " << mode << " is outside the render/score path this build covers (21 = ViewPlanning, 4 = InstantNGP, "
+                 "20 = GetPathPlan)" << std::endl;
     return 3;
   }
   prv_ctx* ctx = nullptr;

@@ -342,3 +342,31 @@ def test_global_path_fixed_end_and_large_sets():
         left.remove(k)
     nn_len = sum(np.linalg.norm(big[nn[i]] - big[nn[i + 1]]) for i in range(63))
     assert length <= nn_len + 1e-9
+
+
+def test_planner_executable_mode20_reproduces_the_reference_path_files(tmp_path):
+    """REFERENCE-PINNED: mode 20 (GetPathPlan, main.cpp:3622-3832) writes <N>_path.txt for every view set it finds;
+    on the reference's own view sets the tours have the stored files' lengths and, where the optimum is unique,
+    their exact lines.  Host only -- runs without a GPU."""
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nerf_prv_amd", "prv_planner")
+    if not os.path.exists(exe):
+        pytest.skip("prv_planner not built")
+    tours = json.load(open(os.path.join(GOLD, "reference_tours.json")))["tours"]
+    vs = tmp_path / "vs"
+    vs.mkdir()
+    for n, t in tours.items():
+        (vs / f"{n}.txt").write_text("".join(f"{p[0]:.17g} {p[1]:.17g} {p[2]:.17g}\n" for p in t["points"]))
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(YAML.format(pre=tmp_path, vs=vs))
+    out = subprocess.run([exe, str(cfg)], input="20\n-1\n", text=True, capture_output=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for n, t in tours.items():
+        pts, ref = np.array(t["points"]), t["path"]
+        got = [int(x) for x in (vs / f"{n}_path.txt").read_text().split()]
+        assert sorted(got) == list(range(int(n))) and got[0] == ref[0]
+        seg = lambda p: sum(np.linalg.norm(pts[p[i]] - pts[p[i + 1]]) for i in range(len(p) - 1))
+        assert abs(seg(got) - seg(ref)) < 2e-6
+        if n in ("6", "10", "11", "12"):
+            assert got == ref
