@@ -24,6 +24,7 @@ extern "C" {
 #include "../../include/prv_host.h"
 }
 #include "planner.hpp"
+#include "fit_curve.hpp"
 
 using namespace prvhost;
 
@@ -358,39 +359,62 @@ int instant_ngp_curves(prv_ctx* ctx, const std::string& cfg, const std::string& 
   const int n_max = sd0->coverage_view_num_max > 0 ? sd0->coverage_view_num_max : 90;
   const int n_add = sd0->coverage_view_num_add > 0 ? sd0->coverage_view_num_add : 1;
   sd0->access_directory(sd0->gt_path);
-  for (int n = 3; n <= n_max; n += n_add) {
+  std::vector<int> counts;
+  for (int n = 3; n <= n_max; n += n_add) counts.push_back(n);
+  const int n_full = fs.has("coverage_view_num_full") ? (int)fs.num("coverage_view_num_full") : 100; // main.cpp:2480-2484
+  counts.push_back(n_full); // the upper bound of the curve ("100.txt")
+  std::vector<double> xs, ys;
+  double max_psnr = 0.0;
+  for (size_t ci = 0; ci < counts.size(); ci++) {
+    const int n = counts[ci];
     const std::string metrics = sd0->gt_path + "/" + std::to_string(n) + ".txt";
-    if (std::ifstream(metrics).is_open()) continue;
-    // the n-view coverage set
-    std::vector<std::vector<double>> pts((size_t)n, std::vector<double>(3, 0.0));
-    std::ifstream fin(sd0->viewspace_path + std::to_string(n) + ".txt");
-    if (fin.is_open()) {
-      for (int i = 0; i < n; i++)
-        for (int j = 0; j < 3; j++) fin >> pts[i][j];
-    } else {
-      std::vector<double> flat((size_t)n * 3);
-      prvh_hemisphere_generate(n, flat.data());
-      for (int i = 0; i < n; i++)
-        for (int j = 0; j < 3; j++) pts[i][j] = flat[(size_t)i * 3 + j];
-    }
-    sd0->num_of_views = n;
-    sd0->pt_sphere = pts;
-    sd0->pt_norm = std::sqrt(pts[0][0] * pts[0][0] + pts[0][1] * pts[0][1] + pts[0][2] * pts[0][2]);
-    View_Space vs(sd0);
-    vs.set_view_space(center, size);
-    Value root = transforms_header(sd0->color_intrinsics, sd0->ray_casting_aabb_scale, size, center, 0);
-    for (size_t i = 0; i < vs.views.size(); i++) {
-      Value v;
-      v["file_path"] = Value(std::to_string(n) + "/rgbaClip_" + std::to_string(i) + ".png");
-      v["transform_matrix"] = matrix_json(view_transform_matrix(vs.views[i], Mat4::Identity(), center));
-      root["frames"].append(v);
-    }
-    const std::string scene = sd0->gt_path + "/" + std::to_string(n) + ".json";
-    write_text(scene, prvjson::to_styled_string(root));
     double psnr = 0, ssim = 0;
-    if ((rc = scorer.evaluate(scene, center, size, &psnr, &ssim)) != PRV_OK) return rc;
-    prvh_write_metrics(metrics.c_str(), psnr, ssim);
-    std::cout << "views " << n << " PSNR " << psnr << " SSIM " << ssim << std::endl;
+    if (prvh_read_metrics(metrics.c_str(), &psnr, &ssim) != 0) { // existing files are kept (:2473)
+      // the n-view coverage set
+      std::vector<std::vector<double>> pts((size_t)n, std::vector<double>(3, 0.0));
+      std::ifstream fin(sd0->viewspace_path + std::to_string(n) + ".txt");
+      if (fin.is_open()) {
+        for (int i = 0; i < n; i++)
+          for (int j = 0; j < 3; j++) fin >> pts[i][j];
+      } else {
+        std::vector<double> flat((size_t)n * 3);
+        prvh_hemisphere_generate(n, flat.data());
+        for (int i = 0; i < n; i++)
+          for (int j = 0; j < 3; j++) pts[i][j] = flat[(size_t)i * 3 + j];
+      }
+      sd0->num_of_views = n;
+      sd0->pt_sphere = pts;
+      sd0->pt_norm = std::sqrt(pts[0][0] * pts[0][0] + pts[0][1] * pts[0][1] + pts[0][2] * pts[0][2]);
+      View_Space vs(sd0);
+      vs.set_view_space(center, size);
+      Value root = transforms_header(sd0->color_intrinsics, sd0->ray_casting_aabb_scale, size, center, 0);
+      for (size_t i = 0; i < vs.views.size(); i++) {
+        Value v;
+        v["file_path"] = Value(std::to_string(n) + "/rgbaClip_" + std::to_string(i) + ".png");
+        v["transform_matrix"] = matrix_json(view_transform_matrix(vs.views[i], Mat4::Identity(), center));
+        root["frames"].append(v);
+      }
+      // the test set's own json is <gt_path>/<evaluate_views>.json: keep the two apart when the sizes coincide
+      const std::string scene = sd0->gt_path + "/" + std::to_string(n) + (n == scorer.eval_views ? "_train.json" : ".json");
+      write_text(scene, prvjson::to_styled_string(root));
+      if ((rc = scorer.evaluate(scene, center, size, &psnr, &ssim)) != PRV_OK) return rc;
+      prvh_write_metrics(metrics.c_str(), psnr, ssim);
+      std::cout << "views " << n << " PSNR " << psnr << " SSIM " << ssim << std::endl;
+    }
+    if (ci + 1 < counts.size()) {
+      xs.push_back((double)n);
+      ys.push_back(psnr);
+    } else {
+      max_psnr = psnr;
+    }
+  }
+  // the label file Origin's fit script leaves next to the curve (NeRF_fit_curve.cpp:119-206)
+  if (xs.size() >= 4) {
+    const FitResult fit = fit_lognormal_cdf(xs, ys, max_psnr);
+    write_label_file(sd0->gt_path + "/label.txt", fit, max_psnr);
+    const Labels L = make_labels(fit.f, max_psnr);
+    std::cout << "label: converged " << (fit.converged ? 1 : 0) << " gap 2% at " << L.gap[2] << " views, gradient 0.02 at "
+              << L.gradient[1] << " views" << std::endl; // main.cpp:2641-2642 uses gradient index 1
   }
   return 0;
 }

