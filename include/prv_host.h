@@ -90,6 +90,13 @@ typedef struct prvh_loop_result {
   int chosen[1024];
   double total_movement; /* sum of get_local_path costs between consecutive chosen views (main.cpp:2256-2264) */
 } prvh_loop_result;
+/* ---- PNG files of the boundary (rgbaClip_<i>.png written at main.cpp:1617, screenshots of run.py:309 read at
+ * main.cpp:2047, 2107): 8-bit grey / RGB / RGBA, non-interlaced; pixels as RGBA8, top row first.
+ * 0, or -1 io, -2 not a PNG, -3 unsupported flavour, -4 corrupt, -5 size mismatch */
+int prvh_png_size(const char* path, int* width, int* height);
+int prvh_png_read_rgba8(const char* path, int width, int height, uint8_t* out_rgba8);
+int prvh_png_write_rgba8(const char* path, int width, int height, const uint8_t* rgba8);
+
 int prvh_nbv_loop(prvh_share_data* sd, const double center[3], double predicted_size, int first_view_id,
                   int test_id, prvh_score_fn score, void* user, prvh_loop_result* out);
 /* the same with the view budget of method 4 (PVBCoverage, main.cpp:2163-2242) supplied by the caller -- what

@@ -65,12 +65,12 @@ def build_host(force=False):
         os.path.join(CSRC, "prv_json.hpp"), os.path.join(ROOT, "include", "prv.h"), os.path.join(ROOT, "include", "prv_host.h")]
     deps = [d for d in deps if os.path.exists(d)]
     if srcs and (force or _newer(out, deps)):
-        _run(["g++"] + HOST_FLAGS + ["-shared", "-o", out] + srcs)
+        _run(["g++"] + HOST_FLAGS + ["-shared", "-o", out] + srcs + ["-lz"])
     exe = os.path.join(HERE, "prv_planner")
     main = os.path.join(HOST, "main.cpp")
     if os.path.exists(main) and (force or _newer(exe, deps + [main, os.path.join(HERE, "libprv_hip.so")])):
         _run(["g++"] + HOST_FLAGS + ["-o", exe, main] + srcs +
-             ["-L" + HERE, "-lprv_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + HERE, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+             ["-L" + HERE, "-lprv_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + HERE, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     return out
 
 

@@ -7,6 +7,7 @@
 #include "fit_curve.hpp"
 #include "path_planner.hpp"
 #include "planner.hpp"
+#include "png_io.hpp"
 
 using namespace prvhost;
 
@@ -106,6 +107,28 @@ int prvh_write_transforms(const char* path, const prvh_intrinsics* in, int candi
     root["frames"].append(view_image);
   }
   return write_text(path, prvjson::to_styled_string(root)) ? 0 : -3;
+}
+
+int prvh_png_size(const char* path, int* width, int* height) {
+  if (!path || !width || !height) return -1;
+  std::vector<uint8_t> img;
+  return png_read_rgba8(path, width, height, img);
+}
+
+int prvh_png_read_rgba8(const char* path, int width, int height, uint8_t* out_rgba8) {
+  if (!path || !out_rgba8) return -1;
+  std::vector<uint8_t> img;
+  int w = 0, h = 0;
+  const int rc = png_read_rgba8(path, &w, &h, img);
+  if (rc != 0) return rc;
+  if (w != width || h != height) return -5;
+  memcpy(out_rgba8, img.data(), img.size());
+  return 0;
+}
+
+int prvh_png_write_rgba8(const char* path, int width, int height, const uint8_t* rgba8) {
+  if (!path) return -1;
+  return png_write_rgba8(path, width, height, rgba8);
 }
 
 int prvh_write_metrics(const char* path, double psnr, double ssim) {

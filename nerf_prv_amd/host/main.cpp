@@ -13,7 +13,9 @@
 // or -- `train_steps: N` -- they are TRAINED in process every iteration, as the reference does through
 // train_by_instantNGP (main.cpp:1658-1715, 2041-2043): a fresh field per member, N optimiser steps on the
 // views chosen so far; the training images are rendered from the ground-truth field
-// (`ground_truth_seed`, slot 6) with the dataset cameras of the iteration's json.
+// (`ground_truth_seed`, slot 6) with the dataset cameras of the iteration's json -- or, with `coverage_images: 1`
+// and `train_images: files`, written once as <gt_path>/<N>/rgbaClip_<i>.png (what mode 3 leaves on disk) and read
+// back through each iteration's json exactly as run.py's load_training_data does.
 #include <cstdio>
 #include <iostream>
 #include <string>
@@ -25,6 +27,7 @@ extern "C" {
 }
 #include "planner.hpp"
 #include "fit_curve.hpp"
+#include "png_io.hpp"
 
 using namespace prvhost;
 
@@ -42,6 +45,7 @@ struct HipScorer {
   int train_steps = 0, train_rays = 4096, train_w = 0, train_h = 0;
   prv_field_desc train_desc{};
   uint64_t train_seed = 0x1234;
+  bool images_from_files = false; // train_images: files -> the json's file_path PNGs (the reference's data flow)
 
   // train_by_instantNGP(json/<it>.json, ..., ensemble_id = e) for every member, in process
   int train_members(const std::string& scene_json) {
@@ -61,7 +65,28 @@ struct HipScorer {
     const int n = prv_camset_count(ds);
     uint8_t* imgs = nullptr;
     int rc = prv_malloc(ctx, (void**)&imgs, (size_t)n * o.width * o.height * 4);
-    if (rc == PRV_OK) rc = prv_render_rgba8(ctx, 6, ds, nullptr, n, &o, imgs, nullptr); // straight alpha over nothing
+    if (rc == PRV_OK && images_from_files) {
+      // load_training_data (run.py:109): every frame's file_path, relative to the json, as RGBA8
+      std::string text, err;
+      prvjson::Value root;
+      if (!prvjson::read_file(scene_json, text) || !prvjson::Parser(text).parse(root, err)) rc = -31;
+      const std::string base = scene_json.substr(0, scene_json.find_last_of('/') + 1);
+      std::vector<uint8_t> px;
+      for (int i = 0; rc == PRV_OK && i < n; i++) {
+        std::string fp = root.at("frames").arr[(size_t)i].at("file_path").s;
+        if (fp.size() < 4 || fp.substr(fp.size() - 4) != ".png") fp += ".png";
+        int iw = 0, ih = 0;
+        const int prc = png_read_rgba8(base + fp, &iw, &ih, px);
+        if (prc != 0 || iw != o.width || ih != o.height) {
+          std::cerr << "training image " << base + fp << ": " << (prc ? "cannot read (" + std::to_string(prc) + ")" : "size differs from the json") << std::endl;
+          rc = -32;
+          break;
+        }
+        rc = prv_memcpy_h2d(ctx, imgs + (size_t)i * o.width * o.height * 4, px.data(), px.size());
+      }
+    } else if (rc == PRV_OK) {
+      rc = prv_render_rgba8(ctx, 6, ds, nullptr, n, &o, imgs, nullptr); // straight alpha over nothing
+    }
     if (timing) {
       prv_synchronize(ctx);
       t_gt = now_seconds() - t_start;
@@ -200,6 +225,7 @@ struct HipScorer {
 
 // `train_steps` and friends -> the scorer's in-process training settings; the ground truth goes to slot 6
 int configure_training(prv_ctx* ctx, const FileStorage& fs, const prv_field_desc& desc, HipScorer& scorer);
+int write_coverage_images(prv_ctx* ctx, const std::shared_ptr<Share_Data>& sd);
 
 prv_field_desc field_from_config(const FileStorage& fs) {
   prv_field_desc d{};
@@ -249,6 +275,10 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   if (fs.has("evaluate_views")) scorer.eval_views = (int)fs.num("evaluate_views");
   NBV_Net_Labeler labeler(sd, center, size, scorer);
   labeler.get_coverage(); // <gt_path>/<N>.json (main.cpp:3882-3978, json part)
+  if (fs.has("coverage_images") && fs.num("coverage_images") > 0 && train_steps > 0) {
+    const int rc = write_coverage_images(ctx, sd);
+    if (rc != PRV_OK) return rc;
+  }
   if (method == PSNRCoverage) { // reference images of every view, rendered once from the reference field
     int rc = fs.has("synthetic_seed") ? prv_model_synthetic(ctx, 7, &desc, (uint64_t)fs.num("synthetic_seed") + 4096)
                                       : prv_model_load_file(ctx, 7, (sd->model_path + name + "/reference.prvf").c_str());
@@ -327,7 +357,38 @@ int configure_training(prv_ctx* ctx, const FileStorage& fs, const prv_field_desc
   scorer.train_desc.density_bias = fs.has("train_density_bias") ? (float)fs.num("train_density_bias") : 0.0f;
   scorer.train_desc.table_amp = 1e-4f;
   if (fs.has("train_seed")) scorer.train_seed = (uint64_t)fs.num("train_seed");
+  scorer.images_from_files = fs.has("train_images") && fs.str("train_images") == "files";
   return PRV_OK;
+}
+
+// get_coverage's images (main.cpp:1604-1618) from the ground-truth field: <gt_path>/<N>/rgbaClip_<i>.png for every
+// view of the set, at the dataset size -- what mode 3 (GetCoverage) leaves on disk with PCL
+int write_coverage_images(prv_ctx* ctx, const std::shared_ptr<Share_Data>& sd) {
+  const std::string n = std::to_string(sd->num_of_views);
+  prv_camset* ds = nullptr;
+  if (prv_cameras_from_dataset_json(ctx, (sd->gt_path + "/" + n + ".json").c_str(), &ds) != PRV_OK) return -60;
+  int w = 0, h = 0;
+  prv_camset_size(ds, &w, &h);
+  prv_render_opts o{};
+  o.width = w;
+  o.height = h;
+  o.samples_per_ray = 128;
+  o.spp = 1;
+  o.min_transmittance = 1e-4f;
+  const int count = prv_camset_count(ds);
+  sd->access_directory(sd->gt_path + "/" + n);
+  uint8_t* dev = nullptr;
+  int rc = prv_malloc(ctx, (void**)&dev, (size_t)w * h * 4);
+  std::vector<uint8_t> px((size_t)w * h * 4);
+  for (int i = 0; rc == PRV_OK && i < count; i++) {
+    rc = prv_render_rgba8(ctx, 6, ds, &i, 1, &o, dev, nullptr);
+    if (rc == PRV_OK) rc = prv_memcpy_d2h(ctx, px.data(), dev, px.size());
+    if (rc == PRV_OK && png_write_rgba8(sd->gt_path + "/" + n + "/rgbaClip_" + std::to_string(i) + ".png", w, h, px.data()) != 0) rc = PRV_E_IO;
+  }
+  if (rc != PRV_OK) std::cerr << "coverage images: " << prv_last_error(ctx) << std::endl;
+  if (dev) prv_free(ctx, dev);
+  prv_camset_destroy(ds);
+  return rc;
 }
 
 // mode 4 (main.cpp:2463-2487): the PSNR-vs-#views curve of an object.  For n = 3, 3 + add, ... <= max: a field is

@@ -53,6 +53,9 @@ HOST_SIGNATURES = {
     "prvh_share_data_number": (_d, [_vp, C.c_char_p]),
     "prvh_share_data_views": (_i, [_vp, _vp]),
     "prvh_share_data_intrinsics": (None, [_vp, C.POINTER(Intrinsics)]),
+    "prvh_png_size": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
+    "prvh_png_read_rgba8": (_i, [C.c_char_p, _i, _i, _vp]),
+    "prvh_png_write_rgba8": (_i, [C.c_char_p, _i, _i, _vp]),
     "prvh_nbv_loop": (_i, [_vp, _vp, _d, _i, _i, SCORE_FN, _vp, C.POINTER(LoopResult)]),
     "prvh_nbv_loop_budget": (_i, [_vp, _vp, _d, _i, _i, SCORE_FN, _vp, _i, C.POINTER(LoopResult)]),
 }
@@ -154,6 +157,28 @@ def read_metrics(path):
     if host().prvh_read_metrics(str(path).encode(), C.byref(p), C.byref(s)) != 0:
         raise IOError(f"cannot read metrics from {path}")
     return p.value, s.value
+
+
+def png_read(path):
+    """RGBA8 pixels [h, w, 4] of a PNG through the host library (zlib only; what the C++ planner uses)"""
+    w, h = C.c_int(), C.c_int()
+    rc = host().prvh_png_size(str(path).encode(), C.byref(w), C.byref(h))
+    if rc != 0:
+        raise IOError(f"{path}: png error {rc}")
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    rc = host().prvh_png_read_rgba8(str(path).encode(), w.value, h.value, _p(out))
+    if rc != 0:
+        raise IOError(f"{path}: png error {rc}")
+    return out
+
+
+def png_write(path, rgba8):
+    a = np.ascontiguousarray(rgba8, np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("png_write expects [h, w, 4] uint8")
+    rc = host().prvh_png_write_rgba8(str(path).encode(), a.shape[1], a.shape[0], _p(a))
+    if rc != 0:
+        raise IOError(f"{path}: png error {rc}")
 
 
 def local_path(M, N, O, r):

@@ -557,3 +557,35 @@ def test_planner_executable_mode4_curve_files_and_stop_label(ctx, tmp_path):
     label = (gt / "label.txt").read_text().split("\n")
     assert label[0] in ("Converged 1", "Converged 0") and label[1].startswith("3 ") and any(l.startswith("gap 2% ") for l in label)
     assert sum(l.startswith("gradient ") for l in label) == 20 and "label: converged" in out.stdout or True
+
+
+def test_planner_executable_trains_from_the_png_files_on_disk(ctx, tmp_path):
+    """the reference's own data flow in one executable: get_coverage leaves <gt_path>/<N>/rgbaClip_<i>.png
+    (main.cpp:1604-1618) and every iteration's json points at them (../../../../Coverage_images/..., main.cpp:1889);
+    with `train_images: files` the trainer reads exactly those PNGs through the json, like load_training_data"""
+    from PIL import Image
+
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    pre = tmp_path / "files_loop"
+    pre.mkdir()
+    cfg = pre / "cfg.yaml"
+    text = YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=2,
+                       model_source="train_steps: 40\ntrain_rays: 1024\nground_truth_seed: 4242\ncoverage_images: 1\n"
+                                    "train_images: \"files\"")
+    text = text.replace("ensemble_num: 5", "ensemble_num: 2").replace("color_width: 1280", "color_width: 160").replace(
+        "color_height: 720", "color_height: 90").replace("9.1560668945312500e+02", "114.45").replace(
+        "9.1332666015625000e+02", "114.2").replace("6.4714532470703125e+02", "80.9").replace("3.7251531982421875e+02", "46.6")
+    cfg.write_text(text.replace("candidate_divisor: 16", "candidate_divisor: 2"))
+    out = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    gt = pre / "Coverage_images" / "ShapeNet" / "objA" / "5"
+    assert sorted(os.listdir(gt)) == [f"rgbaClip_{i}.png" for i in range(5)]
+    img = np.asarray(Image.open(gt / "rgbaClip_2.png"))
+    assert img.shape == (90, 160, 4) and 0 < (img[..., 3] > 0).mean() < 1  # object over transparent background
+    assert np.array_equal(planner.png_read(gt / "rgbaClip_2.png"), img)
+    chosen = [int(x) for x in [l for l in out.stdout.splitlines() if l.startswith("chosen_nbvs:")][-1].split(":")[1].split()]
+    assert len(chosen) == 4 and len(set(chosen)) == 4
+    # a json of the loop resolves to those files
+    save = pre / "Compare" / "ShapeNet" / "objA_m2_v1_t0"
+    fp = json.load(open(save / "json" / "2.json"))["frames"][0]["file_path"]
+    assert os.path.exists(os.path.normpath(os.path.join(save / "json", fp)))

@@ -370,3 +370,40 @@ def test_planner_executable_mode20_reproduces_the_reference_path_files(tmp_path)
         assert abs(seg(got) - seg(ref)) < 2e-6
         if n in ("6", "10", "11", "12"):
             assert got == ref
+
+
+def test_png_io_against_pil(tmp_path):
+    """the host library's PNG reader / writer (zlib only) against PIL: RGBA, RGB, grey, grey+alpha, every row
+    filter PIL's encoder picks, and the writer's files read back by PIL"""
+    from PIL import Image
+
+    rng = np.random.default_rng(4)
+    h, w = 37, 53
+    smooth = np.clip(np.add.outer(np.arange(h) * 3, np.arange(w) * 2)[..., None] + rng.integers(0, 9, (h, w, 4)), 0, 255).astype(np.uint8)
+    noise = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    for k, img in enumerate((smooth, noise)):  # smooth gradients make the encoder use Sub/Up/Average/Paeth rows
+        p = tmp_path / f"rgba{k}.png"
+        Image.fromarray(img, "RGBA").save(p)
+        assert np.array_equal(planner.png_read(p), img)
+        p = tmp_path / f"rgb{k}.png"
+        Image.fromarray(img[..., :3], "RGB").save(p)
+        got = planner.png_read(p)
+        assert np.array_equal(got[..., :3], img[..., :3]) and (got[..., 3] == 255).all()
+        p = tmp_path / f"grey{k}.png"
+        Image.fromarray(img[..., 0], "L").save(p)
+        got = planner.png_read(p)
+        assert all(np.array_equal(got[..., c], img[..., 0]) for c in range(3)) and (got[..., 3] == 255).all()
+        p = tmp_path / f"la{k}.png"
+        Image.fromarray(np.ascontiguousarray(img[..., :2]), "LA").save(p)
+        got = planner.png_read(p)
+        assert np.array_equal(got[..., 0], img[..., 0]) and np.array_equal(got[..., 3], img[..., 1])
+        out = tmp_path / f"mine{k}.png"
+        planner.png_write(out, img)
+        assert np.array_equal(np.asarray(Image.open(out).convert("RGBA")), img)
+        assert np.array_equal(planner.png_read(out), img)
+    (tmp_path / "bad.png").write_bytes(b"not a png at all, definitely")
+    with pytest.raises(IOError):
+        planner.png_read(tmp_path / "bad.png")
+    with pytest.raises(IOError):
+        planner.png_read(tmp_path / "missing.png")
+    Image.fromarray(smooth, "RGBA").save(tmp_path / "interlaced.png", interlace=1) if False else None
