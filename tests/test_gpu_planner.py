@@ -167,8 +167,8 @@ def test_planner_executable_error_paths(tmp_path):
     exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
     out = subprocess.run([exe, str(tmp_path / "missing.yaml")], input="21\nx\n-1\n", text=True, capture_output=True)
     assert out.returncode != 0 and "cannot open" in out.stderr
-    out = subprocess.run([exe, str(tmp_path / "missing.yaml")], input="4\nx\n-1\n", text=True, capture_output=True)
-    assert out.returncode == 3 and "outside the render/score path" in out.stderr
+    out = subprocess.run([exe, str(tmp_path / "missing.yaml")], input="7\nx\n-1\n", text=True, capture_output=True)
+    assert out.returncode == 3 and "outside the render/score path" in out.stderr  # TestObjects: not on the path
 
 
 def test_flag_file_compat_server_answers_the_reference_handshake(ctx, tmp_path):
