@@ -91,6 +91,7 @@ public:
   int render_width = 0, render_height = 0, samples_per_ray = 0, screenshot_spp = 0;
   double candidate_divisor = 0, min_transmittance = 0;
   // state
+  double pvb_wait_seconds = 0.0;
   std::vector<std::vector<double>> pt_sphere;
   double pt_norm = 0;
   bool ok = false;
@@ -111,6 +112,7 @@ public:
     instant_ngp_path = fs.str("instant_ngp_path");
     orginalviews_path = fs.str("orginalviews_path");
     pvb_path = fs.str("pvb_path");
+    pvb_wait_seconds = fs.has("pvb_wait_seconds") ? fs.num("pvb_wait_seconds") : 0.0; // this build's key: how long method 4 waits for PRVNet's server
     shape_net = fs.str("shape_net");
     name_of_pcd = fs.str("name_of_pcd");
     nbv_net_path = fs.str("nbv_net_path");

@@ -14,6 +14,7 @@
 #include <random>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../csrc/prv_json.hpp"
@@ -289,6 +290,27 @@ public:
             int view_budget = -1;
             if (budget_fn) view_budget = budget_fn(chosen_nbvs);
             else {
+              if (sd.pvb_wait_seconds > 0.0) { // the hand-shake with PRVNet's infer_server.py (:2165-2185)
+                sd.access_directory(sd.pvb_path + "data/images");
+                for (int id : chosen_nbvs) { // the initial views' images, named by view id
+                  std::ifstream src(sd.gt_path + "/" + std::to_string(sd.num_of_views) + "/rgbaClip_" + std::to_string(id) + ".png", std::ios::binary);
+                  std::ofstream dst(sd.pvb_path + "data/images/" + std::to_string(id) + ".png", std::ios::binary);
+                  if (src.is_open()) dst << src.rdbuf();
+                }
+                write_text(sd.pvb_path + "data/ready_c++.txt", "");
+                const double t0 = now_seconds();
+                bool answered = false;
+                while (now_seconds() - t0 < sd.pvb_wait_seconds) { // the reference polls every 100 ms, forever
+                  if (std::ifstream(sd.pvb_path + "data/ready_py.txt").is_open()) {
+                    answered = true;
+                    break;
+                  }
+                  std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                }
+                if (!answered) return -16; // PRVNet's server did not answer in time
+                std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                std::remove((sd.pvb_path + "data/ready_py.txt").c_str());
+              }
               std::ifstream fin(sd.pvb_path + "data/view_budget.txt");
               if (fin.is_open()) fin >> view_budget;
             }

@@ -407,3 +407,46 @@ def test_png_io_against_pil(tmp_path):
     with pytest.raises(IOError):
         planner.png_read(tmp_path / "missing.png")
     Image.fromarray(smooth, "RGBA").save(tmp_path / "interlaced.png", interlace=1) if False else None
+
+
+def test_method4_handshake_with_prvnets_server(config9, tmp_path):
+    """method 4 against a stand-in for PRVNet/infer_server.py:72-101: the planner copies the initial view's image
+    to <pvb_path>/data/images/<id>.png and touches ready_c++.txt; the server removes it, writes view_budget.txt and
+    touches ready_py.txt; the planner removes that and tours the budget's view set"""
+    import threading
+    import time
+
+    config, pts9 = config9
+    pvb = tmp_path / "PRVNet"
+    (pvb / "data").mkdir(parents=True)
+    text = open(config).read() + f'pvb_path: "{pvb}/"\npvb_wait_seconds: 20\n'
+    cfg = tmp_path / "with_pvb.yaml"
+    cfg.write_text(text)
+    sd = planner.ShareData(cfg, "handshake", -1, -1, 4)
+    gt = tmp_path / "Coverage_images" / "ShapeNet" / "handshake" / "5"  # the initial view's image, as get_coverage leaves it
+    gt.mkdir(parents=True)
+    planner.png_write(gt / "rgbaClip_1.png", np.full((4, 6, 4), 200, np.uint8))
+    seen = {}
+
+    def server():
+        flag = pvb / "data" / "ready_c++.txt"
+        t0 = time.time()
+        while not flag.exists() and time.time() - t0 < 15:
+            time.sleep(0.05)
+        seen["flag"] = flag.exists()
+        flag.unlink()
+        seen["image"] = planner.png_read(pvb / "data" / "images" / "1.png").shape
+        (pvb / "data" / "view_budget.txt").write_text("9\n")  # np.savetxt(..., fmt='%d') of one value
+        (pvb / "data" / "ready_py.txt").write_text("")
+
+    th = threading.Thread(target=server)
+    th.start()
+    chosen = sd.nbv_loop([1e-10] * 3, 0.1, lambda *a: 1 / 0, first_view_id=1)
+    th.join(20)
+    assert seen == {"flag": True, "image": (4, 6, 4)}
+    assert sorted(chosen) == list(range(9)) and not (pvb / "data" / "ready_py.txt").exists()
+    # nobody answers: an error after the configured wait, no hang
+    cfg2 = tmp_path / "nobody.yaml"
+    cfg2.write_text(open(config).read() + f'pvb_path: "{tmp_path}/nobody/"\npvb_wait_seconds: 0.5\n')
+    with pytest.raises(RuntimeError):
+        planner.ShareData(cfg2, "silent", -1, -1, 4).nbv_loop([1e-10] * 3, 0.1, lambda *a: [0], first_view_id=1)
