@@ -171,7 +171,9 @@ struct HipScorer {
   }
   int eval_views = 100;
 
-  int operator()(int method, int /*iteration*/, const std::string& scene_json, const std::string& render_json,
+  bool save_renders = false; // save_renders: 1 -> the PNG tree the reference's run.py leaves (main.cpp:1676-1684)
+
+  int operator()(int method, int iteration, const std::string& scene_json, const std::string& render_json,
                  const std::vector<int>& ids, std::vector<double>& scores) {
     if (train_steps > 0) {
       const int trc = train_members(scene_json);
@@ -212,6 +214,21 @@ struct HipScorer {
       prv_free(ctx, gt_sel);
     } else {
       rc = prv_score_views(ctx, method, slots.data(), n_members, cams, nullptr, n, &o, nullptr, rec.data(), nullptr, nullptr);
+      if (rc == PRV_OK && save_renders) { // <save_path>/render/<it>/ensemble_<e>/rgbaClip_<view id>.png, the files :2047 reads
+        uint8_t* dev = nullptr;
+        std::vector<uint8_t> px((size_t)o.width * o.height * 4);
+        rc = prv_malloc(ctx, (void**)&dev, (size_t)n * px.size());
+        for (int e = 0; rc == PRV_OK && e < n_members; e++) {
+          const std::string dir = sd->save_path + "/render/" + std::to_string(iteration) + "/ensemble_" + std::to_string(e);
+          sd->access_directory(dir);
+          rc = prv_render_rgba8(ctx, e, cams, nullptr, n, &o, dev, nullptr);
+          for (int k = 0; rc == PRV_OK && k < n; k++) {
+            rc = prv_memcpy_d2h(ctx, px.data(), dev + (size_t)k * px.size(), px.size());
+            if (rc == PRV_OK && png_write_rgba8(dir + "/rgbaClip_" + std::to_string(ids[k]) + ".png", o.width, o.height, px.data()) != 0) rc = PRV_E_IO;
+          }
+        }
+        if (dev) prv_free(ctx, dev);
+      }
     }
     prv_camset_destroy(cams);
     if (rc != PRV_OK) {
@@ -268,6 +285,7 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   scorer.ctx = ctx;
   scorer.sd = sd;
   scorer.n_members = members;
+  scorer.save_renders = fs.has("save_renders") && fs.num("save_renders") > 0;
   if (train_steps > 0) { // members are trained from scratch every iteration
     const int rc = configure_training(ctx, fs, desc, scorer);
     if (rc != PRV_OK) return rc;

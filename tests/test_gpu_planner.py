@@ -571,7 +571,7 @@ def test_planner_executable_trains_from_the_png_files_on_disk(ctx, tmp_path):
     cfg = pre / "cfg.yaml"
     text = YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=2,
                        model_source="train_steps: 40\ntrain_rays: 1024\nground_truth_seed: 4242\ncoverage_images: 1\n"
-                                    "train_images: \"files\"")
+                                    "train_images: \"files\"\nsave_renders: 1")
     text = text.replace("ensemble_num: 5", "ensemble_num: 2").replace("color_width: 1280", "color_width: 160").replace(
         "color_height: 720", "color_height: 90").replace("9.1560668945312500e+02", "114.45").replace(
         "9.1332666015625000e+02", "114.2").replace("6.4714532470703125e+02", "80.9").replace("3.7251531982421875e+02", "46.6")
@@ -587,5 +587,10 @@ def test_planner_executable_trains_from_the_png_files_on_disk(ctx, tmp_path):
     assert len(chosen) == 4 and len(set(chosen)) == 4
     # a json of the loop resolves to those files
     save = pre / "Compare" / "ShapeNet" / "objA_m2_v1_t0"
+    # save_renders: the candidate screenshots of every member, named by view id, as main.cpp:2047 reads them back
+    r0 = save / "render" / "0" / "ensemble_1"
+    assert sorted(os.listdir(r0)) == [f"rgbaClip_{i}.png" for i in (0, 2, 3, 4)]
+    shot = np.asarray(Image.open(r0 / "rgbaClip_3.png"))
+    assert shot.shape == (45, 80, 4) and (shot[..., 3] == 255).all()  # opaque black background (run.py:94)
     fp = json.load(open(save / "json" / "2.json"))["frames"][0]["file_path"]
     assert os.path.exists(os.path.normpath(os.path.join(save / "json", fp)))
