@@ -592,5 +592,13 @@ def test_planner_executable_trains_from_the_png_files_on_disk(ctx, tmp_path):
     assert sorted(os.listdir(r0)) == [f"rgbaClip_{i}.png" for i in (0, 2, 3, 4)]
     shot = np.asarray(Image.open(r0 / "rgbaClip_3.png"))
     assert shot.shape == (45, 80, 4) and (shot[..., 3] == 255).all()  # opaque black background (run.py:94)
+    # the reference scores FROM those files (main.cpp:2045-2097): the oracle's EnsembleRGB over the PNG tree picks
+    # the view the in-memory scoring picked in that iteration
+    from oracle import oracle as orc
+    for it in (0, 1):
+        cand = sorted(int(f.split("_")[1][:-4]) for f in os.listdir(save / "render" / str(it) / "ensemble_0"))
+        sc = [orc.score_ensemble_rgb([np.ascontiguousarray(np.asarray(Image.open(save / "render" / str(it) / f"ensemble_{e}" / f"rgbaClip_{v}.png")))
+                                      for e in range(2)]) for v in cand]
+        assert cand[int(np.argmax(sc))] == chosen[it + 1]
     fp = json.load(open(save / "json" / "2.json"))["frames"][0]["file_path"]
     assert os.path.exists(os.path.normpath(os.path.join(save / "json", fp)))
