@@ -7,6 +7,7 @@
 #include "fit_curve.hpp"
 #include "path_planner.hpp"
 #include "planner.hpp"
+#include "pcd_io.hpp"
 #include "png_io.hpp"
 
 using namespace prvhost;
@@ -107,6 +108,20 @@ int prvh_write_transforms(const char* path, const prvh_intrinsics* in, int candi
     root["frames"].append(view_image);
   }
   return write_text(path, prvjson::to_styled_string(root)) ? 0 : -3;
+}
+
+long long prvh_pcd_read(const char* path, float* xyz_out, uint8_t* rgb_out, long long capacity) {
+  if (!path) return -1;
+  std::vector<float> xyz;
+  std::vector<uint8_t> rgb;
+  const int rc = pcd_read(path, xyz, rgb);
+  if (rc != 0) return rc;
+  const long long n = (long long)(xyz.size() / 3);
+  if (xyz_out && rgb_out && capacity >= n) {
+    memcpy(xyz_out, xyz.data(), xyz.size() * sizeof(float));
+    memcpy(rgb_out, rgb.data(), rgb.size());
+  }
+  return n;
 }
 
 int prvh_png_size(const char* path, int* width, int* height) {

@@ -27,13 +27,14 @@ extern "C" {
 }
 #include "planner.hpp"
 #include "fit_curve.hpp"
+#include "pcd_io.hpp"
 #include "png_io.hpp"
 
 using namespace prvhost;
 
 namespace {
 
-enum { InstantNGP = 4, GetPathPlan = 20, ViewPlanning = 21 }; // main.cpp:2284-2292
+enum { GetCoverage = 3, InstantNGP = 4, GetPathPlan = 20, ViewPlanning = 21 }; // main.cpp:2284-2292
 
 struct HipScorer {
   prv_ctx* ctx = nullptr;
@@ -498,6 +499,98 @@ int instant_ngp_curves(prv_ctx* ctx, const std::string& cfg, const std::string& 
   return 0;
 }
 
+// mode 3 (GetCoverage, main.cpp:2343-2462 -> NBV_Net_Labeler's constructor :636-1035 + get_coverage :1581-1656) for
+// an object given as a coloured cloud <model_path>/<name>.pcd: centre the cloud on its centroid, bounding radius x
+// 17/16 (:827-833), bring it to the object size (the reference draws a random size in [0.075, 0.115] m and keeps it
+// in <gt_path>/size.txt, :851-867; here: that file if it exists, else `object_size`), place the N views, write
+// <gt_path>/<N>.json and the <N>/rgbaClip_<i>.png images (PCL screenshot + convertToAlpha + flip = prv_splat_points).
+int get_coverage_from_cloud(prv_ctx* ctx, const std::string& cfg, const std::string& name) {
+  FileStorage fs;
+  fs.open(cfg);
+  auto sd = std::make_shared<Share_Data>(cfg, name, -1, -1, 0);
+  if (!sd->ok) {
+    std::cerr << sd->error << std::endl;
+    return -1;
+  }
+  std::vector<float> xyz;
+  std::vector<uint8_t> rgb;
+  const std::string cloud = sd->model_path + name + ".pcd";
+  const int prc = pcd_read(cloud, xyz, rgb);
+  if (prc != 0) {
+    std::cerr << "cannot read " << cloud << " (" << prc << ")" << std::endl;
+    return -70;
+  }
+  const size_t n = xyz.size() / 3;
+  double c[3] = {0, 0, 0};
+  for (size_t i = 0; i < n; i++)
+    for (int a = 0; a < 3; a++) c[a] += xyz[3 * i + a];
+  for (int a = 0; a < 3; a++) c[a] /= (double)n;
+  double radius = 0.0;
+  for (size_t i = 0; i < n; i++) {
+    double d2 = 0;
+    for (int a = 0; a < 3; a++) {
+      xyz[3 * i + a] = (float)(xyz[3 * i + a] - c[a]); // "move to centre" (:793-797)
+      d2 += (double)xyz[3 * i + a] * xyz[3 * i + a];
+    }
+    radius = std::max(radius, std::sqrt(d2));
+  }
+  const double predicted_raw = radius * 17.0 / 16.0;
+  sd->access_directory(sd->gt_path);
+  double size = fs.has("object_size") ? fs.num("object_size") : 0.1;
+  {
+    std::ifstream size_reader(sd->gt_path + "/size.txt");
+    double v = -1;
+    if (size_reader.is_open() && (size_reader >> v)) {
+      if (v < 0) {
+        std::cout << "no size. Skip." << std::endl; // :858-862
+        return 0;
+      }
+      size = v;
+    } else {
+      write_text(sd->gt_path + "/size.txt", std::to_string(size) + "\n");
+    }
+  }
+  std::vector<Vec3> pts(n);
+  for (size_t i = 0; i < n; i++) {
+    for (int a = 0; a < 3; a++) xyz[3 * i + a] = (float)(xyz[3 * i + a] * size / predicted_raw);
+    pts[i] = Vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+  }
+  HipScorer none;
+  NBV_Net_Labeler labeler(sd, Vec3(0, 0, 0), size, none);
+  labeler.view_space->get_view_space(pts); // centroid + 17/16 x radius of the scaled cloud (View_Space.hpp:517-558)
+  if (labeler.get_coverage() != 0) return -71;
+  const std::string N = std::to_string(sd->num_of_views);
+  prv_camset* ds = nullptr;
+  if (prv_cameras_from_dataset_json(ctx, (sd->gt_path + "/" + N + ".json").c_str(), &ds) != PRV_OK) return -72;
+  int w = 0, h = 0;
+  prv_camset_size(ds, &w, &h);
+  const int count = prv_camset_count(ds);
+  const int point_size = fs.has("points_size_cloud") ? (int)fs.num("points_size_cloud") : 5; // yaml:18
+  float* xyz_dev = nullptr;
+  uint8_t *rgb_dev = nullptr, *img_dev = nullptr;
+  int rc = prv_malloc(ctx, (void**)&xyz_dev, xyz.size() * 4);
+  if (rc == PRV_OK) rc = prv_malloc(ctx, (void**)&rgb_dev, rgb.size());
+  if (rc == PRV_OK) rc = prv_malloc(ctx, (void**)&img_dev, (size_t)w * h * 4);
+  if (rc == PRV_OK) rc = prv_memcpy_h2d(ctx, xyz_dev, xyz.data(), xyz.size() * 4);
+  if (rc == PRV_OK) rc = prv_memcpy_h2d(ctx, rgb_dev, rgb.data(), rgb.size());
+  const Vec3 oc = labeler.view_space->object_center_world;
+  const double scale = 0.5 / labeler.view_space->predicted_size; // the json's (main.cpp:1599-1602)
+  const double offset[3] = {0.5 + oc.z, 0.5 + oc.x, 0.5 + oc.y};
+  sd->access_directory(sd->gt_path + "/" + N);
+  std::vector<uint8_t> px((size_t)w * h * 4);
+  for (int i = 0; rc == PRV_OK && i < count; i++) {
+    rc = prv_splat_points(ctx, xyz_dev, rgb_dev, n, scale, offset, ds, &i, 1, w, h, point_size, 1, img_dev);
+    if (rc == PRV_OK) rc = prv_memcpy_d2h(ctx, px.data(), img_dev, px.size());
+    if (rc == PRV_OK && png_write_rgba8(sd->gt_path + "/" + N + "/rgbaClip_" + std::to_string(i) + ".png", w, h, px.data()) != 0) rc = PRV_E_IO;
+  }
+  if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+  for (void* p : {(void*)xyz_dev, (void*)rgb_dev, (void*)img_dev})
+    if (p) prv_free(ctx, p);
+  prv_camset_destroy(ds);
+  std::cout << "object " << name << ": " << n << " points, size " << size << " m, " << count << " views" << std::endl;
+  return rc;
+}
+
 // mode 20 (main.cpp:3622-3832): for every view set <viewspace_path>/<N>.txt, N = 3..100, the shortest open tour
 // over the unit view sphere from the (0,0,1) view, written to <N>_path.txt, one id per line (:3826-3830).
 // No GPU involved.  Sets without a (0,0,1) view are reported and skipped ("can not find now view id", :3648).
@@ -550,9 +643,9 @@ int main(int argc, char** argv) {
   std::string name;
   while (std::cin >> name && name != "-1") names.push_back(name);
   if (mode == GetPathPlan) return get_path_plan(cfg) == 0 ? 0 : 1; // host only: before any GPU context exists
-  if (mode != ViewPlanning && mode != InstantNGP) {
+  if (mode != ViewPlanning && mode != InstantNGP && mode != GetCoverage) {
     std::cerr << "mode " << mode << " is outside the render/score path this build covers (21 = ViewPlanning, 4 = InstantNGP, "
-                 "20 = GetPathPlan)" << std::endl;
+                 "3 = GetCoverage, 20 = GetPathPlan)" << std::endl;
     return 3;
   }
   prv_ctx* ctx = nullptr;
@@ -565,10 +658,10 @@ int main(int argc, char** argv) {
     std::cerr << "cannot open " << cfg << std::endl;
     return 5;
   }
-  if (mode == InstantNGP) {
+  if (mode == InstantNGP || mode == GetCoverage) {
     int worst = 0;
     for (const auto& n : names) {
-      const int rc = instant_ngp_curves(ctx, cfg, n);
+      const int rc = mode == InstantNGP ? instant_ngp_curves(ctx, cfg, n) : get_coverage_from_cloud(ctx, cfg, n);
       if (rc != 0) worst = rc;
     }
     prv_destroy(ctx);

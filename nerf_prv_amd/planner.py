@@ -53,6 +53,7 @@ HOST_SIGNATURES = {
     "prvh_share_data_number": (_d, [_vp, C.c_char_p]),
     "prvh_share_data_views": (_i, [_vp, _vp]),
     "prvh_share_data_intrinsics": (None, [_vp, C.POINTER(Intrinsics)]),
+    "prvh_pcd_read": (C.c_longlong, [C.c_char_p, _vp, _vp, C.c_longlong]),
     "prvh_png_size": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
     "prvh_png_read_rgba8": (_i, [C.c_char_p, _i, _i, _vp]),
     "prvh_png_write_rgba8": (_i, [C.c_char_p, _i, _i, _vp]),
@@ -157,6 +158,16 @@ def read_metrics(path):
     if host().prvh_read_metrics(str(path).encode(), C.byref(p), C.byref(s)) != 0:
         raise IOError(f"cannot read metrics from {path}")
     return p.value, s.value
+
+
+def pcd_read(path):
+    """(xyz float32 [n,3], rgb uint8 [n,3]) of a PCD file (ascii / binary, fields x y z [rgb])"""
+    n = host().prvh_pcd_read(str(path).encode(), None, None, 0)
+    if n < 0:
+        raise IOError(f"{path}: pcd error {n}")
+    xyz, rgb = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.uint8)
+    host().prvh_pcd_read(str(path).encode(), _p(xyz), _p(rgb), n)
+    return xyz, rgb
 
 
 def png_read(path):

@@ -602,3 +602,49 @@ def test_planner_executable_trains_from_the_png_files_on_disk(ctx, tmp_path):
         assert cand[int(np.argmax(sc))] == chosen[it + 1]
     fp = json.load(open(save / "json" / "2.json"))["frames"][0]["file_path"]
     assert os.path.exists(os.path.normpath(os.path.join(save / "json", fp)))
+
+
+def test_planner_executable_mode3_then_mode21_from_a_point_cloud(ctx, tmp_path):
+    """the reference's whole data flow from its input asset: mode 3 (GetCoverage) turns <model_path>/<name>.pcd into
+    <gt_path>/<N>.json + <N>/rgbaClip_<i>.png + size.txt; mode 21 then plans views training only from those files"""
+    import struct
+
+    from PIL import Image
+
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    pre = tmp_path / "cloud_flow"
+    (pre / "models").mkdir(parents=True)
+    rng = np.random.default_rng(21)
+    n = 40000
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    xyz = (np.array([0.6, 0.45, 0.3]) * d + [3.0, -2.0, 1.0]).astype(np.float32)  # an ellipsoid shell, off-centre, metres
+    rgb = np.clip(128 + 120 * d, 0, 254).astype(np.uint32)
+    packed = (rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2]
+    with open(pre / "models" / "shell.pcd", "wb") as f:
+        f.write((f"VERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\nWIDTH {n}\nHEIGHT 1\n"
+                 f"VIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA binary\n").encode())
+        for p, v in zip(xyz, packed):
+            f.write(struct.pack("<fffI", *p, int(v)))
+    cfg = pre / "cfg.yaml"
+    text = YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=2,
+                       model_source="train_steps: 40\ntrain_rays: 1024\ntrain_images: \"files\"\npoints_size_cloud: 2")
+    text = text.replace("ensemble_num: 5", "ensemble_num: 2").replace("color_width: 1280", "color_width: 160").replace(
+        "color_height: 720", "color_height: 90").replace("9.1560668945312500e+02", "114.45").replace(
+        "9.1332666015625000e+02", "114.2").replace("6.4714532470703125e+02", "80.9").replace("3.7251531982421875e+02", "46.6")
+    cfg.write_text(text.replace("candidate_divisor: 16", "candidate_divisor: 2"))
+    out = subprocess.run([exe, str(cfg)], input="3\nshell\n-1\n", text=True, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    gt = pre / "Coverage_images" / "ShapeNet" / "shell"
+    assert float((gt / "size.txt").read_text()) == pytest.approx(0.1)
+    meta = json.load(open(gt / "5.json"))
+    assert len(meta["frames"]) == 5 and meta["w"] == 160
+    assert meta["scale"] == pytest.approx(0.5 / 0.1, rel=0.08)  # predicted size ~ the configured object size (17/16 of 16/17)
+    img = np.asarray(Image.open(gt / "5" / "rgbaClip_1.png"))  # the top view: the shell in the middle of the frame
+    a = img[..., 3] > 0
+    assert img.shape == (90, 160, 4) and 0.02 < a.mean() < 0.6 and a[40:50, 70:90].mean() > 0.5 and not a[:5].any()
+    # the planner on those files alone (no ground-truth field anywhere)
+    out = subprocess.run([exe, str(cfg)], input="21\nshell\n-1\n", text=True, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    chosen = [int(x) for x in [l for l in out.stdout.splitlines() if l.startswith("chosen_nbvs:")][-1].split(":")[1].split()]
+    assert len(chosen) == 4 and len(set(chosen)) == 4

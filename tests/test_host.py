@@ -450,3 +450,37 @@ def test_method4_handshake_with_prvnets_server(config9, tmp_path):
     cfg2.write_text(open(config).read() + f'pvb_path: "{tmp_path}/nobody/"\npvb_wait_seconds: 0.5\n')
     with pytest.raises(RuntimeError):
         planner.ShareData(cfg2, "silent", -1, -1, 4).nbv_loop([1e-10] * 3, 0.1, lambda *a: [0], first_view_id=1)
+
+
+def test_pcd_reader_ascii_and_binary(tmp_path):
+    """PCD v0.7 as PCL writes it: packed rgb as a float field, ascii and binary bodies, extra fields skipped"""
+    import struct
+
+    rng = np.random.default_rng(12)
+    n = 50
+    xyz = rng.normal(size=(n, 3)).astype(np.float32)
+    rgb = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    packed = (rgb[:, 0].astype(np.uint32) << 16) | (rgb[:, 1].astype(np.uint32) << 8) | rgb[:, 2]
+    as_float = packed.view(np.float32)
+    head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb curvature\nSIZE 4 4 4 4 4\n"
+            "TYPE F F F F F\nCOUNT 1 1 1 1 1\nWIDTH {n}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA {kind}\n")
+    p = tmp_path / "a.pcd"
+    p.write_text(head.format(n=n, kind="ascii") + "".join(
+        f"{a:.9g} {b:.9g} {c:.9g} {float(f):.9g} 0.5\n" for (a, b, c), f in zip(xyz, as_float)))
+    gx, gc = planner.pcd_read(p)
+    assert np.array_equal(gx, xyz) and np.array_equal(gc, rgb)
+    p = tmp_path / "b.pcd"
+    with open(p, "wb") as f:
+        f.write(head.format(n=n, kind="binary").encode())
+        for (a, b, c), v in zip(xyz, packed):
+            f.write(struct.pack("<fffIf", a, b, c, int(v), 0.5))
+    gx, gc = planner.pcd_read(p)
+    assert np.array_equal(gx, xyz) and np.array_equal(gc, rgb)
+    p = tmp_path / "c.pcd"  # no colour field, unsigned rgb variant elsewhere
+    p.write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA ascii\n1 2 3\n4 5 6\n")
+    gx, gc = planner.pcd_read(p)
+    assert gx.tolist() == [[1, 2, 3], [4, 5, 6]] and (gc == 200).all()
+    (tmp_path / "d.pcd").write_text("VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA binary_compressed\n")
+    for bad in ("d.pcd", "missing.pcd"):
+        with pytest.raises(IOError):
+            planner.pcd_read(tmp_path / bad)
