@@ -452,27 +452,32 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
   }
 }
 
-// mlp_grad[i] += sum over the blocks' partial slots: 64 weights x 4 slot groups per block, every thread's
-// loads independent of each other, the four group sums combined in a fixed order
+// mlp_grad[i] += sum over the blocks' partial slots, in two stages: 16 slot groups summed side by side (grid.y),
+// then the 16 group sums of a weight added in group order -- fixed order throughout, 16x the loads in flight
+constexpr int kDwGroups = 16;
 __global__ __launch_bounds__(256) void train_reduce_dw_kernel(const float* __restrict__ partial, int n_blocks,
-                                                              float* __restrict__ mlp_grad) {
-  __shared__ float part[4][64];
-  const int w = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + w;
-  float a = 0.0f;
-  if (i < PRV_MLP_HALFS) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int b = grp;
-    for (; b + 12 < n_blocks; b += 16) {
+                                                              float* __restrict__ stage) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= PRV_MLP_HALFS) return;
+  const int per = (n_blocks + kDwGroups - 1) / kDwGroups;
+  const int b0 = blockIdx.y * per, b1 = min(n_blocks, b0 + per);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) acc[u] += partial[(size_t)(b + 4 * u) * PRV_MLP_HALFS + i];
-    }
-    for (; b < n_blocks; b += 4) acc[0] += partial[(size_t)b * PRV_MLP_HALFS + i];
-    a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    for (int u = 0; u < 4; u++) acc[u] += partial[(size_t)(b + u) * PRV_MLP_HALFS + i];
   }
-  part[grp][w] = a;
-  __syncthreads();
-  if (grp == 0 && i < PRV_MLP_HALFS) mlp_grad[i] += (part[0][w] + part[1][w]) + (part[2][w] + part[3][w]);
+  for (; b < b1; b++) acc[0] += partial[(size_t)b * PRV_MLP_HALFS + i];
+  stage[(size_t)blockIdx.y * PRV_MLP_HALFS + i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+__global__ __launch_bounds__(256) void train_reduce_dw2_kernel(const float* __restrict__ stage, float* __restrict__ mlp_grad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= PRV_MLP_HALFS) return;
+  float a = 0.0f;
+#pragma unroll
+  for (int g = 0; g < kDwGroups; g++) a += stage[(size_t)g * PRV_MLP_HALFS + i];
+  mlp_grad[i] += a;
 }
 
 // ------------------------------------------------------------------ forward at inference speed
@@ -726,20 +731,47 @@ __device__ __forceinline__ void adam_update(const AdamParams& P, float lr_t, flo
   w = w - (lr_t * m) / (sqrtf(v) + P.eps);
 }
 
+// four table scalars per thread (one 16-byte load of the gradient; most are zero and cost nothing more)
 __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n, float* __restrict__ grad,
                                                          float* __restrict__ w, float* __restrict__ m,
                                                          float* __restrict__ v, uint16_t* __restrict__ w16) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float g = grad[i];
-  if (g == 0.0f) return; // sparse: untouched entries keep their moments
-  grad[i] = 0.0f;
-  float ww = w[i], mm = m[i], vv = v[i];
-  adam_update(P, P.state->lr_t, g, ww, mm, vv);
-  w[i] = ww;
-  m[i] = mm;
-  v[i] = vv;
-  w16[i] = __builtin_bit_cast(uint16_t, (_Float16)ww);
+  const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const float lr_t = P.state->lr_t;
+  if (i4 + 4 <= n) {
+    const float4 g4 = *reinterpret_cast<const float4*>(grad + i4);
+    if (g4.x == 0.0f && g4.y == 0.0f && g4.z == 0.0f && g4.w == 0.0f) return; // sparse: untouched entries keep their moments
+    *reinterpret_cast<float4*>(grad + i4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the touched scalars of a group are one table entry (F = 4) or two (F = 2): whole-group 16-byte loads and
+    // stores of weight and moments instead of four scattered 4-byte ones each (untouched lanes are rewritten as read)
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float4 w4 = *reinterpret_cast<const float4*>(w + i4), m4 = *reinterpret_cast<const float4*>(m + i4),
+                 v4 = *reinterpret_cast<const float4*>(v + i4);
+    float ww[4] = {w4.x, w4.y, w4.z, w4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (g[k] != 0.0f) adam_update(P, lr_t, g[k], ww[k], mm[k], vv[k]);
+    *reinterpret_cast<float4*>(w + i4) = make_float4(ww[0], ww[1], ww[2], ww[3]);
+    *reinterpret_cast<float4*>(m + i4) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    *reinterpret_cast<float4*>(v + i4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    typedef uint16_t ushort4v __attribute__((ext_vector_type(4)));
+    ushort4v h4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) h4[k] = g[k] != 0.0f ? __builtin_bit_cast(uint16_t, (_Float16)ww[k]) : w16[i4 + k];
+    *reinterpret_cast<ushort4v*>(w16 + i4) = h4;
+    return;
+  }
+  for (size_t i = i4; i < n; i++) { // the last, partial group
+    const float g = grad[i];
+    if (g == 0.0f) continue;
+    grad[i] = 0.0f;
+    float ww = w[i], mm = m[i], vv = v[i];
+    adam_update(P, lr_t, g, ww, mm, vv);
+    w[i] = ww;
+    m[i] = mm;
+    v[i] = vv;
+    w16[i] = __builtin_bit_cast(uint16_t, (_Float16)ww);
+  }
 }
 
 __global__ __launch_bounds__(256) void adam_mlp_kernel(AdamParams P, float l2_reg, float* __restrict__ grad,
@@ -926,8 +958,11 @@ hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_bloc
   if (P.n_features == 4) e = forward ? launch_tile<4, true>(P, n_blocks, s) : launch_tile<4, false>(P, n_blocks, s);
   else e = forward ? launch_tile<2, true>(P, n_blocks, s) : launch_tile<2, false>(P, n_blocks, s);
   if (e != hipSuccess || forward) return e;
-  hipLaunchKernelGGL(train_reduce_dw_kernel, dim3((PRV_MLP_HALFS + 63) / 64), dim3(256), 0, s, P.mlp_grad_partial, n_blocks,
-                     P.mlp_grad);
+  // the stage buffer sits behind the slots (n_blocks slots + kDwGroups group sums)
+  float* stage = P.mlp_grad_partial + (size_t)n_blocks * PRV_MLP_HALFS;
+  hipLaunchKernelGGL(train_reduce_dw_kernel, dim3((PRV_MLP_HALFS + 255) / 256, kDwGroups), dim3(256), 0, s, P.mlp_grad_partial,
+                     n_blocks, stage);
+  hipLaunchKernelGGL(train_reduce_dw2_kernel, dim3((PRV_MLP_HALFS + 255) / 256), dim3(256), 0, s, stage, P.mlp_grad);
   return hipGetLastError();
 }
 
@@ -961,7 +996,7 @@ hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, in
 
 hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* w, float* m, float* v, uint16_t* w16,
                              hipStream_t s) {
-  hipLaunchKernelGGL(adam_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P, n, grad, w, m, v, w16);
+  hipLaunchKernelGGL(adam_table_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, P, n, grad, w, m, v, w16);
   return hipGetLastError();
 }
 
