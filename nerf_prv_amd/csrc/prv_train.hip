@@ -482,13 +482,17 @@ __global__ __launch_bounds__(256) void train_reduce_dw2_kernel(const float* __re
 
 // ------------------------------------------------------------------ forward at inference speed
 
+__device__ __forceinline__ void end_step(const AdamParams& P, uint32_t* sample_count, float lr, float beta1, float beta2);
+
 // the 24 MFMA A-fragments of the current fp16 weights (the layout prv_api.cpp: prepack_fragments gives the
 // render kernel), rebuilt on the device after every optimiser step: one thread per fragment element
 __device__ __forceinline__ int frag_hidden_k(int s, int h, int j) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
 
 __global__ __launch_bounds__(256) void prepack_frags_kernel(const uint16_t* __restrict__ mlp, int n_features,
-                                                            uint16_t* __restrict__ frags) {
+                                                            uint16_t* __restrict__ frags, AdamParams P,
+                                                            uint32_t* sample_count, float lr) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && P.state) end_step(P, sample_count, lr, P.beta1, P.beta2); // the step's last kernel: it opens the next one too
   if (i >= kNumFrags * kFragHalfs) return;
   const int f = i / kFragHalfs, lane = (i % kFragHalfs) >> 3, j = i & 7;
   const int r = lane & 31, h = lane >> 5;
@@ -732,6 +736,29 @@ __device__ __forceinline__ void adam_update(const AdamParams& P, float lr_t, flo
 }
 
 // four table scalars per thread (one 16-byte load of the gradient; most are zero and cost nothing more)
+// end-of-step bookkeeping, ONE thread of the step's last kernel, which must not read any of these itself: the step
+// counter, the sample budget (integer rule, mirrored by oracle/prv_train.c) and -- when that kernel also opens the
+// next step (sample_count != NULL) -- the next step's bias-corrected learning rate and the sample counter reset
+__device__ __forceinline__ void end_step(const AdamParams& P, uint32_t* sample_count, float lr, float beta1, float beta2) {
+  const uint32_t done = P.state->step + 1u;
+  P.state->step = done;
+  if (P.target_samples > 0) {
+    const unsigned long long used = *P.used ? *P.used : 1ull;
+    const unsigned long long act = P.state->n_active;
+    unsigned long long a = (unsigned long long)P.target_samples * act / used;
+    a = max(a, act / 2ull);
+    a = min(a, act * 2ull);
+    a = max(a, 1ull);
+    a = min(a, (unsigned long long)P.n_rays);
+    P.state->n_active = (uint32_t)a;
+  }
+  if (sample_count) {
+    const double n = (double)(done + 1u);
+    P.state->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, n)) / (1.0 - pow((double)beta1, n)));
+    *sample_count = 0u;
+  }
+}
+
 __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n, float* __restrict__ grad,
                                                          float* __restrict__ w, float* __restrict__ m,
                                                          float* __restrict__ v, uint16_t* __restrict__ w16) {
@@ -777,10 +804,16 @@ __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n,
 __global__ __launch_bounds__(256) void adam_mlp_kernel(AdamParams P, float l2_reg, float* __restrict__ grad,
                                                        float* __restrict__ w, float* __restrict__ m,
                                                        float* __restrict__ v, uint16_t* __restrict__ w16,
-                                                       float* __restrict__ w16_as_f32) {
+                                                       float* __restrict__ w16_as_f32, const float* __restrict__ stage,
+                                                       int end_of_step) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= PRV_MLP_HALFS) return;
-  const float g = fmaf(l2_reg, w[i], grad[i]);
+  float gsum = grad[i];
+  if (stage) { // the second stage of the weight-gradient reduction, fused: the group sums in group order
+#pragma unroll
+    for (int q = 0; q < kDwGroups; q++) gsum += stage[(size_t)q * PRV_MLP_HALFS + i];
+  }
+  const float g = fmaf(l2_reg, w[i], gsum);
   grad[i] = 0.0f;
   float ww = w[i], mm = m[i], vv = v[i];
   adam_update(P, P.state->lr_t, g, ww, mm, vv);
@@ -790,19 +823,7 @@ __global__ __launch_bounds__(256) void adam_mlp_kernel(AdamParams P, float l2_re
   const _Float16 hh = (_Float16)ww;
   w16[i] = __builtin_bit_cast(uint16_t, hh);
   w16_as_f32[i] = (float)hh;
-  if (i == 0) { // last node of a step; nobody else reads these in this kernel
-    P.state->step = P.state->step + 1u;
-    if (P.target_samples > 0) { // the sample budget (integer rule, mirrored by oracle/prv_train.c)
-      const unsigned long long used = *P.used ? *P.used : 1ull;
-      const unsigned long long act = P.state->n_active;
-      unsigned long long a = (unsigned long long)P.target_samples * act / used;
-      a = max(a, act / 2ull);
-      a = min(a, act * 2ull);
-      a = max(a, 1ull);
-      a = min(a, (unsigned long long)P.n_rays);
-      P.state->n_active = (uint32_t)a;
-    }
-  }
+  if (i == 0 && end_of_step) end_step(P, nullptr, 0.f, 0.f, 0.f); // last node of a step unless a later kernel takes that role
 }
 
 __global__ __launch_bounds__(256) void widen_kernel(const uint16_t* __restrict__ in, size_t n, float* __restrict__ out) {
@@ -953,7 +974,7 @@ hipError_t train_prepare_kernels() {
   return hipSuccess;
 }
 
-hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s) {
+hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s, bool finish_reduce) {
   hipError_t e;
   if (P.n_features == 4) e = forward ? launch_tile<4, true>(P, n_blocks, s) : launch_tile<4, false>(P, n_blocks, s);
   else e = forward ? launch_tile<2, true>(P, n_blocks, s) : launch_tile<2, false>(P, n_blocks, s);
@@ -962,12 +983,16 @@ hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_bloc
   float* stage = P.mlp_grad_partial + (size_t)n_blocks * PRV_MLP_HALFS;
   hipLaunchKernelGGL(train_reduce_dw_kernel, dim3((PRV_MLP_HALFS + 255) / 256, kDwGroups), dim3(256), 0, s, P.mlp_grad_partial,
                      n_blocks, stage);
-  hipLaunchKernelGGL(train_reduce_dw2_kernel, dim3((PRV_MLP_HALFS + 255) / 256), dim3(256), 0, s, stage, P.mlp_grad);
+  if (finish_reduce) hipLaunchKernelGGL(train_reduce_dw2_kernel, dim3((PRV_MLP_HALFS + 255) / 256), dim3(256), 0, s, stage, P.mlp_grad);
   return hipGetLastError();
 }
 
-hipError_t launch_prepack_frags(const uint16_t* mlp, int n_features, uint16_t* frags, hipStream_t s) {
-  hipLaunchKernelGGL(prepack_frags_kernel, dim3((kNumFrags * kFragHalfs + 255) / 256), dim3(256), 0, s, mlp, n_features, frags);
+hipError_t launch_prepack_frags(const uint16_t* mlp, int n_features, uint16_t* frags, const AdamParams* end_of_step,
+                                uint32_t* sample_count, float lr, hipStream_t s) {
+  AdamParams P{};
+  if (end_of_step) P = *end_of_step; // state != NULL: this launch closes the step and opens the next
+  hipLaunchKernelGGL(prepack_frags_kernel, dim3((kNumFrags * kFragHalfs + 255) / 256), dim3(256), 0, s, mlp, n_features, frags, P,
+                     sample_count, lr);
   return hipGetLastError();
 }
 
@@ -1001,9 +1026,9 @@ hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* 
 }
 
 hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float* w, float* m, float* v, uint16_t* w16,
-                           float* w16_as_f32, hipStream_t s) {
+                           float* w16_as_f32, const float* stage, int end_of_step, hipStream_t s) {
   hipLaunchKernelGGL(adam_mlp_kernel, dim3((PRV_MLP_HALFS + 255) / 256), dim3(256), 0, s, P, l2_reg, grad, w, m, v, w16,
-                     w16_as_f32);
+                     w16_as_f32, stage, end_of_step);
   return hipGetLastError();
 }
 

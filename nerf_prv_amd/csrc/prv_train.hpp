@@ -87,8 +87,10 @@ struct DensityParams {
 size_t train_tile_lds_bytes(bool fwd);
 hipError_t train_prepare_kernels();
 hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s);
-hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s);
-hipError_t launch_prepack_frags(const uint16_t* mlp, int n_features, uint16_t* frags, hipStream_t s);
+// backward: finish_reduce = false leaves the second stage of the dW reduction to adam_mlp_kernel (stage = slots + n_blocks)
+hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s, bool finish_reduce = true);
+hipError_t launch_prepack_frags(const uint16_t* mlp, int n_features, uint16_t* frags, const AdamParams* end_of_step,
+                                uint32_t* sample_count, float lr, hipStream_t s);
 hipError_t launch_train_forward_fast(const TrainTileParams& P, const half8* frags, int n_blocks, hipStream_t s);
 hipError_t launch_train_composite(const TrainCompositeParams& P, hipStream_t s);
 hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2, hipStream_t s);
@@ -97,7 +99,7 @@ hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, in
 hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* w, float* m, float* v, uint16_t* w16,
                              hipStream_t s);
 hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float* w, float* m, float* v, uint16_t* w16,
-                           float* w16_as_f32, hipStream_t s);
+                           float* w16_as_f32, const float* stage, int end_of_step, hipStream_t s);
 hipError_t launch_widen(const uint16_t* in, size_t n, float* out, hipStream_t s);
 hipError_t launch_density_refresh(const DensityParams& P, int n_features, hipStream_t s);
 hipError_t launch_density_refresh_fast(const DensityParams& P, int n_features, const half8* frags, int n_blocks, hipStream_t s);
