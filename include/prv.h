@@ -38,6 +38,7 @@ extern "C" {
 #define PRV_E_IO (-3)       /* file / parse error */
 #define PRV_E_NODEVICE (-4) /* no usable GPU */
 #define PRV_E_STATE (-5)    /* e.g. model slot empty */
+#define PRV_E_INTERNAL (-6) /* host allocation failure / unexpected internal error: no exception crosses the ABI */
 
 /* scoring methods; 2 and 3 are the reference's method_of_IG values (Share_Data.hpp:198-202) */
 #define PRV_SCORE_ENSEMBLE_RGB 2         /* main.cpp:2039-2097 */

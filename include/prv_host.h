@@ -14,6 +14,10 @@
 extern "C" {
 #endif
 
+/* No exception crosses this ABI: an int / count function that ran out of memory (or hit any other internal
+ * error) returns PRVH_E_INTERNAL, a double-valued one -1.0, prvh_share_data_create NULL. */
+#define PRVH_E_INTERNAL (-100)
+
 /* View::get_next_camera_pos(now_camera_pose_world = I, object_center_world, type 0)
  * (View_Space.hpp:67-140): pose = world->camera 4x4, row-major */
 void prvh_view_pose(const double init_pos[3], const double center[3], double pose[16]);

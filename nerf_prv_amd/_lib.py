@@ -15,6 +15,7 @@ PRV_E_HIP = -2
 PRV_E_IO = -3
 PRV_E_NODEVICE = -4
 PRV_E_STATE = -5
+PRV_E_INTERNAL = -6
 
 SCORE_ENSEMBLE_RGB = 2
 SCORE_ENSEMBLE_RGB_DENSITY = 3

@@ -9,6 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -84,6 +87,27 @@ int fail(prv_ctx* c, int code, const char* fmt, ...) {
   if (c) c->err = buf;
   else g_create_error = buf;
   return code;
+}
+
+// No exception crosses the C ABI: every entry point that can allocate is a function-try-block ending here.
+int caught(prv_ctx* c) noexcept {
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    try {
+      return fail(c, PRV_E_INTERNAL, "out of host memory");
+    } catch (...) {
+      return PRV_E_INTERNAL;
+    }
+  } catch (const std::exception& e) {
+    try {
+      return fail(c, PRV_E_INTERNAL, "internal error: %s", e.what());
+    } catch (...) {
+      return PRV_E_INTERNAL;
+    }
+  } catch (...) {
+    return PRV_E_INTERNAL;
+  }
 }
 
 #define HIPCHK(c, expr)                                                                           \
@@ -209,6 +233,7 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   HostLevel lv[kMaxLevels];
   uint64_t total = 0;
   if (compute_levels(d, lv, &total) != 0) return fail(c, PRV_E_INVALID, "invalid field descriptor");
+  m.loaded = false; // until everything below has succeeded: a failed install leaves an empty slot, not half a model
   m.desc = d;
   m.table_halfs = total * (uint64_t)d.n_features;
   const uint64_t R = (uint64_t)d.occ_res;
@@ -583,7 +608,7 @@ int prv_device_count(void) {
 
 const char* prv_last_error(const prv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int prv_create(prv_ctx** out, int device_id) {
+int prv_create(prv_ctx** out, int device_id) try {
   if (!out) return fail(nullptr, PRV_E_INVALID, "out is NULL");
   *out = nullptr;
   int n = 0;
@@ -617,7 +642,7 @@ int prv_create(prv_ctx** out, int device_id) {
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
   *out = c;
   return PRV_OK;
-}
+} catch (...) { return caught(nullptr); }
 
 void prv_destroy(prv_ctx* c) {
   if (!c) return;
@@ -647,18 +672,18 @@ void prv_destroy(prv_ctx* c) {
   delete c;
 }
 
-int prv_set_stream(prv_ctx* c, void* s) {
+int prv_set_stream(prv_ctx* c, void* s) try {
   if (!c) return PRV_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stream = (hipStream_t)s; // NULL is HIP's legacy default stream (what torch uses by default)
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
-int prv_synchronize(prv_ctx* c) {
+int prv_synchronize(prv_ctx* c) try {
   if (!c) return PRV_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
 static int drain_events(prv_ctx* c, std::vector<hipEvent_t>& ev, double* ms, int* n) {
   double tot = 0.0;
@@ -674,51 +699,55 @@ static int drain_events(prv_ctx* c, std::vector<hipEvent_t>& ev, double* ms, int
   return PRV_OK;
 }
 
-int prv_profile_begin(prv_ctx* c) {
+int prv_profile_begin(prv_ctx* c) try {
   if (!c) return PRV_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   drain_events(c, c->ev_render, nullptr, nullptr);
   drain_events(c, c->ev_march, nullptr, nullptr);
   c->profiling = true;
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
-int prv_profile_end(prv_ctx* c, double* render_ms, int* render_n, double* march_ms, int* march_n) {
+int prv_profile_end(prv_ctx* c, double* render_ms, int* render_n, double* march_ms, int* march_n) try {
   if (!c) return PRV_E_INVALID;
   c->profiling = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int rc = drain_events(c, c->ev_render, render_ms, render_n);
   if (rc != PRV_OK) return rc;
   return drain_events(c, c->ev_march, march_ms, march_n);
-}
+} catch (...) { return caught(c); }
 
-int prv_malloc(prv_ctx* c, void** p, size_t bytes) {
+int prv_malloc(prv_ctx* c, void** p, size_t bytes) try {
   if (!c || !p) return PRV_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMalloc(p, bytes ? bytes : 1));
   return PRV_OK;
-}
-int prv_free(prv_ctx* c, void* p) {
+} catch (...) { return caught(c); }
+int prv_free(prv_ctx* c, void* p) try {
   if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipFree(p));
   return PRV_OK;
-}
-int prv_memcpy_h2d(prv_ctx* c, void* d, const void* s, size_t bytes) {
+} catch (...) { return caught(c); }
+int prv_memcpy_h2d(prv_ctx* c, void* d, const void* s, size_t bytes) try {
   if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return PRV_OK;
-}
-int prv_memcpy_d2h(prv_ctx* c, void* d, const void* s, size_t bytes) {
+} catch (...) { return caught(c); }
+int prv_memcpy_d2h(prv_ctx* c, void* d, const void* s, size_t bytes) try {
   if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
 // ------------------------------------------------------------------ model
 
-int prv_model_sizes(const prv_field_desc* d, uint64_t* table_halfs, uint64_t* mlp_halfs, uint64_t* occ_words) {
+int prv_model_sizes(const prv_field_desc* d, uint64_t* table_halfs, uint64_t* mlp_halfs, uint64_t* occ_words) try {
   if (!d) return PRV_E_INVALID;
   HostLevel lv[kMaxLevels];
   uint64_t total = 0;
@@ -728,24 +757,24 @@ int prv_model_sizes(const prv_field_desc* d, uint64_t* table_halfs, uint64_t* ml
   const uint64_t R = (uint64_t)d->occ_res;
   if (occ_words) *occ_words = (R * R * R + 31) / 32;
   return PRV_OK;
-}
+} catch (...) { return caught(nullptr); }
 
 int prv_model_load(prv_ctx* c, int slot, const prv_field_desc* d, const uint16_t* table, const uint16_t* mlp,
-                   const uint32_t* occ) {
+                   const uint32_t* occ) try {
   if (!c) return PRV_E_INVALID;
   if (slot < 0 || slot >= PRV_MAX_MODELS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
   if (!d || !table || !mlp || !occ) return fail(c, PRV_E_INVALID, "NULL argument");
   HIPCHK(c, hipSetDevice(c->device));
   return install_model(c, slot, *d, mlp, occ, table);
-}
+} catch (...) { return caught(c); }
 
 static int model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed, bool all_occupied);
-int prv_model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed) {
+int prv_model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed) try {
   return model_synthetic(c, slot, d, seed, false);
-}
-int prv_model_fresh(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed) {
+} catch (...) { return caught(c); }
+int prv_model_fresh(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed) try {
   return model_synthetic(c, slot, d, seed, true);
-}
+} catch (...) { return caught(c); }
 static int model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed, bool all_occupied) {
   if (!c) return PRV_E_INVALID;
   if (slot < 0 || slot >= PRV_MAX_MODELS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
@@ -787,7 +816,7 @@ static int model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64
   return install_model(c, slot, *d, mlp.data(), occ.data(), nullptr);
 }
 
-int prv_model_export(prv_ctx* c, int slot, uint16_t* table, uint16_t* mlp, uint32_t* occ) {
+int prv_model_export(prv_ctx* c, int slot, uint16_t* table, uint16_t* mlp, uint32_t* occ) try {
   if (!c) return PRV_E_INVALID;
   int rc = check_model(c, slot);
   if (rc != PRV_OK) return rc;
@@ -797,9 +826,9 @@ int prv_model_export(prv_ctx* c, int slot, uint16_t* table, uint16_t* mlp, uint3
   if (occ) HIPCHK(c, hipMemcpyAsync(occ, m.occ.p, m.occ_words * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
-int prv_model_save_file(prv_ctx* c, int slot, const char* path) {
+int prv_model_save_file(prv_ctx* c, int slot, const char* path) try {
   if (!c) return PRV_E_INVALID;
   int rc = check_model(c, slot);
   if (rc != PRV_OK) return rc;
@@ -816,9 +845,9 @@ int prv_model_save_file(prv_ctx* c, int slot, const char* path) {
             fwrite(occ.data(), 4, occ.size(), f) == occ.size();
   ok = (fclose(f) == 0) && ok;
   return ok ? PRV_OK : fail(c, PRV_E_IO, "short write to %s", path);
-}
+} catch (...) { return caught(c); }
 
-int prv_model_load_file(prv_ctx* c, int slot, const char* path) {
+int prv_model_load_file(prv_ctx* c, int slot, const char* path) try {
   if (!c) return PRV_E_INVALID;
   if (!path) return fail(c, PRV_E_INVALID, "path is NULL");
   FILE* f = fopen(path, "rb");
@@ -837,7 +866,7 @@ int prv_model_load_file(prv_ctx* c, int slot, const char* path) {
   fclose(f);
   if (!ok) return fail(c, PRV_E_IO, "%s is truncated", path);
   return prv_model_load(c, slot, &d, table.data(), mlp.data(), occ.data());
-}
+} catch (...) { return caught(c); }
 
 // ------------------------------------------------------------------ cameras
 
@@ -855,7 +884,8 @@ static int build_camset(prv_ctx* c, const double* tm, int n, const prv_intrinsic
   if (!std::isfinite(in.cx) || !std::isfinite(in.cy) || !std::isfinite(in.k1) || !std::isfinite(in.k2) ||
       !std::isfinite(in.p1) || !std::isfinite(in.p2))
     return fail(c, PRV_E_INVALID, "non-finite intrinsics");
-  prv_camset* cs = new prv_camset();
+  std::unique_ptr<prv_camset> owner(new prv_camset());
+  prv_camset* cs = owner.get();
   cs->device = c->device;
   cs->width = in.w;
   cs->height = in.h;
@@ -884,12 +914,12 @@ static int build_camset(prv_ctx* c, const double* tm, int n, const prv_intrinsic
     cam.lens[2] = (float)in.p1;
     cam.lens[3] = (float)in.p2;
   }
-  *out = cs;
+  *out = owner.release();
   return PRV_OK;
 }
 
 int prv_cameras_from_matrices(prv_ctx* c, const double* tm, int n, double camera_angle_x, int width, int height,
-                              double scale, const double offset[3], prv_camset** out) {
+                              double scale, const double offset[3], prv_camset** out) try {
   if (!c) return PRV_E_INVALID;
   if (out) *out = nullptr;
   if (width < 1 || height < 1) return fail(c, PRV_E_INVALID, "bad size %dx%d", width, height);
@@ -901,15 +931,15 @@ int prv_cameras_from_matrices(prv_ctx* c, const double* tm, int n, double camera
   in.w = width;
   in.h = height;
   return build_camset(c, tm, n, in, false, scale, offset, out);
-}
+} catch (...) { return caught(c); }
 
 int prv_cameras_from_matrices_intr(prv_ctx* c, const double* tm, int n, const prv_intrinsics* intr, double scale,
-                                   const double offset[3], prv_camset** out) {
+                                   const double offset[3], prv_camset** out) try {
   if (!c) return PRV_E_INVALID;
   if (out) *out = nullptr;
   if (!intr) return fail(c, PRV_E_INVALID, "intrinsics are NULL");
   return build_camset(c, tm, n, *intr, true, scale, offset, out);
-}
+} catch (...) { return caught(c); }
 
 // header + frames of a transforms.json; dataset = use the file's own intrinsics block
 static int cameras_from_json(prv_ctx* c, const char* path, bool dataset, prv_camset** out) {
@@ -961,8 +991,12 @@ static int cameras_from_json(prv_ctx* c, const char* path, bool dataset, prv_cam
   return build_camset(c, tm.data(), (int)frames.size(), in, true, scale, offset, out);
 }
 
-int prv_cameras_from_json(prv_ctx* c, const char* path, prv_camset** out) { return cameras_from_json(c, path, false, out); }
-int prv_cameras_from_dataset_json(prv_ctx* c, const char* path, prv_camset** out) { return cameras_from_json(c, path, true, out); }
+int prv_cameras_from_json(prv_ctx* c, const char* path, prv_camset** out) try {
+  return cameras_from_json(c, path, false, out);
+} catch (...) { return caught(c); }
+int prv_cameras_from_dataset_json(prv_ctx* c, const char* path, prv_camset** out) try {
+  return cameras_from_json(c, path, true, out);
+} catch (...) { return caught(c); }
 
 int prv_camset_lens(const prv_camset* cs, int i, float lens[4]) {
   if (!cs || i < 0 || i >= (int)cs->cams.size() || !lens) return PRV_E_INVALID;
@@ -993,7 +1027,7 @@ void prv_camset_destroy(prv_camset* cs) { delete cs; }
 // ------------------------------------------------------------------ render
 
 int prv_render(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, int n_views, const prv_render_opts* o,
-               float* out, prv_stats* st) {
+               float* out, prv_stats* st) try {
   if (!c) return PRV_E_INVALID;
   int rc;
   if ((rc = check_model(c, slot)) != PRV_OK || (rc = check_opts(c, o)) != PRV_OK) return rc;
@@ -1002,10 +1036,10 @@ int prv_render(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, 
   if ((rc = check_device_ptr(c, out, "out_rgba_dev")) != PRV_OK) return rc;
   if ((rc = render_views(c, slot, cs, view_ids, n_views, o, out, nullptr, true)) != PRV_OK) return rc;
   return fetch_stats(c, o, n_views, 1, st);
-}
+} catch (...) { return caught(c); }
 
 int prv_render_rgba8(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, int n_views,
-                     const prv_render_opts* o, uint8_t* out, prv_stats* st) {
+                     const prv_render_opts* o, uint8_t* out, prv_stats* st) try {
   if (!c) return PRV_E_INVALID;
   int rc;
   if ((rc = check_model(c, slot)) != PRV_OK || (rc = check_opts(c, o)) != PRV_OK) return rc;
@@ -1016,10 +1050,10 @@ int prv_render_rgba8(prv_ctx* c, int slot, const prv_camset* cs, const int* view
   if ((rc = ensure(c, c->img_f32, std::max<size_t>(16, (size_t)n_views * npix * 16))) != PRV_OK) return rc;
   if ((rc = render_views(c, slot, cs, view_ids, n_views, o, (float*)c->img_f32.p, out, true)) != PRV_OK) return rc;
   return fetch_stats(c, o, n_views, 1, st);
-}
+} catch (...) { return caught(c); }
 
 int prv_first_hit(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, int n_views, int W, int H,
-                  float max_range, int32_t* out) {
+                  float max_range, int32_t* out) try {
   if (!c) return PRV_E_INVALID;
   int rc;
   if ((rc = check_model(c, slot)) != PRV_OK) return rc;
@@ -1027,6 +1061,7 @@ int prv_first_hit(prv_ctx* c, int slot, const prv_camset* cs, const int* view_id
     return fail(c, PRV_E_INVALID, "bad argument");
   if (n_views == 0) return PRV_OK;
   HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = check_device_ptr(c, out, "out_voxel_dev")) != PRV_OK) return rc;
   std::vector<CamDev> cams(n_views);
   for (int i = 0; i < n_views; i++) {
     const int v = view_ids ? view_ids[i] : i;
@@ -1038,11 +1073,11 @@ int prv_first_hit(prv_ctx* c, int slot, const prv_camset* cs, const int* view_id
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, launch_first_hit(c->models[slot].dev, (const CamDev*)c->view_ids.p, n_views, W, H, max_range, out, c->stream));
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
 int prv_splat_points(prv_ctx* c, const float* xyz, const uint8_t* rgb, size_t n, double scale, const double offset[3],
                      const prv_camset* cs, const int* view_ids, int n_views, int W, int H, int point_size, int flip180,
-                     uint8_t* out) {
+                     uint8_t* out) try {
   if (!c) return PRV_E_INVALID;
   if (!cs || n_views < 0 || W < 1 || H < 1 || W > 16384 || H > 16384 || (!out && n_views > 0) || (n > 0 && (!xyz || !rgb)))
     return fail(c, PRV_E_INVALID, "bad argument");
@@ -1067,16 +1102,17 @@ int prv_splat_points(prv_ctx* c, const float* xyz, const uint8_t* rgb, size_t n,
   HIPCHK(c, launch_splat_points(xyz, rgb, n, (float)scale, off, (const CamDev*)c->view_ids.p, n_views, W, H, point_size,
                                 flip180, (unsigned long long*)c->stage.p, (uint32_t*)out, c->stream));
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
 int prv_precept(prv_ctx* c, int slot, const float* voxels, int n, const double c2w[16], const prv_rs2_intrinsics* k,
-                float max_range, int32_t* out) {
+                float max_range, int32_t* out) try {
   if (!c) return PRV_E_INVALID;
   int rc;
   if ((rc = check_model(c, slot)) != PRV_OK) return rc;
   if (n < 0 || !c2w || !k || (n > 0 && (!voxels || !out))) return fail(c, PRV_E_INVALID, "bad argument");
   if (n == 0) return PRV_OK;
   HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = check_device_ptr(c, voxels, "voxels_dev")) != PRV_OK || (rc = check_device_ptr(c, out, "out_voxel_dev")) != PRV_OK) return rc;
   PreceptPose pose;
   memcpy(pose.c2w, c2w, sizeof(pose.c2w));
   { // w2c = inverse of the rigid c2w, in double (view_pose_world.inverse(), main.cpp:243)
@@ -1109,15 +1145,17 @@ int prv_precept(prv_ctx* c, int slot, const float* voxels, int n, const double c
   in.width = k->width; in.height = k->height; in.model = k->model;
   HIPCHK(c, launch_precept(c->models[slot].dev, voxels, n, pose, in, max_range, out, c->stream));
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
-int prv_quantize_rgba8(prv_ctx* c, const float* rgba, size_t n, const float bg[4], uint8_t* out) {
+int prv_quantize_rgba8(prv_ctx* c, const float* rgba, size_t n, const float bg[4], uint8_t* out) try {
   if (!c) return PRV_E_INVALID;
   if (!rgba || !out || !bg) return fail(c, PRV_E_INVALID, "NULL argument");
   HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = check_device_ptr(c, rgba, "rgba_dev")) != PRV_OK || (rc = check_device_ptr(c, out, "out_rgba8_dev")) != PRV_OK) return rc;
   if (n) HIPCHK(c, launch_quantize(rgba, n, bg, out, c->stream));
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
 // ------------------------------------------------------------------ scores
 
@@ -1155,7 +1193,7 @@ static int score_psnr_dev(prv_ctx* c, const float* rgba, const float* gt, int n_
 }
 
 int prv_score_ensemble_images(prv_ctx* c, int method, const uint8_t* const* imgs, int E, int n_views, size_t npix,
-                              prv_score_record* rec_host) {
+                              prv_score_record* rec_host) try {
   if (!c) return PRV_E_INVALID;
   if (method != PRV_SCORE_ENSEMBLE_RGB && method != PRV_SCORE_ENSEMBLE_RGB_DENSITY)
     return fail(c, PRV_E_INVALID, "method %d is not an ensemble score", method);
@@ -1164,32 +1202,37 @@ int prv_score_ensemble_images(prv_ctx* c, int method, const uint8_t* const* imgs
   if (npix == 0) return fail(c, PRV_E_INVALID, "empty images");
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
+  for (int e = 0; e < E; e++)
+    if (!imgs[e]) return fail(c, PRV_E_INVALID, "image set %d is NULL", e);
+    else if ((rc = check_device_ptr(c, imgs[e], "rgba8_dev")) != PRV_OK) return rc;
   if ((rc = ensure(c, c->records, (size_t)n_views * sizeof(prv_score_record))) != PRV_OK) return rc;
   if ((rc = score_ensemble_dev(c, method, imgs, E, n_views, npix, (prv_score_record*)c->records.p)) != PRV_OK) return rc;
   return prv_memcpy_d2h(c, rec_host, c->records.p, (size_t)n_views * sizeof(prv_score_record));
-}
+} catch (...) { return caught(c); }
 
 int prv_score_psnr_images(prv_ctx* c, const float* rgba, const float* gt, int n_views, size_t npix, const float bg[4],
-                          prv_score_record* rec_host) {
+                          prv_score_record* rec_host) try {
   if (!c) return PRV_E_INVALID;
   if (!rgba || !gt || !bg || n_views < 0 || !rec_host) return fail(c, PRV_E_INVALID, "bad argument");
   if (n_views == 0) return PRV_OK;
   if (npix == 0) return fail(c, PRV_E_INVALID, "empty images");
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
+  if ((rc = check_device_ptr(c, rgba, "rgba_dev")) != PRV_OK || (rc = check_device_ptr(c, gt, "gt_rgba_dev")) != PRV_OK) return rc;
   if ((rc = ensure(c, c->records, (size_t)n_views * sizeof(prv_score_record))) != PRV_OK) return rc;
   if ((rc = score_psnr_dev(c, rgba, gt, n_views, npix, bg, (prv_score_record*)c->records.p)) != PRV_OK) return rc;
   return prv_memcpy_d2h(c, rec_host, c->records.p, (size_t)n_views * sizeof(prv_score_record));
-}
+} catch (...) { return caught(c); }
 
 int prv_evaluate_images(prv_ctx* c, const float* rgba, const float* gt, int n_views, int W, int H, const float bg[4],
-                        double* psnr_host, double* ssim_host) {
+                        double* psnr_host, double* ssim_host) try {
   if (!c) return PRV_E_INVALID;
   if (!rgba || !gt || !bg || n_views < 0 || W < 5 || H < 5) return fail(c, PRV_E_INVALID, "bad argument (images must be at least 5x5)");
   if (n_views == 0) return PRV_OK;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t npix = (size_t)W * H;
   int rc;
+  if ((rc = check_device_ptr(c, rgba, "rgba_dev")) != PRV_OK || (rc = check_device_ptr(c, gt, "gt_rgba_dev")) != PRV_OK) return rc;
   if (psnr_host) {
     std::vector<prv_score_record> rec(n_views);
     if ((rc = prv_score_psnr_images(c, rgba, gt, n_views, npix, bg, rec.data())) != PRV_OK) return rc;
@@ -1207,15 +1250,16 @@ int prv_evaluate_images(prv_ctx* c, const float* rgba, const float* gt, int n_vi
     if ((rc = prv_memcpy_d2h(c, ssim_host, c->dbg[2].p, (size_t)n_views * sizeof(double))) != PRV_OK) return rc;
   }
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
 int prv_evaluate(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, int n_views, const prv_render_opts* o,
-                 const float* gt, double* mean_psnr, double* mean_ssim) {
+                 const float* gt, double* mean_psnr, double* mean_ssim) try {
   if (!c) return PRV_E_INVALID;
   int rc;
   if ((rc = check_model(c, slot)) != PRV_OK || (rc = check_opts(c, o)) != PRV_OK) return rc;
   if (!cs || !gt || n_views < 1) return fail(c, PRV_E_INVALID, "bad argument");
   HIPCHK(c, hipSetDevice(c->device));
+  if ((rc = check_device_ptr(c, gt, "gt_rgba_dev")) != PRV_OK) return rc;
   const size_t npix = (size_t)o->width * o->height;
   if ((rc = ensure(c, c->img_f32, (size_t)n_views * npix * 16)) != PRV_OK) return rc;
   if ((rc = render_views(c, slot, cs, view_ids, n_views, o, (float*)c->img_f32.p, nullptr, true)) != PRV_OK) return rc;
@@ -1230,11 +1274,11 @@ int prv_evaluate(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   if (mean_psnr) *mean_psnr = tp / n_views;
   if (mean_ssim) *mean_ssim = ts / n_views;
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
 int prv_score_views(prv_ctx* c, int method, const int* model_slots, int n_models, const prv_camset* cs,
                     const int* view_ids, int n_views, const prv_render_opts* o, const float* gt,
-                    prv_score_record* rec_host, prv_score_record* rec_dev, prv_stats* st) {
+                    prv_score_record* rec_host, prv_score_record* rec_dev, prv_stats* st) try {
   if (!c) return PRV_E_INVALID;
   int rc;
   if ((rc = check_opts(c, o)) != PRV_OK) return rc;
@@ -1274,7 +1318,7 @@ int prv_score_views(prv_ctx* c, int method, const int* model_slots, int n_models
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return fetch_stats(c, o, n_views, n_models, st);
-}
+} catch (...) { return caught(c); }
 
 // arg-max rule of main.cpp:1971-1972, 2088-2091: ascending ids, strict '>', start at -1e100
 int prv_argmax(const prv_score_record* r, const int* ids, int n) {
@@ -1289,7 +1333,7 @@ int prv_argmax(const prv_score_record* r, const int* ids, int n) {
   return best_id;
 }
 
-int prv_rank(const prv_score_record* r, const int* ids, int n, int* order) {
+int prv_rank(const prv_score_record* r, const int* ids, int n, int* order) try {
   if (n < 0 || (n > 0 && (!r || !ids || !order))) return PRV_E_INVALID;
   std::vector<int> idx(n);
   for (int i = 0; i < n; i++) idx[i] = i;
@@ -1299,11 +1343,11 @@ int prv_rank(const prv_score_record* r, const int* ids, int n, int* order) {
   });
   for (int i = 0; i < n; i++) order[i] = ids[idx[i]];
   return PRV_OK;
-}
+} catch (...) { return caught(nullptr); }
 
 // ------------------------------------------------------------------ stage hooks
 
-int prv_debug_raygen(prv_ctx* c, const prv_camset* cs, int view, int W, int H, int spp_k, float* o, float* d, float* t) {
+int prv_debug_raygen(prv_ctx* c, const prv_camset* cs, int view, int W, int H, int spp_k, float* o, float* d, float* t) try {
   if (!c) return PRV_E_INVALID;
   if (!cs || view < 0 || view >= (int)cs->cams.size() || W < 1 || H < 1 || !o || !d || !t)
     return fail(c, PRV_E_INVALID, "bad argument");
@@ -1320,7 +1364,7 @@ int prv_debug_raygen(prv_ctx* c, const prv_camset* cs, int view, int W, int H, i
   HIPCHK(c, hipMemcpyAsync(t, c->dbg[2].p, n * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return PRV_OK;
-}
+} catch (...) { return caught(c); }
 
 static int debug_field_common(prv_ctx* c, int slot, const float* pos, const float* dir, int n, uint16_t* feat,
                               float* out36, int32_t* occ) {
@@ -1345,17 +1389,17 @@ static int debug_field_common(prv_ctx* c, int slot, const float* pos, const floa
   return PRV_OK;
 }
 
-int prv_debug_encode(prv_ctx* c, int slot, const float* pos, int n, uint16_t* feat) {
+int prv_debug_encode(prv_ctx* c, int slot, const float* pos, int n, uint16_t* feat) try {
   if (!c) return PRV_E_INVALID;
   if (!feat && n > 0) return fail(c, PRV_E_INVALID, "feat is NULL");
   return debug_field_common(c, slot, pos, nullptr, n, feat, nullptr, nullptr);
-}
+} catch (...) { return caught(c); }
 
-int prv_debug_field(prv_ctx* c, int slot, const float* pos, const float* dir, int n, float* out36, int32_t* occ) {
+int prv_debug_field(prv_ctx* c, int slot, const float* pos, const float* dir, int n, float* out36, int32_t* occ) try {
   if (!c) return PRV_E_INVALID;
   if (n > 0 && (!dir || !out36)) return fail(c, PRV_E_INVALID, "NULL argument");
   return debug_field_common(c, slot, pos, dir, n, nullptr, out36, occ);
-}
+} catch (...) { return caught(c); }
 
 } // extern "C"
 

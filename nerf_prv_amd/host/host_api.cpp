@@ -39,7 +39,7 @@ void prvh_transform_matrix(const double pose[16], double tm[16]) {
   memcpy(tm, r.m.data(), sizeof(double) * 16);
 }
 
-int prvh_view_space(const double* pt, int n, double radius, const double center[3], double* out_pos) {
+int prvh_view_space(const double* pt, int n, double radius, const double center[3], double* out_pos) try {
   if (n <= 0) return 0;
   const double pt_norm = std::sqrt(pt[0] * pt[0] + pt[1] * pt[1] + pt[2] * pt[2]);
   int k = 0;
@@ -50,7 +50,7 @@ int prvh_view_space(const double* pt, int n, double radius, const double center[
     k++;
   }
   return k;
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
 void prvh_bbx(const double* pts, int n, double center[3], double* predicted_size) {
   Vec3 c(0, 0, 0);
@@ -62,7 +62,7 @@ void prvh_bbx(const double* pts, int n, double center[3], double* predicted_size
   *predicted_size = s * (17.0 / 16.0);
 }
 
-int prvh_hemisphere_read(const char* path, int n, double* out) {
+int prvh_hemisphere_read(const char* path, int n, double* out) try {
   std::ifstream f(path);
   if (!f.is_open()) return -1;
   int rows = 0;
@@ -72,9 +72,9 @@ int prvh_hemisphere_read(const char* path, int n, double* out) {
     memcpy(out + rows * 3, v, sizeof(v));
   }
   return rows;
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
-int prvh_hemisphere_generate(int n, double* out) {
+int prvh_hemisphere_generate(int n, double* out) try {
   if (n < 1) return 0;
   out[0] = 0; out[1] = 0; out[2] = 1; // the top view every reference set contains (main.cpp:2212)
   const double golden = std::acos(-1.0) * (3.0 - std::sqrt(5.0));
@@ -87,11 +87,11 @@ int prvh_hemisphere_generate(int n, double* out) {
     out[i * 3 + 2] = z;
   }
   return n;
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
 int prvh_write_transforms(const char* path, const prvh_intrinsics* in, int candidate_header, double divisor,
                           int aabb_scale, double predicted_size, const double center[3], const double* init_pos,
-                          const int* ids, int n, const char* path_prefix) {
+                          const int* ids, int n, const char* path_prefix) try {
   if (!path || !in || !center || (n > 0 && !init_pos)) return -1;
   rs2_intrinsics K;
   K.width = in->width; K.height = in->height;
@@ -108,9 +108,9 @@ int prvh_write_transforms(const char* path, const prvh_intrinsics* in, int candi
     root["frames"].append(view_image);
   }
   return write_text(path, prvjson::to_styled_string(root)) ? 0 : -3;
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
-long long prvh_pcd_read(const char* path, float* xyz_out, uint8_t* rgb_out, long long capacity) {
+long long prvh_pcd_read(const char* path, float* xyz_out, uint8_t* rgb_out, long long capacity) try {
   if (!path) return -1;
   std::vector<float> xyz;
   std::vector<uint8_t> rgb;
@@ -122,15 +122,15 @@ long long prvh_pcd_read(const char* path, float* xyz_out, uint8_t* rgb_out, long
     memcpy(rgb_out, rgb.data(), rgb.size());
   }
   return n;
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
-int prvh_png_size(const char* path, int* width, int* height) {
+int prvh_png_size(const char* path, int* width, int* height) try {
   if (!path || !width || !height) return -1;
   std::vector<uint8_t> img;
   return png_read_rgba8(path, width, height, img);
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
-int prvh_png_read_rgba8(const char* path, int width, int height, uint8_t* out_rgba8) {
+int prvh_png_read_rgba8(const char* path, int width, int height, uint8_t* out_rgba8) try {
   if (!path || !out_rgba8) return -1;
   std::vector<uint8_t> img;
   int w = 0, h = 0;
@@ -139,23 +139,23 @@ int prvh_png_read_rgba8(const char* path, int width, int height, uint8_t* out_rg
   if (w != width || h != height) return -5;
   memcpy(out_rgba8, img.data(), img.size());
   return 0;
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
-int prvh_png_write_rgba8(const char* path, int width, int height, const uint8_t* rgba8) {
+int prvh_png_write_rgba8(const char* path, int width, int height, const uint8_t* rgba8) try {
   if (!path) return -1;
   return png_write_rgba8(path, width, height, rgba8);
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
-int prvh_write_metrics(const char* path, double psnr, double ssim) {
+int prvh_write_metrics(const char* path, double psnr, double ssim) try {
   if (!path) return -1;
   char buf[128];
   // python's str(float) is the shortest round-trip form; %.17g round-trips too and every reader
   // on the path parses with strtod
   snprintf(buf, sizeof(buf), "PSNR\t%.17g\nSSIM\t%.17g", psnr, ssim);
   return write_text(path, buf) ? 0 : -3;
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
-int prvh_read_metrics(const char* path, double* psnr, double* ssim) {
+int prvh_read_metrics(const char* path, double* psnr, double* ssim) try {
   if (!path) return -1;
   std::ifstream f(path);
   if (!f.is_open()) return -3;
@@ -167,15 +167,15 @@ int prvh_read_metrics(const char* path, double* psnr, double* ssim) {
     if (name == "SSIM" && ssim) { *ssim = value; got |= 2; }
   }
   return got == 3 ? 0 : -3;
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
-double prvh_local_path(const double M[3], const double N[3], const double O[3], double r, int* type_out) {
+double prvh_local_path(const double M[3], const double N[3], const double O[3], double r, int* type_out) try {
   const auto lp = get_local_path(Vec3(M[0], M[1], M[2]), Vec3(N[0], N[1], N[2]), Vec3(O[0], O[1], O[2]), r);
   if (type_out) *type_out = lp.first;
   return lp.second;
-}
+} catch (...) { return -1.0; }
 
-double prvh_global_path(const double* pos, int n, int start, int end, const double O[3], double r, int* order_out, int* exact_out) {
+double prvh_global_path(const double* pos, int n, int start, int end, const double O[3], double r, int* order_out, int* exact_out) try {
   if (!pos || n < 1 || start < 0 || start >= n || end >= n || !O) return -1.0;
   std::vector<View> views;
   std::vector<int> label;
@@ -189,15 +189,15 @@ double prvh_global_path(const double* pos, int n, int start, int end, const doub
   if (order_out) std::copy(path.begin(), path.end(), order_out);
   if (exact_out) *exact_out = gp.exact ? 1 : 0;
   return len;
-}
+} catch (...) { return -1.0; }
 
-int prvh_fit_curve(const double* x, const double* y, int n, double max_psnr, double params_out[4], int* converged_out) {
+int prvh_fit_curve(const double* x, const double* y, int n, double max_psnr, double params_out[4], int* converged_out) try {
   if (!x || !y || n < 4 || !params_out) return -1;
   const FitResult r = fit_lognormal_cdf(std::vector<double>(x, x + n), std::vector<double>(y, y + n), max_psnr);
   params_out[0] = r.f.y0; params_out[1] = r.f.A; params_out[2] = r.f.xc; params_out[3] = r.f.w;
   if (converged_out) *converged_out = r.converged ? 1 : 0;
   return std::isfinite(r.rss) ? 0 : -2;
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
 void prvh_fit_labels(const double params[4], double max_psnr, int gap_out[11], int gradient_out[20]) {
   LognormalCDF f;
@@ -207,15 +207,15 @@ void prvh_fit_labels(const double params[4], double max_psnr, int gap_out[11], i
   if (gradient_out) std::copy(L.gradient, L.gradient + 20, gradient_out);
 }
 
-int prvh_write_label(const char* path, const double params[4], int converged, double max_psnr) {
+int prvh_write_label(const char* path, const double params[4], int converged, double max_psnr) try {
   if (!path || !params) return -1;
   FitResult r;
   r.f.y0 = params[0]; r.f.A = params[1]; r.f.xc = params[2]; r.f.w = params[3];
   r.converged = converged != 0;
   return write_label_file(path, r, max_psnr) ? 0 : -3;
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
-prvh_share_data* prvh_share_data_create(const char* yaml, const char* name, int num_of_views, int id_of_batch, int method) {
+prvh_share_data* prvh_share_data_create(const char* yaml, const char* name, int num_of_views, int id_of_batch, int method) try {
   auto sd = std::make_shared<Share_Data>(yaml ? yaml : "", name ? name : "", num_of_views, id_of_batch, method);
   if (!sd->ok) {
     g_error = sd->error;
@@ -224,7 +224,7 @@ prvh_share_data* prvh_share_data_create(const char* yaml, const char* name, int 
   auto* h = new prvh_share_data();
   h->sd = sd;
   return h;
-}
+} catch (...) { return nullptr; }
 void prvh_share_data_destroy(prvh_share_data* h) { delete h; }
 const char* prvh_share_data_error(void) { return g_error.c_str(); }
 
@@ -242,7 +242,7 @@ const char* prvh_share_data_string(const prvh_share_data* h, const char* f) {
   return v ? v->c_str() : "";
 }
 
-double prvh_share_data_number(const prvh_share_data* h, const char* f) {
+double prvh_share_data_number(const prvh_share_data* h, const char* f) try {
   if (!h || !f) return 0;
   const Share_Data& s = *h->sd;
   const std::string k = f;
@@ -254,16 +254,16 @@ double prvh_share_data_number(const prvh_share_data* h, const char* f) {
   NUM(samples_per_ray) NUM(screenshot_spp) NUM(candidate_divisor) NUM(min_transmittance) NUM(cost_on) NUM(cost_rate) NUM(show)
 #undef NUM
   return 0;
-}
+} catch (...) { return -1.0; }
 
-int prvh_share_data_views(const prvh_share_data* h, double* out) {
+int prvh_share_data_views(const prvh_share_data* h, double* out) try {
   if (!h) return -1;
   const auto& p = h->sd->pt_sphere;
   if (out)
     for (size_t i = 0; i < p.size(); i++)
       for (int j = 0; j < 3; j++) out[i * 3 + j] = p[i][j];
   return (int)p.size();
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
 void prvh_share_data_intrinsics(const prvh_share_data* h, prvh_intrinsics* o) {
   if (!h || !o) return;
@@ -274,12 +274,12 @@ void prvh_share_data_intrinsics(const prvh_share_data* h, prvh_intrinsics* o) {
 }
 
 int prvh_nbv_loop(prvh_share_data* h, const double center[3], double predicted_size, int first_view_id, int test_id,
-                  prvh_score_fn score, void* user, prvh_loop_result* out) {
+                  prvh_score_fn score, void* user, prvh_loop_result* out) try {
   return prvh_nbv_loop_budget(h, center, predicted_size, first_view_id, test_id, score, user, 0, out);
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
 int prvh_nbv_loop_budget(prvh_share_data* h, const double center[3], double predicted_size, int first_view_id, int test_id,
-                         prvh_score_fn score, void* user, int view_budget, prvh_loop_result* out) {
+                         prvh_score_fn score, void* user, int view_budget, prvh_loop_result* out) try {
   if (!h || !center || !out) return -1;
   Scorer s = [score, user](int method, int iteration, const std::string& scene, const std::string& render,
                            const std::vector<int>& ids, std::vector<double>& scores) -> int {
@@ -293,6 +293,6 @@ int prvh_nbv_loop_budget(prvh_share_data* h, const double center[3], double pred
   for (int i = 0; i < out->n_chosen; i++) out->chosen[i] = labeler.chosen_nbvs[i];
   out->total_movement = labeler.total_movement_cost;
   return rc;
-}
+} catch (...) { return PRVH_E_INTERNAL; }
 
 } // extern "C"

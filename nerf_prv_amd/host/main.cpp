@@ -631,6 +631,11 @@ int get_path_plan(const std::string& cfg) {
   return written > 0 ? 0 : -1;
 }
 
+int env_int(const char* key, int fallback) {
+  const char* v = getenv(key);
+  return v && *v ? atoi(v) : fallback;
+}
+
 } // namespace
 
 int main(int argc, char** argv) {
@@ -642,14 +647,29 @@ int main(int argc, char** argv) {
   std::cout << "input object names (-1 to stop):" << std::endl; // main.cpp:2299-2309
   std::string name;
   while (std::cin >> name && name != "-1") names.push_back(name);
-  if (mode == GetPathPlan) return get_path_plan(cfg) == 0 ? 0 : 1; // host only: before any GPU context exists
+  // BASELINE config 5 (several objects, 8 GPUs): the objects are independent, so one process per GPU takes the
+  // names i % world == rank -- launched by torchrun or by hand with RANK / WORLD_SIZE / LOCAL_RANK; no collective
+  const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0);
+  if (world < 1 || rank < 0 || rank >= world) {
+    std::cerr << "RANK " << rank << " / WORLD_SIZE " << world << " make no sense" << std::endl;
+    return 2;
+  }
+  if (world > 1) {
+    std::vector<std::string> mine;
+    for (size_t i = 0; i < names.size(); i++)
+      if ((int)(i % (size_t)world) == rank) mine.push_back(names[i]);
+    names.swap(mine);
+  }
+  if (mode == GetPathPlan) return rank != 0 || get_path_plan(cfg) == 0 ? 0 : 1; // host only: before any GPU context exists
   if (mode != ViewPlanning && mode != InstantNGP && mode != GetCoverage) {
     std::cerr << "mode " << mode << " is outside the render/score path this build covers (21 = ViewPlanning, 4 = InstantNGP, "
                  "3 = GetCoverage, 20 = GetPathPlan)" << std::endl;
     return 3;
   }
   prv_ctx* ctx = nullptr;
-  if (prv_create(&ctx, 0) != PRV_OK) {
+  const int n_dev = prv_device_count();
+  const int device = n_dev > 0 ? env_int("LOCAL_RANK", rank) % n_dev : 0; // fewer GPUs than ranks: they share
+  if (prv_create(&ctx, device) != PRV_OK) {
     std::cerr << "prv: " << prv_last_error(nullptr) << std::endl;
     return 4;
   }

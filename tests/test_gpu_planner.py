@@ -163,6 +163,37 @@ def test_planner_executable_matches_python_driven_loop(ctx, tmp_path, method):
     assert len(set(runs["cpp"])) == 4
 
 
+def test_planner_executable_shards_objects_over_ranks(ctx, tmp_path):
+    """BASELINE config 5: several objects, one process per GPU, object i -> rank i % world (RANK / WORLD_SIZE /
+    LOCAL_RANK as torchrun exports them); here two ranks share the one GPU and run side by side"""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(YAML.format(pre=tmp_path, vs=os.path.join(GOLD, "hemisphere"), method=3,
+                               model_source=f"synthetic_seed: {SEED}"))
+    names = ["objA", "objB", "objC"]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([exe, str(cfg)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate("21\n" + "\n".join(names) + "\n-1\n", timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "object objA" in outs[0][0] and "object objC" in outs[0][0] and "object objB" not in outs[0][0]
+    assert "object objB" in outs[1][0] and "object objA" not in outs[1][0]
+    chosen = {}
+    for n in names:
+        save = tmp_path / "Compare" / "ShapeNet" / f"{n}_m3_v1_t0"
+        assert (save / "run_time.txt").exists() and (save / "json" / "3.json").exists()
+    for o in outs:
+        for l in o[0].splitlines():
+            if l.startswith("chosen_nbvs:"):
+                chosen[len(chosen)] = l
+    assert len(chosen) == 3 and len(set(chosen.values())) == 1  # same synthetic members -> same plan for every object
+    bad = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True,
+                         env=dict(os.environ, RANK="3", WORLD_SIZE="2"))
+    assert bad.returncode == 2 and "make no sense" in bad.stderr
+
+
 def test_planner_executable_error_paths(tmp_path):
     exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
     out = subprocess.run([exe, str(tmp_path / "missing.yaml")], input="21\nx\n-1\n", text=True, capture_output=True)
