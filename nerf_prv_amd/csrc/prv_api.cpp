@@ -1161,17 +1161,22 @@ int prv_quantize_rgba8(prv_ctx* c, const float* rgba, size_t n, const float bg[4
 
 static int score_ensemble_dev(prv_ctx* c, int method, const uint8_t* const* imgs, int E, int n_views, size_t npix,
                               prv_score_record* rec_dev) {
-  const int nblk = score_blocks(npix);
+  // addends of a batch of views (8 B x 3 or 2 per pixel), then one sequential sum per view; batches bound the buffer
+  const size_t per_view = npix * (method == PRV_SCORE_ENSEMBLE_RGB ? 3 : 2) * sizeof(double);
+  const int batch = (int)std::min<size_t>((size_t)n_views, std::max<size_t>(1, ((size_t)1 << 30) / per_view));
+  const int nblk = (int)std::min<size_t>(1024, std::max<size_t>(1, (npix + 255) / 256));
   int rc;
-  if ((rc = ensure(c, c->partial, (size_t)n_views * nblk * 2 * sizeof(double))) != PRV_OK) return rc;
+  if ((rc = ensure(c, c->partial, (size_t)batch * per_view)) != PRV_OK) return rc;
   EnsembleParams P;
   memset(&P, 0, sizeof(P));
   for (int e = 0; e < E; e++) P.imgs[e] = (const uint32_t*)imgs[e];
   P.E = E;
   P.pixels_per_view = npix;
   P.partial = (double*)c->partial.p;
-  HIPCHK(c, launch_score_ensemble(P, method, n_views, nblk, c->stream));
-  HIPCHK(c, launch_score_finalize(P.partial, n_views, nblk, method, npix, rec_dev, c->stream));
+  for (int v0 = 0; v0 < n_views; v0 += batch) {
+    P.view0 = v0;
+    HIPCHK(c, launch_score_ensemble(P, method, std::min(batch, n_views - v0), nblk, rec_dev, c->stream));
+  }
   return PRV_OK;
 }
 

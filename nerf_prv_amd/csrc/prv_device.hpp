@@ -204,6 +204,15 @@ __device__ __forceinline__ void rs2_deproject(float point[3], const Rs2Intr& in,
   point[2] = depth;
 }
 
+// float -> half (round to nearest even) of a value that HAS been rounded to float.  Without the barrier clang folds
+// `(half)(a * b)`, `(half)(a - b)` or `(half)fmaf(..)` into v_fma_mix{lo,hi}_f16, which rounds the exact result ONCE,
+// to half; the arithmetic contract with the oracle is "round to float, then to half", and the two differ on one
+// value in 2^13 (found by tests/test_gpu_sweep.py on tables with a non-power-of-two amplitude).
+__device__ __forceinline__ _Float16 to_half(float x) {
+  asm("" : "+v"(x));
+  return (_Float16)x;
+}
+
 // real spherical harmonics degree 4; op order identical to the oracle
 __device__ __forceinline__ void sh4(float x, float y, float z, float o[16]) {
   float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
@@ -289,7 +298,7 @@ __device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table,
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     const float w1 = __builtin_amdgcn_fractf(pos[a]); // pos >= 0.5: pos - floor(pos), exact
-    wa[a][0] = (_Float16)(1.0f - w1);
+    wa[a][0] = to_half(1.0f - w1);
     wa[a][1] = (_Float16)w1;
     c0[a] = (uint32_t)(int)pos[a];                    // truncation = floor; never exceeds res-1
     c1[a] = min(c0[a] + 1u, L.res_m1);
@@ -480,7 +489,7 @@ __device__ __forceinline__ half8 sh_fragment(int h, float dx, float dy, float dz
   sh4(dx, dy, dz, s);
   half8 r;
 #pragma unroll
-  for (int j = 0; j < 8; j++) r[j] = (_Float16)(h ? s[8 + j] : s[j]);
+  for (int j = 0; j < 8; j++) r[j] = to_half(h ? s[8 + j] : s[j]);
   return r;
 }
 

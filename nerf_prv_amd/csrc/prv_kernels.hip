@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
       last = (m0 | m1 | m2 | m3) == 0u;
       const float t = fmaf((float)i + 0.5f, dt, t0);
 #if PRV_ABLATE & 1
-      f0[0] = (_Float16)t; f1[3] = (_Float16)dt;
+      f0[0] = to_half(t); f1[3] = to_half(dt);
 #else
       encode_half<F, NPAIR>(P.field.table, lvl, h, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f0, f1);
 #endif
@@ -440,46 +440,91 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* sm) {
   return r;
 }
 
-// ensemble scores from uint8 RGBA images (main.cpp:2053-2086 method 2, 2113-2150 method 3)
+// ensemble scores from uint8 RGBA images (main.cpp:2053-2086 method 2, 2113-2150 method 3), in two passes so that
+// the score is the reference's own SEQUENTIAL double sum (rows, columns, then the statements of the loop body in
+// order), bit for bit, not a tree of partial sums: views whose scores tie mathematically (ensembles that agree on
+// almost every pixel produce a handful of distinct variance values) then tie, or break, exactly as they do in the
+// reference's loop.  Pass 1 (parallel): the addends of every pixel, each computed with the reference's operation
+// order.  cv::imread hands the reference BGRA pixels, so its "r, g, b" are bytes 2, 1, 0 of the PNG's RGBA order.
 template <int METHOD>
-__global__ __launch_bounds__(256) void score_ensemble_kernel(EnsembleParams P) {
-  __shared__ double sm[4];
-  const int v = blockIdx.y;
+__global__ __launch_bounds__(256) void score_ensemble_terms_kernel(EnsembleParams P) {
+  constexpr int K = METHOD == PRV_SCORE_ENSEMBLE_RGB ? 3 : 2;
   const size_t npix = P.pixels_per_view;
-  double acc = 0.0;
+  const size_t v = blockIdx.y;
+  double* terms = P.partial + v * npix * K;
   for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
     uint32_t px[PRV_MAX_MODELS];
-    for (int e = 0; e < P.E; e++) px[e] = P.imgs[e][(size_t)v * npix + p];
+    for (int e = 0; e < P.E; e++) px[e] = P.imgs[e][((size_t)P.view0 + v) * npix + p];
     double var3[3];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
+    for (int k = 0; k < 3; k++) {
+      const int sh = 8 * (2 - k); // reference channel k = byte 2 - k
       double mean = 0.0;
-      for (int e = 0; e < P.E; e++) mean += (double)((px[e] >> (8 * c)) & 255u);
+      for (int e = 0; e < P.E; e++) mean += (double)((px[e] >> sh) & 255u);
       mean /= (double)P.E;
       double var = 0.0;
       for (int e = 0; e < P.E; e++) {
-        double dlt = (double)((px[e] >> (8 * c)) & 255u) - mean;
+        double dlt = (double)((px[e] >> sh) & 255u) - mean;
         var += dlt * dlt;
       }
-      var3[c] = var / (double)P.E;
+      var3[k] = var / (double)P.E;
     }
     if (METHOD == PRV_SCORE_ENSEMBLE_RGB) {
 #pragma unroll
-      for (int c = 0; c < 3; c++)
-        if (var3[c] > 1e-10) acc += log(var3[c]);
+      for (int k = 0; k < 3; k++) terms[p * 3 + k] = var3[k] > 1e-10 ? log(var3[k]) : 0.0; // x + 0.0 == x: a skipped addend
     } else {
       double md = 0.0;
       for (int e = 0; e < P.E; e++) md += (double)(px[e] >> 24) / 255.0;
       md /= (double)P.E;
-      acc += (var3[0] + var3[1] + var3[2]) / 3.0;
-      acc += (1.0 - md) * (1.0 - md);
+      terms[p * 2 + 0] = (var3[0] + var3[1] + var3[2]) / 3.0;
+      terms[p * 2 + 1] = (1.0 - md) * (1.0 - md);
     }
   }
-  double s = block_reduce_sum(acc, sm);
-  if (threadIdx.x == 0) P.partial[(size_t)v * gridDim.x + blockIdx.x] = s;
 }
-template __global__ void score_ensemble_kernel<PRV_SCORE_ENSEMBLE_RGB>(EnsembleParams);
-template __global__ void score_ensemble_kernel<PRV_SCORE_ENSEMBLE_RGB_DENSITY>(EnsembleParams);
+template __global__ void score_ensemble_terms_kernel<PRV_SCORE_ENSEMBLE_RGB>(EnsembleParams);
+template __global__ void score_ensemble_terms_kernel<PRV_SCORE_ENSEMBLE_RGB_DENSITY>(EnsembleParams);
+
+// Pass 2: one wave per view adds the view's addends in order.  The chain of dependent double adds is the cost
+// (~n_terms x the add latency: 10,800 addends at the reference's 80x45 -> tens of microseconds, all views in
+// parallel); the wave streams the addends through LDS 512 at a time -- coalesced loads of the next chunk are in
+// flight while every lane adds the current one from broadcast LDS reads -- so memory latency stays off the chain.
+__global__ __launch_bounds__(64) void score_sequential_sum_kernel(const double* __restrict__ terms, size_t n_terms,
+                                                                  prv_score_record* __restrict__ rec) {
+  __shared__ double buf[2][512];
+  const size_t v = blockIdx.x;
+  const double* t = terms + v * n_terms;
+  const int lane = threadIdx.x;
+  const size_t n_chunks = (n_terms + 511) / 512;
+  double r[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const size_t i = (size_t)j * 64 + lane;
+    r[j] = i < n_terms ? t[i] : 0.0;
+  }
+  double sum = 0.0;
+  for (size_t c = 0; c < n_chunks; c++) {
+    double* b = buf[c & 1];
+#pragma unroll
+    for (int j = 0; j < 8; j++) b[j * 64 + lane] = r[j];
+    __syncthreads();
+    if (c + 1 < n_chunks) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const size_t i = (c + 1) * 512 + (size_t)j * 64 + lane;
+        r[j] = i < n_terms ? t[i] : 0.0; // padding adds +0.0: the sum never is -0.0, so its bits do not change
+      }
+    }
+#pragma unroll 16
+    for (int i = 0; i < 512; i++) sum += b[i];
+  }
+  if (lane == 0) {
+    prv_score_record out;
+    out.score = sum;
+    out.psnr = 0.f;
+    out.coverage = 0.f;
+    rec[v] = out;
+  }
+}
 
 // PSNR recipe of run.py:257-263 + mean opacity; two partial sums per block
 __global__ __launch_bounds__(256) void score_psnr_kernel(PsnrParams P) {
@@ -633,7 +678,7 @@ __global__ __launch_bounds__(256) void synth_table_kernel(uint16_t* __restrict__
     unsigned long long hsh = mix64(seed + 1ull * 0xD1B54A32D192ED03ull + (unsigned long long)i * 0x9E3779B97F4A7C15ull);
     uint32_t u = (uint32_t)(hsh >> 40);
     float v = (float)u * (1.0f / 8388608.0f) - 1.0f;
-    _Float16 hv = (_Float16)(v * amp);
+    _Float16 hv = to_half(v * amp);
     table[i] = __builtin_bit_cast(uint16_t, hv);
   }
 }
@@ -878,12 +923,16 @@ hipError_t launch_quantize(const float* in, size_t n, const float bg[4], uint8_t
   return hipGetLastError();
 }
 
-hipError_t launch_score_ensemble(const EnsembleParams& P, int method, int n_views, int n_blocks, hipStream_t s) {
+hipError_t launch_score_ensemble(const EnsembleParams& P, int method, int n_views, int n_blocks, prv_score_record* rec,
+                                 hipStream_t s) {
   dim3 grid((unsigned)n_blocks, (unsigned)n_views);
+  const size_t n_terms = P.pixels_per_view * (method == PRV_SCORE_ENSEMBLE_RGB ? 3 : 2);
   if (method == PRV_SCORE_ENSEMBLE_RGB)
-    hipLaunchKernelGGL(score_ensemble_kernel<PRV_SCORE_ENSEMBLE_RGB>, grid, dim3(256), 0, s, P);
+    hipLaunchKernelGGL(score_ensemble_terms_kernel<PRV_SCORE_ENSEMBLE_RGB>, grid, dim3(256), 0, s, P);
   else
-    hipLaunchKernelGGL(score_ensemble_kernel<PRV_SCORE_ENSEMBLE_RGB_DENSITY>, grid, dim3(256), 0, s, P);
+    hipLaunchKernelGGL(score_ensemble_terms_kernel<PRV_SCORE_ENSEMBLE_RGB_DENSITY>, grid, dim3(256), 0, s, P);
+  hipLaunchKernelGGL(score_sequential_sum_kernel, dim3((unsigned)n_views), dim3(64), 0, s, (const double*)P.partial, n_terms,
+                     rec + P.view0);
   return hipGetLastError();
 }
 

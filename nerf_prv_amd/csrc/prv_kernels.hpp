@@ -50,8 +50,9 @@ struct RenderParams {
 struct EnsembleParams {
   const uint32_t* imgs[PRV_MAX_MODELS];
   int E;
+  int view0; // first view of this batch (the addend buffer holds one batch)
   size_t pixels_per_view;
-  double* partial;
+  double* partial; // addends: [view - view0][pixel][k]
 };
 
 struct PsnrParams {
@@ -82,7 +83,8 @@ hipError_t launch_splat_points(const float* xyz, const uint8_t* rgb, size_t n, f
                                const CamDev* cams, int n_views, int W, int H, int point_size, int flip180,
                                unsigned long long* zbuf, uint32_t* out, hipStream_t s);
 hipError_t launch_quantize(const float* in, size_t n, const float bg[4], uint8_t* out, hipStream_t s);
-hipError_t launch_score_ensemble(const EnsembleParams& P, int method, int n_views, int n_blocks, hipStream_t s);
+hipError_t launch_score_ensemble(const EnsembleParams& P, int method, int n_views, int n_blocks, prv_score_record* rec,
+                                 hipStream_t s);
 hipError_t launch_score_psnr(const PsnrParams& P, int n_views, int n_blocks, hipStream_t s);
 hipError_t launch_ssim(const float* img, const float* gt, int n_views, int W, int H, const float bg[4], float* la,
                        float* lb, double* partial, int n_blocks, double* out, hipStream_t s);

@@ -127,7 +127,7 @@ __device__ __forceinline__ void train_encode_level(const uint16_t* __restrict__ 
     const float fl = floorf(pos);
     const float w = pos - fl;
     c0[a] = (uint32_t)(int)fl;
-    wh[a][0] = (_Float16)(1.0f - w);
+    wh[a][0] = to_half(1.0f - w);
     wh[a][1] = (_Float16)w;
   }
   _Float16 acc[F];
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
         float sh[16];
         sh4(dir[0], dir[1], dir[2], sh);
 #pragma unroll
-        for (int k = 0; k < 16; k++) A[(kAIn2 + 16 + k) * kTS + s] = live ? (_Float16)sh[k] : (_Float16)0.0f;
+        for (int k = 0; k < 16; k++) A[(kAIn2 + 16 + k) * kTS + s] = live ? to_half(sh[k]) : (_Float16)0.0f;
       }
       if (!FWD && g == 1) {
         G[(kGOrr + 0) * kTS + s] = seed.y;
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n,
     w[i] = ww;
     m[i] = mm;
     v[i] = vv;
-    w16[i] = __builtin_bit_cast(uint16_t, (_Float16)ww);
+    w16[i] = __builtin_bit_cast(uint16_t, to_half(ww));
   }
 }
 
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256) void adam_mlp_kernel(AdamParams P, float l2_re
   w[i] = ww;
   m[i] = mm;
   v[i] = vv;
-  const _Float16 hh = (_Float16)ww;
+  const _Float16 hh = to_half(ww);
   w16[i] = __builtin_bit_cast(uint16_t, hh);
   w16_as_f32[i] = (float)hh;
   if (i == 0 && end_of_step) end_step(P, nullptr, 0.f, 0.f, 0.f); // last node of a step unless a later kernel takes that role

@@ -750,7 +750,9 @@ void orc_quantize_rgba8(const float* rgba, size_t npix, const float bg[4], uint8
 double orc_score_ensemble_rgb(const uint8_t* const* imgs, int E, size_t npix) {
   double view_uncertainty = 0.0;
   for (size_t p = 0; p < npix; p++) {
-    for (int c = 0; c < 3; c++) {
+    /* cv::imread(IMREAD_UNCHANGED) hands the reference BGRA pixels (:2049): its "r, g, b" = bytes 2, 1, 0 of the
+     * PNG's RGBA order, and that is the order its three addends enter the sum */
+    for (int c = 2; c >= 0; c--) {
       double mean = 0.0;
       for (int e = 0; e < E; e++) mean += imgs[e][p * 4 + c];
       mean /= E;
@@ -770,8 +772,9 @@ double orc_score_ensemble_rgb(const uint8_t* const* imgs, int E, size_t npix) {
 double orc_score_ensemble_rgbdensity(const uint8_t* const* imgs, int E, size_t npix) {
   double view_uncertainty = 0.0;
   for (size_t p = 0; p < npix; p++) {
-    double var3[3];
-    for (int c = 0; c < 3; c++) {
+    double var3[3]; /* reference channel k = byte 2 - k (BGRA, see above) */
+    for (int k = 0; k < 3; k++) {
+      const int c = 2 - k;
       double mean = 0.0;
       for (int e = 0; e < E; e++) mean += imgs[e][p * 4 + c];
       mean /= E;
@@ -780,7 +783,7 @@ double orc_score_ensemble_rgbdensity(const uint8_t* const* imgs, int E, size_t n
         double dlt = imgs[e][p * 4 + c] - mean;
         var += dlt * dlt;
       }
-      var3[c] = var / E;
+      var3[k] = var / E;
     }
     double mean_density = 0.0;
     for (int e = 0; e < E; e++) mean_density += imgs[e][p * 4 + 3] / 255.0; /* :2127 */

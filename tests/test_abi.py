@@ -90,3 +90,24 @@ def test_headers_are_plain_c(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "table halfs" in out.stdout and "tm03 0.25" in out.stdout  # json translation = (z, x, y) of the position
+
+
+def test_device_code_keeps_the_rounding_contract(tmp_path):
+    """the code objects inside libprv_hip.so: gfx950 only; the MLPs really are on the matrix cores; and no
+    `v_fma_mix{lo,hi}_f16` -- that instruction is how clang folds `(half)(a * b)` into ONE rounding, where the
+    arithmetic contract with the oracle is round-to-float-then-to-half (prv_device.hpp: to_half)"""
+    import shutil
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not installed")
+    so = os.path.join(ROOT, "nerf_prv_amd", "libprv_hip.so")
+    assert os.path.exists(so), "libprv_hip.so missing: run __graft_entry__.build()"
+    shutil.copy(so, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, check=True, capture_output=True)
+    objs = sorted(p for p in os.listdir(tmp_path) if "amdgcn" in p)
+    assert objs and all(p.endswith("gfx950") for p in objs), objs
+    text = "".join(subprocess.run([objdump, "-d", p], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+                   for p in objs)
+    assert not re.search(r"v_fma_mix(lo|hi)_f16", text)
+    assert text.count("v_mfma_f32_32x32x16_f16") >= 24 and "v_mfma_f32_32x32x2_f32" in text

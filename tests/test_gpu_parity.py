@@ -268,10 +268,22 @@ def test_ensemble_scores_from_bytes(ctx, oracle, method, E):
     rec = ctx.score_ensemble_images(method, dev)
     fn = oracle.score_ensemble_rgb if method == 2 else oracle.score_ensemble_rgbdensity
     want = np.array([fn([i[v] for i in imgs]) for v in range(n_views)])
-    np.testing.assert_allclose(rec["score"], want, rtol=1e-12)
+    # the device adds the per-pixel addends in the reference loop's order, one sequential double sum per view:
+    # EnsembleRGBDensity is bit-identical; EnsembleRGB adds logs, where the two log implementations may differ
+    # in the last bit of an addend
+    if method == 3:
+        assert np.array_equal(rec["score"], want)
+    else:
+        np.testing.assert_allclose(rec["score"], want, rtol=1e-13)
     ids = np.arange(n_views)
     assert np.array_equal(ctx.rank(rec, ids), oracle.rank(want, ids))
     assert ctx.argmax(rec, ids) == oracle.argmax(want, ids)
+    # a duplicated view ties exactly and the lower id wins (strict '>' of main.cpp:2088)
+    dup = [torch.cat([d, d[:1]]) for d in dev]
+    rec2 = ctx.score_ensemble_images(method, dup)
+    assert rec2["score"][0] == rec2["score"][n_views]
+    order = list(ctx.rank(rec2, np.arange(n_views + 1)))
+    assert order.index(0) + 1 == order.index(n_views)
 
 
 def test_score_views_psnr_and_ranking(ctx, oracle, fields, cams):

@@ -1,0 +1,151 @@
+"""Seeded random sweep of the render path against the CPU oracle: field shapes (levels x features, table sizes,
+base / finest resolutions, occupancy resolutions incl. ones the coarse march test does not cover), image shapes
+(odd, non-square, one pixel wide), sample counts, sub-sample counts, transmittance cut-offs, pinhole and lens
+cameras, cameras inside and outside the unit cube.  Same bars as test_gpu_parity.py: grid features bit for bit,
+pixels within 1e-3 (north_star), evaluated-sample counts equal up to the early-termination rounding."""
+import numpy as np
+import pytest
+
+from nerf_prv_amd import api
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+PIX_ATOL = 1e-3
+
+
+def random_case(rng):
+    F = int(rng.choice([2, 4]))
+    L = 32 // F
+    base = int(rng.integers(2, 17))
+    kw = dict(n_levels=L, n_features=F, log2_hashmap=int(rng.integers(8, 17)), base_res=base,
+              finest_res=int(rng.integers(base, 200)), occ_res=int(rng.choice([1, 5, 8, 16, 24, 30, 32, 64])),
+              density_bias=float(rng.uniform(0.0, 4.0)), table_amp=float(rng.uniform(0.5, 4.0)))
+    w, h = int(rng.integers(1, 49)), int(rng.integers(1, 33))
+    return dict(field=kw, w=w, h=h, S=int(rng.integers(1, 129)), spp=int(rng.choice([1, 1, 2, 3, 4, 16])),
+                min_T=float(rng.choice([0.0, 1e-4, 1e-2, 0.3])), lens=bool(rng.integers(0, 2)),
+                n_views=int(rng.integers(1, 5)), predicted_size=float(rng.choice([0.1, 0.2, 0.45])),
+                seed=int(rng.integers(1, 1 << 40)))
+
+
+@pytest.mark.parametrize("case_id", range(40))
+def test_random_render_case(ctx, oracle, case_id):
+    rng = np.random.default_rng(0xC0FFEE + case_id)
+    case = random_case(rng)
+    d_o, d_p = oracle.desc(**case["field"]), api.field_desc(**case["field"])
+    f = oracle.OracleField(d_o, seed=case["seed"])
+    ctx.synthetic_model(2, d_p, case["seed"])
+    t, m, o = ctx.export_model(2, d_p)
+    to, mo, oo = f.params()
+    assert np.array_equal(t, to) and np.array_equal(m, mo) and np.array_equal(o, oo), case
+    # grid features at random positions (incl. the cube's faces and corners): fp16 bit patterns
+    pos = rng.random((200, 3)).astype(np.float32)
+    pos[:8] = np.array([[x, y, z] for x in (0.0, 1.0) for y in (0.0, 1.0) for z in (0.0, 1.0)], np.float32)
+    pos[8:16, 0] = np.float32(1.0)
+    assert np.array_equal(ctx.debug_encode(2, pos), f.encode(pos)), case
+    # cameras: a few hemisphere views; a large predicted_size puts them inside the cube
+    pts = util.fibonacci_hemisphere(case["n_views"] + 1)[1:] if case["n_views"] > 1 else util.fibonacci_hemisphere(1)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts, predicted_size=case["predicted_size"])
+    w, h = case["w"], case["h"]
+    if case["lens"]:
+        intr = {"fl_x": 915.6 * w / 1280, "fl_y": 913.3 * h / 720, "cx": 0.5055 * w, "cy": 0.5174 * h, "w": w, "h": h,
+                "k1": float(rng.uniform(-0.2, 0.2)), "k2": float(rng.uniform(-0.2, 0.2)),
+                "p1": float(rng.uniform(-0.01, 0.01)), "p2": float(rng.uniform(-0.01, 0.01))}
+        cs = ctx.cameras_from_matrices_intr(tms, intr, scale, offset)
+        ocams = oracle.cameras_from_dataset(tms, intr, scale, offset, w, h)
+    else:
+        cs = ctx.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+        ocams = oracle.cameras_from_transforms(tms, util.FOV_X, w, h, scale, offset)
+    for v in range(len(ocams)):  # rays bit for bit, every sub-sample pattern used
+        for k in {0, case["spp"] - 1}:
+            o_d, d_d, t_d = ctx.debug_raygen(cs, v, w, h, k)
+            o_o, d_o2, t_o = oracle.raygen(ocams[v], w, h, k)
+            assert np.array_equal(o_d, o_o) and np.array_equal(d_d, d_o2) and np.array_equal(t_d, t_o), (case, v, k)
+    img, st = ctx.render(2, cs, None, api.render_opts(w, h, case["S"], case["spp"], case["min_T"]))
+    img = img.cpu().numpy()
+    n_eval = 0
+    for v, oc in enumerate(ocams):
+        want, ne = f.render(oc, w, h, case["S"], case["spp"], case["min_T"])
+        n_eval += ne
+        assert np.abs(img[v] - want).max() <= PIX_ATOL, (case, v, float(np.abs(img[v] - want).max()))
+    assert abs(int(st.samples_evaluated) - n_eval) <= max(2, n_eval // 10000), (case, int(st.samples_evaluated), n_eval)
+    assert st.rays == len(ocams) * w * h * case["spp"]
+    cs.close()
+    f.close()
+
+
+def rel_l2(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.mark.parametrize("case_id", range(10))
+def test_random_training_case(ctx, oracle, case_id):
+    """one training batch on a random field / image set / option set: the same rays and live samples bit for bit
+    (sample counts equal), loss and gradients within 1e-3 (north_star) of the double-accumulating oracle"""
+    rng = np.random.default_rng(0x7EA + case_id)
+    F = int(rng.choice([2, 4]))
+    base = int(rng.integers(2, 9))
+    kw = dict(n_levels=32 // F, n_features=F, log2_hashmap=int(rng.integers(8, 13)), base_res=base,
+              finest_res=int(rng.integers(base + 1, 64)), occ_res=int(rng.choice([4, 8, 16, 20])),
+              density_bias=float(rng.uniform(0.0, 2.0)), table_amp=float(rng.uniform(0.05, 1.0)))
+    w, h, n_views = int(rng.integers(3, 33)), int(rng.integers(3, 25)), int(rng.integers(1, 7))
+    intr = {"fl_x": 0.8 * w, "fl_y": 0.78 * w, "cx": 0.51 * w, "cy": 0.48 * h, "w": w, "h": h,
+            "k1": float(rng.uniform(-0.1, 0.1)), "k2": float(rng.uniform(-0.1, 0.1)),
+            "p1": float(rng.uniform(-0.005, 0.005)), "p2": float(rng.uniform(-0.005, 0.005))}
+    pts = util.fibonacci_hemisphere(n_views)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts, predicted_size=float(rng.choice([0.1, 0.3])))
+    ocams = oracle.cameras_from_dataset(tms, intr, scale, offset)
+    cams = ctx.cameras_from_matrices_intr(tms, intr, scale, offset)
+    imgs = rng.integers(0, 256, (n_views, h, w, 4), dtype=np.uint8)
+    imgs[..., 3] = np.where(rng.random((n_views, h, w)) < 0.3, 0, np.where(rng.random((n_views, h, w)) < 0.5, 255, imgs[..., 3]))
+    f = oracle.OracleField(oracle.desc(**kw), seed=int(rng.integers(1, 1 << 40)))
+    t, m, o = f.params()
+    if rng.random() < 0.5:
+        o = np.full_like(o, 0xFFFFFFFF)  # a fresh network: every cell occupied
+    f = oracle.OracleField(f.desc, params=(t, m, o))
+    ctx.load_model(3, api.field_desc(**kw), t, m, o)
+    opts = dict(n_rays=int(rng.integers(1, 700)), n_samples=int(rng.integers(1, 129)), occ_every=0,
+                random_bg=int(rng.integers(0, 2)), min_T=float(rng.choice([0.0, 1e-4, 1e-2])),
+                seed=int(rng.integers(1, 1 << 40)), target_samples=int(rng.choice([0, 1 << 18])))
+    otr = oracle.OracleTrainer(f, oracle.train_opts(**opts), ocams, imgs)
+    gtr = api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(**opts))
+    want_loss, want_tg, want_mg = otr.gradients()
+    loss, tg, mg = gtr.gradients()
+    assert gtr.info()["samples_last"] == otr.samples_last, (kw, opts)
+    assert gtr.info()["active_rays"] == otr.active_rays
+    assert loss == pytest.approx(want_loss, rel=1e-3, abs=1e-7), (kw, opts)
+    if np.abs(want_mg).max() > 1e-9:
+        assert rel_l2(mg, want_mg) < 1e-3 and rel_l2(tg, want_tg) < 1e-3, (kw, opts, rel_l2(mg, want_mg), rel_l2(tg, want_tg))
+    gtr.close()
+    cams.close()
+
+
+@pytest.mark.parametrize("case_id", range(12))
+def test_random_score_case(ctx, oracle, case_id):
+    """ensemble scores from random bytes: any ensemble size, image shape and view count.  The device adds the
+    per-pixel addends in the reference loop's own order (one sequential double sum per view), so EnsembleRGBDensity
+    scores are BIT-identical to the oracle's; EnsembleRGB adds logarithms, where the device's log and libm's may
+    differ in the last bit of an addend -> 1e-13.  Rankings and arg-max identical, mathematically tied views
+    (ensembles that agree on almost every pixel) included."""
+    rng = np.random.default_rng(0x5C0 + case_id)
+    E, n_views = int(rng.integers(2, 9)), int(rng.integers(1, 20))
+    h, w = int(rng.integers(1, 70)), int(rng.integers(1, 90))
+    method = int(rng.choice([2, 3]))
+    imgs = [rng.integers(0, 256, (n_views, h, w, 4), dtype=np.uint8) for _ in range(E)]
+    if rng.random() < 0.5:  # mostly agreeing members: variances near the 1e-10 cut-off and exact zeros
+        for e in range(1, E):
+            imgs[e] = imgs[0].copy()
+            flip = rng.random(imgs[e].shape) < 0.02
+            imgs[e][flip] ^= 1
+    dev = [ctx.torch.from_numpy(im).to(ctx.device) for im in imgs]
+    rec = ctx.score_ensemble_images(method, dev)
+    fn = oracle.score_ensemble_rgb if method == 2 else oracle.score_ensemble_rgbdensity
+    want = np.array([fn([im[v] for im in imgs]) for v in range(n_views)])
+    if method == 3:
+        assert np.array_equal(rec["score"], want)
+    else:
+        np.testing.assert_allclose(rec["score"], want, rtol=1e-13, atol=1e-13)
+        print("bit-identical EnsembleRGB scores:", int((rec["score"] == want).sum()), "of", n_views)
+    ids = np.arange(n_views, dtype=np.int32)
+    assert list(ctx.rank(rec, ids)) == list(oracle.rank(want, ids))
+    assert ctx.argmax(rec, ids) == oracle.argmax(want, ids)
