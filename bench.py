@@ -40,14 +40,35 @@ def measured_traffic(args, samples_per_launch):
     return per_sample * samples_per_launch
 
 
+def usable_cores():
+    """host cores this process may actually use: the affinity mask, capped by a cgroup CPU quota when there is one
+    (the GPU boxes expose 256 logical CPUs behind a 16-CPU quota: 256 threads there are 16 cores' worth of time)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(args, tms, scale, offset, fov_x):
     """the oracle (a scalar C port of the same algorithm) on the host cores, bounded sample"""
     from oracle import oracle as orc
 
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     f = orc.OracleField(orc.desc(), seed=SEED_A)
     cams = orc.cameras_from_transforms(tms, fov_x, args.width, args.height, scale, offset)
-    rows = (args.height // 2 - 32, args.height // 2 + 32)
+    threads = min(threads, 256)  # the oracle's pthread pool tops out there
+    band = min(args.height, max(64, threads))  # one row per thread at least: every core the line claims has work
+    rows = ((args.height - band) // 2, (args.height - band) // 2 + band)
     f.render(cams[0], args.width, args.height, args.samples, 1, 1e-4, threads=threads, rows=(rows[0], rows[0] + 1))
     n_eval, n_views, t0 = 0, 0, time.perf_counter()
     for v in range(len(cams)):
@@ -60,7 +81,7 @@ def cpu_baseline(args, tms, scale, offset, fov_x):
     return {
         "value": n_eval / dt,
         "unit": "ray-samples/s",
-        "cores": threads,
+        "cores": min(threads, band),
         "kind": "port",
         "sample": f"rows {rows[0]}-{rows[1]} of {n_views} views at {args.width}x{args.height}, "
                   f"{args.samples} samples/ray, {n_eval} samples evaluated in {dt:.1f} s "

@@ -679,6 +679,7 @@ typedef struct {
 static void* render_worker(void* arg) {
   render_job* j = (render_job*)arg;
   float inv_spp = 1.0f / (float)j->spp;
+  uint64_t n_eval = 0; /* thread-local: the jobs sit side by side in memory, a shared-line counter would throttle the baseline */
   for (int y = j->y0 + j->tid; y < j->y1; y += j->nth)
     for (int x = 0; x < j->w; x++) {
       float acc[4] = {0, 0, 0, 0};
@@ -686,12 +687,13 @@ static void* render_worker(void* arg) {
         float ox, oy, o[3], d[3], px[4];
         orc_spp_offset(k, &ox, &oy);
         orc_raygen(j->cam, x, y, ox, oy, o, d);
-        march_ray(j->f, o, d, j->S, j->min_T, px, &j->n_eval);
+        march_ray(j->f, o, d, j->S, j->min_T, px, &n_eval);
         for (int c = 0; c < 4; c++) acc[c] += px[c];
       }
       float* dst = j->rgba + ((size_t)y * j->w + x) * 4;
       for (int c = 0; c < 4; c++) dst[c] = acc[c] * inv_spp;
     }
+  j->n_eval = n_eval;
   return NULL;
 }
 
