@@ -149,3 +149,76 @@ def test_random_score_case(ctx, oracle, case_id):
     ids = np.arange(n_views, dtype=np.int32)
     assert list(ctx.rank(rec, ids)) == list(oracle.rank(want, ids))
     assert ctx.argmax(rec, ids) == oracle.argmax(want, ids)
+
+
+def _random_cameras(ctx, oracle, rng, w, h, n_views, lens):
+    pts = util.fibonacci_hemisphere(n_views + 1)[1:] if n_views > 1 else util.fibonacci_hemisphere(1)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts, predicted_size=float(rng.choice([0.1, 0.2, 0.45])))
+    if lens:
+        intr = {"fl_x": 0.75 * w, "fl_y": 0.72 * w, "cx": 0.49 * w, "cy": 0.53 * h, "w": w, "h": h,
+                "k1": float(rng.uniform(-0.2, 0.2)), "k2": float(rng.uniform(-0.2, 0.2)),
+                "p1": float(rng.uniform(-0.01, 0.01)), "p2": float(rng.uniform(-0.01, 0.01))}
+        return ctx.cameras_from_matrices_intr(tms, intr, scale, offset), oracle.cameras_from_dataset(tms, intr, scale, offset, w, h), (tms, scale, offset)
+    return (ctx.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset),
+            oracle.cameras_from_transforms(tms, util.FOV_X, w, h, scale, offset), (tms, scale, offset))
+
+
+@pytest.mark.parametrize("case_id", range(12))
+def test_random_first_hit_case(ctx, oracle, case_id):
+    """the occupancy ray-caster (a13) on random grids, cameras and ranges: integer cell ids, exact"""
+    rng = np.random.default_rng(0xF1 + case_id)
+    F = int(rng.choice([2, 4]))
+    kw = dict(n_levels=32 // F, n_features=F, log2_hashmap=8, base_res=2, finest_res=8,
+              occ_res=int(rng.choice([1, 3, 8, 17, 32, 64, 100])))
+    f = oracle.OracleField(oracle.desc(**kw), seed=5)
+    t, m, o = f.params()
+    o = rng.integers(0, 1 << 32, o.shape, dtype=np.uint32) & rng.integers(0, 1 << 32, o.shape, dtype=np.uint32)
+    if rng.random() < 0.5:
+        o &= rng.integers(0, 1 << 32, o.shape, dtype=np.uint32)  # sparser
+    f = oracle.OracleField(f.desc, params=(t, m, o))
+    ctx.load_model(2, api.field_desc(**kw), t, m, o)
+    w, h = int(rng.integers(1, 40)), int(rng.integers(1, 30))
+    cs, ocams, _ = _random_cameras(ctx, oracle, rng, w, h, int(rng.integers(1, 4)), bool(rng.integers(0, 2)))
+    max_range = float(rng.choice([1e30, 1.0, 1.4, 0.3]))
+    got = ctx.first_hit(2, cs, None, w, h, max_range=max_range).cpu().numpy()
+    for v, oc in enumerate(ocams):
+        assert np.array_equal(got[v], oracle.first_hit_image(f, oc, w, h, max_range=max_range)), (kw, v, max_range)
+    cs.close()
+
+
+@pytest.mark.parametrize("case_id", range(8))
+def test_random_splat_case(ctx, oracle, case_id):
+    """ground-truth splats (8f-4) of random clouds: bytes identical, whatever the order of the depth atomics"""
+    rng = np.random.default_rng(0x5B1A7 + case_id)
+    n = int(rng.integers(0, 30000))
+    xyz = (rng.normal(size=(n, 3)) * float(rng.choice([0.01, 0.03, 0.08]))).astype(np.float32)
+    if n > 10:
+        xyz[: n // 4] = xyz[n // 4: 2 * (n // 4)]  # coincident points: equal depths, the colour breaks the tie
+    rgb = rng.integers(0, 256, size=(n, 3), dtype=np.uint8)
+    w, h = int(rng.integers(1, 120)), int(rng.integers(1, 70))
+    cs, ocams, (tms, scale, offset) = _random_cameras(ctx, oracle, rng, w, h, int(rng.integers(1, 4)), True)
+    size, flip = int(rng.integers(1, 9)), bool(rng.integers(0, 2))
+    got = ctx.splat_points(xyz, rgb, scale, offset, cs, None, w, h, point_size=size, flip180=flip).cpu().numpy()
+    for v, oc in enumerate(ocams):
+        want = oracle.splat_points(xyz, rgb, scale, offset, oc, w, h, point_size=size, flip180=flip)
+        assert np.array_equal(got[v], want), (n, w, h, size, flip, v)
+    cs.close()
+
+
+@pytest.mark.parametrize("case_id", range(8))
+def test_random_evaluation_case(ctx, oracle, case_id):
+    """PSNR / coverage / SSIM of random image pairs (a10) against the oracle's double-precision restatement"""
+    rng = np.random.default_rng(0xE7A1 + case_id)
+    n, h, w = int(rng.integers(1, 5)), int(rng.integers(5, 60)), int(rng.integers(5, 80))
+    a = rng.random((n, h, w, 4)).astype(np.float32)
+    a[..., :3] *= a[..., 3:4]  # premultiplied
+    b = np.clip(a + rng.normal(scale=float(rng.choice([0.002, 0.05, 0.3])), size=a.shape), 0, 1).astype(np.float32)
+    bg = tuple(float(x) for x in rng.choice([0.0, 1.0, 0.5], 3)) + (1.0,)
+    ta, tb = ctx.torch.from_numpy(a).to(ctx.device), ctx.torch.from_numpy(b).to(ctx.device)
+    rec = ctx.score_psnr_images(ta, tb, bg)
+    ps, ss = ctx.evaluate_images(ta, tb, bg)
+    for v in range(n):
+        want_p, want_c = oracle.score_psnr_coverage(a[v], b[v], bg)
+        assert rec["psnr"][v] == pytest.approx(want_p, rel=1e-5) and ps[v] == pytest.approx(want_p, rel=1e-5)
+        assert rec["coverage"][v] == pytest.approx(want_c, rel=1e-5)
+        assert ss[v] == pytest.approx(oracle.ssim(a[v], b[v], bg), rel=1e-3, abs=1e-5)

@@ -63,6 +63,25 @@ def test_pose_matches_golden_and_oracle(oracle, n):
         np.testing.assert_allclose(pose[:3, :3] @ pose[:3, :3].T, np.eye(3), atol=1e-6)  # X from a 1e-10 cross product
 
 
+def test_random_poses_match_the_oracle(oracle):
+    """500 seeded random view positions and object centres (tiny like the reference's 1e-10, millimetres,
+    centimetres; the pole included): the C++ View::get_next_camera_pos and the oracle's restatement of
+    View_Space.hpp:67-140 choose the same roll and agree to round-off"""
+    rng = np.random.default_rng(7)
+    for i in range(500):
+        d = rng.normal(size=3)
+        d[2] = abs(d[2])
+        d /= np.linalg.norm(d)
+        if i % 50 == 0:
+            d = np.array([0.0, 0.0, 1.0])  # the pole: Z x view degenerates (Hemisphere/N.txt row 0 of some sets)
+        c = rng.normal(size=3) * rng.choice([1e-10, 1e-3, 0.05])
+        p = d * rng.uniform(0.1, 1.0) + c
+        a = planner.transform_matrix(planner.view_pose(p, c))
+        b = oracle.transform_matrix(oracle.view_pose(p, c))
+        assert np.isfinite(a).all()
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12, err_msg=f"case {i}: {p} {c}")
+
+
 def test_bbx_and_generated_hemisphere(oracle):
     g = json.load(open(os.path.join(GOLD, "golden_cameras.json")))["bbx"]
     c, s = planner.bbx(np.array(g["cloud"]))
