@@ -148,7 +148,7 @@ def main():
     fov_x = 2.0 * np.arctan(0.5 * 1280 / 915.60668945312500)  # the reference camera's 69.9 deg
     tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
     cams = ctx.cameras_from_matrices(tms, fov_x, args.width, args.height, scale, offset)
-    my_ids, per_rank = planner.shard_views(n_views, rank, world)
+    my_ids, per_rank = planner.shard_views(n_views, rank, world, interleaved=True)  # balances pole vs equator views
     opts = api.render_opts(args.width, args.height, args.samples, 1, 1e-4)
 
     # reference images of this rank's views, resident in HBM before the timed region
@@ -158,7 +158,7 @@ def main():
     def step(want_stats=False):
         _, st = ctx.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cams, my_ids, opts, gt=gt, records_dev=rec_dev,
                                 to_host=False, want_stats=want_stats)
-        records = planner.gather_records(rec_dev, per_rank, n_views, device=device)  # the ONE collective
+        records = planner.gather_records(rec_dev, per_rank, n_views, device=device, interleaved=True)  # the ONE collective
         order = api.rank_host(records, np.arange(n_views, dtype=np.int32))
         return st, records, order
 

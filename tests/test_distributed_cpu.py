@@ -35,11 +35,11 @@ def _scores(n_views):
     return score_shard
 
 
-def _worker(rank, world, port, n_views, q):
+def _worker(rank, world, port, n_views, q, interleaved=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        records, order = planner.scoring_round(n_views, _scores(n_views))
+        records, order = planner.scoring_round(n_views, _scores(n_views), interleaved=interleaved)
         q.put((rank, records.tobytes(), order.tolist()))
     finally:
         dist.destroy_process_group()
@@ -53,13 +53,14 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("interleaved", [False, True])
 @pytest.mark.parametrize("n_views", [7, 8])  # ragged and even shards
-def test_two_rank_scoring_round_equals_single_process(n_views):
+def test_two_rank_scoring_round_equals_single_process(n_views, interleaved):
     ref_records, ref_order = planner.scoring_round(n_views, _scores(n_views))  # world = 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_views, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_views, q, interleaved)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=180) for _ in procs]
@@ -80,6 +81,11 @@ def test_shard_layout():
     assert per == 1 and len(ids) == 0  # more ranks than views: empty shard is legal
     cover = np.concatenate([planner.shard_views(1000, r, 8)[0] for r in range(8)])
     assert cover.tolist() == list(range(1000))
+    ids, per = planner.shard_views(10, 1, 4, interleaved=True)
+    assert per == 3 and ids.tolist() == [1, 5, 9]
+    cover = np.concatenate([planner.shard_views(1001, r, 8, interleaved=True)[0] for r in range(8)])
+    assert sorted(cover.tolist()) == list(range(1001))
+    assert all(len(planner.shard_views(1001, r, 8, interleaved=True)[0]) <= 126 for r in range(8))
 
 
 def _member(e, sizes):
