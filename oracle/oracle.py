@@ -68,6 +68,7 @@ def lib():
         L.orc_f2h.restype, L.orc_f2h.argtypes = C.c_uint16, [C.c_float]
         L.orc_h2f.restype, L.orc_h2f.argtypes = C.c_float, [C.c_uint16]
         L.orc_d2h.restype, L.orc_d2h.argtypes = C.c_uint16, [C.c_double]
+        L.orc_d2h_soft.restype, L.orc_d2h_soft.argtypes = C.c_uint16, [C.c_double]
         L.orc_field_levels.argtypes = [C.POINTER(FieldDesc), C.POINTER(Level), C.POINTER(C.c_uint32)]
         L.orc_field_synthetic.restype = C.POINTER(Field)
         L.orc_field_synthetic.argtypes = [C.POINTER(FieldDesc), C.c_uint64]

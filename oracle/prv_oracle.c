@@ -8,6 +8,7 @@
  */
 #include "prv_oracle.h"
 
+#include <immintrin.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -69,7 +70,27 @@ float orc_h2f(uint16_t h) {
 
 /* double -> binary16, round-to-nearest-even in ONE rounding (used to model fp16 fma/mul exactly:
  * the exact product/sum of binary16 operands fits a double) */
+uint16_t orc_d2h_soft(double v);
 uint16_t orc_d2h(double v) {
+  /* fast path, bit-identical to the general routine below (tests/test_oracle_known_answers.py sweeps both): for a
+   * result in the normal binary16 range, adding and subtracting 2^(E+42) (E = exponent of |v|) rounds |v| to 11
+   * significant bits with the hardware's round-to-nearest-even -- the one rounding wanted -- and the outcome
+   * converts to float and on to binary16 exactly (F16C) */
+  double a = fabs(v);
+  if (a >= 6.103515625e-05 && a < 65520.0) {
+    uint64_t x;
+    memcpy(&x, &a, 8);
+    uint64_t cb = ((x >> 52) + 42u) << 52;
+    double c;
+    memcpy(&c, &cb, 8);
+    volatile double t = a + c; /* volatile: the pair must not be folded away */
+    double r = t - c;
+    uint16_t h = (uint16_t)_cvtss_sh((float)r, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+    return (uint16_t)(h | (signbit(v) ? 0x8000u : 0u));
+  }
+  return orc_d2h_soft(v);
+}
+uint16_t orc_d2h_soft(double v) {
   uint64_t x;
   memcpy(&x, &v, 8);
   uint16_t sign = (uint16_t)((x >> 48) & 0x8000u);

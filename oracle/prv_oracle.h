@@ -66,6 +66,7 @@ typedef struct {
 /* ---- fp16 helpers (IEEE binary16, round-to-nearest-even) ---- */
 uint16_t orc_f2h(float f);
 uint16_t orc_d2h(double v); /* one rounding, for modelling fp16 mul/fma */
+uint16_t orc_d2h_soft(double v); /* the same in integer arithmetic only: the definition orc_d2h's fast path is tested against */
 float orc_h2f(uint16_t h);
 
 /* ---- field ---- */

@@ -177,3 +177,23 @@ def test_ground_truth_splat_known_answers(oracle):
     assert np.array_equal(f, img[::-1, ::-1])
     # behind the camera: nothing
     assert oracle.splat_points([world((0.5, 0.5, 3.0))], [red], 1.0, (0, 0, 0), cam, w, h, 1, False)[..., 3].sum() == 0
+
+
+def test_binary16_rounding_fast_path_equals_the_integer_definition(oracle):
+    """orc_d2h (one rounding from double to binary16 -- how the oracle models fp16 mul / fma) has a hardware fast
+    path; it must equal the integer-arithmetic definition on every half, every midpoint between adjacent halfs
+    (the ties) and the doubles next to them, the range ends, and a seeded random set -- and numpy's own
+    float64 -> float16 conversion (also a single rounding) on all of them"""
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    h = np.arange(0, 0x7C00, dtype=np.uint16).view(np.float16).astype(np.float64)
+    mids = (h[:-1] + h[1:]) / 2
+    vals = np.concatenate([h, mids, np.nextafter(mids, np.inf), np.nextafter(mids, -np.inf),
+                           [65504, 65519.99, 65520, 65520.01, 1e5, np.inf, 6.103515625e-05, 5.96e-8, 2.98e-8, 0.0],
+                           rng.uniform(-70000, 70000, 20000), rng.normal(size=20000) * 10.0 ** rng.integers(-9, 5, 20000)])
+    vals = np.concatenate([vals, -vals])
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16).view(np.uint16)
+    for v, w in zip(vals, want):
+        a = L.orc_d2h(float(v))
+        assert a == L.orc_d2h_soft(float(v)) == int(w), v
