@@ -2,10 +2,10 @@
 """Build tests/golden/reference_tours.json from the reference's DATA files (run in the build
 container, where /root/reference is mounted; the GPU box never reads it).
 
-For N in 3..14 and 16 the reference ships a candidate view set `PRV_simulation/Hemisphere/N.txt`
+For every N in 3..100 the reference ships a candidate view set `PRV_simulation/Hemisphere/N.txt`
 (N unit vectors) and `N_path.txt`, the visiting order its Global_Path_Planner (Gurobi TSP) found
 for that set (written at main.cpp:3826-3830).  Those orders are the only expected OUTPUTS in the
-reference tree; this fixture carries them, with their input points, as plain numbers.
+reference tree; this fixture carries all 98 of them, with their input points, as plain numbers.
 """
 import json
 import os
@@ -14,9 +14,10 @@ SRC = "/root/reference/PRV_simulation/Hemisphere"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tours.json")
 
 tours = {}
-for n in list(range(3, 15)) + [16]:
+for n in range(3, 101):
     pts = [[float(x) for x in line.split()] for line in open(os.path.join(SRC, f"{n}.txt")) if line.strip()]
     path = [int(x) for x in open(os.path.join(SRC, f"{n}_path.txt")).read().split()]
+    pts = pts[:n]
     assert len(pts) == n and sorted(path) == list(range(n))
     tours[str(n)] = {"points": pts, "path": path}
 with open(OUT, "w") as f:

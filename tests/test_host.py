@@ -308,23 +308,43 @@ def test_stopping_criterion_fit_and_labels(tmp_path):
         planner.fit_curve([3, 5, 7], [1, 2, 3], 10.0)
 
 
-@pytest.mark.parametrize("n", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
-def test_global_path_matches_the_reference_stored_tours(n):
-    """REFERENCE-PINNED (fixture tests/golden/reference_tours.json): Hemisphere/N_path.txt are outputs of the reference's Global_Path_Planner
-    (Gurobi TSP, main.cpp:3652-3655, 3826-3830).  The exact planner here must reach the same length
-    (orders may differ only between equally short mirror tours) and start at the (0,0,1) view."""
+def _reference_tour(n):
     tour = json.load(open(os.path.join(GOLD, "reference_tours.json")))["tours"][str(n)]
     pts, ref = np.array(tour["points"], np.float64), tour["path"]
     assert sorted(ref) == list(range(n))
     top = int(np.argmin(np.linalg.norm(pts - [0, 0, 1], axis=1)))
     assert ref[0] == top  # main.cpp:3642-3644: the path starts at the top view
+    seg = lambda p: sum(np.linalg.norm(pts[p[i]] - pts[p[i + 1]]) for i in range(n - 1))
+    return pts, ref, top, seg
+
+
+@pytest.mark.parametrize("n", range(3, 21))
+def test_global_path_matches_the_reference_stored_tours(n):
+    """REFERENCE-PINNED (fixture tests/golden/reference_tours.json): Hemisphere/N_path.txt are outputs of the reference's Global_Path_Planner
+    (Gurobi TSP, main.cpp:3652-3655, 3826-3830).  The exact planner here must reach the same length
+    (orders may differ only between equally short mirror tours) and start at the (0,0,1) view."""
+    pts, ref, top, seg = _reference_tour(n)
     order, length, exact = planner.global_path(pts, top)  # unit view sphere, no obstacle (r = 0)
     assert exact and sorted(order) == list(range(n)) and order[0] == top
-    seg = lambda p: sum(np.linalg.norm(pts[p[i]] - pts[p[i + 1]]) for i in range(n - 1))
     assert abs(seg(order) - length) < 1e-12
     assert abs(length - seg(ref)) < 2e-6  # the files carry 6 significant digits
     if n in (6, 10, 11, 12):
         assert order == ref  # unique optimum: the same visiting order
+
+
+@pytest.mark.parametrize("n", [21, 22, 25, 33, 44, 50, 63, 64, 76, 84, 100])
+def test_large_view_sets_reach_the_reference_tour_length(n):
+    """REFERENCE-PINNED: beyond 20 views the planner is an iterated local search, not a proof -- yet on the
+    reference's own view sets it ends at the stored Gurobi tour's length, or below it (the stored tours of
+    N = 24, 26, 37, 59, 73 are not optimal).  All 80 sets of 21..100 views: scripts/tourcheck.py,
+    profiles/r01_m_reference_tours.txt; here a sample incl. the sets that were hardest to reach."""
+    pts, ref, top, seg = _reference_tour(n)
+    order, length, exact = planner.global_path(pts, top)
+    assert not exact and sorted(order) == list(range(n)) and order[0] == top
+    assert abs(seg(order) - length) < 1e-12
+    assert length <= seg(ref) + 2e-6
+    if n in (22, 25):
+        assert order == ref
 
 
 def test_local_path_line_arc_and_blocked_cases():
@@ -373,6 +393,7 @@ def test_planner_executable_mode20_reproduces_the_reference_path_files(tmp_path)
     if not os.path.exists(exe):
         pytest.skip("prv_planner not built")
     tours = json.load(open(os.path.join(GOLD, "reference_tours.json")))["tours"]
+    tours = {n: t for n, t in tours.items() if int(n) <= 16 or int(n) in (22, 25, 34)}  # the rest: the tests above
     vs = tmp_path / "vs"
     vs.mkdir()
     for n, t in tours.items():
@@ -387,7 +408,7 @@ def test_planner_executable_mode20_reproduces_the_reference_path_files(tmp_path)
         assert sorted(got) == list(range(int(n))) and got[0] == ref[0]
         seg = lambda p: sum(np.linalg.norm(pts[p[i]] - pts[p[i + 1]]) for i in range(len(p) - 1))
         assert abs(seg(got) - seg(ref)) < 2e-6
-        if n in ("6", "10", "11", "12"):
+        if n in ("6", "10", "11", "12", "22", "25", "34"):
             assert got == ref
 
 
