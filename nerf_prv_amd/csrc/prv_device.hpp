@@ -152,7 +152,8 @@ __device__ __forceinline__ bool occupied(const FieldDev& f, float px, float py, 
   int cx = min((int)(clamp01(px) * fR), R - 1);
   int cy = min((int)(clamp01(py) * fR), R - 1);
   int cz = min((int)(clamp01(pz) * fR), R - 1);
-  uint32_t bit = (uint32_t)cx + (uint32_t)R * ((uint32_t)cy + (uint32_t)R * (uint32_t)cz);
+  // R <= 1024: every factor is below 2^24, so the full-rate 24-bit multiply gives the same integers as v_mul_lo_u32
+  uint32_t bit = (uint32_t)cx + __umul24((uint32_t)R, (uint32_t)cy + __umul24((uint32_t)R, (uint32_t)cz));
   return (f.occ[bit >> 5] >> (bit & 31)) & 1u;
 }
 
@@ -163,7 +164,7 @@ __device__ __forceinline__ bool occupied_coarse(const FieldDev& f, float px, flo
   const int cx = min((int)(clamp01(px) * fR), R - 1);
   const int cy = min((int)(clamp01(py) * fR), R - 1);
   const int cz = min((int)(clamp01(pz) * fR), R - 1);
-  const uint32_t bit = (uint32_t)cx + (uint32_t)R * ((uint32_t)cy + (uint32_t)R * (uint32_t)cz);
+  const uint32_t bit = (uint32_t)cx + __umul24((uint32_t)R, (uint32_t)cy + __umul24((uint32_t)R, (uint32_t)cz));
   return (f.occ_coarse[bit >> 5] >> (bit & 31)) & 1u;
 }
 

@@ -48,7 +48,7 @@ __device__ __forceinline__ bool occ_bit(const uint32_t* __restrict__ occ, int R,
   const float fr = (float)R;
   int cx = min((int)(clamp01(px) * fr), R - 1), cy = min((int)(clamp01(py) * fr), R - 1),
       cz = min((int)(clamp01(pz) * fr), R - 1);
-  const uint32_t bit = (uint32_t)cx + (uint32_t)R * ((uint32_t)cy + (uint32_t)R * (uint32_t)cz);
+  const uint32_t bit = (uint32_t)cx + __umul24((uint32_t)R, (uint32_t)cy + __umul24((uint32_t)R, (uint32_t)cz)); // R <= 1024
   return (occ[bit >> 5] >> (bit & 31u)) & 1u;
 }
 
