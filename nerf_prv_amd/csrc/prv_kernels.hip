@@ -86,17 +86,29 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
           g_hi = min(P.S, (int)((tb - t0) * inv_dt) + 3);
         }
       }
-      for (int g = g_lo; g < g_hi; g += 4) {
-        if (coarse_ok) {
-          const float tm = fmaf((float)g + 2.0f, dt, t0);
-          if (!occupied_coarse(P.field, fmaf(tm, d[0], o[0]), fmaf(tm, d[1], o[1]), fmaf(tm, d[2], o[2]))) continue;
+      // one mask word (32 samples = 8 groups) at a time, so the word is a plain register and a sample's bit goes in
+      // with one shift-or instead of a select chain over m[0..3]; the four fine tests of a group are issued
+      // together (four loads in flight, one wait)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t w = 0u;
+        const int lo = max(g_lo, 32 * k), hi = min(g_hi, 32 * k + 32);
+        for (int g = lo; g < hi; g += 4) {
+          if (coarse_ok) {
+            const float tm = fmaf((float)g + 2.0f, dt, t0);
+            if (!occupied_coarse(P.field, fmaf(tm, d[0], o[0]), fmaf(tm, d[1], o[1]), fmaf(tm, d[2], o[2]))) continue;
+          }
+          bool occ[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int i = g + q;
+            const float t = fmaf((float)i + 0.5f, dt, t0);
+            occ[q] = occupied(P.field, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2])) && i < P.S;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) w |= (uint32_t)occ[q] << ((g + q) & 31);
         }
-        const int hi = min(g + 4, P.S);
-        for (int i = g; i < hi; i++) {
-          const float t = fmaf((float)i + 0.5f, dt, t0);
-          const bool occ = occupied(P.field, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]));
-          if (occ) m[i >> 5] |= 1u << (i & 31);
-        }
+        m[k] = w;
       }
       live = (m[0] | m[1] | m[2] | m[3]) != 0u;
     }
