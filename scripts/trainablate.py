@@ -44,5 +44,5 @@ else:
             v = st[base:base + 32].astype(np.int64)
             nz = np.flatnonzero(v)
             if len(nz) > 1:
-                d = np.diff(v[nz]) / 100.0  # s_memtime ticks at 100 MHz -> microseconds
-                print(name, "stamps", list(nz), "deltas us:", " ".join(f"{x:.1f}" for x in d))
+                d = np.diff(v[nz]) / 2400.0  # s_memtime ticks at the shader clock (~2.4 GHz) -> microseconds
+                print(name, "stamps", [int(x) for x in nz], "deltas us:", " ".join(f"{x:.2f}" for x in d), f"total {d.sum():.1f}")
