@@ -222,3 +222,40 @@ def test_random_evaluation_case(ctx, oracle, case_id):
         assert rec["psnr"][v] == pytest.approx(want_p, rel=1e-5) and ps[v] == pytest.approx(want_p, rel=1e-5)
         assert rec["coverage"][v] == pytest.approx(want_c, rel=1e-5)
         assert ss[v] == pytest.approx(oracle.ssim(a[v], b[v], bg), rel=1e-3, abs=1e-5)
+
+
+def test_view_batches_do_not_change_anything(ctx, oracle, monkeypatch):
+    """a render call deals its views to the ray queue in batches when the queue would outgrow its budget (the
+    128-views-per-GPU configuration does); a context with a 1 MiB budget renders 17 views in several batches and
+    must give the same bytes, floats, scores and counts as the one-batch context -- with view subsets, repeats
+    and sub-samples"""
+    monkeypatch.setenv("PRV_QUEUE_MB", "1")
+    small = api.Context(0)
+    monkeypatch.delenv("PRV_QUEUE_MB")
+    try:
+        d_p = api.field_desc(**util.SMALL)
+        for c in (ctx, small):
+            c.synthetic_model(0, d_p, util.SEED_A)
+            c.synthetic_model(1, d_p, util.SEED_B)
+        pts = util.fibonacci_hemisphere(17)
+        tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+        w, h = 48, 40  # 48*40*96 B = 184 KB per view and sub-sample: 5 views per batch at spp 1, 1 at spp 4
+        ids = np.array([3, 16, 0, 0, 7, 8, 9, 1, 2, 15, 14, 13, 3, 5, 6, 4, 10, 11, 12], np.int32)
+        for spp in (1, 4):
+            opts = api.render_opts(w, h, 64, spp, 1e-4, background=(0.2, 0.4, 0.6, 1.0))
+            outs = []
+            for c in (ctx, small):
+                cs = c.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+                img, st = c.render(0, cs, ids, opts)
+                u8, _ = c.render_rgba8(0, cs, ids, opts)
+                gt, _ = c.render(1, cs, ids, opts, want_stats=False)
+                rec, _ = c.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cs, ids, opts, gt=gt)
+                ens, _ = c.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, [0, 1], cs, ids, opts)
+                outs.append((img.cpu().numpy(), u8.cpu().numpy(), int(st.samples_evaluated), rec.copy(), ens.copy()))
+                cs.close()
+            a, b = outs
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] > 0
+            assert a[3].tobytes() == b[3].tobytes() and a[4].tobytes() == b[4].tobytes()
+            assert np.array_equal(a[0][2], a[0][3]) and np.array_equal(a[0][0], a[0][12])  # repeated ids
+    finally:
+        small.close()
