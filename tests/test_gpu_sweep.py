@@ -259,3 +259,39 @@ def test_view_batches_do_not_change_anything(ctx, oracle, monkeypatch):
             assert np.array_equal(a[0][2], a[0][3]) and np.array_equal(a[0][0], a[0][12])  # repeated ids
     finally:
         small.close()
+
+
+@pytest.mark.parametrize("env", [{"PRV_REFILL_MIN": "8"}, {"PRV_REFILL_MIN": "1"}, {"PRV_QUEUE_SEGMENTS": "1"},
+                                 {"PRV_QUEUE_SEGMENTS": "3"}, {"PRV_DEHASH_MB": "64"}, {"PRV_NO_PAIR": "1"},
+                                 {"PRV_BLOCKS_PER_CU": "1"}, {"PRV_BLOCKS_PER_CU": "6", "PRV_REFILL_MIN": "16"}])
+@pytest.mark.parametrize("which", ["F4", "F2"])
+def test_placement_and_layout_switches_change_speed_only(ctx, oracle, monkeypatch, env, which):
+    """the tuning switches of the render path (slot refill granularity, queue segments per XCD, hashed levels stored
+    densely, paired loads off, resident blocks per CU) decide where and in which order rays are rendered and how the
+    table is laid out in memory -- never the arithmetic: images and counts are bit-identical to the defaults"""
+    kw = util.SMALL if which == "F4" else util.SMALL_F2
+    d_p = api.field_desc(**kw)
+    pts = util.fibonacci_hemisphere(5)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    w, h = 56, 44
+    opts = api.render_opts(w, h, 96, 1, 1e-4)
+    ctx.synthetic_model(2, d_p, util.SEED_A)
+    cs = ctx.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+    want, st0 = ctx.render(2, cs, None, opts)
+    feat0 = ctx.debug_encode(2, np.random.default_rng(1).random((300, 3)).astype(np.float32))
+    cs.close()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = api.Context(0)
+    for k in env:
+        monkeypatch.delenv(k)
+    try:
+        other.synthetic_model(2, d_p, util.SEED_A)
+        cs = other.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+        got, st1 = other.render(2, cs, None, opts)
+        assert np.array_equal(got.cpu().numpy(), want.cpu().numpy()), env
+        assert st1.samples_evaluated == st0.samples_evaluated > 0
+        assert np.array_equal(other.debug_encode(2, np.random.default_rng(1).random((300, 3)).astype(np.float32)), feat0)
+        cs.close()
+    finally:
+        other.close()
