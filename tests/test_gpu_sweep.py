@@ -295,3 +295,40 @@ def test_placement_and_layout_switches_change_speed_only(ctx, oracle, monkeypatc
         cs.close()
     finally:
         other.close()
+
+
+@pytest.mark.parametrize("env", [{"PRV_TRAIN_GRAPH": "0"}, {"PRV_TRAIN_FAST_FWD": "0"},
+                                 {"PRV_TRAIN_GRAPH": "0", "PRV_TRAIN_FAST_FWD": "0"}])
+def test_trainer_switches_hold_the_same_bars(ctx, oracle, monkeypatch, env):
+    """the trainer's two switches -- plain launches instead of the captured step graph, f32 tile forward instead of
+    the f16-MFMA forward -- against the oracle on the same batch and over a few optimiser steps: same ray batch,
+    loss and gradients within 1e-3, steps tracking the oracle like the default configuration does"""
+    kw = dict(n_levels=8, n_features=4, log2_hashmap=10, base_res=4, finest_res=24, occ_res=16, density_bias=1.0, table_amp=0.5)
+    intr = {"fl_x": 20.0, "fl_y": 19.5, "cx": 12.3, "cy": 7.8, "w": 24, "h": 16, "k1": 0.05, "k2": -0.02, "p1": 0.001, "p2": -0.002}
+    gt = oracle.OracleField(oracle.desc(**dict(kw, density_bias=3.0, table_amp=2.0)), seed=util.SEED_B)
+    tms, scale, offset = util.hemisphere_transforms(oracle, util.fibonacci_hemisphere(6))
+    ocams = oracle.cameras_from_dataset(tms, intr, scale, offset)
+    imgs = np.stack([oracle.quantize_rgba8(gt.render(c, 24, 16, 32, 1, 1e-4)[0], (0, 0, 0, 0)) for c in ocams])
+    cams = ctx.cameras_from_matrices_intr(tms, intr, scale, offset)
+    f = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
+    t, m, o = f.params()
+    o = np.full_like(o, 0xFFFFFFFF)
+    f = oracle.OracleField(f.desc, params=(t, m, o))
+    ctx.load_model(3, api.field_desc(**kw), t, m, o)
+    opts = dict(n_rays=160, n_samples=24, occ_every=4, occ_sigma_thresh=0.3)
+    otr = oracle.OracleTrainer(f, oracle.train_opts(**opts), ocams, imgs)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    gtr = api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(**opts))  # reads the switches
+    for k in env:
+        monkeypatch.delenv(k)
+    want_loss, want_tg, want_mg = otr.gradients()
+    loss, tg, mg = gtr.gradients()
+    assert gtr.info()["samples_last"] == otr.samples_last > 500
+    assert loss == pytest.approx(want_loss, rel=1e-3)
+    assert rel_l2(mg, want_mg) < 1e-3 and rel_l2(tg, want_tg) < 1e-3
+    want = np.array([otr.step() for _ in range(6)])
+    np.testing.assert_allclose(gtr.steps(6), want, rtol=2e-3)
+    assert gtr.info()["active_rays"] == otr.active_rays
+    gtr.close()
+    cams.close()
