@@ -468,11 +468,12 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   const int W = o->width, H = o->height;
   const size_t npix = (size_t)W * H;
   int rc;
-  if ((rc = ensure(c, c->counters, 64 + 8 * 64)) != PRV_OK) return rc;
+  if ((rc = ensure(c, c->counters, 64 + 8 * 64 + 33 * 8 + 64)) != PRV_OK) return rc; // count | stats | 8 heads | dev histogram
   uint32_t* q_count = (uint32_t*)c->counters.p;
   uint32_t* q_head = q_count + 16; // 8 segment heads, one 64-byte line each
   unsigned long long* stat = (unsigned long long*)((char*)c->counters.p + 16);
   if (zero_stats) HIPCHK(c, hipMemsetAsync(stat, 0, 16, c->stream));
+  if (zero_stats && (c->dbg_flags & 8)) HIPCHK(c, hipMemsetAsync(stat + 72, 0, 33 * 8, c->stream));
   if (n_views == 0) return PRV_OK;
 
   // cameras at this resolution, uploaded per call (tiny)
@@ -588,6 +589,15 @@ int fetch_stats(prv_ctx* c, const prv_render_opts* o, int n_views, int n_models,
   st->rays = (uint64_t)n_views * n_models * o->width * o->height * o->spp;
   st->samples_nominal = st->rays * (uint64_t)o->samples_per_ray;
   st->samples_evaluated = ev;
+  if (c->dbg_flags & 8) { // dev: slot-occupancy histogram of the render launches since the stats were cleared
+    unsigned long long hist[33];
+    HIPCHK(c, hipMemcpy(hist, (char*)c->counters.p + 16 + 72 * 8, sizeof(hist), hipMemcpyDeviceToHost));
+    unsigned long long tot = 0;
+    for (int i = 1; i <= 32; i++) tot += hist[i];
+    fprintf(stderr, "slot occupancy per wave-round (active slots: share of rounds):");
+    for (int i = 1; i <= 32; i++) fprintf(stderr, " %d:%.3f", i, tot ? (double)hist[i] / (double)tot : 0.0);
+    fprintf(stderr, "\n");
+  }
   return PRV_OK;
 }
 

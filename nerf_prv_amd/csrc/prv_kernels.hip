@@ -149,7 +149,9 @@ template <int F, int NPAIR>
 __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
   __shared__ half8 wl[kNumFrags * 64];
   __shared__ LevelDev lvl[kMaxLevels];
+  __shared__ unsigned hist[33];
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = P.field.frags[i];
+  if (threadIdx.x < 33) hist[threadIdx.x] = 0u;
   stage_levels(P.field, lvl);
   __syncthreads();
 
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
     }
     n_eval += (unsigned long long)__popc(act);
     n_rounds++;
+    if ((P.dbg & 8) && lane == 0) atomicAdd(&hist[__popc(act)], 1u); // dev: how full the wave's 32 slots are, per round
 
     // ---- next live sample of every active slot (identical in both lanes of a pair)
     half8 f0 = {0, 0, 0, 0, 0, 0, 0, 0}, f1 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -300,6 +303,10 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
   if (lane == 0 && n_eval) {
     atomicAdd(P.stat_evaluated, n_eval);
     atomicAdd(P.stat_evaluated + 1, n_rounds); // wave-rounds: slot utilisation = evaluated / (32 * rounds)
+  }
+  if (P.dbg & 8) {
+    __syncthreads();
+    if (threadIdx.x < 33 && hist[threadIdx.x]) atomicAdd(P.stat_evaluated + 72 + threadIdx.x, (unsigned long long)hist[threadIdx.x]);
   }
 }
 

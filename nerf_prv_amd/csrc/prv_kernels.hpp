@@ -43,7 +43,7 @@ struct RenderParams {
   int spp_k;
   int last_pass;
   int refill_min;
-  int dbg; // dev-only ablation bits (PRV_DBG env): 1 no table loads, 2 no MLP, 4 no compositing math
+  int dbg; // dev-only bits (PRV_DBG env): 1 no table loads, 2 no MLP, 4 no compositing math, 8 slot-occupancy histogram
   float bg[4];
 };
 
