@@ -871,6 +871,16 @@ int prv_model_load_file(prv_ctx* c, int slot, const char* path) try {
     fclose(f);
     return fail(c, PRV_E_IO, "%s is not a PRVF model file of ABI version %d", path, PRV_ABI_VERSION);
   }
+  { // the descriptor is input, not truth: the file must have the size it implies BEFORE buffers of that size exist
+    const long at = ftell(f);
+    const bool seek_ok = at >= 0 && fseek(f, 0, SEEK_END) == 0;
+    const long end = seek_ok ? ftell(f) : -1;
+    if (!seek_ok || end < at || fseek(f, at, SEEK_SET) != 0 ||
+        (uint64_t)(end - at) != th * 2ull + mh * 2ull + ow * 4ull) {
+      fclose(f);
+      return fail(c, PRV_E_IO, "%s is truncated (or not the field its header describes)", path);
+    }
+  }
   std::vector<uint16_t> table(th), mlp(mh);
   std::vector<uint32_t> occ(ow);
   const bool ok = fread(table.data(), 2, th, f) == th && fread(mlp.data(), 2, mh, f) == mh && fread(occ.data(), 4, ow, f) == ow;

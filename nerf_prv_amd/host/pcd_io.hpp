@@ -40,7 +40,21 @@ inline int pcd_read(const std::string& path, std::vector<float>& xyz, std::vecto
   const size_t nf = fields.size();
   if (nf == 0 || sizes.size() != nf || types.size() != nf || points == 0) return -2;
   if (counts.empty()) counts.assign(nf, 1);
+  if (counts.size() != nf) return -2;
   if (data_kind != "ascii" && data_kind != "binary") return -3;
+  for (size_t i = 0; i < nf; i++) // a header is input, not truth: sizes and counts decide offsets and column numbers
+    if ((sizes[i] != 1 && sizes[i] != 2 && sizes[i] != 4 && sizes[i] != 8) || counts[i] < 1 || counts[i] > 1024) return -2;
+  {
+    // the body must be able to hold what the header announces (a point takes `stride` bytes, or at least two
+    // characters per column as text) -- before anything is allocated for it
+    size_t per_point = 0;
+    for (size_t i = 0; i < nf; i++) per_point += data_kind == "binary" ? (size_t)sizes[i] * (size_t)counts[i] : 2u * (size_t)counts[i];
+    const std::streampos here = f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streampos end = f.tellg();
+    f.seekg(here);
+    if (here < 0 || end < here || points > (size_t)(end - here) / per_point + 1) return -4;
+  }
   int ix = -1, iy = -1, iz = -1, ic = -1;
   std::vector<size_t> offs(nf, 0);
   size_t stride = 0, cols = 0;

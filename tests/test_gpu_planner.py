@@ -110,6 +110,21 @@ def test_model_file_roundtrip(ctx, tmp_path):
     with pytest.raises(api.PrvError) as e:
         ctx.load_model_file(2, tmp_path / "bad.prvf")
     assert e.value.code == api.L.PRV_E_IO
+    # a header that announces gigabytes in a file of a few bytes, and a file cut short: refused from the file's size,
+    # before any buffer of the announced size exists
+    import ctypes as C
+    import struct
+
+    good = open(path, "rb").read()
+    big = api.field_desc(n_levels=16, n_features=2, log2_hashmap=24, base_res=16, finest_res=2048, occ_res=512)
+    (tmp_path / "liar.prvf").write_bytes(good[:8] + bytes(C.string_at(C.addressof(big), C.sizeof(big))) + b"\0" * 100)
+    (tmp_path / "cut.prvf").write_bytes(good[: len(good) // 2])
+    (tmp_path / "long.prvf").write_bytes(good + b"\0" * 4)
+    for name in ("liar", "cut", "long"):
+        with pytest.raises(api.PrvError) as e:
+            ctx.load_model_file(2, tmp_path / f"{name}.prvf")
+        assert e.value.code == api.L.PRV_E_IO, name
+    assert struct.unpack("<I", good[:4])[0] == 0x46565250
 
 
 @pytest.mark.parametrize("method", [2, 3, 5])

@@ -524,3 +524,26 @@ def test_pcd_reader_ascii_and_binary(tmp_path):
     for bad in ("d.pcd", "missing.pcd"):
         with pytest.raises(IOError):
             planner.pcd_read(tmp_path / bad)
+
+
+def test_malformed_point_cloud_headers_are_refused(tmp_path):
+    """a PCD header is input, not truth (found by scripts/fuzz_host_inputs.cpp under ASan): counts / sizes that do
+    not fit the fields, zero or negative column counts, and point counts the body cannot hold are error codes"""
+    head = "VERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F U\n{count}WIDTH {n}\nHEIGHT 1\nPOINTS {n}\nDATA ascii\n"
+    body = "0.1 0.2 0.3 255\n0.4 0.5 0.6 65280\n"
+    good = tmp_path / "good.pcd"
+    good.write_text(head.format(count="COUNT 1 1 1 1\n", n=2) + body)
+    xyz, rgb = planner.pcd_read(good)
+    assert xyz.shape == (2, 3) and rgb[1].tolist() == [0, 255, 0]
+    for name, text in {
+        "count_zero": head.format(count="COUNT 0 0 0 0\n", n=2) + body,
+        "count_negative": head.format(count="COUNT 1 -1 1 1\n", n=2) + body,
+        "count_short": head.format(count="COUNT 1 1\n", n=2) + body,
+        "size_odd": head.format(count="", n=2).replace("SIZE 4 4 4 4", "SIZE 4 4 4 3") + body,
+        "points_beyond_body": head.format(count="", n=10 ** 9) + body,
+        "points_few_more": head.format(count="", n=40) + body,
+    }.items():
+        bad = tmp_path / f"{name}.pcd"
+        bad.write_text(text)
+        with pytest.raises(IOError):
+            planner.pcd_read(bad)
