@@ -694,3 +694,62 @@ def test_planner_executable_mode3_then_mode21_from_a_point_cloud(ctx, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     chosen = [int(x) for x in [l for l in out.stdout.splitlines() if l.startswith("chosen_nbvs:")][-1].split(":")[1].split()]
     assert len(chosen) == 4 and len(set(chosen)) == 4
+
+
+def _two_rank_nbv_worker(rank, world, port, tj, render_json, q):
+    """one rank of a 2-process NBV iteration on the one GPU: gloo carries the two collectives (the test box has
+    a single device, RCCL refuses two ranks on it); everything else is the production path"""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = api.Context(0)
+        desc = api.field_desc(**TRAIN_FIELD)
+        losses = planner.train_ensemble(c, 3, tj, 48, desc, seed=50,
+                                        opts=api.train_opts(n_rays=512, n_samples=48, occ_sigma_thresh=0.01 * 48 / 3 ** 0.5))
+        members = [c.export_model(e, desc) for e in range(3)]
+        cams = c.cameras_from_json(render_json)
+        opts = api.render_opts(20, 12, 48, 2, 0.01, background=(0, 0, 0, 1))
+
+        def score_shard(ids):
+            rec, _ = c.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, [0, 1, 2], cams, ids, opts)
+            return rec
+
+        records, order = planner.scoring_round(len(cams), score_shard, interleaved=True)
+        q.put((rank, sorted(losses), [m[0].tobytes() + m[1].tobytes() + m[2].tobytes() for m in members],
+               records.tobytes(), order.tolist()))
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_nbv_iteration_on_one_gpu(ctx, tmp_path):
+    """(e) end to end at world size 2: rank r trains the ensemble members e % 2 == r, ONE all-gather hands every
+    rank every member, each rank scores its interleaved shard of the candidates with the whole ensemble, ONE
+    all-gather of 16-byte records, identical ranking everywhere.  Both ranks end with byte-identical members,
+    records and rankings."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    tj, pos, k, c = write_dataset(ctx, tmp_path, n_views=6)
+    render_json = tmp_path / "render.json"
+    planner.write_transforms(render_json, k, planner.view_space(util.fibonacci_hemisphere(11), 0.3, c), c, 0.1, candidate=True)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_two_rank_nbv_worker, args=(r, 2, port, str(tj), str(render_json), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, own0, mem0, rec0, ord0), (r1, own1, mem1, rec1, ord1) = got
+    assert own0 == [0, 2] and own1 == [1]  # who trained what
+    assert mem0 == mem1 and len(set(mem0)) == 3  # every rank holds the same three, different, members
+    assert rec0 == rec1 and ord0 == ord1 and sorted(ord0) == list(range(11))
