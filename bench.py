@@ -279,7 +279,10 @@ def main():
                 "mfma_util_frac": samples_per_launch * 20480 / kernel_s / 2.5e15,  # of the ~2.5 PFLOP/s dense f16 peak
                 "note": ("algorithmic gather bytes (512 B per evaluated sample) over the 8 TB/s HBM peak, as SURVEY 8d "
                          "prescribes; the 256^3 table (17.7 MiB) is L2 / Infinity-Cache resident, so frac > 1 is a cache "
-                         "effect: `traffic` = measured fabric-side bytes per launch (PMC pass); the 512^3 field "
+                         "effect: `traffic` = measured fabric-side bytes per launch (FETCH_SIZE + WRITE_SIZE, separate PMC passes; "
+                         "FETCH_SIZE is NOT doubled here: the guide's x2 applies to wide coalesced reads tallied as 128-B "
+                         "requests, these are per-lane gathers, calibrated at one 64-B request per missing load, "
+                         "profiles/r01_gather_calib.txt); the 512^3 field "
                          "(--field 512, 64 MiB table) is the HBM-bound case, frac 0.44 = the random-64-B-request ceiling "
                          "(DESIGN.md section 3)") if args.field == "256" else
                         ("64 MiB table: L2 hit rate 29 %, fabric reads ~535 B per sample; 3.5 TB/s of algorithmic bytes "
