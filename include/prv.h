@@ -43,7 +43,9 @@ extern "C" {
 /* scoring methods; 2 and 3 are the reference's method_of_IG values (Share_Data.hpp:198-202) */
 #define PRV_SCORE_ENSEMBLE_RGB 2         /* main.cpp:2039-2097 */
 #define PRV_SCORE_ENSEMBLE_RGB_DENSITY 3 /* main.cpp:2099-2161 */
-#define PRV_SCORE_PSNR_COVERAGE 5        /* run.py:257-263 PSNR vs supplied images + mean opacity */
+#define PRV_SCORE_PSNR_COVERAGE 5        /* -PSNR (run.py:257-263, vs supplied images) + w * mean((1 - alpha)^2), the
+                                            density term of main.cpp:2148; w = prv_set_coverage_weight */
+#define PRV_COVERAGE_WEIGHT_DEFAULT 1.0  /* the reference adds its density term with unit weight too (main.cpp:2147-2148) */
 
 #define PRV_MAX_MODELS 8
 #define PRV_MLP_HALFS 10240 /* 32*64 + 64*16 + 32*64 + 64*64 + 64*16, canonical [in][out] */
@@ -80,7 +82,7 @@ typedef struct prv_render_opts {
 } prv_render_opts;
 
 typedef struct prv_score_record { /* 16 bytes: the unit of the multi-GPU all-gather */
-  double score;                   /* ranking key: larger = chosen first */
+  double score;                   /* ranking key: larger = chosen first; NaN ranks last */
   float psnr;                     /* dB (method 5), else 0 */
   float coverage;                 /* mean opacity of the render (method 5), else 0 */
 } prv_score_record;
@@ -105,6 +107,11 @@ int prv_abi_version(void);
 int prv_set_stream(prv_ctx* ctx, void* hip_stream);
 int prv_synchronize(prv_ctx* ctx);
 int prv_device_count(void);
+/* method 5's ranking key is  -PSNR_dB + weight * mean_pixels((1 - alpha)^2) : the worst-reconstructed and
+ * least-covered view first.  The second term is the reference's own density term ((1 - mean_density)^2 per
+ * pixel, main.cpp:2148, added with weight 1 to the colour term of method 3), here the mean over the view's
+ * pixels so that it does not depend on the image size.  weight 0 ranks by PSNR alone. */
+int prv_set_coverage_weight(prv_ctx* ctx, double weight);
 
 /* Per-kernel timing with HIP events on the context's stream (for roofline accounting):
  * between begin and end every march_compact and render_queue launch is bracketed by an
@@ -216,7 +223,8 @@ int prv_precept(prv_ctx* ctx, int model_slot, const float* voxels_dev, int n, co
 int prv_score_ensemble_images(prv_ctx* ctx, int method, const uint8_t* const* imgs_dev,
                               int n_members, int n_views, size_t pixels_per_view,
                               prv_score_record* records_host);
-/* replaces: run.py:257-263 per image.  score = -psnr (worst-reconstructed view first). */
+/* replaces: run.py:257-263 per image.  score = -psnr + coverage weight * mean((1 - alpha)^2), see
+ * prv_set_coverage_weight (worst-reconstructed, least-covered view first). */
 int prv_score_psnr_images(prv_ctx* ctx, const float* rgba_dev, const float* gt_rgba_dev,
                           int n_views, size_t pixels_per_view, const float bg[4],
                           prv_score_record* records_host);
@@ -244,7 +252,8 @@ int prv_score_views(prv_ctx* ctx, int method, const int* model_slots, int n_mode
                     prv_score_record* records_host, prv_score_record* records_dev,
                     prv_stats* stats);
 /* replaces: the arg-max bookkeeping main.cpp:1971-1972, 2088-2091, 2096.
- * order = view ids sorted by (score descending, id ascending); host only. */
+ * order = view ids sorted by (score descending, id ascending), NaN scores after every number (the reference's
+ * strict '>' never selects a NaN either); host only. */
 int prv_rank(const prv_score_record* records, const int* view_ids, int n, int* order);
 int prv_argmax(const prv_score_record* records, const int* view_ids, int n);
 
@@ -267,7 +276,7 @@ int prv_splat_points(prv_ctx* ctx, const float* xyz_dev, const uint8_t* rgb_dev,
  * The model slot is trained IN PLACE: after every prv_train_steps call the slot renders / scores with the
  * trained weights and occupancy. */
 typedef struct prv_train_opts {
-  int32_t n_rays;    /* rays per step */
+  int32_t n_rays;    /* rays per step (with target_samples: the cap of the adaptive count; default 2^16) */
   int32_t n_samples; /* samples per ray between the AABB hits, <= 128 */
   float lr, beta1, beta2, eps, l2_reg; /* Adam; l2_reg on the MLP weights only */
   float min_T;       /* early termination of a training ray */

@@ -86,6 +86,7 @@ SIGNATURES = {
     "prv_abi_version": (_i, []),
     "prv_set_stream": (_i, [_vp, _vp]),
     "prv_synchronize": (_i, [_vp]),
+    "prv_set_coverage_weight": (_i, [_vp, C.c_double]),
     "prv_device_count": (_i, []),
     "prv_profile_begin": (_i, [_vp]),
     "prv_profile_end": (_i, [_vp, _P(C.c_double), _P(_i), _P(C.c_double), _P(_i)]),

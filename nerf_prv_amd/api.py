@@ -135,6 +135,10 @@ class Context:
     def synchronize(self):
         self._chk(self.lib.prv_synchronize(self.handle))
 
+    def set_coverage_weight(self, weight):
+        """SCORE_PSNR_COVERAGE's key = -PSNR + weight * mean((1 - alpha)^2); default 1, 0 = PSNR alone"""
+        self._chk(self.lib.prv_set_coverage_weight(self.handle, float(weight)))
+
     def profile_begin(self):
         self._chk(self.lib.prv_profile_begin(self.handle))
 

@@ -36,6 +36,7 @@ struct Buffer {
 struct Model {
   bool loaded = false;
   bool dirty = false; // a trainer changed the canonical arrays: the derived render state is rebuilt on first use
+  uint64_t generation = 0; // bumped whenever NEW parameters are installed (load / synthetic / fresh / file), not by a trainer's publish
   prv_field_desc desc{};
   FieldDev dev{};
   uint64_t table_halfs = 0, occ_words = 0;
@@ -75,6 +76,7 @@ struct prv_ctx {
   size_t stage_budget = (size_t)4 << 30; // staging bytes for multi-sample renders (spp x batch x image)
   size_t dehash_budget = 0; // bytes per hashed level allowed for a physically dense copy (0 = keep hashed)
   size_t queue_budget = (size_t)4 << 30; // ray-queue bytes per batch of views (288 GB of HBM: one batch for 64 views at 800x800)
+  double coverage_weight = PRV_COVERAGE_WEIGHT_DEFAULT; // method 5: score = -PSNR + weight * mean((1 - alpha)^2)
 };
 
 namespace {
@@ -690,6 +692,13 @@ int prv_set_stream(prv_ctx* c, void* s) try {
   return PRV_OK;
 } catch (...) { return caught(c); }
 
+int prv_set_coverage_weight(prv_ctx* c, double weight) try {
+  if (!c) return PRV_E_INVALID;
+  if (!std::isfinite(weight)) return fail(c, PRV_E_INVALID, "coverage weight must be finite");
+  c->coverage_weight = weight;
+  return PRV_OK;
+} catch (...) { return caught(c); }
+
 int prv_synchronize(prv_ctx* c) try {
   if (!c) return PRV_E_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -776,6 +785,7 @@ int prv_model_load(prv_ctx* c, int slot, const prv_field_desc* d, const uint16_t
   if (slot < 0 || slot >= PRV_MAX_MODELS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
   if (!d || !table || !mlp || !occ) return fail(c, PRV_E_INVALID, "NULL argument");
   HIPCHK(c, hipSetDevice(c->device));
+  c->models[slot].generation++; // a live trainer of this slot holds stale masters from now on (train_check)
   return install_model(c, slot, *d, mlp, occ, table);
 } catch (...) { return caught(c); }
 
@@ -824,6 +834,7 @@ static int model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64
   int rc = ensure(c, m.table, total * (uint64_t)d->n_features * 2);
   if (rc != PRV_OK) return rc;
   HIPCHK(c, launch_synth_table((uint16_t*)m.table.p, total * (uint64_t)d->n_features, seed, d->table_amp, c->stream));
+  m.generation++;
   return install_model(c, slot, *d, mlp.data(), occ.data(), nullptr);
 }
 
@@ -1202,10 +1213,10 @@ static int score_ensemble_dev(prv_ctx* c, int method, const uint8_t* const* imgs
 }
 
 static int score_psnr_dev(prv_ctx* c, const float* rgba, const float* gt, int n_views, size_t npix, const float bg[4],
-                          prv_score_record* rec_dev) {
+                          double coverage_weight, prv_score_record* rec_dev) {
   const int nblk = score_blocks(npix);
   int rc;
-  if ((rc = ensure(c, c->partial, (size_t)n_views * nblk * 2 * sizeof(double))) != PRV_OK) return rc;
+  if ((rc = ensure(c, c->partial, (size_t)n_views * nblk * 3 * sizeof(double))) != PRV_OK) return rc;
   PsnrParams P;
   memset(&P, 0, sizeof(P));
   P.rgba = rgba;
@@ -1214,7 +1225,7 @@ static int score_psnr_dev(prv_ctx* c, const float* rgba, const float* gt, int n_
   memcpy(P.bg, bg, sizeof(P.bg));
   P.partial = (double*)c->partial.p;
   HIPCHK(c, launch_score_psnr(P, n_views, nblk, c->stream));
-  HIPCHK(c, launch_score_finalize(P.partial, n_views, nblk, PRV_SCORE_PSNR_COVERAGE, npix, rec_dev, c->stream));
+  HIPCHK(c, launch_score_finalize(P.partial, n_views, nblk, PRV_SCORE_PSNR_COVERAGE, npix, coverage_weight, rec_dev, c->stream));
   return PRV_OK;
 }
 
@@ -1246,7 +1257,7 @@ int prv_score_psnr_images(prv_ctx* c, const float* rgba, const float* gt, int n_
   int rc;
   if ((rc = check_device_ptr(c, rgba, "rgba_dev")) != PRV_OK || (rc = check_device_ptr(c, gt, "gt_rgba_dev")) != PRV_OK) return rc;
   if ((rc = ensure(c, c->records, (size_t)n_views * sizeof(prv_score_record))) != PRV_OK) return rc;
-  if ((rc = score_psnr_dev(c, rgba, gt, n_views, npix, bg, (prv_score_record*)c->records.p)) != PRV_OK) return rc;
+  if ((rc = score_psnr_dev(c, rgba, gt, n_views, npix, bg, c->coverage_weight, (prv_score_record*)c->records.p)) != PRV_OK) return rc;
   return prv_memcpy_d2h(c, rec_host, c->records.p, (size_t)n_views * sizeof(prv_score_record));
 } catch (...) { return caught(c); }
 
@@ -1261,8 +1272,10 @@ int prv_evaluate_images(prv_ctx* c, const float* rgba, const float* gt, int n_vi
   if ((rc = check_device_ptr(c, rgba, "rgba_dev")) != PRV_OK || (rc = check_device_ptr(c, gt, "gt_rgba_dev")) != PRV_OK) return rc;
   if (psnr_host) {
     std::vector<prv_score_record> rec(n_views);
-    if ((rc = prv_score_psnr_images(c, rgba, gt, n_views, npix, bg, rec.data())) != PRV_OK) return rc;
-    // the record carries psnr as float; recompute in double from the score (= -psnr) for the metrics file
+    if ((rc = ensure(c, c->records, (size_t)n_views * sizeof(prv_score_record))) != PRV_OK) return rc;
+    // coverage weight 0: the score is then exactly -psnr in double (the record's psnr field is a float)
+    if ((rc = score_psnr_dev(c, rgba, gt, n_views, npix, bg, 0.0, (prv_score_record*)c->records.p)) != PRV_OK) return rc;
+    if ((rc = prv_memcpy_d2h(c, rec.data(), c->records.p, (size_t)n_views * sizeof(prv_score_record))) != PRV_OK) return rc;
     for (int i = 0; i < n_views; i++) psnr_host[i] = -rec[i].score;
   }
   if (ssim_host) {
@@ -1334,7 +1347,7 @@ int prv_score_views(prv_ctx* c, int method, const int* model_slots, int n_models
   } else {
     if ((rc = render_views(c, model_slots[0], cs, view_ids, n_views, o, (float*)c->img_f32.p, nullptr, true)) != PRV_OK)
       return rc;
-    if (n_views && (rc = score_psnr_dev(c, (const float*)c->img_f32.p, gt, n_views, npix, o->background, rec)) != PRV_OK)
+    if (n_views && (rc = score_psnr_dev(c, (const float*)c->img_f32.p, gt, n_views, npix, o->background, c->coverage_weight, rec)) != PRV_OK)
       return rc;
   }
   if (rec_dev && n_views)
@@ -1363,8 +1376,12 @@ int prv_rank(const prv_score_record* r, const int* ids, int n, int* order) try {
   if (n < 0 || (n > 0 && (!r || !ids || !order))) return PRV_E_INVALID;
   std::vector<int> idx(n);
   for (int i = 0; i < n; i++) idx[i] = i;
+  // a strict weak order also when a score is NaN (a diverged ensemble member produces exactly that): NaN ranks
+  // after every number -- the arg-max rule's strict '>' never picks it either -- and NaNs tie among themselves
   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
-    if (r[a].score != r[b].score) return r[a].score > r[b].score;
+    const bool na = std::isnan(r[a].score), nb = std::isnan(r[b].score);
+    if (na != nb) return nb;
+    if (!na && r[a].score != r[b].score) return r[a].score > r[b].score;
     return ids[a] < ids[b];
   });
   for (int i = 0; i < n; i++) order[i] = ids[idx[i]];

@@ -545,14 +545,15 @@ __global__ __launch_bounds__(64) void score_sequential_sum_kernel(const double* 
   }
 }
 
-// PSNR recipe of run.py:257-263 + mean opacity; two partial sums per block
+// PSNR recipe of run.py:257-263 + mean opacity + the density term of main.cpp:2148 ((1 - alpha)^2 per pixel);
+// three partial sums per block
 __global__ __launch_bounds__(256) void score_psnr_kernel(PsnrParams P) {
   __shared__ double sm[4];
   const int v = blockIdx.y;
   const size_t npix = P.pixels_per_view;
   const float4* img = reinterpret_cast<const float4*>(P.rgba) + (size_t)v * npix;
   const float4* gt = reinterpret_cast<const float4*>(P.gt) + (size_t)v * npix;
-  double se = 0.0, cov = 0.0;
+  double se = 0.0, cov = 0.0, unc = 0.0;
   for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
     const float4 a4 = img[p], r4 = gt[p];
     const float ra = 1.0f - a4.w, rg = 1.0f - r4.w;
@@ -567,12 +568,16 @@ __global__ __launch_bounds__(256) void score_psnr_kernel(PsnrParams P) {
       se += dlt * dlt;
     }
     cov += (double)a4.w;
+    const double u = 1.0 - (double)a4.w;
+    unc += u * u;
   }
   double s0 = block_reduce_sum(se, sm);
   double s1 = block_reduce_sum(cov, sm);
+  double s2 = block_reduce_sum(unc, sm);
   if (threadIdx.x == 0) {
-    P.partial[((size_t)v * gridDim.x + blockIdx.x) * 2 + 0] = s0;
-    P.partial[((size_t)v * gridDim.x + blockIdx.x) * 2 + 1] = s1;
+    P.partial[((size_t)v * gridDim.x + blockIdx.x) * 3 + 0] = s0;
+    P.partial[((size_t)v * gridDim.x + blockIdx.x) * 3 + 1] = s1;
+    P.partial[((size_t)v * gridDim.x + blockIdx.x) * 3 + 2] = s2;
   }
 }
 
@@ -657,7 +662,7 @@ __global__ void ssim_finalize_kernel(const double* __restrict__ partial, int n_v
 
 // one thread per view: sum the block partials in block order, emit the record
 __global__ void score_finalize_kernel(const double* __restrict__ partial, int n_views, int n_blocks,
-                                      int method, size_t pixels_per_view,
+                                      int method, size_t pixels_per_view, double coverage_weight,
                                       prv_score_record* __restrict__ rec) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n_views) return;
@@ -665,14 +670,17 @@ __global__ void score_finalize_kernel(const double* __restrict__ partial, int n_
   out.psnr = 0.f;
   out.coverage = 0.f;
   if (method == PRV_SCORE_PSNR_COVERAGE) {
-    double se = 0.0, cov = 0.0;
+    double se = 0.0, cov = 0.0, unc = 0.0;
     for (int b = 0; b < n_blocks; b++) {
-      se += partial[((size_t)v * n_blocks + b) * 2 + 0];
-      cov += partial[((size_t)v * n_blocks + b) * 2 + 1];
+      se += partial[((size_t)v * n_blocks + b) * 3 + 0];
+      cov += partial[((size_t)v * n_blocks + b) * 3 + 1];
+      unc += partial[((size_t)v * n_blocks + b) * 3 + 2];
     }
     const double mse = se / (double)(pixels_per_view * 3);
     const double psnr = -10.0 * log10(mse);
-    out.score = -psnr;
+    // worst-reconstructed AND least-covered view first: -PSNR plus the reference's density term (main.cpp:2148,
+    // (1 - alpha)^2 per pixel, here its mean) times the documented weight (prv_set_coverage_weight, default 1)
+    out.score = -psnr + coverage_weight * (unc / (double)pixels_per_view);
     out.psnr = (float)psnr;
     out.coverage = (float)(cov / (double)pixels_per_view);
   } else {
@@ -974,9 +982,9 @@ hipError_t launch_ssim(const float* img, const float* gt, int n_views, int W, in
 }
 
 hipError_t launch_score_finalize(const double* partial, int n_views, int n_blocks, int method,
-                                 size_t pixels_per_view, prv_score_record* rec, hipStream_t s) {
+                                 size_t pixels_per_view, double coverage_weight, prv_score_record* rec, hipStream_t s) {
   hipLaunchKernelGGL(score_finalize_kernel, dim3((unsigned)((n_views + 63) / 64)), dim3(64), 0, s, partial,
-                     n_views, n_blocks, method, pixels_per_view, rec);
+                     n_views, n_blocks, method, pixels_per_view, coverage_weight, rec);
   return hipGetLastError();
 }
 

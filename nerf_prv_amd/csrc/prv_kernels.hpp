@@ -89,7 +89,7 @@ hipError_t launch_score_psnr(const PsnrParams& P, int n_views, int n_blocks, hip
 hipError_t launch_ssim(const float* img, const float* gt, int n_views, int W, int H, const float bg[4], float* la,
                        float* lb, double* partial, int n_blocks, double* out, hipStream_t s);
 hipError_t launch_score_finalize(const double* partial, int n_views, int n_blocks, int method,
-                                 size_t pixels_per_view, prv_score_record* rec, hipStream_t s);
+                                 size_t pixels_per_view, double coverage_weight, prv_score_record* rec, hipStream_t s);
 hipError_t launch_synth_table(uint16_t* table, size_t n, uint64_t seed, float amp, hipStream_t s);
 hipError_t launch_debug_raygen(const CamDev& cam, int W, int H, int spp_k, float* o, float* d, float* t,
                                hipStream_t s);

@@ -43,7 +43,7 @@ struct HipScorer {
   float* gt_dev = nullptr; // method 5: reference images of ALL views at the candidate size
   int gt_w = 0, gt_h = 0;
   // training in the loop
-  int train_steps = 0, train_rays = 4096, train_w = 0, train_h = 0;
+  int train_steps = 0, train_rays = 0 /* 0: the library default */, train_w = 0, train_h = 0;
   prv_field_desc train_desc{};
   uint64_t train_seed = 0x1234;
   bool images_from_files = false; // train_images: files -> the json's file_path PNGs (the reference's data flow)
@@ -100,7 +100,7 @@ struct HipScorer {
       t_fresh += now_seconds() - t0;
       prv_train_opts to;
       prv_train_default_opts(&to);
-      to.n_rays = train_rays;
+      if (train_rays > 0) to.n_rays = train_rays;
       to.seed += (uint64_t)e;
       prv_trainer* tr = nullptr;
       t0 = now_seconds();
@@ -242,7 +242,18 @@ struct HipScorer {
 };
 
 // `train_steps` and friends -> the scorer's in-process training settings; the ground truth goes to slot 6
-int configure_training(prv_ctx* ctx, const FileStorage& fs, const prv_field_desc& desc, HipScorer& scorer);
+int configure_training(prv_ctx* ctx, const FileStorage& fs, const prv_field_desc& desc, int train_steps, HipScorer& scorer);
+
+// Optimiser steps per member per iteration.  The reference retrains every ensemble member on the views chosen so
+// far in EVERY iteration with `--n_steps <n_steps>` (main.cpp:1668, 2041-2043), so the yaml's `n_steps` is the
+// default; `train_steps: N` overrides the count.  Scoring members that are NOT retrained (files / synthetic seeds:
+// a ranking that does not depend on the acquired views) is an explicit opt-in: `train_steps: 0` or
+// `pretrained_members: 1`.
+int configured_train_steps(const FileStorage& fs, const Share_Data& sd) {
+  if (fs.has("pretrained_members") && fs.num("pretrained_members") > 0) return 0;
+  if (fs.has("train_steps")) return std::max(0, (int)fs.num("train_steps"));
+  return std::max(0, sd.n_steps);
+}
 int write_coverage_images(prv_ctx* ctx, const std::shared_ptr<Share_Data>& sd);
 
 prv_field_desc field_from_config(const FileStorage& fs) {
@@ -269,7 +280,11 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   fs.open(cfg);
   const prv_field_desc desc = field_from_config(fs);
   const int members = (method == EnsembleRGB || method == EnsembleRGBDensity) ? sd->ensemble_num : 1;
-  const int train_steps = fs.has("train_steps") ? (int)fs.num("train_steps") : 0;
+  const int train_steps = configured_train_steps(fs, *sd);
+  if (train_steps == 0 && method != RandomIterative && method != RandomOneshot && method != PVBCoverage)
+    std::cerr << "WARNING: the members are NOT retrained on the chosen views (train_steps: 0 / pretrained_members: 1): "
+                 "the view ranking of this run does not depend on the views it acquires (the reference retrains "
+                 "n_steps per member per iteration, main.cpp:1668)" << std::endl;
   for (int e = 0; e < members && train_steps == 0; e++) {
     int rc;
     if (fs.has("synthetic_seed")) rc = prv_model_synthetic(ctx, e, &desc, (uint64_t)fs.num("synthetic_seed") + (uint64_t)e);
@@ -288,7 +303,7 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   scorer.n_members = members;
   scorer.save_renders = fs.has("save_renders") && fs.num("save_renders") > 0;
   if (train_steps > 0) { // members are trained from scratch every iteration
-    const int rc = configure_training(ctx, fs, desc, scorer);
+    const int rc = configure_training(ctx, fs, desc, train_steps, scorer);
     if (rc != PRV_OK) return rc;
   }
   if (fs.has("evaluate_views")) scorer.eval_views = (int)fs.num("evaluate_views");
@@ -362,14 +377,14 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   return rc;
 }
 
-int configure_training(prv_ctx* ctx, const FileStorage& fs, const prv_field_desc& desc, HipScorer& scorer) {
+int configure_training(prv_ctx* ctx, const FileStorage& fs, const prv_field_desc& desc, int train_steps, HipScorer& scorer) {
   const int rc = prv_model_synthetic(ctx, 6, &desc, fs.has("ground_truth_seed") ? (uint64_t)fs.num("ground_truth_seed") : 0x5EED0002ull);
   if (rc != PRV_OK) {
     std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
     return rc;
   }
-  scorer.train_steps = (int)fs.num("train_steps");
-  scorer.train_rays = fs.has("train_rays") ? (int)fs.num("train_rays") : 4096;
+  scorer.train_steps = train_steps;
+  if (fs.has("train_rays")) scorer.train_rays = (int)fs.num("train_rays"); // else prv_train_default_opts' batch
   scorer.train_w = fs.has("train_width") ? (int)fs.num("train_width") : 0;
   scorer.train_h = fs.has("train_height") ? (int)fs.num("train_height") : 0;
   scorer.train_desc = desc;
@@ -417,10 +432,6 @@ int write_coverage_images(prv_ctx* ctx, const std::shared_ptr<Share_Data>& sd) {
 int instant_ngp_curves(prv_ctx* ctx, const std::string& cfg, const std::string& name) {
   FileStorage fs;
   fs.open(cfg);
-  if (!fs.has("train_steps") || fs.num("train_steps") <= 0) {
-    std::cerr << "mode 4 trains: set train_steps in the configuration" << std::endl;
-    return -50;
-  }
   const prv_field_desc desc = field_from_config(fs);
   const double size = fs.has("object_size") ? fs.num("object_size") : 0.1;
   const Vec3 center(1e-10, 1e-10, 1e-10);
@@ -429,11 +440,16 @@ int instant_ngp_curves(prv_ctx* ctx, const std::string& cfg, const std::string& 
     std::cerr << sd0->error << std::endl;
     return -1;
   }
+  const int train_steps = configured_train_steps(fs, *sd0);
+  if (train_steps <= 0) {
+    std::cerr << "mode 4 trains: n_steps / train_steps must be positive" << std::endl;
+    return -50;
+  }
   HipScorer scorer;
   scorer.ctx = ctx;
   scorer.sd = sd0;
   scorer.n_members = 1;
-  int rc = configure_training(ctx, fs, desc, scorer);
+  int rc = configure_training(ctx, fs, desc, train_steps, scorer);
   if (rc != PRV_OK) return rc;
   if (fs.has("evaluate_views")) scorer.eval_views = (int)fs.num("evaluate_views");
   const int n_max = sd0->coverage_view_num_max > 0 ? sd0->coverage_view_num_max : 90;

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -56,6 +57,9 @@ inline int png_read_rgba8(const std::string& path, int* width, int* height, std:
   int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
   if (w == 0 || h == 0 || w > 65535 || h > 65535 || depth != 8 || ch == 0 || interlace != 0) return -3;
   const size_t stride = (size_t)w * ch;
+  // the header is input, not truth: deflate expands at most 1032:1 (+ a few bytes of framing), so an IDAT payload that
+  // cannot inflate to the size the header claims is refused BEFORE anything of that size is allocated
+  if ((stride + 1) * (size_t)h > idat.size() * 1032 + 1024) return -4;
   std::vector<uint8_t> raw((stride + 1) * h);
   uLongf raw_len = (uLongf)raw.size();
   if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return -4;

@@ -42,7 +42,7 @@ class TrainOpts(C.Structure):
                 ("occ_sigma_thresh", C.c_float), ("target_samples", C.c_int32)]
 
 
-TRAIN_DEFAULTS = dict(n_rays=4096, n_samples=128, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, l2_reg=1e-6, min_T=1e-4,
+TRAIN_DEFAULTS = dict(n_rays=65536, n_samples=128, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, l2_reg=1e-6, min_T=1e-4,
                       seed=0x7EA10001, random_bg=1, occ_every=16, occ_decay=0.95,
                       occ_sigma_thresh=0.01 * 1024 / 3 ** 0.5, target_samples=1 << 18)
 
@@ -118,6 +118,8 @@ def lib():
         L.orc_score_ensemble_rgbdensity.restype = C.c_double
         L.orc_score_ensemble_rgbdensity.argtypes = [vp, C.c_int, C.c_size_t]
         L.orc_score_psnr_coverage.argtypes = [vp, vp, C.c_size_t, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_score_view.argtypes = [vp, vp, C.c_size_t, vp, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]
         L.orc_ssim.restype, L.orc_ssim.argtypes = C.c_double, [vp, vp, C.c_int, C.c_int, vp]
         L.orc_rank.argtypes = [vp, vp, C.c_int, vp]
         L.orc_argmax.restype, L.orc_argmax.argtypes = C.c_int, [vp, vp, C.c_int]
@@ -350,6 +352,15 @@ def score_psnr_coverage(rgba, gt, bg=(0, 0, 0, 0)):
     p, c = C.c_double(), C.c_double()
     lib().orc_score_psnr_coverage(_p(a), _p(g), a.size // 4, _p(b), C.byref(p), C.byref(c))
     return p.value, c.value
+
+
+def score_view(rgba, gt, bg=(0, 0, 0, 0), coverage_weight=1.0):
+    """PRV_SCORE_PSNR_COVERAGE's ranking key and its parts -> (score, psnr, coverage)"""
+    a, g = np.ascontiguousarray(rgba, np.float32), np.ascontiguousarray(gt, np.float32)
+    b = np.asarray(bg, np.float32)
+    s, p, c = C.c_double(), C.c_double(), C.c_double()
+    lib().orc_score_view(_p(a), _p(g), a.size // 4, _p(b), float(coverage_weight), C.byref(s), C.byref(p), C.byref(c))
+    return s.value, p.value, c.value
 
 
 def ssim(rgba, gt, bg=(0, 0, 0, 0)):

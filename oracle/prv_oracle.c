@@ -839,6 +839,19 @@ void orc_score_psnr_coverage(const float* rgba, const float* gt, size_t npix, co
   *coverage = cov / (double)npix;
 }
 
+/* the ranking key of PRV_SCORE_PSNR_COVERAGE: -PSNR + weight * mean((1 - alpha)^2) -- the second term is the
+ * density term of main.cpp:2148 (there per pixel of the ensemble mean, weight 1), averaged over the pixels */
+void orc_score_view(const float* rgba, const float* gt, size_t npix, const float bg[4], double coverage_weight,
+                    double* score, double* psnr, double* coverage) {
+  double unc = 0.0;
+  orc_score_psnr_coverage(rgba, gt, npix, bg, psnr, coverage);
+  for (size_t i = 0; i < npix; i++) {
+    double u = 1.0 - (double)rgba[i * 4 + 3];
+    unc += u * u;
+  }
+  *score = -*psnr + coverage_weight * (unc / (double)npix);
+}
+
 /* SSIM as run.py:260 calls it: compute_error("SSIM", A, R) on the sRGB-clipped images.
  * ASSUMED from upstream scripts/common.py (absent from the tree, unpinned): luminance
  * 0.2126 r' + 0.7152 g' + 0.0722 b' with c' = max(0,c)^0.4545454545, separable 5-tap blur
@@ -907,7 +920,8 @@ int orc_argmax(const double* scores, const int* ids, int n) {
   return best_id;
 }
 
-/* full ranking = repeated arg-max: descending score, ties -> lower id first */
+/* full ranking = repeated arg-max: descending score, ties -> lower id first; a NaN score (never selected by
+ * the strict '>' of main.cpp:2088) ranks after every number, NaNs among themselves by id */
 void orc_rank(const double* scores, const int* ids, int n, int* order) {
   for (int i = 0; i < n; i++) order[i] = i;
   for (int i = 1; i < n; i++) { /* insertion sort, stable */
@@ -915,7 +929,9 @@ void orc_rank(const double* scores, const int* ids, int n, int* order) {
     int j = i - 1;
     while (j >= 0) {
       int q = order[j];
-      int before = scores[k] > scores[q] || (scores[k] == scores[q] && ids[k] < ids[q]);
+      int nk = scores[k] != scores[k], nq = scores[q] != scores[q];
+      int before = nk != nq ? nq
+                            : (!nk && scores[k] > scores[q]) || ((nk || scores[k] == scores[q]) && ids[k] < ids[q]);
       if (!before) break;
       order[j + 1] = q;
       j--;

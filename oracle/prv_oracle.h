@@ -137,6 +137,9 @@ double orc_score_ensemble_rgbdensity(const uint8_t* const* imgs, int E, size_t n
 /* run.py:257-263 (PSNR of sRGB-clipped images) + mean opacity */
 void orc_score_psnr_coverage(const float* rgba, const float* gt_rgba, size_t npix,
                              const float bg[4], double* psnr, double* coverage);
+/* PRV_SCORE_PSNR_COVERAGE's key: -psnr + coverage_weight * mean((1 - alpha)^2) (density term of main.cpp:2148) */
+void orc_score_view(const float* rgba, const float* gt_rgba, size_t npix, const float bg[4], double coverage_weight,
+                    double* score, double* psnr, double* coverage);
 /* mean SSIM of two images (run.py:260; recipe assumed from upstream common.py) */
 double orc_ssim(const float* rgba, const float* gt_rgba, int w, int h, const float bg[4]);
 /* full ranking: stable sort by (-score, id)  (arg-max rule main.cpp:2088-2091) */

@@ -17,8 +17,12 @@ static uint32_t rnd() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; ret
 static std::vector<uint8_t> slurp(const char* p) { std::ifstream f(p, std::ios::binary); return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), {}); }
 static void spit(const char* p, const std::vector<uint8_t>& v) { std::ofstream f(p, std::ios::binary); f.write((const char*)v.data(), (std::streamsize)v.size()); }
 static std::vector<uint8_t> mutate(std::vector<uint8_t> v) {
-  const int kind = rnd() % 4;
+  const int kind = rnd() % 5;
   if (v.empty()) return v;
+  if (kind == 4 && v.size() > 24) { // a PNG's IHDR width / height bytes (offsets 16..23): headers that promise more than the payload holds
+    for (int k = 0; k < 1 + (int)(rnd() % 3); k++) v[16 + rnd() % 8] = (uint8_t)rnd();
+    return v;
+  }
   if (kind == 0) v.resize(rnd() % v.size());
   else if (kind == 1) for (int k = 0; k < 1 + (int)(rnd() % 8); k++) v[rnd() % v.size()] = (uint8_t)rnd();
   else if (kind == 2) { size_t a = rnd() % v.size(); size_t n = rnd() % 64; v.insert(v.begin() + a, n, (uint8_t)rnd()); }

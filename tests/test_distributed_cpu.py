@@ -28,8 +28,7 @@ def _scores(n_views):
         for k, v in enumerate(ids):
             a, _ = fa.render(cams[v], 12, 12, 32, 1, 1e-4, threads=1)
             b, _ = fb.render(cams[v], 12, 12, 32, 1, 1e-4, threads=1)
-            p, c = orc.score_psnr_coverage(a, b)
-            rec[k] = (-p, p, c)
+            rec[k] = orc.score_view(a, b)
         return rec
 
     return score_shard

@@ -64,11 +64,12 @@ def test_full_size_scores_are_consistent_and_ranking_matches_host_recompute(ctx,
     assert rec.tobytes() == rec2.tobytes()  # fused round == render then score
     # checker: the oracle's PSNR recipe on the GPU's own images (bytes identical in, 1e-6 out)
     x, g = img.cpu().numpy(), gt.cpu().numpy()
-    want = np.array([oracle.score_psnr_coverage(x[v], g[v]) for v in range(len(x))])
-    np.testing.assert_allclose(rec["psnr"], want[:, 0], rtol=1e-5)
-    np.testing.assert_allclose(rec["coverage"], want[:, 1], rtol=1e-6)
+    want = np.array([oracle.score_view(x[v], g[v]) for v in range(len(x))])  # (score, psnr, coverage)
+    np.testing.assert_allclose(rec["score"], want[:, 0], rtol=1e-6)
+    np.testing.assert_allclose(rec["psnr"], want[:, 1], rtol=1e-5)
+    np.testing.assert_allclose(rec["coverage"], want[:, 2], rtol=1e-6)
     ids = np.arange(len(x))
-    assert np.array_equal(ctx.rank(rec, ids), oracle.rank(-want[:, 0], ids))
+    assert np.array_equal(ctx.rank(rec, ids), oracle.rank(want[:, 0], ids))
     # identical images -> mse 0 -> psnr +inf, score -inf, ranked last (run.py:263 has no guard either)
     same = ctx.score_psnr_images(img, img)
     assert np.isinf(same["psnr"]).all() and (same["score"] == -np.inf).all()

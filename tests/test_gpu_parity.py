@@ -298,13 +298,21 @@ def test_score_views_psnr_and_ranking(ctx, oracle, fields, cams):
     for oc in ocams:
         a, _ = f.render(oc, w, h, 64, 1, 1e-4)
         b, _ = fb.render(oc, w, h, 64, 1, 1e-4)
-        want.append(oracle.score_psnr_coverage(a, b))
+        want.append(oracle.score_view(a, b))  # (score, psnr, coverage), coverage weight 1
     want = np.array(want)
-    np.testing.assert_allclose(rec["psnr"], want[:, 0], rtol=RTOL)
-    np.testing.assert_allclose(rec["coverage"], want[:, 1], rtol=RTOL)
-    np.testing.assert_allclose(rec["score"], -want[:, 0], rtol=RTOL)
+    np.testing.assert_allclose(rec["psnr"], want[:, 1], rtol=RTOL)
+    np.testing.assert_allclose(rec["coverage"], want[:, 2], rtol=RTOL)
+    np.testing.assert_allclose(rec["score"], want[:, 0], rtol=RTOL)
     ids = np.arange(len(ocams))
-    assert np.array_equal(ctx.rank(rec, ids), oracle.rank(-want[:, 0], ids))  # integer ranking exact
+    assert np.array_equal(ctx.rank(rec, ids), oracle.rank(want[:, 0], ids))  # integer ranking exact
+    # the documented weight: 0 ranks by PSNR alone, w adds w * mean((1 - alpha)^2) (main.cpp:2148's density term)
+    ctx.set_coverage_weight(0.0)
+    rec0, _ = ctx.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cs, None, opts, gt=gt)
+    ctx.set_coverage_weight(2.5)
+    rec25, _ = ctx.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cs, None, opts, gt=gt)
+    ctx.set_coverage_weight(1.0)
+    np.testing.assert_allclose(rec0["score"], -want[:, 1], rtol=RTOL)
+    np.testing.assert_allclose(rec25["score"] - rec0["score"], 2.5 * (rec["score"] - rec0["score"]), rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.parametrize("method,E", [(2, 2), (3, 5)])

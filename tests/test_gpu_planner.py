@@ -139,7 +139,7 @@ def test_planner_executable_matches_python_driven_loop(ctx, tmp_path, method):
         pre.mkdir()
         cfg = pre / "cfg.yaml"
         cfg.write_text(YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=method,
-                                   model_source=f"synthetic_seed: {SEED}"))
+                                   model_source=f"synthetic_seed: {SEED}\npretrained_members: 1"))
         if who == "cpp":
             out = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
             assert out.returncode == 0, out.stdout + out.stderr
@@ -503,6 +503,30 @@ def test_planner_executable_trains_its_ensemble_every_iteration(ctx, tmp_path):
     # a finished run is not repeated (the reference skips objects whose run_time.txt exists, main.cpp:3878-3881)
     out2 = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300)
     assert out2.returncode == 0 and "chosen_nbvs:\n" in out2.stdout
+
+
+def test_planner_retrains_by_default_with_the_reference_key_n_steps(ctx, tmp_path):
+    """the reference retrains every member every iteration with `--n_steps <n_steps>` (main.cpp:1668, 2041-2043): a
+    config that only carries the reference's own key trains (the selection then depends on the acquired views);
+    scoring static members is an explicit opt-in (`train_steps: 0` / `pretrained_members: 1`) and says so loudly"""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    runs = {}
+    for name, source in (("default", "n_steps: 40\ntrain_rays: 1024\ntrain_width: 64\ntrain_height: 36\nground_truth_seed: 4242"),
+                         ("static", f"n_steps: 40\nsynthetic_seed: {SEED}\ntrain_steps: 0")):
+        pre = tmp_path / name
+        pre.mkdir()
+        cfg = pre / "cfg.yaml"
+        text = YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=2, model_source=source)
+        cfg.write_text(text.replace("ensemble_num: 5", "ensemble_num: 2"))
+        env = dict(os.environ, PRV_PLANNER_TIMING="1")
+        out = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        runs[name] = out
+    # default: three iterations, each trains the two members on the views chosen so far (1, 2, 3 views)
+    trained = [l for l in runs["default"].stderr.splitlines() if l.startswith("train_members:")]
+    assert [int(l.split("views ")[1].split()[0]) for l in trained] == [1, 2, 3]
+    assert "NOT retrained" not in runs["default"].stderr
+    assert "NOT retrained" in runs["static"].stderr and "train_members:" not in runs["static"].stderr
 
 
 def test_coverage_images_from_a_point_cloud_train_a_field(ctx, tmp_path):

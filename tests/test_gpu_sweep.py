@@ -218,7 +218,8 @@ def test_random_evaluation_case(ctx, oracle, case_id):
     rec = ctx.score_psnr_images(ta, tb, bg)
     ps, ss = ctx.evaluate_images(ta, tb, bg)
     for v in range(n):
-        want_p, want_c = oracle.score_psnr_coverage(a[v], b[v], bg)
+        want_s, want_p, want_c = oracle.score_view(a[v], b[v], bg)
+        assert rec["score"][v] == pytest.approx(want_s, rel=1e-6)
         assert rec["psnr"][v] == pytest.approx(want_p, rel=1e-5) and ps[v] == pytest.approx(want_p, rel=1e-5)
         assert rec["coverage"][v] == pytest.approx(want_c, rel=1e-5)
         assert ss[v] == pytest.approx(oracle.ssim(a[v], b[v], bg), rel=1e-3, abs=1e-5)

@@ -177,6 +177,32 @@ def test_ensemble_members_step_side_by_side(ctx, oracle, scene):
         api.train_many([trs[0], trs[0]], 1)  # the same slot twice
 
 
+def test_trainer_refuses_a_slot_that_was_reinstalled_under_it(ctx, oracle, scene):
+    """a slot re-installed with the SAME descriptor while a trainer is alive: the trainer's fp32 masters, moments and
+    captured graph belong to the old parameters -- stepping it would overwrite the new model without a word.  It
+    fails with PRV_E_STATE instead, the new model stays what was installed, and a new trainer works."""
+    kw, ocams, cams, imgs = scene
+    d = api.field_desc(**dict(kw, table_amp=1e-4))
+    u8 = ctx.torch.from_numpy(imgs)
+    ctx.fresh_model(3, d, 41)
+    tr = api.Trainer(ctx, 3, cams, u8, api.train_opts(n_rays=128, n_samples=24))
+    tr.steps(3)
+    trained = [a.copy() for a in ctx.export_model(3, d)]
+    for reinstall in (lambda: ctx.fresh_model(3, d, 42), lambda: ctx.load_model(3, d, *trained)):
+        reinstall()
+        installed = [a.copy() for a in ctx.export_model(3, d)]
+        with pytest.raises(api.PrvError) as e:
+            tr.steps(1)
+        assert e.value.code == api.L.PRV_E_STATE and "re-installed" in str(e.value)
+        with pytest.raises(api.PrvError):
+            tr.gradients()
+        assert all(np.array_equal(a, b) for a, b in zip(installed, ctx.export_model(3, d)))  # untouched
+    tr.close()
+    tr2 = api.Trainer(ctx, 3, cams, u8, api.train_opts(n_rays=128, n_samples=24))
+    assert np.isfinite(tr2.steps(2)).all()
+    tr2.close()
+
+
 def test_trainer_outliving_its_context_is_inert(oracle, scene):
     """destroying the context first must not leave a dangling trainer (interpreter shutdown order)"""
     kw, ocams, cams_unused, imgs = scene

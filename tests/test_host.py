@@ -223,6 +223,31 @@ def config9(tmp_path):
     return p, pts
 
 
+def test_png_reader_refuses_a_header_its_payload_cannot_fill(tmp_path):
+    """a tiny file whose IHDR claims 65535 x 65535 RGBA (17 GB raw) is refused from the IDAT size alone -- deflate
+    expands at most 1032:1 -- before a buffer of the claimed size exists (no bad_alloc, no OOM kill)"""
+    import resource
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    for w, h in ((65535, 65535), (40000, 9), (3, 60000)):
+        png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + \
+            chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+        p = tmp_path / f"huge_{w}x{h}.png"
+        p.write_bytes(png)
+        before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+        with pytest.raises(IOError, match="png error -4"):
+            planner.png_read(p)
+        assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < 64 * 1024  # KiB: nothing header-sized was touched
+    # an honest, highly compressible image still decodes (all-zero 2000 x 1500: ratio ~1000:1)
+    ok = np.zeros((1500, 2000, 4), np.uint8)
+    planner.png_write(tmp_path / "flat.png", ok)
+    assert np.array_equal(planner.png_read(tmp_path / "flat.png"), ok)
+
+
 def test_nbv_loop_pvb_coverage(config9, tmp_path):
     """method 4 (main.cpp:2163-2242) with PRVNet's answer supplied: the budget's coverage set (N.txt) replaces the
     view space, all of it is visited along the shortest tour from its top view, view_budget.txt is left for the

@@ -197,3 +197,34 @@ def test_binary16_rounding_fast_path_equals_the_integer_definition(oracle):
     for v, w in zip(vals, want):
         a = L.orc_d2h(float(v))
         assert a == L.orc_d2h_soft(float(v)) == int(w), v
+
+
+def test_rank_orders_nan_scores_last_in_oracle_and_library(oracle):
+    """a diverged ensemble member yields NaN scores: the ranking stays a strict weak order (NaN after every
+    number, NaNs by ascending id), identically in the oracle and in the library's host-only prv_rank, and the
+    arg-max rule (strict '>', main.cpp:2088-2091) never selects a NaN"""
+    from nerf_prv_amd import api
+
+    orc = oracle
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        n = int(rng.integers(1, 40))
+        scores = np.round(rng.normal(size=n), 1)  # ties on purpose
+        scores[rng.random(n) < 0.3] = np.nan
+        if trial == 0:
+            scores[:] = np.nan
+        scores[rng.random(n) < 0.1] = -np.inf
+        ids = rng.permutation(1000)[:n].astype(np.int32)
+        want = orc.rank(scores, ids)
+        rec = np.zeros(n, api.RECORD_DTYPE)
+        rec["score"] = scores
+        got = api.rank_host(rec, ids)
+        assert np.array_equal(got, want)
+        # the definition, spelled out: numbers by (score desc, id asc), then NaNs by id asc
+        num = [i for i in range(n) if not np.isnan(scores[i])]
+        nan = [i for i in range(n) if np.isnan(scores[i])]
+        ref = sorted(num, key=lambda i: (-scores[i], ids[i])) + sorted(nan, key=lambda i: ids[i])
+        assert [int(ids[i]) for i in ref] == want.tolist()
+        am = orc.argmax(scores, ids)
+        finite_best = [i for i in num if scores[i] > -1e100]
+        assert am == (min((ids[i] for i in finite_best if scores[i] == max(scores[j] for j in finite_best)), default=-1))
