@@ -7,13 +7,24 @@ reduce each to a PSNR/coverage score against reference images already resident i
 all-gather the 16-byte records over RCCL (N > 1), rank.  BASELINE.json configs[1].
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Prints ONE JSON line on rank 0.
+With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank per GPU, RCCL),
+never touches a GPU itself, forwards rank 0's JSON line and exits with the children's code.
+Under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
+
+    --mode weak    (default) --views-per-gpu views per rank, total grows with N
+    --mode strong  --views-total views sharded over the ranks (BASELINE configs[3]: 1024 views, --field 512)
+
+Prints ONE JSON line on rank 0.  Parity status of every number here: the GPU path is checked
+against this repository's own CPU oracle (tests/), which is NOT pinned to the reference binary
+(instant-ngp is absent from the reference tree) -- stated in the line as "parity".
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,24 +32,78 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 SEED_A, SEED_B = 0x5EED0001, 0x5EED0002
-BYTES_PER_SAMPLE = 512  # L*8 corners*F*2 B = 8*8*4*2: hash-table gather per field evaluation
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+BYTES_PER_SAMPLE = 512   # L*8 corners*F*2 B = 8*8*4*2 = 16*8*2*2: hash-table gather per field evaluation
+FLOP_PER_SAMPLE = 20480  # 10,240 MAC of the two MLPs
+MFMA_PER_ROUND = 24      # v_mfma_f32_32x32x16_f16 per 32-sample wave-round (prv_device.hpp: mlp_forward)
+# peaks, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # 8 TB/s spec
+L2_PEAK_GBS = 34500.0        # aggregate L2, ~34.5 TB/s
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16
+N_SIMD, MAX_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its SIMD's VALU for 4 cycles
+VALU_PEAK_GINST = N_SIMD * MAX_CLOCK_HZ / 4.0 / 1e9  # 614.4 G wave-instructions/s at the 2.4 GHz maximum clock
+ROUND_COST_FILE = os.path.join("profiles", "r02_round_cost.json")  # VALU instructions per wave-round, from the PMC pass
+TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")    # fabric-side bytes per launch, from the PMC passes
 
 
-def measured_traffic(args, samples_per_launch):
-    """HBM-side bytes per render_queue launch from the committed PMC pass (profiles/), scaled by the
-    evaluated-sample count; None unless the workload is the one that was profiled"""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path) or (args.width, args.height, args.samples, args.field) != (800, 800, 128, "256"):
-        return None
-    with open(path) as f:
-        k = json.load(f)["render_queue_kernel"]
-    per_sample = (k["fetch_kib_per_launch"] + k["write_kib_per_launch"]) * 1024.0 / k["samples_evaluated_per_launch"]
-    return per_sample * samples_per_launch
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--views-per-gpu", type=int, default=64)
+    ap.add_argument("--views-total", type=int, default=1024, help="--mode strong: the fixed candidate set")
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--field", choices=["256", "512"], default="256")
+    ap.add_argument("--scene", choices=["default", "baseline"], default="default",
+                    help="baseline = BASELINE.md section 6 literally: table U(-0.1,0.1), no density bias")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-training", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the field512 / baseline-scene / first-hit side measurements")
+    ap.add_argument("--train-steps", type=int, default=300)
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------ launcher (N > 1, plain invocation)
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """parent of a plain `python bench.py --gpus N`: N fresh rank processes under torch.distributed.run.
+    Nothing here imports torch or touches a GPU; stdout of the children (rank 0's JSON line) is forwarded."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL needs dmabuf IPC on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            sys.stderr.write(out)  # launcher / rank chatter is not the result
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited cleanly without a JSON line\n")
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------ CPU side (rank 0, N = 1 only)
 
 def usable_cores():
     """host cores this process may actually use: the affinity mask, capped by a cgroup CPU quota when there is one
@@ -59,14 +124,13 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(args, tms, scale, offset, fov_x):
+def cpu_baseline(args, fkw, tms, scale, offset, fov_x):
     """the oracle (a scalar C port of the same algorithm) on the host cores, bounded sample"""
     from oracle import oracle as orc
 
-    threads = usable_cores()
-    f = orc.OracleField(orc.desc(), seed=SEED_A)
+    threads = min(usable_cores(), 256)  # the oracle's pthread pool tops out there
+    f = orc.OracleField(orc.desc(**fkw), seed=SEED_A)
     cams = orc.cameras_from_transforms(tms, fov_x, args.width, args.height, scale, offset)
-    threads = min(threads, 256)  # the oracle's pthread pool tops out there
     band = min(args.height, max(64, threads))  # one row per thread at least: every core the line claims has work
     rows = ((args.height - band) // 2, (args.height - band) // 2 + band)
     f.render(cams[0], args.width, args.height, args.samples, 1, 1e-4, threads=threads, rows=(rows[0], rows[0] + 1))
@@ -78,45 +142,189 @@ def cpu_baseline(args, tms, scale, offset, fov_x):
         if time.perf_counter() - t0 > args.cpu_seconds:
             break
     dt = time.perf_counter() - t0
+    cores = min(threads, band)
+    fh_rate, fh_cores = first_hit_cpu(f, cams[0], args, cores)
     return {
         "value": n_eval / dt,
         "unit": "ray-samples/s",
-        "cores": min(threads, band),
+        "cores": cores,
         "kind": "port",
         "sample": f"rows {rows[0]}-{rows[1]} of {n_views} views at {args.width}x{args.height}, "
                   f"{args.samples} samples/ray, {n_eval} samples evaluated in {dt:.1f} s "
                   f"(oracle/prv_oracle.c, pthreads over rows)",
-        "first_hit_rays_per_s": first_hit_cpu(f, cams[0], args),
+        "first_hit_rays_per_s": fh_rate,
+        "first_hit_cores": fh_cores,
     }
 
 
-def first_hit_cpu(f, cam, args):
-    """the oracle's scalar first-hit DDA on ONE core, 64 rows of one view (the reference spawns one OS
-    thread per voxel, main.cpp:124-130; a single tight loop is the kinder comparison)"""
+def first_hit_cpu(f, cam, args, cores):
+    """the oracle's scalar first-hit DDA over one whole view, the rows dealt to `cores` threads (ctypes calls drop
+    the GIL, so the bands run side by side) -- the same cores the marcher line claims, not one"""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import oracle as orc
 
-    rows = (args.height // 2 - 32, args.height // 2 + 32)
+    cores = max(1, min(cores, args.height))
+    edges = [args.height * k // cores for k in range(cores + 1)]
+    bands = [(edges[k], edges[k + 1]) for k in range(cores) if edges[k + 1] > edges[k]]
+    orc.first_hit_image(f, cam, args.width, args.height, rows=(0, 1))
     t0 = time.perf_counter()
-    orc.first_hit_image(f, cam, args.width, args.height, rows=rows)
-    return (rows[1] - rows[0]) * args.width / (time.perf_counter() - t0)
+    with ThreadPoolExecutor(max_workers=len(bands)) as pool:
+        list(pool.map(lambda b: orc.first_hit_image(f, cam, args.width, args.height, rows=b), bands))
+    return args.height * args.width / (time.perf_counter() - t0), len(bands)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--views-per-gpu", type=int, default=64)
-    ap.add_argument("--width", type=int, default=800)
-    ap.add_argument("--height", type=int, default=800)
-    ap.add_argument("--samples", type=int, default=128)
-    ap.add_argument("--field", choices=["256", "512"], default="256")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-training", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=500)
-    args = ap.parse_args()
+def load_json(rel):
+    path = os.path.join(ROOT, rel)
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)
 
+
+# ------------------------------------------------------------------ one rank
+
+class Round:
+    """one workload (field, scene, view set) on this rank: reference images resident, a scoring round per step()"""
+
+    def __init__(self, env, fkw, n_views, args, slots=(0, 1)):
+        api, planner, torch, np = env["api"], env["planner"], env["torch"], env["np"]
+        self.env, self.args, self.n_views = env, args, n_views
+        ctx, rank, world = env["ctx"], env["rank"], env["world"]
+        self.desc = api.L.FieldDesc(**fkw)
+        self.slot = slots[0]
+        ctx.synthetic_model(slots[0], self.desc, SEED_A)  # the field being scored
+        ctx.synthetic_model(slots[1], self.desc, SEED_B)  # the field the reference images come from
+        # candidate set: generated hemisphere, radius 0.3 around the origin (+1e-10), object size 0.1
+        # -> cameras at 1.5 cube units from the centre of the unit cube (BASELINE.md section 6)
+        pts = planner.hemisphere_generate(n_views)
+        self.fov_x = 2.0 * np.arctan(0.5 * 1280 / 915.60668945312500)  # the reference camera's 69.9 deg
+        self.tms, self.scale, self.offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
+        self.cams = ctx.cameras_from_matrices(self.tms, self.fov_x, args.width, args.height, self.scale, self.offset)
+        self.my_ids, self.per_rank = planner.shard_views(n_views, rank, world, interleaved=True)  # balances pole vs equator views
+        self.opts = api.render_opts(args.width, args.height, args.samples, 1, 1e-4)
+        # reference images of this rank's views, resident in HBM before any timed region
+        self.gt, _ = ctx.render(slots[1], self.cams, self.my_ids, self.opts, want_stats=False)
+        self.rec_dev = torch.zeros(max(1, self.per_rank) * 16, dtype=torch.uint8, device=env["device"])
+
+    def step(self, want_stats=False):
+        env = self.env
+        api, planner, np = env["api"], env["planner"], env["np"]
+        _, st = env["ctx"].score_views(api.L.SCORE_PSNR_COVERAGE, [self.slot], self.cams, self.my_ids, self.opts, gt=self.gt,
+                                       records_dev=self.rec_dev, to_host=False, want_stats=want_stats)
+        if env["use_dist"]:
+            records = planner.gather_records(self.rec_dev, self.per_rank, self.n_views, device=env["device"],
+                                             interleaved=True)  # the ONE collective
+        else:  # one rank: its records are the round's records
+            records = self.rec_dev.cpu().numpy().view(api.RECORD_DTYPE)[: self.n_views].copy()
+        order = api.rank_host(records, np.arange(self.n_views, dtype=np.int32))
+        return st, records, order
+
+    def measure(self, steps, warmup):
+        """W untimed steps, then EXACTLY `steps` timed ones between barriers; -> dict of raw measurements"""
+        env = self.env
+        torch, dist, ctx = env["torch"], env["dist"], env["ctx"]
+
+        def barrier():
+            torch.cuda.synchronize()
+            if env["use_dist"]:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        st, records, order = self.step(want_stats=True)  # also sizes every workspace
+        for _ in range(max(0, warmup - 1)):
+            self.step()
+        barrier()
+        ctx.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, records, order = self.step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = ctx.profile_end()
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=env["device"])
+        tot = torch.tensor([float(st.samples_evaluated), float(st.samples_nominal), float(st.rays)], dtype=torch.float64,
+                           device=env["device"])
+        if env["use_dist"]:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        ev_all, nom_all, rays_all = (float(x) for x in tot.tolist())
+        return dict(elapsed=float(tmax.item()), steps=steps, prof=prof, st=st, order=order, ev_all=ev_all, nom_all=nom_all,
+                    rays_all=rays_all)
+
+    def close(self):
+        self.cams.close()
+        self.gt = None
+
+
+def kernel_figures(m, variant, hbm_bound):
+    """roofline object of the dominant kernel (render_queue) from a Round.measure() result.
+
+    In-run quantities: launch durations (HIP events on the launch stream), evaluated samples and wave-rounds
+    (counted by the kernel itself).  Per-round VALU instruction counts are a property of the binary; they come
+    from the committed PMC pass (SQ_INSTS_VALU / wave-rounds) and are labelled *_from_profile."""
+    prof, st, k = m["prof"], m["st"], m["steps"]
+    launches = max(1, prof["render_launches"])
+    kernel_s = prof["render_ms"] * 1e-3 / launches
+    samples = st.samples_evaluated * k / launches
+    rounds = st.wave_rounds * k / launches
+    alg_gbs = samples * BYTES_PER_SAMPLE / kernel_s / 1e9
+    mfma_tflops = samples * FLOP_PER_SAMPLE / kernel_s / 1e12
+    # the MFMA pipe's own occupancy: 24 instructions of 8 passes x 4 cycles per wave-round, padded slots included
+    mfma_pipe_frac = rounds * MFMA_PER_ROUND * 32 / (kernel_s * N_SIMD * MAX_CLOCK_HZ)
+    cost = (load_json(ROUND_COST_FILE) or {}).get(variant)
+    valu_ginst = rounds * cost["valu_insts_per_round"] / kernel_s / 1e9 if cost else None
+    valu_frac = valu_ginst / VALU_PEAK_GINST if cost else None
+    traffic = (load_json(TRAFFIC_FILE) or {}).get(variant)
+    out = {
+        "kernel": "render_queue_kernel" + variant,
+        "units_per_launch": samples,
+        "wave_rounds_per_launch": rounds,
+        "slot_utilisation": samples / max(1.0, 32.0 * rounds),
+        "avg_launch_ms": kernel_s * 1e3,
+        "launches": launches,
+        "march_avg_launch_ms": prof["march_ms"] / max(1, prof["march_launches"]),
+        "bytes_per_unit": BYTES_PER_SAMPLE,
+        "algorithmic_gather_GBps": alg_gbs,
+        "hbm_algorithmic_frac": alg_gbs / HBM_PEAK_GBS,
+        "l2_algorithmic_frac": alg_gbs / L2_PEAK_GBS,
+        "mfma_tflops": mfma_tflops,
+        "mfma_useful_frac": mfma_tflops / MFMA_F16_PEAK_TFLOPS,
+        "mfma_pipe_frac": mfma_pipe_frac,
+        "valu_insts_per_round_from_profile": cost["valu_insts_per_round"] if cost else None,
+        "valu_issue_frac": valu_frac,
+        "traffic_from_profile": None,
+    }
+    if traffic:
+        per_sample = (traffic["fetch_kib_per_launch"] + traffic["write_kib_per_launch"]) * 1024.0 / traffic["samples_evaluated_per_launch"]
+        out["traffic_from_profile"] = {"bytes_per_launch": per_sample * samples, "bytes_per_unit": per_sample, "file": TRAFFIC_FILE,
+                                       "note": "FETCH_SIZE + WRITE_SIZE of the committed PMC passes scaled by this run's sample count; not measured in this run"}
+    if hbm_bound:
+        # table >> L2 + Infinity Cache share: every gather is a memory-side request, the algorithmic bytes ARE the traffic
+        out.update({"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
+                    "note": "64 MiB table: fabric-side reads ~= algorithmic bytes (profiles/), random 64-B requests; the gather "
+                            "calibration (profiles/r01_gather_calib.txt) puts the ceiling for this access shape at ~3.8 TB/s"})
+    else:
+        # cache-resident table: HBM is not the binding resource (hbm_algorithmic_frac > 1 would be a cache effect, not a
+        # fraction of anything).  The binding resource is SIMD issue: VALU instructions on the 1024 SIMDs.
+        cands = {"valu_issue": valu_frac, "mfma_pipe": mfma_pipe_frac, "l2": alg_gbs / L2_PEAK_GBS}
+        bound = max((v, n) for n, v in cands.items() if v is not None)[1]
+        if bound == "valu_issue":
+            out.update({"bound": "valu_issue", "achieved": valu_ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s", "frac": valu_frac})
+        elif bound == "mfma_pipe":
+            out.update({"bound": "mfma", "achieved": mfma_pipe_frac * N_SIMD * MAX_CLOCK_HZ / 1e9, "peak": N_SIMD * MAX_CLOCK_HZ / 1e9,
+                        "unit": "G MFMA-pipe cycles/s", "frac": mfma_pipe_frac})
+        else:
+            out.update({"bound": "l2", "achieved": alg_gbs, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / L2_PEAK_GBS})
+        out["note"] = ("17.4 MiB table is L2 / Infinity-Cache resident, so the HBM figure is not a bound here (hbm_algorithmic_frac "
+                       "is kept for reference only).  frac = VALU wave-instructions issued per second (wave-rounds counted by the "
+                       "kernel in this run x VALU instructions per round from the PMC pass) over 1024 SIMDs x 2.4 GHz / 4 cycles; "
+                       "the clock under load is below 2.4 GHz, so the true issue occupancy is higher than frac")
+    return out
+
+
+def run_rank(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -124,7 +332,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dry = os.environ.get("PRV_BENCH_DRY_RUN") == "1"
+    if dry:
+        return dry_run(args, rank, world, np, torch, dist)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("PRV_FORCE_DIST") == "1"  # the latter: exercise RCCL with one rank
@@ -136,168 +347,180 @@ def main():
     from nerf_prv_amd import api, planner
 
     ctx = api.Context(local_rank)  # raises when libprv_hip.so / the GPU is missing: no fallback
-    fdict = dict(api.FIELD_256 if args.field == "256" else api.FIELD_512)
-    desc = api.L.FieldDesc(**fdict)
-    ctx.synthetic_model(0, desc, SEED_A)  # the field being scored
-    ctx.synthetic_model(1, desc, SEED_B)  # the field the reference images come from
+    env = dict(api=api, planner=planner, torch=torch, dist=dist, np=np, ctx=ctx, rank=rank, world=world, device=device,
+               use_dist=use_dist)
 
-    # candidate set: generated hemisphere, radius 0.3 around the origin (+1e-10), object size 0.1
-    # -> cameras at 1.5 cube units from the centre of the unit cube
-    n_views = args.views_per_gpu * world
-    pts = planner.hemisphere_generate(n_views)
-    fov_x = 2.0 * np.arctan(0.5 * 1280 / 915.60668945312500)  # the reference camera's 69.9 deg
-    tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
-    cams = ctx.cameras_from_matrices(tms, fov_x, args.width, args.height, scale, offset)
-    my_ids, per_rank = planner.shard_views(n_views, rank, world, interleaved=True)  # balances pole vs equator views
-    opts = api.render_opts(args.width, args.height, args.samples, 1, 1e-4)
+    def field_kw(field, scene):
+        kw = dict(api.FIELD_256 if field == "256" else api.FIELD_512)
+        if scene == "baseline":  # BASELINE.md section 6 literally
+            kw.update(table_amp=0.1, density_bias=0.0)
+        return kw
 
-    # reference images of this rank's views, resident in HBM before the timed region
-    gt, _ = ctx.render(1, cams, my_ids, opts, want_stats=False)
-    rec_dev = torch.zeros(per_rank * 16, dtype=torch.uint8, device=device)
+    def variant_of(field):
+        return "<4, 2>" if field == "256" else "<2, 5>"
 
-    def step(want_stats=False):
-        _, st = ctx.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cams, my_ids, opts, gt=gt, records_dev=rec_dev,
-                                to_host=False, want_stats=want_stats)
-        records = planner.gather_records(rec_dev, per_rank, n_views, device=device, interleaved=True)  # the ONE collective
-        order = api.rank_host(records, np.arange(n_views, dtype=np.int32))
-        return st, records, order
+    n_views = args.views_per_gpu * world if args.mode == "weak" else args.views_total
+    fkw = field_kw(args.field, args.scene)
+    main = Round(env, fkw, n_views, args)
+    m = main.measure(args.steps, args.warmup)
+    k, elapsed = args.steps, m["elapsed"]
 
-    st, records, order = step(want_stats=True)  # also sizes every workspace
-    evaluated_per_step, nominal_per_step, rays_per_step = st.samples_evaluated, st.samples_nominal, st.rays
-    for _ in range(max(0, args.warmup - 1)):
-        step()
-
-    def barrier():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    ctx.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, records, order = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.profile_end()
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        solo = dict(env, world=1, rank=0, use_dist=False)  # side measurements: this GPU alone, no collective
+        # (1) the HBM-bound configuration (BASELINE configs[3]'s field) timed in the SAME run
+        if args.field == "256" and args.scene == "default":
+            r = Round(solo, field_kw("512", "default"), args.views_per_gpu, args, slots=(2, 3))
+            mm = r.measure(max(3, min(10, args.steps)), 2)
+            extras["field512"] = {
+                "workload": f"{args.views_per_gpu} views {args.width}x{args.height}, synthetic 512^3 field (L=16 F=2 log2T=21, 64 MiB table)",
+                "value": mm["ev_all"] * mm["steps"] / mm["elapsed"], "unit": "ray-samples/s", "steps": mm["steps"],
+                "ms_per_step": mm["elapsed"] / mm["steps"] * 1e3,
+                "samples_evaluated_per_step": mm["st"].samples_evaluated,
+                "roofline": kernel_figures(mm, variant_of("512"), hbm_bound=True),
+            }
+            r.close()
+        # (2) the scene BASELINE.md section 6 specifies literally (table U(-0.1,0.1), no density bias): rays do not
+        #     terminate early there, every occupied sample is evaluated
+        if args.scene == "default":
+            r = Round(solo, field_kw(args.field, "baseline"), args.views_per_gpu, args, slots=(2, 3))
+            mm = r.measure(max(2, min(5, args.steps)), 1)
+            extras["scene_baseline"] = {
+                "workload": f"{args.views_per_gpu} views, table U(-0.1,0.1), density_bias 0 (BASELINE.md section 6)",
+                "value": mm["ev_all"] * mm["steps"] / mm["elapsed"], "unit": "ray-samples/s", "steps": mm["steps"],
+                "ms_per_step": mm["elapsed"] / mm["steps"] * 1e3,
+                "samples_evaluated_per_step": mm["st"].samples_evaluated,
+                "samples_per_ray": mm["st"].samples_evaluated / max(1, mm["st"].rays),
+                "roofline": kernel_figures(mm, variant_of(args.field), hbm_bound=args.field == "512"),
+            }
+            r.close()
 
     # BASELINE config 1 analogue (the reference's CPU render path, main.cpp:98-284): first occupied voxel
     # per ray over the same views; GPU (prv_first_hit) here, the oracle's scalar DDA in cpu_baseline
     first_hit = None
-    if rank == 0:
-        cells = ctx.first_hit(0, cams, my_ids, args.width, args.height)
+    if rank == 0 and not args.no_extras:
+        cells = ctx.first_hit(0, main.cams, main.my_ids, args.width, args.height)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(5):
-            cells = ctx.first_hit(0, cams, my_ids, args.width, args.height)
+            cells = ctx.first_hit(0, main.cams, main.my_ids, args.width, args.height)
         torch.cuda.synchronize()
         dt_fh = (time.perf_counter() - t1) / 5
-        first_hit = {"gpu_rays_per_s": len(my_ids) * args.width * args.height / dt_fh,
+        first_hit = {"gpu_rays_per_s": len(main.my_ids) * args.width * args.height / dt_fh,
                      "hit_fraction": float((cells >= 0).float().mean().item())}
 
     # the other half of an NBV iteration: in-process training of the field (run.py:185-208), outside the timed
-    # region and not part of `value`: a fresh 256^3 field trained on this rank's reference images
+    # region and not part of `value`: a fresh field trained on this rank's reference images
     training = None
     if rank == 0 and not args.no_training:
-        tcams = ctx.cameras_from_matrices(np.asarray(tms)[my_ids], fov_x, args.width, args.height, scale, offset)
+        tcams = ctx.cameras_from_matrices(np.asarray(main.tms)[main.my_ids], main.fov_x, args.width, args.height, main.scale,
+                                          main.offset)
         u8, _ = ctx.render_rgba8(1, tcams, None, api.render_opts(args.width, args.height, args.samples, 1, 1e-4,
                                                                 background=(0, 0, 0, 0)))
-        tdesc = api.L.FieldDesc(**dict(fdict, table_amp=1e-4, density_bias=0.0))
-        ctx.fresh_model(2, tdesc, 0x1234)
-        tr = api.Trainer(ctx, 2, tcams, u8, api.train_opts())
+        tdesc = api.L.FieldDesc(**dict(fkw, table_amp=1e-4, density_bias=0.0))
+        ctx.fresh_model(4, tdesc, 0x1234)
+        tr = api.Trainer(ctx, 4, tcams, u8, api.train_opts())
         tr.steps(300)  # past the all-occupied start
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         losses = tr.steps(args.train_steps)
         torch.cuda.synchronize()
         dt_tr = time.perf_counter() - t2
+        used = tr.info()["samples_last"]
         training = {"steps_per_s": args.train_steps / dt_tr, "ms_per_step": dt_tr / args.train_steps * 1e3,
-                    "rays_per_step": int(tr.opts.n_rays), "samples_per_ray": int(tr.opts.n_samples),
-                    "used_samples_last_batch": tr.info()["samples_last"], "loss_last": float(losses[-1]),
-                    "note": "fresh field, 300 warm-up steps untimed; f16-MFMA forward, f32-MFMA backward, sparse Adam"}
+                    "samples_per_s": used * args.train_steps / dt_tr,
+                    "rays_per_step_cap": int(tr.opts.n_rays), "active_rays_last_batch": tr.info()["active_rays"],
+                    "samples_per_ray": int(tr.opts.n_samples), "used_samples_last_batch": used, "loss_last": float(losses[-1]),
+                    "note": "fresh field, 300 warm-up steps untimed; batch adapts to ~2^18 composited samples per step (upstream's "
+                            "batch); f16-MFMA forward, f32-MFMA backward, sparse Adam; samples_per_s uses the last batch's count"}
         tr.close()
         tcams.close()
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    tot = torch.tensor([float(evaluated_per_step), float(nominal_per_step), float(rays_per_step)], dtype=torch.float64,
-                       device=device)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(tmax.item())
-    ev_all, nom_all, rays_all = (float(x) for x in tot.tolist())
-
     if rank == 0:
-        k = args.steps
-        launches = max(1, prof["render_launches"])
-        kernel_s = prof["render_ms"] * 1e-3 / launches  # average render_queue launch duration
-        samples_per_launch = evaluated_per_step * k / launches
-        achieved = samples_per_launch * BYTES_PER_SAMPLE / kernel_s / 1e9
+        roof = kernel_figures(m, variant_of(args.field), hbm_bound=args.field == "512")
         out = {
             "metric": "ray-samples/s (field evaluations composited; candidate views rendered + scored)",
-            "value": ev_all * k / elapsed,
+            "value": m["ev_all"] * k / elapsed,
             "unit": "ray-samples/s",
             "n_gpus": world,
             "steps": k,
             "warmup": args.warmup,
             "ms_per_step": elapsed / k * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.mode,
             "vs_baseline": None,
             "dtype": "f16",
             "dtype_note": "fp16 table, blend and MLP operands (MFMA f16 -> f32 accumulate); f32 rays, positions, compositing",
             "data": "synthetic",
+            "parity": "vs own CPU oracle (oracle/), unpinned: the reference's render arithmetic lives in instant-ngp, absent from its tree",
             "config": {
-                "workload": f"render+score {args.views_per_gpu} hemisphere views/GPU, {args.width}x{args.height}, "
+                "workload": f"render+score {len(main.my_ids)} hemisphere views/GPU, {args.width}x{args.height}, "
                             f"{args.samples} samples/ray, synthetic {args.field}^3 hash-grid field "
-                            f"(L={fdict['n_levels']} F={fdict['n_features']} log2T={fdict['log2_hashmap']}), "
+                            f"(L={fkw['n_levels']} F={fkw['n_features']} log2T={fkw['log2_hashmap']}"
+                            f"{', scene baseline: table U(-0.1,0.1), no bias' if args.scene == 'baseline' else ''}), "
                             "PSNR+coverage score vs resident reference images",
                 "views_total": n_views,
-                "parallelism": f"views sharded {args.views_per_gpu}/GPU, one all-gather of 16-B records",
+                "parallelism": (f"views sharded {args.views_per_gpu}/GPU" if args.mode == "weak" else
+                                f"{n_views} views sharded over {world} GPUs") + ", interleaved; one all-gather of 16-B records",
             },
-            "nominal_ray_samples_per_s": nom_all * k / elapsed,
-            "rays_per_s": rays_all * k / elapsed,
+            "rccl_ranks": world if use_dist else 0,
+            "nominal_ray_samples_per_s": m["nom_all"] * k / elapsed,
+            "rays_per_s": m["rays_all"] * k / elapsed,
             "views_scored_per_s": n_views * k / elapsed,
-            "samples_evaluated_per_step_per_gpu": evaluated_per_step,
-            "samples_nominal_per_step_per_gpu": nominal_per_step,
-            "ranking_head": [int(x) for x in order[:8]],
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "render_queue_kernel",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args, samples_per_launch),
-                "bytes_per_unit": BYTES_PER_SAMPLE,
-                "units_per_launch": samples_per_launch,
-                "avg_launch_ms": kernel_s * 1e3,
-                "launches": launches,
-                "march_avg_launch_ms": prof["march_ms"] / max(1, prof["march_launches"]),
-                "mfma_tflops": samples_per_launch * 20480 / kernel_s / 1e12,
-                "mfma_util_frac": samples_per_launch * 20480 / kernel_s / 2.5e15,  # of the ~2.5 PFLOP/s dense f16 peak
-                "note": ("algorithmic gather bytes (512 B per evaluated sample) over the 8 TB/s HBM peak, as SURVEY 8d "
-                         "prescribes; the 256^3 table (17.7 MiB) is L2 / Infinity-Cache resident, so frac > 1 is a cache "
-                         "effect: `traffic` = measured fabric-side bytes per launch (FETCH_SIZE + WRITE_SIZE, separate PMC passes; "
-                         "FETCH_SIZE is NOT doubled here: the guide's x2 applies to wide coalesced reads tallied as 128-B "
-                         "requests, these are per-lane gathers, calibrated at one 64-B request per missing load, "
-                         "profiles/r01_gather_calib.txt); the 512^3 field "
-                         "(--field 512, 64 MiB table) is the HBM-bound case, frac 0.44 = the random-64-B-request ceiling "
-                         "(DESIGN.md section 3)") if args.field == "256" else
-                        ("64 MiB table: L2 hit rate 29 %, fabric reads ~535 B per sample; 3.5 TB/s of algorithmic bytes "
-                         "against the 3.8 TB/s this GPU serves as random 64-B requests (profiles/r01_gather_calib.txt)"),
-            },
+            "samples_evaluated_per_step_per_gpu": m["st"].samples_evaluated,
+            "samples_nominal_per_step_per_gpu": m["st"].samples_nominal,
+            "samples_per_ray": m["st"].samples_evaluated / max(1, m["st"].rays),
+            "ranking_head": [int(x) for x in m["order"][:8]],
+            "roofline": roof,
             "first_hit": first_hit,
             "training": training,
         }
+        out.update(extras)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, tms, scale, offset, fov_x)
+            out["cpu_baseline"] = cpu_baseline(args, fkw, main.tms, main.scale, main.offset, main.fov_x)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    main.close()
     ctx.close()
+    return 0
+
+
+def dry_run(args, rank, world, np, torch, dist):
+    """PRV_BENCH_DRY_RUN=1 (tests only): launcher -> rendezvous (gloo) -> shard -> gather -> identical ranking, with
+    records that are a fixed function of the view id.  No GPU, no field, NO performance figure: value is null."""
+    from nerf_prv_amd import api, planner
+
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_views = args.views_per_gpu * world if args.mode == "weak" else args.views_total
+    ids, per = planner.shard_views(n_views, rank, world, interleaved=True)
+    rec = np.zeros(len(ids), api.RECORD_DTYPE)
+    rec["score"] = np.sin(ids.astype(np.float64) * 12.9898) * 43758.5453 % 1.0
+    records = planner.gather_records(rec, per, n_views, interleaved=True)
+    order = api.rank_host(records, np.arange(n_views, dtype=np.int32))
+    digest = torch.tensor([int(np.frombuffer(records.tobytes(), np.uint8).astype(np.int64).sum()), int(order[0])])
+    if world > 1:
+        all_d = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(all_d, digest)
+        assert all(bool((d == digest).all()) for d in all_d), "ranks disagree on the gathered records"
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work, no performance figure)", "value": None, "dry_run": True, "n_gpus": world,
+                          "scaling": args.mode, "views_total": n_views, "ranking_head": [int(x) for x in order[:8]],
+                          "records_checksum": int(digest[0])}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))  # before anything touches a GPU
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

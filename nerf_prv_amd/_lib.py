@@ -54,6 +54,11 @@ class Rs2Intrinsics(C.Structure):
                 ("fy", C.c_float), ("model", C.c_int32), ("coeffs", C.c_float * 5)]
 
 
+class ModelLayout(C.Structure):
+    _fields_ = [("table_bytes_canonical", C.c_uint64), ("table_bytes_physical", C.c_uint64), ("n_pair_steps", C.c_int32),
+                ("kernel_features", C.c_int32), ("kernel_pair_steps", C.c_int32), ("n_hashed_levels", C.c_int32)]
+
+
 class ScoreRecord(C.Structure):
     _fields_ = [("score", C.c_double), ("psnr", C.c_float), ("coverage", C.c_float)]
 
@@ -134,6 +139,7 @@ SIGNATURES = {
     "prv_train_gradients": (_i, [_vp, _vp, _vp, _P(C.c_float)]),
     "prv_train_master": (_i, [_vp, _vp, _vp]),
     "prv_train_refresh_occupancy": (_i, [_vp]),
+    "prv_debug_model_layout": (_i, [_vp, _i, C.POINTER(ModelLayout)]),
     "prv_debug_raygen": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "prv_debug_encode": (_i, [_vp, _i, _vp, _i, _vp]),
     "prv_debug_field": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),

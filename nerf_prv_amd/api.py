@@ -333,6 +333,12 @@ class Context:
         return self.lib.prv_argmax(_ptr(records), _ptr(ids), len(ids))
 
     # -- stage hooks
+    def model_layout(self, slot):
+        """kernel-side layout of a loaded field and the render_queue_kernel<F, NPAIR> instance it runs on"""
+        out = L.ModelLayout()
+        self._chk(self.lib.prv_debug_model_layout(self.handle, slot, C.byref(out)))
+        return {k: getattr(out, k) for k, _ in out._fields_}
+
     def debug_raygen(self, camset, view, width, height, spp_index=0):
         n = width * height
         o, d, t = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 2), np.float32)

@@ -1390,6 +1390,25 @@ int prv_rank(const prv_score_record* r, const int* ids, int n, int* order) try {
 
 // ------------------------------------------------------------------ stage hooks
 
+int prv_debug_model_layout(prv_ctx* c, int slot, prv_model_layout* out) try {
+  if (!c) return PRV_E_INVALID;
+  int rc = check_model(c, slot);
+  if (rc != PRV_OK) return rc;
+  if (!out) return fail(c, PRV_E_INVALID, "out is NULL");
+  const Model& m = c->models[slot];
+  HostLevel lv[kMaxLevels];
+  uint64_t total = 0;
+  compute_levels(m.desc, lv, &total);
+  out->table_bytes_canonical = m.table_halfs * 2;
+  out->table_bytes_physical = m.phys.bytes;
+  out->n_pair_steps = m.dev.n_pair_steps;
+  out->kernel_features = m.dev.n_features;
+  out->kernel_pair_steps = render_instance_pair_steps(m.dev);
+  out->n_hashed_levels = 0;
+  for (int l = 0; l < m.desc.n_levels; l++) out->n_hashed_levels += lv[l].hashed ? 1 : 0;
+  return PRV_OK;
+} catch (...) { return caught(c); }
+
 int prv_debug_raygen(prv_ctx* c, const prv_camset* cs, int view, int W, int H, int spp_k, float* o, float* d, float* t) try {
   if (!c) return PRV_E_INVALID;
   if (!cs || view < 0 || view >= (int)cs->cams.size() || W < 1 || H < 1 || !o || !d || !t)

@@ -916,13 +916,18 @@ hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_
 
 // instances: paired loads on the first NPAIR gather steps (host picks the largest instance <= the
 // field's count of leading dense-dense steps)
+int render_instance_pair_steps(const FieldDev& fd) {
+  if (fd.n_features == 4) return fd.n_pair_steps >= 2 ? 2 : 0;
+  return fd.n_pair_steps >= 5 ? 5 : 0;
+}
+
 hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s) {
-  const int np = P.field.n_pair_steps;
+  const int np = render_instance_pair_steps(P.field);
   if (P.field.n_features == 4) {
-    if (np >= 2) hipLaunchKernelGGL((render_queue_kernel<4, 2>), dim3(n_blocks), dim3(256), 0, s, P);
+    if (np == 2) hipLaunchKernelGGL((render_queue_kernel<4, 2>), dim3(n_blocks), dim3(256), 0, s, P);
     else hipLaunchKernelGGL((render_queue_kernel<4, 0>), dim3(n_blocks), dim3(256), 0, s, P);
   } else {
-    if (np >= 5) hipLaunchKernelGGL((render_queue_kernel<2, 5>), dim3(n_blocks), dim3(256), 0, s, P);
+    if (np == 5) hipLaunchKernelGGL((render_queue_kernel<2, 5>), dim3(n_blocks), dim3(256), 0, s, P);
     else hipLaunchKernelGGL((render_queue_kernel<2, 0>), dim3(n_blocks), dim3(256), 0, s, P);
   }
   return hipGetLastError();

@@ -72,6 +72,7 @@ hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_
 hipError_t launch_spp_reduce(const float* stage, size_t n_pixels, int spp, const float bg[4], float* out, uint32_t* out_u8,
                              hipStream_t s);
 hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s);
+int render_instance_pair_steps(const FieldDev& fd); // NPAIR of the render_queue_kernel<F, NPAIR> instance launch_render picks
 struct PreceptPose {
   double w2c[16], c2w[16];
 };

@@ -332,8 +332,15 @@ def gather_records(local, per_rank, n_views, group=None, device=None, interleave
     else:
         out = torch.empty(world * per_rank * 16, dtype=torch.uint8, device=send.device)
         dist.all_gather_into_tensor(out, send, group=group)
-    gathered = out.cpu().numpy().view(RECORD_DTYPE)
-    if interleaved and world > 1:  # slot r*per_rank + k holds view k*world + r
+    return assemble_records(out.cpu().numpy().view(RECORD_DTYPE), per_rank, n_views, world, interleaved)
+
+
+def assemble_records(gathered, per_rank, n_views, world, interleaved=False):
+    """the gathered array (world blocks of per_rank records, rank order) -> n_views records in view order:
+    contiguous shards are already in order, interleaved shards are un-permuted (slot r*per_rank + k holds view
+    k*world + r).  Padding slots of ragged shards are dropped."""
+    gathered = np.asarray(gathered).view(RECORD_DTYPE).reshape(-1)
+    if interleaved and world > 1:
         v = np.arange(n_views)
         return gathered[(v % world) * per_rank + v // world].copy()
     return gathered[:n_views].copy()
