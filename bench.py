@@ -249,8 +249,8 @@ class Round:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         ev_all, nom_all, rays_all = (float(x) for x in tot.tolist())
-        return dict(elapsed=float(tmax.item()), steps=steps, prof=prof, st=st, order=order, ev_all=ev_all, nom_all=nom_all,
-                    rays_all=rays_all)
+        return dict(elapsed=float(tmax.item()), steps=steps, prof=prof, st=st, order=order, records=records, ev_all=ev_all,
+                    nom_all=nom_all, rays_all=rays_all)
 
     def close(self):
         self.cams.close()
@@ -323,6 +323,46 @@ def kernel_figures(m, variant, hbm_bound):
     return out
 
 
+def cxx_rccl_check(env, main, timeout_s=90.0):
+    """N > 1 only, OUTSIDE the timed region: the same scoring round through the C ABI's own communicator
+    (prv_comm_create "rccl" -> ncclCommInitRank; prv_score_views_sharded -> ONE ncclAllGather of the records on the
+    context's stream; include/prv.h) -- what the C++ planner (prv_planner `shard: views`) runs -- compared with the
+    records torch.distributed gathered.  Runs on a watchdog thread: a failure or a hang here is REPORTED in the line,
+    it can not take the measurement down."""
+    import threading
+
+    api, ctx, rank, world = env["api"], env["ctx"], env["rank"], env["world"]
+    result = {"ok": False, "stage": "create"}
+
+    def work():
+        try:
+            comm = api.Comm(ctx, rank, world, transport="rccl")
+            result["stage"] = "score"
+            rec, _ = comm.score_views(api.L.SCORE_PSNR_COVERAGE, [main.slot], main.cams, main.n_views, main.opts, gt_shard=main.gt,
+                                      interleaved=True)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                rec, _ = comm.score_views(api.L.SCORE_PSNR_COVERAGE, [main.slot], main.cams, main.n_views, main.opts, gt_shard=main.gt,
+                                          interleaved=True)
+            result["ms_per_round"] = (time.perf_counter() - t0) / 3 * 1e3
+            result["records"] = rec
+            result["transport"] = comm.transport
+            result["stage"] = "done"
+            result["ok"] = True
+            comm.barrier()
+            comm.close()
+        except Exception as e:  # reported, not raised
+            result["error"] = f"{type(e).__name__}: {e}"
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        result["error"] = f"no answer within {timeout_s:.0f} s (stage: {result['stage']})"
+        result["hung"] = True
+    return result
+
+
 def run_rank(args):
     import numpy as np
     import torch
@@ -366,6 +406,16 @@ def run_rank(args):
     k, elapsed = args.steps, m["elapsed"]
 
     extras = {}
+    cxx = None
+    if use_dist and os.environ.get("PRV_BENCH_NO_CXX_COMM") != "1":  # N > 1 (or PRV_FORCE_DIST=1: one rank, same calls)
+        cxx = cxx_rccl_check(env, main)
+        if rank == 0:
+            same = bool(cxx.get("ok")) and cxx["records"].tobytes() == m["records"].tobytes()
+            extras["cxx_rccl_round"] = {"ok": bool(cxx.get("ok")), "records_identical_to_torch_gather": same,
+                                        "transport": cxx.get("transport"), "ms_per_round": cxx.get("ms_per_round"),
+                                        "error": cxx.get("error"),
+                                        "what": "the same round through prv_score_views_sharded (C ABI: ncclAllGather of the "
+                                                "records inside libprv_hip.so), untimed check"}
     if rank == 0 and not args.no_extras:
         solo = dict(env, world=1, rank=0, use_dist=False)  # side measurements: this GPU alone, no collective
         # (1) the HBM-bound configuration (BASELINE configs[3]'s field) timed in the SAME run
@@ -479,6 +529,8 @@ def run_rank(args):
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, fkw, main.tms, main.scale, main.offset, main.fov_x)
         print(json.dumps(out), flush=True)
+    if cxx is not None and cxx.get("hung"):
+        os._exit(0)  # a watchdog thread is still stuck inside a collective: the line is out, leave without joining it
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -267,6 +267,40 @@ int prv_splat_points(prv_ctx* ctx, const float* xyz_dev, const uint8_t* rgb_dev,
                      const double offset[3], const prv_camset* cs, const int* view_ids, int n_views, int width,
                      int height, int point_size, int flip180, uint8_t* out_rgba8_dev);
 
+/* ---- several GPUs: view sharding + one all-gather ----------------------------- */
+/* replaces: nothing in the reference -- its loops over the candidates are serial (main.cpp:2045-2094, 2105-2158;
+ * run.py:293) and it has no multi-GPU path.  One process per GPU (RANK / WORLD_SIZE / LOCAL_RANK as torchrun exports
+ * them): the candidate views of a round are dealt to the ranks, every rank scores its shard with the whole ensemble,
+ * ONE all-gather of the 16-byte records gives every rank the whole round, the same prv_rank / prv_argmax on every
+ * rank gives the same integer ranking.
+ * transport "rccl" (default): ncclAllGather / ncclBroadcast on device buffers over xGMI, on the context's stream;
+ *   librccl is loaded at run time, rank 0's ncclUniqueId reaches the others over a TCP star at `rendezvous`
+ *   ("host:port"; NULL = $MASTER_ADDR : $PRV_COMM_PORT, else $MASTER_PORT + 23).
+ * transport "socket": the same calls staged through host memory and that star -- for ranks that SHARE a GPU (RCCL
+ *   refuses that), i.e. tests.  NULL transport = $PRV_COMM, else "rccl". */
+typedef struct prv_comm prv_comm;
+int prv_comm_create(prv_ctx* ctx, int rank, int world, const char* transport, const char* rendezvous, prv_comm** out);
+void prv_comm_destroy(prv_comm* comm);
+int prv_comm_rank(const prv_comm* comm);
+int prv_comm_world(const prv_comm* comm);
+const char* prv_comm_transport(const prv_comm* comm); /* "rccl" | "socket" */
+/* recv_dev = world blocks of bytes_per_rank in rank order, identical on every rank; enqueued on the context's stream */
+int prv_comm_all_gather(prv_comm* comm, const void* send_dev, size_t bytes_per_rank, void* recv_dev);
+int prv_comm_barrier(prv_comm* comm);
+/* the views of `rank`: a contiguous block [rank*per, ...) or, interleaved, rank, rank+world, ... (a hemisphere set runs
+ * pole -> equator and top views cost more).  ids_out (may be NULL) holds up to per entries; returns per = ceil(n/world). */
+int prv_shard_views(int n_views, int rank, int world, int interleaved, int* ids_out, int* n_mine);
+/* the sharded scoring round: prv_score_views on this rank's shard of views [0, n_views_total) of `cs`, one all-gather,
+ * records_host = all n_views_total records in view order on every rank.  gt_shard_dev (method 5): the reference images
+ * of THIS rank's views, in shard order.  comm NULL = one rank.  stats: this rank's share. */
+int prv_score_views_sharded(prv_ctx* ctx, prv_comm* comm, int method, const int* model_slots, int n_models,
+                            const prv_camset* cs, int n_views_total, int interleaved, const prv_render_opts* opts,
+                            const float* gt_shard_dev, prv_score_record* records_host, prv_stats* stats);
+/* the exchange step of a multi-GPU NBV iteration (the reference trains its members one after another in one process,
+ * main.cpp:2041-2043): member e was trained in slot e of rank e % world; afterwards slot e of EVERY rank holds it bit
+ * for bit.  Device to device: one group of broadcasts on the slots' canonical buffers (table | MLP | occupancy). */
+int prv_model_exchange(prv_ctx* ctx, prv_comm* comm, int n_members, const prv_field_desc* desc);
+
 /* ---- training ------------------------------------------------------------- */
 /* replaces: the `while testbed.frame()` loop run.py:185-208 drives for `--train --n_steps 2500`
  * (main.cpp:1668) on the dataset of testbed.load_training_data (run.py:109): random rays over the dataset

@@ -105,6 +105,18 @@ int prvh_png_size(const char* path, int* width, int* height);
 int prvh_png_read_rgba8(const char* path, int width, int height, uint8_t* out_rgba8);
 int prvh_png_write_rgba8(const char* path, int width, int height, const uint8_t* rgba8);
 
+/* ---- the TCP star between the ranks of one job (nerf_prv_amd/csrc/prv_star.hpp) ----
+ * the rendezvous of prv_comm (it carries rank 0's ncclUniqueId to the other ranks) and the host-staged `socket`
+ * transport behind the same calls; exposed here so it can be exercised without a GPU.  Rank 0 listens on addr:port
+ * (NULL / <= 0: $MASTER_ADDR, $PRV_COMM_PORT or $MASTER_PORT + 23), the others connect. */
+typedef struct prvh_star prvh_star;
+prvh_star* prvh_star_open(int rank, int world, const char* addr, int port, double timeout_s);
+void prvh_star_close(prvh_star*);
+/* recv = world blocks of `bytes` in rank order, identical on every rank; 0 or < 0 */
+int prvh_star_all_gather(prvh_star*, const void* send, uint64_t bytes, void* recv);
+int prvh_star_broadcast(prvh_star*, void* buf, uint64_t bytes, int root);
+int prvh_star_barrier(prvh_star*);
+
 int prvh_nbv_loop(prvh_share_data* sd, const double center[3], double predicted_size, int first_view_id,
                   int test_id, prvh_score_fn score, void* user, prvh_loop_result* out);
 /* the same with the view budget of method 4 (PVBCoverage, main.cpp:2163-2242) supplied by the caller -- what

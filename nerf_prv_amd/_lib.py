@@ -139,6 +139,16 @@ SIGNATURES = {
     "prv_train_gradients": (_i, [_vp, _vp, _vp, _P(C.c_float)]),
     "prv_train_master": (_i, [_vp, _vp, _vp]),
     "prv_train_refresh_occupancy": (_i, [_vp]),
+    "prv_comm_create": (_i, [_vp, _i, _i, C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
+    "prv_comm_destroy": (None, [_vp]),
+    "prv_comm_rank": (_i, [_vp]),
+    "prv_comm_world": (_i, [_vp]),
+    "prv_comm_transport": (C.c_char_p, [_vp]),
+    "prv_comm_all_gather": (_i, [_vp, _vp, C.c_size_t, _vp]),
+    "prv_comm_barrier": (_i, [_vp]),
+    "prv_shard_views": (_i, [_i, _i, _i, _i, _vp, C.POINTER(_i)]),
+    "prv_score_views_sharded": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, C.POINTER(RenderOpts), _vp, _vp, C.POINTER(Stats)]),
+    "prv_model_exchange": (_i, [_vp, _vp, _i, C.POINTER(FieldDesc)]),
     "prv_debug_model_layout": (_i, [_vp, _i, C.POINTER(ModelLayout)]),
     "prv_debug_raygen": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "prv_debug_encode": (_i, [_vp, _i, _vp, _i, _vp]),

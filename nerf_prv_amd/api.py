@@ -361,6 +361,72 @@ class Context:
         return out, occ
 
 
+class Comm:
+    """the ranks of one job as the C ABI sees them (include/prv.h, "several GPUs"): RCCL on device buffers, or the
+    host-staged socket transport for ranks that share a GPU"""
+
+    def __init__(self, ctx, rank, world, transport=None, rendezvous=None):
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        ctx._chk(ctx.lib.prv_comm_create(ctx.handle, int(rank), int(world), transport.encode() if transport else None,
+                                         rendezvous.encode() if rendezvous else None, C.byref(self.handle)))
+        self.rank, self.world = int(rank), int(world)
+
+    @property
+    def transport(self):
+        return self.ctx.lib.prv_comm_transport(self.handle).decode()
+
+    def all_gather(self, send):
+        """send: device tensor -> device uint8 tensor of world blocks in rank order"""
+        t = self.ctx.torch
+        send = send.contiguous()
+        nbytes = send.numel() * send.element_size()
+        out = t.empty(self.world * nbytes, dtype=t.uint8, device=send.device)
+        self.ctx._chk(self.ctx.lib.prv_comm_all_gather(self.handle, _ptr(send), nbytes, _ptr(out)))
+        self.ctx.synchronize()
+        return out
+
+    def barrier(self):
+        self.ctx._chk(self.ctx.lib.prv_comm_barrier(self.handle))
+
+    def score_views(self, method, slots, camset, n_views, opts, gt_shard=None, interleaved=True, want_stats=False):
+        """the sharded scoring round -> (records[n_views] in view order, identical on every rank; local stats)"""
+        slots = np.ascontiguousarray(slots, np.int32)
+        rec = np.zeros(int(n_views), RECORD_DTYPE)
+        st = L.Stats()
+        self.ctx._chk(self.ctx.lib.prv_score_views_sharded(self.ctx.handle, self.handle, method, _ptr(slots), len(slots),
+                                                           camset.handle, int(n_views), int(bool(interleaved)), C.byref(opts),
+                                                           _ptr(gt_shard), _ptr(rec), C.byref(st) if want_stats else None))
+        return rec, st
+
+    def exchange_models(self, n_members, desc):
+        """member e trained in slot e of rank e % world -> slot e of every rank (device to device)"""
+        self.ctx._chk(self.ctx.lib.prv_model_exchange(self.ctx.handle, self.handle, int(n_members), C.byref(desc)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.prv_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_views(n_views, rank, world, interleaved=False):
+    """prv_shard_views -> (ids, per_rank)"""
+    lib = L.load()
+    per = -(-int(n_views) // int(world)) if world > 0 else 0
+    ids = np.zeros(max(1, per), np.int32)
+    n = C.c_int()
+    per = lib.prv_shard_views(int(n_views), int(rank), int(world), int(bool(interleaved)), _ptr(ids), C.byref(n))
+    if per < 0:
+        raise PrvError(per, "prv_shard_views")
+    return ids[: n.value].copy(), per
+
+
 def rank_host(records, view_ids):
     """ranking without a context (pure host entry point of the C ABI)"""
     lib = L.load()

@@ -1466,3 +1466,4 @@ int prv_debug_field(prv_ctx* c, int slot, const float* pos, const float* dir, in
 } // extern "C"
 
 #include "prv_train_api.inc"
+#include "prv_comm_api.inc"

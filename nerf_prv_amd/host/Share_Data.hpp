@@ -197,6 +197,17 @@ public:
     ok = true;
   }
 
+  // ranks > 0 of a views-sharded job run the same loop as rank 0 and must not write into rank 0's tree: every
+  // output path moves from <pre_path> to <new_pre> (inputs -- model_path, viewspace_path -- stay)
+  void relocate_outputs(const std::string& new_pre) {
+    auto move = [&](std::string& p) {
+      if (p.compare(0, pre_path.size(), pre_path) == 0) p = new_pre + p.substr(pre_path.size());
+    };
+    move(gt_path);
+    move(save_path);
+    pre_path = new_pre;
+  }
+
   // create every directory level of cd (Share_Data.hpp:639-649, POSIX instead of <direct.h>)
   void access_directory(const std::string& cd) const {
     std::string temp;

@@ -9,12 +9,17 @@
 #include "planner.hpp"
 #include "pcd_io.hpp"
 #include "png_io.hpp"
+#include "../csrc/prv_star.hpp"
 
 using namespace prvhost;
 
 namespace {
 thread_local std::string g_error;
 }
+
+struct prvh_star {
+  prvstar::Star star;
+};
 
 struct prvh_share_data {
   std::shared_ptr<Share_Data> sd;
@@ -293,6 +298,33 @@ int prvh_nbv_loop_budget(prvh_share_data* h, const double center[3], double pred
   for (int i = 0; i < out->n_chosen; i++) out->chosen[i] = labeler.chosen_nbvs[i];
   out->total_movement = labeler.total_movement_cost;
   return rc;
+} catch (...) { return PRVH_E_INTERNAL; }
+
+
+prvh_star* prvh_star_open(int rank, int world, const char* addr, int port, double timeout_s) try {
+  std::unique_ptr<prvh_star> h(new prvh_star());
+  if (!h->star.open(rank, world, addr ? addr : "", port, timeout_s > 0 ? timeout_s : 120.0)) {
+    g_error = h->star.error;
+    return nullptr;
+  }
+  return h.release();
+} catch (...) { return nullptr; }
+
+void prvh_star_close(prvh_star* h) { delete h; }
+
+int prvh_star_all_gather(prvh_star* h, const void* send, uint64_t bytes, void* recv) try {
+  if (!h || !send || !recv) return -1;
+  return h->star.all_gather(send, (size_t)bytes, recv) ? 0 : -3;
+} catch (...) { return PRVH_E_INTERNAL; }
+
+int prvh_star_broadcast(prvh_star* h, void* buf, uint64_t bytes, int root) try {
+  if (!h || !buf) return -1;
+  return h->star.broadcast(buf, (size_t)bytes, root) ? 0 : -3;
+} catch (...) { return PRVH_E_INTERNAL; }
+
+int prvh_star_barrier(prvh_star* h) try {
+  if (!h) return -1;
+  return h->star.barrier() ? 0 : -3;
 } catch (...) { return PRVH_E_INTERNAL; }
 
 } // extern "C"

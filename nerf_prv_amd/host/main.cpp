@@ -38,6 +38,11 @@ enum { GetCoverage = 3, InstantNGP = 4, GetPathPlan = 20, ViewPlanning = 21 }; /
 
 struct HipScorer {
   prv_ctx* ctx = nullptr;
+  // views-sharded job (`shard: views` / PRV_SHARD=views under RANK / WORLD_SIZE): every rank runs the same loop on the
+  // same object; the members are trained by their owners (e % world) and exchanged, the candidates of an iteration are
+  // dealt to the ranks and ONE all-gather of the 16-byte records gives every rank every score
+  prv_comm* comm = nullptr;
+  int rank = 0, world = 1;
   std::shared_ptr<Share_Data> sd;
   int n_members = 1;
   float* gt_dev = nullptr; // method 5: reference images of ALL views at the candidate size
@@ -92,9 +97,11 @@ struct HipScorer {
       prv_synchronize(ctx);
       t_gt = now_seconds() - t_start;
     }
-    // the members train side by side (prv_train_steps_multi), each from its own seeds
+    // the members train side by side (prv_train_steps_multi), each from its own seeds; with several ranks a member
+    // is trained by rank e % world and reaches the others through prv_model_exchange below
     std::vector<prv_trainer*> trs;
     for (int e = 0; rc == PRV_OK && e < n_members; e++) {
+      if (e % world != rank) continue;
       double t0 = now_seconds();
       rc = prv_model_fresh(ctx, e, &train_desc, train_seed + (uint64_t)e);
       t_fresh += now_seconds() - t0;
@@ -112,6 +119,7 @@ struct HipScorer {
     if (rc == PRV_OK && !trs.empty()) rc = prv_train_steps_multi(trs.data(), (int)trs.size(), train_steps, nullptr);
     t_steps = now_seconds() - t0;
     for (prv_trainer* tr : trs) prv_train_destroy(tr);
+    if (rc == PRV_OK && comm) rc = prv_model_exchange(ctx, comm, n_members, &train_desc);
     if (timing)
       std::cerr << "train_members: views " << n << " gt " << t_gt << " s, fresh " << t_fresh << " s, create " << t_create
                 << " s, steps " << t_steps << " s, total " << now_seconds() - t_start << " s" << std::endl;
@@ -199,22 +207,26 @@ struct HipScorer {
     std::vector<int> slots(n_members);
     for (int e = 0; e < n_members; e++) slots[e] = e;
     std::vector<prv_score_record> rec(n);
+    // this rank's shard of the frames of the render json (all of them with one rank): interleaved, as bench.py deals them
+    std::vector<int> mine((size_t)std::max(1, (n + world - 1) / world));
+    int n_mine = 0;
+    prv_shard_views(n, rank, world, 1, mine.data(), &n_mine);
     int rc;
     if (method == PSNRCoverage) {
       // frame k of the render json is candidate ids[k]: pick its reference image out of the full set
       const size_t px = (size_t)o.width * o.height * 4;
       float* gt_sel = nullptr;
-      if (prv_malloc(ctx, (void**)&gt_sel, (size_t)n * px * sizeof(float)) != PRV_OK) return -21;
+      if (prv_malloc(ctx, (void**)&gt_sel, (size_t)std::max(1, n_mine) * px * sizeof(float)) != PRV_OK) return -21;
       std::vector<float> tmp(px);
-      for (int k = 0; k < n; k++) { // device-to-device through the host keeps this file free of HIP headers
-        prv_memcpy_d2h(ctx, tmp.data(), gt_dev + (size_t)ids[k] * px, px * sizeof(float));
+      for (int k = 0; k < n_mine; k++) { // device-to-device through the host keeps this file free of HIP headers
+        prv_memcpy_d2h(ctx, tmp.data(), gt_dev + (size_t)ids[mine[k]] * px, px * sizeof(float));
         prv_memcpy_h2d(ctx, gt_sel + (size_t)k * px, tmp.data(), px * sizeof(float));
       }
       o.background[3] = 0.f;
-      rc = prv_score_views(ctx, PRV_SCORE_PSNR_COVERAGE, slots.data(), 1, cams, nullptr, n, &o, gt_sel, rec.data(), nullptr, nullptr);
+      rc = prv_score_views_sharded(ctx, comm, PRV_SCORE_PSNR_COVERAGE, slots.data(), 1, cams, n, 1, &o, gt_sel, rec.data(), nullptr);
       prv_free(ctx, gt_sel);
     } else {
-      rc = prv_score_views(ctx, method, slots.data(), n_members, cams, nullptr, n, &o, nullptr, rec.data(), nullptr, nullptr);
+      rc = prv_score_views_sharded(ctx, comm, method, slots.data(), n_members, cams, n, 1, &o, nullptr, rec.data(), nullptr);
       if (rc == PRV_OK && save_renders) { // <save_path>/render/<it>/ensemble_<e>/rgbaClip_<view id>.png, the files :2047 reads
         uint8_t* dev = nullptr;
         std::vector<uint8_t> px((size_t)o.width * o.height * 4);
@@ -237,6 +249,11 @@ struct HipScorer {
       return rc;
     }
     for (int k = 0; k < n; k++) scores[k] = rec[k].score;
+    if (getenv("PRV_PLANNER_DUMP_RECORDS")) { // tests: the gathered records of every iteration, byte for byte
+      sd->access_directory(sd->save_path + "/records");
+      write_text(sd->save_path + "/records/" + std::to_string(iteration) + ".bin",
+                 std::string((const char*)rec.data(), rec.size() * sizeof(prv_score_record)));
+    }
     return 0;
   }
 };
@@ -270,12 +287,14 @@ prv_field_desc field_from_config(const FileStorage& fs) {
   return d;
 }
 
-int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name, int method) {
+int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name, int method, prv_comm* comm) {
   auto sd = std::make_shared<Share_Data>(cfg, name, -1, -1, method); // main.cpp:3876
   if (!sd->ok) {
     std::cerr << sd->error << std::endl;
     return -1;
   }
+  const int rank = comm ? prv_comm_rank(comm) : 0, world = comm ? prv_comm_world(comm) : 1;
+  if (rank > 0) sd->relocate_outputs(sd->pre_path + "rank" + std::to_string(rank) + "/"); // same loop, own scratch tree
   FileStorage fs;
   fs.open(cfg);
   const prv_field_desc desc = field_from_config(fs);
@@ -300,6 +319,9 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   HipScorer scorer;
   scorer.ctx = ctx;
   scorer.sd = sd;
+  scorer.comm = comm;
+  scorer.rank = rank;
+  scorer.world = world;
   scorer.n_members = members;
   scorer.save_renders = fs.has("save_renders") && fs.num("save_renders") > 0;
   if (train_steps > 0) { // members are trained from scratch every iteration
@@ -663,14 +685,29 @@ int main(int argc, char** argv) {
   std::cout << "input object names (-1 to stop):" << std::endl; // main.cpp:2299-2309
   std::string name;
   while (std::cin >> name && name != "-1") names.push_back(name);
-  // BASELINE config 5 (several objects, 8 GPUs): the objects are independent, so one process per GPU takes the
-  // names i % world == rank -- launched by torchrun or by hand with RANK / WORLD_SIZE / LOCAL_RANK; no collective
+  // Several GPUs, one process per GPU, launched by torchrun or by hand with RANK / WORLD_SIZE / LOCAL_RANK:
+  //  shard objects (default; BASELINE config 5): the objects are independent, rank r takes the names i % world == r,
+  //    no collective;
+  //  shard views (`shard: views` in the yaml or PRV_SHARD=views; BASELINE config 4): every rank runs the loop of every
+  //    object, the candidates of an iteration are dealt to the ranks, ONE all-gather of the score records per round
+  //    (RCCL over xGMI; PRV_COMM=socket for ranks that share a GPU), trained members exchanged device to device.
   const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0);
   if (world < 1 || rank < 0 || rank >= world) {
     std::cerr << "RANK " << rank << " / WORLD_SIZE " << world << " make no sense" << std::endl;
     return 2;
   }
-  if (world > 1) {
+  bool shard_views = false;
+  {
+    FileStorage fs0;
+    const char* e = getenv("PRV_SHARD");
+    std::string how = e && *e ? e : (fs0.open(cfg) && fs0.has("shard") ? fs0.str("shard") : "objects");
+    if (how != "objects" && how != "views") {
+      std::cerr << "shard must be 'objects' or 'views', not '" << how << "'" << std::endl;
+      return 2;
+    }
+    shard_views = how == "views" && world > 1 && mode == ViewPlanning;
+  }
+  if (world > 1 && !shard_views) {
     std::vector<std::string> mine;
     for (size_t i = 0; i < names.size(); i++)
       if ((int)(i % (size_t)world) == rank) mine.push_back(names[i]);
@@ -694,6 +731,15 @@ int main(int argc, char** argv) {
     std::cerr << "cannot open " << cfg << std::endl;
     return 5;
   }
+  prv_comm* comm = nullptr;
+  if (shard_views) {
+    if (prv_comm_create(ctx, rank, world, nullptr, nullptr, &comm) != PRV_OK) {
+      std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+      prv_destroy(ctx);
+      return 6;
+    }
+    std::cout << "rank " << rank << " of " << world << ": views sharded, transport " << prv_comm_transport(comm) << std::endl;
+  }
   if (mode == InstantNGP || mode == GetCoverage) {
     int worst = 0;
     for (const auto& n : names) {
@@ -711,9 +757,10 @@ int main(int argc, char** argv) {
   for (const auto& n : names)
     for (int m : methods) {
       std::cout << "object " << n << " method " << m << std::endl;
-      const int rc = view_planning(ctx, cfg, n, m);
+      const int rc = view_planning(ctx, cfg, n, m, comm);
       if (rc != 0) worst = rc;
     }
+  if (comm) prv_comm_destroy(comm);
   prv_destroy(ctx);
   return worst == 0 ? 0 : 1;
 }

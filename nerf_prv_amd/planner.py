@@ -57,6 +57,11 @@ HOST_SIGNATURES = {
     "prvh_png_size": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
     "prvh_png_read_rgba8": (_i, [C.c_char_p, _i, _i, _vp]),
     "prvh_png_write_rgba8": (_i, [C.c_char_p, _i, _i, _vp]),
+    "prvh_star_open": (_vp, [_i, _i, C.c_char_p, _i, _d]),
+    "prvh_star_close": (None, [_vp]),
+    "prvh_star_all_gather": (_i, [_vp, _vp, C.c_uint64, _vp]),
+    "prvh_star_broadcast": (_i, [_vp, _vp, C.c_uint64, _i]),
+    "prvh_star_barrier": (_i, [_vp]),
     "prvh_nbv_loop": (_i, [_vp, _vp, _d, _i, _i, SCORE_FN, _vp, C.POINTER(LoopResult)]),
     "prvh_nbv_loop_budget": (_i, [_vp, _vp, _d, _i, _i, SCORE_FN, _vp, _i, C.POINTER(LoopResult)]),
 }

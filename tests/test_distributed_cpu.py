@@ -126,3 +126,64 @@ def test_two_rank_ensemble_exchange(n_members):
         assert fields == want
     with pytest.raises(ValueError):
         planner.exchange_members({0: _member(0, sizes)}, 2, sizes)  # world 1 must bring both members
+
+
+# ---- the C++ side of the N > 1 path: the TCP star behind prv_comm's rendezvous and its socket transport -------
+
+def _star_worker(rank, world, port, q):
+    import ctypes as C
+
+    h = planner.host()
+    star = h.prvh_star_open(rank, world, b"127.0.0.1", port, 60.0)
+    assert star, "star rendezvous failed"
+    try:
+        # (1) all-gather of ragged-looking 16-byte records, as the scoring round gathers them
+        per = 3
+        send = np.zeros(per, RECORD_DTYPE)
+        send["score"] = np.arange(per) + 100.0 * rank
+        send["psnr"] = rank
+        recv = np.zeros(per * world, RECORD_DTYPE)
+        assert h.prvh_star_all_gather(star, send.ctypes.data_as(C.c_void_p), send.nbytes, recv.ctypes.data_as(C.c_void_p)) == 0
+        # (2) a large block (the ensemble exchange's size class) broadcast from a non-zero root
+        big = np.full(3_000_001, rank, np.uint8)
+        if rank == world - 1:
+            big[:] = np.arange(big.size) % 251
+        assert h.prvh_star_broadcast(star, big.ctypes.data_as(C.c_void_p), big.nbytes, world - 1) == 0
+        assert h.prvh_star_barrier(star) == 0
+        q.put((rank, recv.tobytes(), int(big.astype(np.int64).sum())))
+    finally:
+        h.prvh_star_close(star)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_star_all_gather_and_broadcast_between_processes(world):
+    """the rendezvous / socket transport of the C ABI's communicator, without a GPU: every rank ends with the same
+    gathered records in rank order, a broadcast from the last rank reaches everyone"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_star_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.zeros(3 * world, RECORD_DTYPE)
+    for r in range(world):
+        want["score"][3 * r: 3 * r + 3] = np.arange(3) + 100.0 * r
+        want["psnr"][3 * r: 3 * r + 3] = r
+    want_sum = int((np.arange(3_000_001) % 251).sum())
+    for rank, rec_bytes, s in got:
+        assert rec_bytes == want.tobytes() and s == want_sum
+
+
+def test_shard_views_of_the_c_abi_matches_the_python_sharding():
+    from nerf_prv_amd import api
+
+    for n, world in ((0, 1), (7, 2), (8, 2), (1024, 8), (5, 8), (13, 4)):
+        for interleaved in (False, True):
+            for r in range(world):
+                ids_c, per_c = api.shard_views(n, r, world, interleaved)
+                ids_p, per_p = planner.shard_views(n, r, world, interleaved)
+                assert per_c == per_p and np.array_equal(ids_c, ids_p), (n, world, interleaved, r)

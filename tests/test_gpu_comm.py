@@ -1,0 +1,218 @@
+"""The C++ side of the N > 1 path on the GPU box (one MI355X):
+
+  * transport "rccl" with ONE rank: librccl really loads, ncclCommInitRank / ncclAllGather / ncclBroadcast really run on
+    the context's stream (what an 8-GPU job calls, at world size 1);
+  * two PROCESSES sharing the one GPU over the "socket" transport (RCCL refuses two ranks on a device): the sharded
+    scoring round and the device-side ensemble exchange through the C ABI, and prv_planner's `shard: views` mode -- records
+    and chosen views byte-identical to the one-process loop."""
+import os
+import socket
+import subprocess
+
+import numpy as np
+import pytest
+
+from nerf_prv_amd import api, planner
+from tests import util
+from tests.test_gpu_planner import GOLD, ROOT, SEED, YAML, small_desc
+
+pytestmark = pytest.mark.gpu
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def feed_all_then_wait(procs, text, timeout=300):
+    """ranks that talk to each other must ALL have their console input before anyone is waited for"""
+    for p in procs:
+        p.stdin.write(text)
+        p.stdin.close()
+        p.stdin = None  # communicate() must not touch it again
+    return [p.communicate(timeout=timeout) for p in procs]
+
+
+def scene(c, n_views=11, w=40, h=24):
+    d = small_desc()
+    for e in range(3):
+        c.synthetic_model(e, d, SEED + e)
+    c.synthetic_model(7, d, SEED + 99)
+    tms, scale, offset = planner.hemisphere_transforms(util.fibonacci_hemisphere(n_views), 0.3, 0.1, [1e-10] * 3)
+    cams = c.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+    return d, cams, api.render_opts(w, h, 64, 2, 0.01, background=(0, 0, 0, 1))
+
+
+def test_rccl_transport_with_one_rank_runs_the_real_collectives(ctx):
+    d, cams, opts = scene(ctx)
+    comm = api.Comm(ctx, 0, 1, transport="rccl", rendezvous=f"127.0.0.1:{free_port()}")
+    try:
+        assert comm.transport == "rccl"
+        t = ctx.torch
+        send = t.arange(4096, dtype=t.int32, device=ctx.device)
+        out = comm.all_gather(send)
+        assert bool((out.view(t.int32) == send).all())  # ncclAllGather, one rank: the identity
+        comm.barrier()
+        # the sharded round through RCCL == the plain round
+        for method, slots in ((api.L.SCORE_ENSEMBLE_RGB_DENSITY, [0, 1, 2]), (api.L.SCORE_ENSEMBLE_RGB, [0, 1])):
+            want, _ = ctx.score_views(method, slots, cams, None, opts)
+            got, st = comm.score_views(method, slots, cams, len(cams), opts, want_stats=True)
+            assert got.tobytes() == want.tobytes() and st.samples_evaluated > 0
+        gt, _ = ctx.render(7, cams, None, api.render_opts(opts.width, opts.height, 64, 2, 0.01))
+        o5 = api.render_opts(opts.width, opts.height, 64, 2, 0.01)
+        want, _ = ctx.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cams, None, o5, gt=gt)
+        got, _ = comm.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cams, len(cams), o5, gt_shard=gt)
+        assert got.tobytes() == want.tobytes()
+        # ncclBroadcast group over the three members' buffers: one rank owns them all, nothing may change
+        before = [[a.copy() for a in ctx.export_model(e, d)] for e in range(3)]
+        comm.exchange_models(3, d)
+        for e in range(3):
+            assert all(np.array_equal(a, b) for a, b in zip(before[e], ctx.export_model(e, d)))
+    finally:
+        comm.close()
+        cams.close()
+
+
+def _comm_worker(rank, world, port, outdir):
+    """one of two processes on the one GPU: own context, socket transport"""
+    c = api.Context(0)
+    comm = api.Comm(c, rank, world, transport="socket", rendezvous=f"127.0.0.1:{port}")
+    try:
+        d, cams, opts = scene(c)
+        t = c.torch
+        # (1) raw all-gather of device buffers
+        send = t.full((1000,), rank + 1, dtype=t.int16, device=c.device)
+        out = comm.all_gather(send).view(t.int16).cpu().numpy().reshape(world, 1000)
+        assert all((out[r] == r + 1).all() for r in range(world))
+        # (2) the sharded round: ragged (11 views over 2 ranks), both shard orders
+        rec_i, st = comm.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, [0, 1, 2], cams, len(cams), opts, interleaved=True, want_stats=True)
+        rec_b, _ = comm.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, [0, 1, 2], cams, len(cams), opts, interleaved=False)
+        ids, per = api.shard_views(len(cams), rank, world, True)
+        gt, _ = c.render(7, cams, ids, api.render_opts(opts.width, opts.height, 64, 2, 0.01), want_stats=False)
+        rec_5, _ = comm.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cams, len(cams), api.render_opts(opts.width, opts.height, 64, 2, 0.01),
+                                    gt_shard=gt)
+        # (3) the ensemble exchange: every rank re-makes ITS members differently (seed by rank), then exchanges
+        for e in range(3):
+            if e % world == rank:
+                c.synthetic_model(e, d, 1000 + e)
+            else:
+                c.synthetic_model(e, d, 5)  # something else, to be overwritten
+        comm.exchange_models(3, d)
+        members = [c.export_model(e, d) for e in range(3)]
+        after, _ = c.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, [0, 1, 2], cams, None, opts)  # renders with the exchanged fields
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), rec_i=rec_i.view(np.uint8), rec_b=rec_b.view(np.uint8), rec_5=rec_5.view(np.uint8),
+                 after=after.view(np.uint8), evaluated=st.samples_evaluated,
+                 **{f"m{e}_{k}": members[e][k] for e in range(3) for k in range(3)})
+        comm.barrier()
+    finally:
+        comm.close()
+        c.close()
+
+
+def test_two_processes_on_one_gpu_shard_score_gather_and_exchange(ctx, tmp_path):
+    import torch.multiprocessing as mp
+
+    port = free_port()
+    mctx = mp.get_context("spawn")
+    procs = [mctx.Process(target=_comm_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(2))
+    # the one-process answers
+    d, cams, opts = scene(ctx)
+    want, st = ctx.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, [0, 1, 2], cams, None, opts, want_stats=True)
+    gt, _ = ctx.render(7, cams, None, api.render_opts(opts.width, opts.height, 64, 2, 0.01), want_stats=False)
+    want5, _ = ctx.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cams, None, api.render_opts(opts.width, opts.height, 64, 2, 0.01), gt=gt)
+    for r in (r0, r1):
+        assert r["rec_i"].tobytes() == want.tobytes() and r["rec_b"].tobytes() == want.tobytes()  # both shard orders, every rank
+        assert r["rec_5"].tobytes() == want5.tobytes()
+    assert int(r0["evaluated"]) + int(r1["evaluated"]) == st.samples_evaluated  # the shards evaluate exactly the whole
+    # exchanged members: bit-identical on both ranks and equal to what their owners made
+    for e in range(3):
+        ctx.synthetic_model(e, d, 1000 + e)
+        mine = ctx.export_model(e, d)
+        for k in range(3):
+            assert np.array_equal(r0[f"m{e}_{k}"], r1[f"m{e}_{k}"]) and np.array_equal(r0[f"m{e}_{k}"], mine[k])
+    after, _ = ctx.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, [0, 1, 2], cams, None, opts)
+    assert r0["after"].tobytes() == r1["after"].tobytes() == after.tobytes()  # and they RENDER the same (derived state rebuilt)
+    cams.close()
+
+
+@pytest.mark.parametrize("method", [3, 5])
+def test_planner_views_sharded_over_two_ranks_equals_the_one_process_loop(ctx, tmp_path, method):
+    """prv_planner mode 21 with `shard: views` under RANK / WORLD_SIZE / LOCAL_RANK (two processes on the one GPU, socket
+    transport): every iteration's gathered records and the chosen views are byte-identical to the one-process loop, on
+    BOTH ranks (static members: in-process training is not bit-reproducible run to run -- float atomics)."""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    runs = {}
+    for who in ("one", "two"):
+        pre = tmp_path / f"{who}_{method}"
+        pre.mkdir()
+        cfg = pre / "cfg.yaml"
+        cfg.write_text(YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=method,
+                                   model_source=f"synthetic_seed: {SEED}\npretrained_members: 1\nshard: \"views\""))
+        base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        base.update(PRV_PLANNER_DUMP_RECORDS="1")
+        if who == "one":
+            out = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300, env=base)
+            assert out.returncode == 0, out.stdout + out.stderr
+            outs = [out.stdout]
+        else:
+            port = free_port()
+            procs = []
+            for r in range(2):
+                env = dict(base, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), PRV_COMM="socket", MASTER_ADDR="127.0.0.1",
+                           PRV_COMM_PORT=str(port))
+                procs.append(subprocess.Popen([exe, str(cfg)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                              text=True, env=env))
+            res = feed_all_then_wait(procs, "21\nobjA\n-1\n")
+            for p, (so, se) in zip(procs, res):
+                assert p.returncode == 0, so + se
+            outs = [so for so, _ in res]
+            assert all("views sharded, transport socket" in so for so in outs)
+        chosen = [[int(x) for x in [l for l in so.splitlines() if l.startswith("chosen_nbvs:")][-1].split(":")[1].split()] for so in outs]
+        recs = []
+        for r in range(len(outs)):
+            root = pre if r == 0 else pre / f"rank{r}"
+            save = root / "Compare" / "ShapeNet" / f"objA_m{method}_v1_t0"
+            recs.append([(save / "records" / f"{it}.bin").read_bytes() for it in range(3)])
+        runs[who] = (chosen, recs)
+    (c1, r1), (c2, r2) = runs["one"], runs["two"]
+    assert c2[0] == c2[1] == c1[0] and len(c1[0]) == 4
+    assert r2[0] == r2[1] == r1[0] and all(len(b) == 16 * (4 - it) for it, b in enumerate(r1[0]))  # 5 views, 4..2 candidates left
+
+
+def test_planner_views_sharded_trains_its_members_on_their_owners(ctx, tmp_path):
+    """the training half in `shard: views` mode: member e is trained by rank e % 2, exchanged device-side, both ranks
+    score with the whole ensemble -- both ranks end every iteration with byte-identical records and the same views"""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    pre = tmp_path / "train_views"
+    pre.mkdir()
+    cfg = pre / "cfg.yaml"
+    text = YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=2,
+                       model_source="n_steps: 40\ntrain_rays: 1024\ntrain_width: 64\ntrain_height: 36\nground_truth_seed: 4242\nshard: \"views\"")
+    cfg.write_text(text)
+    port = free_port()
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    procs = []
+    for r in range(2):
+        env = dict(base, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), PRV_COMM="socket", MASTER_ADDR="127.0.0.1",
+                   PRV_COMM_PORT=str(port), PRV_PLANNER_DUMP_RECORDS="1", PRV_PLANNER_TIMING="1")
+        procs.append(subprocess.Popen([exe, str(cfg)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    res = feed_all_then_wait(procs, "21\nobjA\n-1\n")
+    for p, (so, se) in zip(procs, res):
+        assert p.returncode == 0, so + se
+    chosen = [[int(x) for x in [l for l in so.splitlines() if l.startswith("chosen_nbvs:")][-1].split(":")[1].split()] for so, _ in res]
+    assert chosen[0] == chosen[1] and len(set(chosen[0])) == 4
+    for it in range(3):
+        a = (pre / "Compare" / "ShapeNet" / "objA_m2_v1_t0" / "records" / f"{it}.bin").read_bytes()
+        b = (pre / "rank1" / "Compare" / "ShapeNet" / "objA_m2_v1_t0" / "records" / f"{it}.bin").read_bytes()
+        assert a == b and len(a) == 16 * (4 - it)
+        assert np.isfinite(np.frombuffer(a, api.RECORD_DTYPE)["score"]).all()
+    assert all(se.count("train_members:") == 3 for _, se in res)  # both ranks went through the training step each iteration
