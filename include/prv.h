@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PRV_ABI_VERSION 1
+#define PRV_ABI_VERSION 2 /* 2: prv_field_desc.per_level_scale */
 
 /* error codes (0 = ok, < 0 = error; message via prv_last_error) */
 #define PRV_OK 0
@@ -66,6 +66,10 @@ typedef struct prv_field_desc {
   int32_t occ_res;
   float density_bias; /* sigma = exp(out0 + density_bias) */
   float table_amp;    /* synthetic generator only: table ~ U(-amp, amp) */
+  float per_level_scale; /* 0: the levels grow geometrically from base_res to finest_res (double precision, nominal
+                            integer resolutions hit exactly).  > 0: tiny-cuda-nn's recipe in float32 -- scale_l =
+                            exp2f(l * log2f(per_level_scale)) * base_res - 1, res_l = ceilf(scale_l) + 1 -- the level
+                            geometry an imported instant-ngp snapshot was trained with; finest_res is then only a label */
 } prv_field_desc;
 
 /* render options == the knobs run.py sets on the Testbed before render():
@@ -146,6 +150,19 @@ int prv_model_export(prv_ctx* ctx, int slot, uint16_t* table, uint16_t* mlp, uin
  * ABI version, prv_field_desc, then table / mlp / occupancy arrays in the canonical layout. */
 int prv_model_save_file(prv_ctx* ctx, int slot, const char* path);
 int prv_model_load_file(prv_ctx* ctx, int slot, const char* path);
+/* replaces: testbed.load_snapshot(<file>.ingp | .msgpack) / save_snapshot (run.py:123-127, 210-211) for snapshots
+ * written by instant-ngp itself -- the weights BASELINE configs[2] names.  Reads the msgpack (gzip-compressed for
+ * .ingp) network config + "snapshot" {params_binary fp16, density_grid_binary, nerf.aabb_scale}, maps tiny-cuda-nn's
+ * parameter order (density MLP | rgb MLP | hash grid; FullyFusedMLP matrices [out][in], outputs padded to 16) to the
+ * canonical layout above and the density grid (Morton order, optical thickness) to the occupancy bits; the level
+ * geometry follows the file's per_level_scale (prv_field_desc.per_level_scale).  Anything this build cannot
+ * represent is refused with PRV_E_INVALID and a message (aabb_scale != 1, L*F != 32, other MLP shapes, ...).
+ * LAYOUT ASSUMED FROM UPSTREAM, UNPINNED: neither instant-ngp nor a snapshot exists in the reference tree or the
+ * build container; save_ingp is the exact inverse and the pair is tested against an independent Python writer. */
+int prv_model_load_ingp(prv_ctx* ctx, int slot, const char* path);
+int prv_model_save_ingp(prv_ctx* ctx, int slot, const char* path);
+/* the descriptor of the field in a slot (e.g. of a snapshot just loaded) */
+int prv_model_desc(prv_ctx* ctx, int slot, prv_field_desc* out);
 
 /* ---- cameras ------------------------------------------------------------- */
 /* replaces: json.load(--screenshot_transforms) + set_nerf_camera_matrix + fov from

@@ -105,6 +105,16 @@ int prvh_png_size(const char* path, int* width, int* height);
 int prvh_png_read_rgba8(const char* path, int width, int height, uint8_t* out_rgba8);
 int prvh_png_write_rgba8(const char* path, int width, int height, const uint8_t* rgba8);
 
+/* ---- instant-ngp snapshots on the host (nerf_prv_amd/csrc/prv_ingp.hpp; what prv_model_load_ingp / save_ingp of
+ * include/prv.h do, minus the GPU): <file>.ingp | .msgpack <-> descriptor + canonical arrays.  desc points at a
+ * prv_field_desc (include/prv.h).  Read: call once with NULL arrays for the sizes, then with arrays of those sizes.
+ * 0, or PRV_E_IO (-3) unreadable / malformed, PRV_E_INVALID (-1) not representable; message in err (may be NULL). */
+struct prv_field_desc;
+int prvh_ingp_read(const char* path, struct prv_field_desc* desc, uint64_t* n_table_halfs, uint64_t* n_occ_words,
+                   uint16_t* table, uint16_t* mlp, uint32_t* occ, char* err, int err_cap);
+int prvh_ingp_write(const char* path, const struct prv_field_desc* desc, const uint16_t* table, uint64_t n_table_halfs,
+                    const uint16_t* mlp, const uint32_t* occ, uint64_t n_occ_words, char* err, int err_cap);
+
 /* ---- the TCP star between the ranks of one job (nerf_prv_amd/csrc/prv_star.hpp) ----
  * the rendezvous of prv_comm (it carries rank 0's ncclUniqueId to the other ranks) and the host-staged `socket`
  * transport behind the same calls; exposed here so it can be exercised without a GPU.  Rank 0 listens on addr:port

@@ -35,6 +35,7 @@ class FieldDesc(C.Structure):
         ("occ_res", C.c_int32),
         ("density_bias", C.c_float),
         ("table_amp", C.c_float),
+        ("per_level_scale", C.c_float),
     ]
 
 
@@ -105,6 +106,9 @@ SIGNATURES = {
     "prv_model_fresh": (_i, [_vp, _i, _P(FieldDesc), C.c_uint64]),
     "prv_model_export": (_i, [_vp, _i, _vp, _vp, _vp]),
     "prv_model_save_file": (_i, [_vp, _i, C.c_char_p]),
+    "prv_model_load_ingp": (_i, [_vp, _i, C.c_char_p]),
+    "prv_model_save_ingp": (_i, [_vp, _i, C.c_char_p]),
+    "prv_model_desc": (_i, [_vp, _i, C.POINTER(FieldDesc)]),
     "prv_model_load_file": (_i, [_vp, _i, C.c_char_p]),
     "prv_cameras_from_json": (_i, [_vp, C.c_char_p, _P(_vp)]),
     "prv_cameras_from_matrices": (_i, [_vp, _vp, _i, C.c_double, _i, _i, C.c_double, _vp, _P(_vp)]),

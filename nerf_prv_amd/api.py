@@ -188,6 +188,19 @@ class Context:
     def load_model_file(self, slot, path):
         self._chk(self.lib.prv_model_load_file(self.handle, slot, str(path).encode()))
 
+    def load_ingp(self, slot, path):
+        """an instant-ngp snapshot (.ingp / .msgpack) -> slot; returns its FieldDesc"""
+        self._chk(self.lib.prv_model_load_ingp(self.handle, slot, str(path).encode()))
+        return self.model_desc(slot)
+
+    def save_ingp(self, slot, path):
+        self._chk(self.lib.prv_model_save_ingp(self.handle, slot, str(path).encode()))
+
+    def model_desc(self, slot):
+        d = L.FieldDesc()
+        self._chk(self.lib.prv_model_desc(self.handle, slot, C.byref(d)))
+        return d
+
     # -- cameras
     def cameras_from_json(self, path):
         h = C.c_void_p()
@@ -649,12 +662,19 @@ class Testbed:
         self._drop_trainer()
 
     def load_snapshot(self, path):  # run.py:127
-        self.ctx.load_model_file(self._slot, path)
+        """instant-ngp's own snapshots (.ingp / .msgpack) or this build's .prvf"""
+        if str(path).lower().endswith((".ingp", ".msgpack")):
+            self.ctx.load_ingp(self._slot, path)
+        else:
+            self.ctx.load_model_file(self._slot, path)
         self._have_model = True
         self._drop_trainer()
 
     def save_snapshot(self, path, include_optimizer_state=False):  # run.py:211
-        self.ctx.save_model(self._slot, path)
+        if str(path).lower().endswith((".ingp", ".msgpack")):
+            self.ctx.save_ingp(self._slot, path)
+        else:
+            self.ctx.save_model(self._slot, path)
 
     def set_nerf_camera_matrix(self, m):
         m = np.asarray(m, np.float64)

@@ -49,10 +49,10 @@ def build_hip(force=False):
     out = os.path.join(HERE, "libprv_hip.so")
     srcs = [os.path.join(CSRC, f) for f in ("prv_kernels.hip", "prv_train.hip", "prv_api.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("prv_device.hpp", "prv_kernels.hpp", "prv_json.hpp", "prv_train.hpp",
-                                                   "prv_train_api.inc", "prv_comm_api.inc", "prv_star.hpp")] + [
+                                                   "prv_train_api.inc", "prv_comm_api.inc", "prv_star.hpp", "prv_levels.hpp", "prv_ingp.hpp")] + [
         os.path.join(ROOT, "include", "prv.h")]
     if force or _newer(out, deps):
-        _run([hipcc()] + HIP_FLAGS + ["-o", out] + srcs + ["-ldl"])  # librccl itself is dlopen'ed (prv_comm_api.inc)
+        _run([hipcc()] + HIP_FLAGS + ["-o", out] + srcs + ["-ldl", "-lz"])  # zlib: .ingp snapshots; librccl itself is dlopen'ed (prv_comm_api.inc)
     return out
 
 
@@ -62,7 +62,8 @@ def build_host(force=False):
     out = os.path.join(HERE, "libprv_host.so")
     srcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".cpp") and f != "main.cpp")
     deps = srcs + [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [
-        os.path.join(CSRC, "prv_json.hpp"), os.path.join(CSRC, "prv_star.hpp"), os.path.join(ROOT, "include", "prv.h"),
+        os.path.join(CSRC, "prv_json.hpp"), os.path.join(CSRC, "prv_star.hpp"), os.path.join(CSRC, "prv_ingp.hpp"),
+        os.path.join(CSRC, "prv_levels.hpp"), os.path.join(ROOT, "include", "prv.h"),
         os.path.join(ROOT, "include", "prv_host.h")]
     deps = [d for d in deps if os.path.exists(d)]
     if srcs and (force or _newer(out, deps)):

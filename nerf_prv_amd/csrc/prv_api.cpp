@@ -18,6 +18,8 @@
 
 #include "prv_json.hpp"
 #include "prv_kernels.hpp"
+#include "prv_levels.hpp"
+#include "prv_ingp.hpp"
 #include "prv_train.hpp"
 
 using namespace prv;
@@ -138,39 +140,7 @@ void release(Buffer& b) {
   b.bytes = 0;
 }
 
-// ---- level table (same published recipe as the oracle, written independently)
-struct HostLevel {
-  float scale;
-  uint32_t res, offset, size, hashed;
-};
-
-int compute_levels(const prv_field_desc& d, HostLevel* lv, uint64_t* total) {
-  if (d.n_levels < 1 || d.n_levels > kMaxLevels) return -1;
-  if (d.n_features != 2 && d.n_features != 4) return -1;
-  if (d.n_levels * d.n_features != 32) return -1;
-  if (d.log2_hashmap < 4 || d.log2_hashmap > 28) return -1;
-  if (d.base_res < 2 || d.finest_res < d.base_res || d.finest_res > 4096) return -1;
-  if (d.occ_res < 1 || d.occ_res > 1024) return -1;
-  const double growth =
-      d.n_levels > 1 ? std::exp((std::log((double)d.finest_res) - std::log((double)d.base_res)) / (d.n_levels - 1)) : 1.0;
-  const uint64_t T = 1ull << d.log2_hashmap;
-  uint64_t off = 0;
-  for (int l = 0; l < d.n_levels; l++) {
-    double s = (double)d.base_res * std::pow(growth, (double)l) - 1.0;
-    const double nearest = std::floor(s + 0.5);
-    if (std::fabs(s - nearest) < 1e-9) s = nearest;
-    lv[l].scale = (float)s;
-    lv[l].res = (uint32_t)std::ceil(s) + 1u;
-    const uint64_t dense = (uint64_t)lv[l].res * lv[l].res * lv[l].res;
-    lv[l].hashed = dense > T;
-    lv[l].size = lv[l].hashed ? (uint32_t)T : (uint32_t)((dense + 7) & ~7ull);
-    lv[l].offset = (uint32_t)off;
-    off += lv[l].size;
-  }
-  if (off * (uint64_t)d.n_features * 2ull >= (1ull << 32)) return -1; // 32-bit byte offsets in the gather
-  *total = off;
-  return 0;
-}
+static_assert(kMaxFieldLevels == kMaxLevels, "level tables of the host and the kernels must agree");
 
 // ---- MFMA A-fragment prepack.  Canonical weights W[layer][in][out] (fp16 bits).
 // Fragment (layer, mt, s): lane (r,h), element j = W[kmap(s,h,j)][32*mt + r], zero past n_out.
@@ -367,6 +337,7 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
     LevelDev& L = f.levels[l];
     L.scale = lv[l].scale;
     L.res_m1 = lv[l].res - 1;
+    if (lv[l].res > 4096) return fail(c, PRV_E_INVALID, "level %d has %u vertices per axis (limit 4096)", l, lv[l].res);
     if (lv[l].hashed && !dehash[l]) { // the kernel multiplies with v_mul_u32_u24: keep the low 24 bits
       L.my_b = (2654435761u * ebytes) & 0xffffffu;
       L.mz_b = (805459861u * ebytes) & 0xffffffu;
@@ -898,6 +869,42 @@ int prv_model_load_file(prv_ctx* c, int slot, const char* path) try {
   fclose(f);
   if (!ok) return fail(c, PRV_E_IO, "%s is truncated", path);
   return prv_model_load(c, slot, &d, table.data(), mlp.data(), occ.data());
+} catch (...) { return caught(c); }
+
+int prv_model_load_ingp(prv_ctx* c, int slot, const char* path) try {
+  if (!c) return PRV_E_INVALID;
+  if (!path) return fail(c, PRV_E_INVALID, "path is NULL");
+  prvingp::Field f;
+  std::string err;
+  const int rc = prvingp::read_snapshot(path, f, err);
+  if (rc != 0) return fail(c, rc, "instant-ngp snapshot %s: %s", path, err.c_str());
+  return prv_model_load(c, slot, &f.desc, f.table.data(), f.mlp.data(), f.occ.data());
+} catch (...) { return caught(c); }
+
+int prv_model_save_ingp(prv_ctx* c, int slot, const char* path) try {
+  if (!c) return PRV_E_INVALID;
+  int rc = check_model(c, slot);
+  if (rc != PRV_OK) return rc;
+  if (!path) return fail(c, PRV_E_INVALID, "path is NULL");
+  const Model& m = c->models[slot];
+  prvingp::Field f;
+  f.desc = m.desc;
+  f.table.resize(m.table_halfs);
+  f.mlp.resize(PRV_MLP_HALFS);
+  f.occ.resize(m.occ_words);
+  if ((rc = prv_model_export(c, slot, f.table.data(), f.mlp.data(), f.occ.data())) != PRV_OK) return rc;
+  std::string err;
+  rc = prvingp::write_snapshot(path, f, err);
+  return rc == 0 ? PRV_OK : fail(c, rc, "instant-ngp snapshot %s: %s", path, err.c_str());
+} catch (...) { return caught(c); }
+
+int prv_model_desc(prv_ctx* c, int slot, prv_field_desc* out) try {
+  if (!c) return PRV_E_INVALID;
+  int rc = model_present(c, slot);
+  if (rc != PRV_OK) return rc;
+  if (!out) return fail(c, PRV_E_INVALID, "out is NULL");
+  *out = c->models[slot].desc;
+  return PRV_OK;
 } catch (...) { return caught(c); }
 
 // ------------------------------------------------------------------ cameras

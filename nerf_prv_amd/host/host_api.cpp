@@ -10,6 +10,7 @@
 #include "pcd_io.hpp"
 #include "png_io.hpp"
 #include "../csrc/prv_star.hpp"
+#include "../csrc/prv_ingp.hpp"
 
 using namespace prvhost;
 
@@ -300,6 +301,43 @@ int prvh_nbv_loop_budget(prvh_share_data* h, const double center[3], double pred
   return rc;
 } catch (...) { return PRVH_E_INTERNAL; }
 
+
+static void put_err(char* err, int cap, const std::string& m) {
+  if (err && cap > 0) snprintf(err, (size_t)cap, "%s", m.c_str());
+}
+
+int prvh_ingp_read(const char* path, prv_field_desc* desc, uint64_t* n_table, uint64_t* n_occ, uint16_t* table, uint16_t* mlp,
+                   uint32_t* occ, char* err, int err_cap) try {
+  if (!path) return -1;
+  prvingp::Field f;
+  std::string m;
+  const int rc = prvingp::read_snapshot(path, f, m);
+  if (rc != 0) {
+    put_err(err, err_cap, m);
+    return rc;
+  }
+  if (desc) *desc = f.desc;
+  if (n_table) *n_table = f.table.size();
+  if (n_occ) *n_occ = f.occ.size();
+  if (table) memcpy(table, f.table.data(), f.table.size() * 2);
+  if (mlp) memcpy(mlp, f.mlp.data(), f.mlp.size() * 2);
+  if (occ) memcpy(occ, f.occ.data(), f.occ.size() * 4);
+  return 0;
+} catch (...) { return PRVH_E_INTERNAL; }
+
+int prvh_ingp_write(const char* path, const prv_field_desc* desc, const uint16_t* table, uint64_t n_table, const uint16_t* mlp,
+                    const uint32_t* occ, uint64_t n_occ, char* err, int err_cap) try {
+  if (!path || !desc || !table || !mlp || !occ) return -1;
+  prvingp::Field f;
+  f.desc = *desc;
+  f.table.assign(table, table + n_table);
+  f.mlp.assign(mlp, mlp + prvingp::kMlpHalfs);
+  f.occ.assign(occ, occ + n_occ);
+  std::string m;
+  const int rc = prvingp::write_snapshot(path, f, m);
+  if (rc != 0) put_err(err, err_cap, m);
+  return rc;
+} catch (...) { return PRVH_E_INTERNAL; }
 
 prvh_star* prvh_star_open(int rank, int world, const char* addr, int port, double timeout_s) try {
   std::unique_ptr<prvh_star> h(new prvh_star());

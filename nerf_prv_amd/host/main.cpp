@@ -284,6 +284,7 @@ prv_field_desc field_from_config(const FileStorage& fs) {
   d.occ_res = (int)get("field_occ_res", 128);
   d.density_bias = (float)get("field_density_bias", 3.0);
   d.table_amp = (float)get("synthetic_table_amp", 4.0);
+  d.per_level_scale = (float)get("field_per_level_scale", 0.0); // > 0: tiny-cuda-nn's level recipe (include/prv.h)
   return d;
 }
 
@@ -307,7 +308,17 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   for (int e = 0; e < members && train_steps == 0; e++) {
     int rc;
     if (fs.has("synthetic_seed")) rc = prv_model_synthetic(ctx, e, &desc, (uint64_t)fs.num("synthetic_seed") + (uint64_t)e);
-    else rc = prv_model_load_file(ctx, e, (sd->model_path + name + "/member_" + std::to_string(e) + ".prvf").c_str());
+    else { // <model_path>/<object>/member_<e>.prvf, or the instant-ngp snapshot of the same name (.ingp / .msgpack)
+      const std::string stem = sd->model_path + name + "/member_" + std::to_string(e);
+      rc = PRV_E_IO;
+      for (const char* ext : {".prvf", ".ingp", ".msgpack"}) {
+        if (!std::ifstream(stem + ext).is_open()) continue;
+        rc = std::string(ext) == ".prvf" ? prv_model_load_file(ctx, e, (stem + ext).c_str()) : prv_model_load_ingp(ctx, e, (stem + ext).c_str());
+        break;
+      }
+      if (rc == PRV_E_IO && !std::ifstream(stem + ".prvf").is_open() && !std::ifstream(stem + ".ingp").is_open() && !std::ifstream(stem + ".msgpack").is_open())
+        rc = prv_model_load_file(ctx, e, (stem + ".prvf").c_str()); // for its error message
+    }
     if (rc != PRV_OK) {
       std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
       return rc;

@@ -57,6 +57,8 @@ HOST_SIGNATURES = {
     "prvh_png_size": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
     "prvh_png_read_rgba8": (_i, [C.c_char_p, _i, _i, _vp]),
     "prvh_png_write_rgba8": (_i, [C.c_char_p, _i, _i, _vp]),
+    "prvh_ingp_read": (_i, [C.c_char_p, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _vp, _vp, _vp, C.c_char_p, _i]),
+    "prvh_ingp_write": (_i, [C.c_char_p, _vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_char_p, _i]),
     "prvh_star_open": (_vp, [_i, _i, C.c_char_p, _i, _d]),
     "prvh_star_close": (None, [_vp]),
     "prvh_star_all_gather": (_i, [_vp, _vp, C.c_uint64, _vp]),
@@ -195,6 +197,30 @@ def png_write(path, rgba8):
     rc = host().prvh_png_write_rgba8(str(path).encode(), a.shape[1], a.shape[0], _p(a))
     if rc != 0:
         raise IOError(f"{path}: png error {rc}")
+
+
+def ingp_read(path):
+    """instant-ngp snapshot (.ingp / .msgpack) -> (FieldDesc, table u16, mlp u16, occ u32), canonical layout; no GPU"""
+    d = L.FieldDesc()
+    nt, no = C.c_uint64(), C.c_uint64()
+    err = C.create_string_buffer(512)
+    rc = host().prvh_ingp_read(str(path).encode(), C.byref(d), C.byref(nt), C.byref(no), None, None, None, err, 512)
+    if rc != 0:
+        raise (ValueError if rc == L.PRV_E_INVALID else IOError)(f"{path}: {err.value.decode()} (rc={rc})")
+    table, mlp, occ = np.zeros(nt.value, np.uint16), np.zeros(L.MLP_HALFS, np.uint16), np.zeros(no.value, np.uint32)
+    rc = host().prvh_ingp_read(str(path).encode(), C.byref(d), None, None, _p(table), _p(mlp), _p(occ), err, 512)
+    if rc != 0:
+        raise IOError(f"{path}: {err.value.decode()} (rc={rc})")
+    return d, table, mlp, occ
+
+
+def ingp_write(path, desc, table, mlp, occ):
+    table, mlp, occ = (np.ascontiguousarray(table, np.uint16), np.ascontiguousarray(mlp, np.uint16),
+                       np.ascontiguousarray(occ, np.uint32))
+    err = C.create_string_buffer(512)
+    rc = host().prvh_ingp_write(str(path).encode(), C.byref(desc), _p(table), table.size, _p(mlp), _p(occ), occ.size, err, 512)
+    if rc != 0:
+        raise (ValueError if rc == L.PRV_E_INVALID else IOError)(f"{path}: {err.value.decode()} (rc={rc})")
 
 
 def local_path(M, N, O, r):

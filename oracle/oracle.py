@@ -17,7 +17,7 @@ MAX_LEVELS = 16
 
 class FieldDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in "n_levels n_features log2_hashmap base_res finest_res occ_res".split()] + [
-        ("density_bias", C.c_float), ("table_amp", C.c_float)]
+        ("density_bias", C.c_float), ("table_amp", C.c_float), ("per_level_scale", C.c_float)]
 
 
 class Level(C.Structure):

@@ -145,12 +145,21 @@ int orc_field_levels(const orc_field_desc* d, orc_level* out, uint32_t* total) {
   uint64_t T = 1ull << d->log2_hashmap;
   uint32_t off = 0;
   for (int l = 0; l < d->n_levels; l++) {
-    double s = (double)d->base_res * pow(b, (double)l) - 1.0;
-    /* guard pow() round-off so the nominal integer resolutions are hit exactly */
-    double sr = floor(s + 0.5);
-    if (fabs(s - sr) < 1e-9) s = sr;
-    out[l].scale = (float)s;
-    uint32_t res = (uint32_t)ceil(s) + 1u;
+    uint32_t res;
+    if (d->per_level_scale > 0.0f) {
+      /* tiny-cuda-nn grid.h: scale = exp2f(level * log2f(per_level_scale)) * base_resolution - 1.0f (float32),
+       * resolution = ceilf(scale) + 1 */
+      float sc = exp2f((float)l * log2f(d->per_level_scale)) * (float)d->base_res - 1.0f;
+      out[l].scale = sc;
+      res = (uint32_t)ceilf(sc) + 1u;
+    } else {
+      double s = (double)d->base_res * pow(b, (double)l) - 1.0;
+      /* guard pow() round-off so the nominal integer resolutions are hit exactly */
+      double sr = floor(s + 0.5);
+      if (fabs(s - sr) < 1e-9) s = sr;
+      out[l].scale = (float)s;
+      res = (uint32_t)ceil(s) + 1u;
+    }
     out[l].res = res;
     uint64_t dense = (uint64_t)res * res * res;
     if (dense <= T) {

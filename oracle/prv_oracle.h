@@ -43,6 +43,8 @@ typedef struct {
   int32_t occ_res;      /* occupancy grid resolution (cells per axis) */
   float density_bias;   /* sigma = exp(out0 + density_bias) */
   float table_amp;      /* synthetic table ~ U(-amp, amp) */
+  float per_level_scale; /* 0: geometric growth base_res -> finest_res in double; > 0: tiny-cuda-nn's float32 recipe
+                            (grid.h grid_scale / grid_resolution), the geometry of an imported instant-ngp snapshot */
 } orc_field_desc;
 
 typedef struct {

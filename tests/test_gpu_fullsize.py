@@ -32,8 +32,7 @@ def test_rows_of_a_full_size_view_match_the_oracle(ctx, oracle, scene):
     ocam = oracle.cameras_from_transforms(tms, util.FOV_X, W, H, scale, offset)[3]
     rows = (396, 404)
     want, _ = f.render(ocam, W, H, S, 1, 1e-4, threads=8, rows=rows)
-    err = np.abs(img[rows[0]:rows[1]] - want[rows[0]:rows[1]])
-    assert err.max() <= 1e-3  # north_star tolerance, pixels in [0,1]
+    util.assert_pixels_close(img[rows[0]:rows[1]], want[rows[0]:rows[1]])  # north_star: 1e-3 relative (floor: tests/util.py)
     assert want[rows[0]:rows[1], :, 3].max() > 0.5  # the rows do cross the object
 
 

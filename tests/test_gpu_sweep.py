@@ -68,6 +68,11 @@ def test_random_render_case(ctx, oracle, case_id):
         want, ne = f.render(oc, w, h, case["S"], case["spp"], case["min_T"])
         n_eval += ne
         assert np.abs(img[v] - want).max() <= PIX_ATOL, (case, v, float(np.abs(img[v] - want).max()))
+        # north_star's RELATIVE 1e-3 (floor 1/255, tests/util.py) wherever no ray stops on a different sample than the
+        # oracle's: with min_T up to 0.3 in this sweep one extra / missing sample legitimately moves a pixel by up to
+        # min_T, so the relative bar applies to the cases that march to 1e-4
+        if case["min_T"] <= 1e-4:
+            util.assert_pixels_close(img[v], want)
     assert abs(int(st.samples_evaluated) - n_eval) <= max(2, n_eval // 10000), (case, int(st.samples_evaluated), n_eval)
     assert st.rays == len(ocams) * w * h * case["spp"]
     cs.close()
