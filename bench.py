@@ -35,7 +35,8 @@ if ROOT not in sys.path:
 SEED_A, SEED_B = 0x5EED0001, 0x5EED0002
 BYTES_PER_SAMPLE = 512   # L*8 corners*F*2 B = 8*8*4*2 = 16*8*2*2: hash-table gather per field evaluation
 FLOP_PER_SAMPLE = 20480  # 10,240 MAC of the two MLPs
-MFMA_PER_ROUND = 24      # v_mfma_f32_32x32x16_f16 per 32-sample wave-round (prv_device.hpp: mlp_forward)
+MFMA_PER_ROUND = 24      # v_mfma_f32_32x32x16_f16 per 32-slot round (prv_device.hpp: mlp_forward / mlp_forward2; the 64-slot
+                         # kernel counts a wave iteration as two rounds)
 # peaks, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0        # 8 TB/s spec
 L2_PEAK_GBS = 34500.0        # aggregate L2, ~34.5 TB/s
@@ -277,7 +278,7 @@ def kernel_figures(m, variant, hbm_bound):
     valu_frac = valu_ginst / VALU_PEAK_GINST if cost else None
     traffic = (load_json(TRAFFIC_FILE) or {}).get(variant)
     out = {
-        "kernel": "render_queue_kernel" + variant,
+        "kernel": "render_queue" + variant.replace("<", "_kernel<", 1),
         "units_per_launch": samples,
         "wave_rounds_per_launch": rounds,
         "slot_utilisation": samples / max(1.0, 32.0 * rounds),
@@ -396,8 +397,9 @@ def run_rank(args):
             kw.update(table_amp=0.1, density_bias=0.0)
         return kw
 
-    def variant_of(field):
-        return "<4, 2>" if field == "256" else "<2, 5>"
+    def variant_of(slot):
+        lay = ctx.model_layout(slot)
+        return f"{64 if lay['kernel_slots'] == 64 else ''}<{lay['kernel_features']}, {lay['kernel_pair_steps']}>"
 
     n_views = args.views_per_gpu * world if args.mode == "weak" else args.views_total
     fkw = field_kw(args.field, args.scene)
@@ -427,7 +429,7 @@ def run_rank(args):
                 "value": mm["ev_all"] * mm["steps"] / mm["elapsed"], "unit": "ray-samples/s", "steps": mm["steps"],
                 "ms_per_step": mm["elapsed"] / mm["steps"] * 1e3,
                 "samples_evaluated_per_step": mm["st"].samples_evaluated,
-                "roofline": kernel_figures(mm, variant_of("512"), hbm_bound=True),
+                "roofline": kernel_figures(mm, variant_of(2), hbm_bound=True),
             }
             r.close()
         # (2) the scene BASELINE.md section 6 specifies literally (table U(-0.1,0.1), no density bias): rays do not
@@ -441,7 +443,7 @@ def run_rank(args):
                 "ms_per_step": mm["elapsed"] / mm["steps"] * 1e3,
                 "samples_evaluated_per_step": mm["st"].samples_evaluated,
                 "samples_per_ray": mm["st"].samples_evaluated / max(1, mm["st"].rays),
-                "roofline": kernel_figures(mm, variant_of(args.field), hbm_bound=args.field == "512"),
+                "roofline": kernel_figures(mm, variant_of(2), hbm_bound=args.field == "512"),
             }
             r.close()
 
@@ -487,7 +489,7 @@ def run_rank(args):
         tcams.close()
 
     if rank == 0:
-        roof = kernel_figures(m, variant_of(args.field), hbm_bound=args.field == "512")
+        roof = kernel_figures(m, variant_of(0), hbm_bound=args.field == "512")
         out = {
             "metric": "ray-samples/s (field evaluations composited; candidate views rendered + scored)",
             "value": m["ev_all"] * k / elapsed,

@@ -374,8 +374,10 @@ typedef struct prv_model_layout {
   uint64_t table_bytes_physical;  /* kernel layout: power-of-two strides on the dense levels, size-aligned levels */
   int32_t n_pair_steps;           /* leading gather steps whose two levels are dense (x-neighbour pairs in one load) */
   int32_t kernel_features;        /* F of the instance */
-  int32_t kernel_pair_steps;      /* NPAIR of the instance */
+  int32_t kernel_pair_steps;      /* 32-slot kernel: NPAIR of the instance; 64-slot kernel: NDENSE of the instance */
   int32_t n_hashed_levels;
+  int32_t kernel_slots;           /* ray slots per wave of the render kernel: 64 (render_queue64_kernel) or 32 */
+  int32_t n_dense_levels;         /* leading physically dense levels */
 } prv_model_layout;
 int prv_debug_model_layout(prv_ctx* ctx, int model_slot, prv_model_layout* out);
 /* rays of view i at (w,h): o,d = n*3, t = n*2 (AABB entry/exit; exit<=entry => miss) */

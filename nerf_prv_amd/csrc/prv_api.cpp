@@ -43,7 +43,7 @@ struct Model {
   FieldDev dev{};
   uint64_t table_halfs = 0, occ_words = 0;
   float occ_lo[3] = {0, 0, 0}, occ_hi[3] = {1, 1, 1};
-  Buffer table, phys, occ, occ_coarse, frags, mlp; // table/mlp = canonical (ABI) copies kept for export; phys = kernel layout
+  Buffer table, phys, occ, occ_coarse, frags, frags64, mlp; // table/mlp = canonical (ABI) copies kept for export; phys = kernel layout
 };
 
 } // namespace
@@ -74,6 +74,8 @@ struct prv_ctx {
   int refill_min = 32;
   std::vector<struct prv_trainer*> trainers; // live trainers of this context (detached by prv_destroy)
   int queue_segments = 8; // ray-queue segments = XCDs (PRV_QUEUE_SEGMENTS: 1 = single shared head)
+  int render64 = 1;       // render_queue64_kernel (64 ray slots per wave); PRV_RENDER64=0: the 32-slot kernel
+  int merge_max = -1;     // render_queue64 tail merge threshold (PRV_MERGE_MAX; 0 = off; -1 = by table size, see render_views)
   int dbg_flags = 0;
   size_t stage_budget = (size_t)4 << 30; // staging bytes for multi-sample renders (spp x batch x image)
   size_t dehash_budget = 0; // bytes per hashed level allowed for a physically dense copy (0 = keep hashed)
@@ -151,13 +153,18 @@ const int kOff[5] = {0, 2048, 3072, 5120, 9216};
 // hidden unit held by element j of lane half h in k-step s of a 64-wide activation
 inline int hidden_k(int s, int h, int j) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
 
-void prepack_fragments(const uint16_t* mlp, int n_features, std::vector<uint16_t>& frags) {
+// v64 = the fragment set of render_queue64: first-layer k rows in canonical feature order (the lane gathers every
+// level of its own sample), and the units the compositing needs repeated in padding rows that land in lane half 1:
+// density layer 2's unit 0 at row 20 (register 8), colour layer 3's units 0..2 at rows 20..22 (registers 8..10).
+void prepack_fragments(const uint16_t* mlp, int n_features, std::vector<uint16_t>& frags, bool v64 = false) {
   frags.assign((size_t)kNumFrags * kFragHalfs, 0);
   int f = 0;
   auto emit = [&](int layer, int mt, int s, int (*kmap)(int, int, int)) {
     uint16_t* dst = frags.data() + (size_t)f * kFragHalfs;
     for (int lane = 0; lane < 64; lane++) {
-      const int r = lane & 31, h = lane >> 5, out = 32 * mt + r;
+      const int r = lane & 31, h = lane >> 5;
+      int out = 32 * mt + r;
+      if (v64 && (layer == 1 || layer == 4) && out >= 20 && out < 20 + (layer == 1 ? 1 : 3)) out -= 20;
       for (int j = 0; j < 8; j++) {
         const int k = kmap(s, h, j);
         dst[lane * 8 + j] = out < kOut[layer] ? mlp[kOff[layer] + k * kOut[layer] + out] : (uint16_t)0;
@@ -169,8 +176,10 @@ void prepack_fragments(const uint16_t* mlp, int n_features, std::vector<uint16_t
   auto k_feat4 = [](int s, int h, int j) { return 4 * (2 * (s * 2 + j / 4) + h) + j % 4; };
   auto k_feat2 = [](int s, int h, int j) { return 2 * (2 * (s * 4 + j / 2) + h) + j % 2; };
   auto k_rgb_in = [](int s, int h, int j) { return s == 0 ? hidden_k(0, h, j) : 16 + 8 * h + j; }; // [dens | SH]
+  auto k_canon = [](int s, int h, int j) { return 16 * s + 8 * h + j; };
   for (int mt = 0; mt < 2; mt++)
-    for (int s = 0; s < 2; s++) emit(0, mt, s, n_features == 4 ? (int (*)(int, int, int))k_feat4 : (int (*)(int, int, int))k_feat2);
+    for (int s = 0; s < 2; s++)
+      emit(0, mt, s, v64 ? (int (*)(int, int, int))k_canon : n_features == 4 ? (int (*)(int, int, int))k_feat4 : (int (*)(int, int, int))k_feat2);
   for (int s = 0; s < 4; s++) emit(1, 0, s, hidden_k);
   for (int mt = 0; mt < 2; mt++)
     for (int s = 0; s < 2; s++) emit(2, mt, s, k_rgb_in);
@@ -215,6 +224,7 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   if ((rc = ensure(c, m.table, m.table_halfs * 2)) != PRV_OK) return rc;
   if ((rc = ensure(c, m.occ, m.occ_words * 4)) != PRV_OK) return rc;
   if ((rc = ensure(c, m.frags, (size_t)kNumFrags * kFragHalfs * 2)) != PRV_OK) return rc;
+  if ((rc = ensure(c, m.frags64, (size_t)kNumFrags * kFragHalfs * 2)) != PRV_OK) return rc;
   if ((rc = ensure(c, m.mlp, PRV_MLP_HALFS * 2)) != PRV_OK) return rc;
   if (table_host) HIPCHK(c, hipMemcpyAsync(m.table.p, table_host, m.table_halfs * 2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(m.occ.p, occ_host, m.occ_words * 4, hipMemcpyHostToDevice, c->stream));
@@ -273,9 +283,11 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
     if ((rc = ensure(c, m.occ_coarse, coarse.size() * 4)) != PRV_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(m.occ_coarse.p, coarse.data(), coarse.size() * 4, hipMemcpyHostToDevice, c->stream));
   }
-  std::vector<uint16_t> frags;
+  std::vector<uint16_t> frags, frags64;
   prepack_fragments(mlp, d.n_features, frags);
+  prepack_fragments(mlp, d.n_features, frags64, true);
   HIPCHK(c, hipMemcpyAsync(m.frags.p, frags.data(), frags.size() * 2, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(m.frags64.p, frags64.data(), frags64.size() * 2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(m.mlp.p, mlp, PRV_MLP_HALFS * 2, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream)); // host staging vectors go out of scope
   // ---- physical layout: power-of-two strides for dense levels, size-aligned level offsets
@@ -287,15 +299,15 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   for (int l = 0; l < d.n_levels; l++) {
     order[l] = l;
     // a hashed level may be STORED densely (coherent gathers) when that fits the budget
-    const uint32_t sxl = ceil_log2(lv[l].res + 1); // +1: room for the duplicated border entry
-    const uint64_t dense_entries = 1ull << (3 * sxl); // >= pow2 ceiling of res << 2sx
+    const uint32_t sxl = ceil_log2(lv[l].res + 1); // +1: room for the duplicated border vertex / row / plane
+    const uint64_t dense_entries = 1ull << (3 * sxl); // >= pow2 ceiling of (res + 1) << 2sx
     dehash[l] = lv[l].hashed && sxl <= 9 && dense_entries * ebytes <= c->dehash_budget;
     if (lv[l].hashed && !dehash[l]) {
       sx[l] = 0;
       psize[l] = lv[l].size;
     } else {
       sx[l] = sxl;
-      psize[l] = 1u << ceil_log2(lv[l].res << (2 * sx[l]));
+      psize[l] = 1u << ceil_log2((lv[l].res + 1u) << (2 * sx[l])); // res + 1 planes: the last one is duplicated
     }
   }
   std::stable_sort(order, order + d.n_levels, [&](int a, int b) { return psize[a] > psize[b]; });
@@ -318,6 +330,8 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   f.occ = (const uint32_t*)m.occ.p;
   f.occ_coarse = (d.occ_res % 4 == 0 && d.occ_res >= 8) ? (const uint32_t*)m.occ_coarse.p : nullptr;
   f.frags = (const half8*)m.frags.p;
+  f.frags64 = (const half8*)m.frags64.p;
+  f.render64 = c->render64;
   f.n_levels = d.n_levels;
   f.n_features = d.n_features;
   f.occ_res = d.occ_res;
@@ -333,6 +347,9 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
          (!lv[2 * f.n_pair_steps + 1].hashed || dehash[2 * f.n_pair_steps + 1]))
     f.n_pair_steps++;
   if (getenv("PRV_NO_PAIR")) f.n_pair_steps = 0;
+  f.n_dense_levels = 0;
+  while (f.n_dense_levels < d.n_levels && (!lv[f.n_dense_levels].hashed || dehash[f.n_dense_levels])) f.n_dense_levels++;
+  if (getenv("PRV_NO_PAIR")) f.n_dense_levels = 0;
   for (int l = 0; l < d.n_levels; l++) {
     LevelDev& L = f.levels[l];
     L.scale = lv[l].scale;
@@ -350,7 +367,8 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
       if (L.mz_b >= (1u << 24) || lv[l].res > 4096) return fail(c, PRV_E_INVALID, "dense level too large");
     }
     L.off_b = poff[l] * ebytes;
-    L.pad0 = L.pad1 = 0;
+    L.myz_b = L.my_b + L.mz_b;
+    L.pad1 = 0;
   }
   m.loaded = true;
   m.dirty = false;
@@ -535,6 +553,10 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     rp.spp_k = 0;
     rp.last_pass = mp.last_pass;
     rp.refill_min = c->refill_min;
+    // tail merge pays while the table is cache resident (256^3 field: -3 % launch time, slot utilisation 0.765 -> 0.805)
+    // and costs when every gather goes to HBM (512^3 field: +2 %): merged tails gather incoherently.  Measured:
+    // profiles/r02_k_tail_merge.txt
+    rp.merge_max = c->merge_max >= 0 ? c->merge_max : (m.table_halfs * 2 <= ((size_t)32 << 20) ? 16 : 0);
     rp.dbg = c->dbg_flags;
     memcpy(rp.bg, o->background, sizeof(rp.bg));
     if (c->profiling) {
@@ -621,6 +643,8 @@ int prv_create(prv_ctx** out, int device_id) try {
     c->refill_min = g;
   }
   if (const char* s = getenv("PRV_QUEUE_SEGMENTS")) c->queue_segments = std::min(8, std::max(1, atoi(s)));
+  if (const char* s = getenv("PRV_RENDER64")) c->render64 = atoi(s) != 0;
+  if (const char* s = getenv("PRV_MERGE_MAX")) c->merge_max = std::min(31, std::max(0, atoi(s)));
   if (const char* s = getenv("PRV_DEHASH_MB")) c->dehash_budget = (size_t)std::max(0, atoi(s)) << 20;
   if (const char* s = getenv("PRV_DBG")) c->dbg_flags = atoi(s);
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
@@ -641,6 +665,7 @@ void prv_destroy(prv_ctx* c) {
     release(m.occ_coarse);
     release(m.occ);
     release(m.frags);
+    release(m.frags64);
     release(m.mlp);
   }
   release(c->queue);
@@ -1411,6 +1436,8 @@ int prv_debug_model_layout(prv_ctx* c, int slot, prv_model_layout* out) try {
   out->n_pair_steps = m.dev.n_pair_steps;
   out->kernel_features = m.dev.n_features;
   out->kernel_pair_steps = render_instance_pair_steps(m.dev);
+  out->kernel_slots = m.dev.render64 ? 64 : 32;
+  out->n_dense_levels = m.dev.n_dense_levels;
   out->n_hashed_levels = 0;
   for (int l = 0; l < m.desc.n_levels; l++) out->n_hashed_levels += lv[l].hashed ? 1 : 0;
   return PRV_OK;

@@ -38,7 +38,8 @@ struct LevelDev {
   uint32_t my_b, mz_b;
   uint32_t m_b;
   uint32_t off_b;  // byte offset of the level, aligned to its size
-  uint32_t pad0, pad1;
+  uint32_t myz_b;  // dense levels: my_b + mz_b (the (y+1, z+1) neighbour of the v2 gather)
+  uint32_t pad1;
 };
 
 struct FieldDev {
@@ -46,9 +47,12 @@ struct FieldDev {
   const uint32_t* occ;    // occ_res^3 bits, x fastest
   const uint32_t* occ_coarse; // (occ_res/4)^3 bits: any occupied fine cell in the 4^3 block OR its 26 neighbours (or null)
   const half8* frags;     // kNumFrags * 64 half8, MFMA A fragments (prepacked weights)
+  const half8* frags64;   // the same for render_queue64 (canonical first-layer k order, result copies in padding rows)
   LevelDev levels[kMaxLevels];
   int n_levels, n_features, occ_res;
   int n_pair_steps; // leading gather steps whose two levels are physically dense (paired loads)
+  int n_dense_levels; // leading levels that are physically dense (render_queue64: clamp-free one-add neighbours)
+  int render64;       // 1: prv_render launches render_queue64_kernel (default), 0: the 32-slot kernel
   float density_bias;
   float occ_lo[3], occ_hi[3]; // bounding box of the occupied cells, grown by one cell (march pass clips to it)
 };
@@ -384,6 +388,121 @@ __device__ __forceinline__ void encode_half(const uint16_t* __restrict__ table, 
   }
 }
 
+// ---------------------------------------------------------------- v2 gather: one lane = one sample, every level
+// (render_queue64_kernel: 64 ray slots per wave).  Same arithmetic as encode_level -- positions, cells, fp16 weights and the
+// fp16 fma chain are bit-identical -- with fewer instructions around it:
+//  * DENSE levels (compile time: the leading levels of the field that are physically dense): the physical layout
+//    duplicates the last vertex of every row, the last row of every plane and the last plane, so the +1 neighbours
+//    need no clamp on any axis and are one add away: base, base + my, base + mz, base + my + mz (4 paired loads);
+//  * the (1 - w, w) weight pairs of all three axes come out of one v_cvt_pk_f16_f32 each.
+__device__ __forceinline__ half2v cvt_pk_f16(float lo, float hi) { // {RNE(lo), RNE(hi)}: two independent roundings, no fusing
+  half2v r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+template <int F, bool DENSE>
+__device__ __forceinline__ void encode_level2(const uint16_t* __restrict__ table, const LevelDev& L, float px, float py, float pz,
+                                              half2v out[F / 2]) {
+  constexpr int ESH = F == 4 ? 3 : 2;
+  const float pos[3] = {fmaf(L.scale, px, 0.5f), fmaf(L.scale, py, 0.5f), fmaf(L.scale, pz, 0.5f)};
+  uint32_t c0[3];
+  half2v wa[3]; // (1-w, w) per axis, fp16
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float w1 = __builtin_amdgcn_fractf(pos[a]);
+    wa[a] = cvt_pk_f16(1.0f - w1, w1);
+    c0[a] = (uint32_t)(int)pos[a];
+  }
+  uint32_t vw[8][F / 2];
+  if (DENSE) {
+    // the level constants are wave-uniform here (scalar registers): the level offset and the +y neighbour go into two
+    // SCALAR base pointers (SALU adds), so the four paired loads need one vector add between them -- (b, base),
+    // (b, base + my), (b + mz, base), (b + mz, base + my)
+    const char* base0 = reinterpret_cast<const char*>(table) + L.off_b;
+    const char* base1 = base0 + L.my_b;
+    const uint32_t b = (c0[0] << ESH) + __umul24(c0[1], L.my_b) + __umul24(c0[2], L.mz_b);
+    const uint32_t bz = b + L.mz_b;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const EntryPair<F> e = EntryPair<F>::load(((q & 1) ? base1 : base0) + ((q >> 1) ? bz : b));
+#pragma unroll
+      for (int k = 0; k < F / 2; k++) {
+        vw[2 * q][k] = e.w[k];
+        vw[2 * q + 1][k] = e.w[F / 2 + k];
+      }
+    }
+  } else {
+    uint32_t c1[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) c1[a] = min(c0[a] + 1u, L.res_m1);
+    const uint32_t tx[2] = {(c0[0] << ESH) & L.m_b, (c1[0] << ESH) & L.m_b};
+    const uint32_t ty[2] = {__umul24(c0[1], L.my_b) & L.m_b, __umul24(c1[1], L.my_b) & L.m_b};
+    const uint32_t tz[2] = {(__umul24(c0[2], L.mz_b) & L.m_b) | L.off_b, (__umul24(c1[2], L.mz_b) & L.m_b) | L.off_b};
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const uint32_t byte_off = tx[c & 1] ^ ty[(c >> 1) & 1] ^ tz[c >> 2];
+      const Entry<F> e = Entry<F>::load(reinterpret_cast<const char*>(table) + byte_off);
+#pragma unroll
+      for (int k = 0; k < F / 2; k++) vw[c][k] = e.w[k];
+    }
+  }
+  half2v wp[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const half2v wy = {wa[1][q & 1], wa[1][q & 1]}, wz = {wa[2][q >> 1], wa[2][q >> 1]};
+    wp[q] = (wa[0] * wy) * wz;
+  }
+#pragma unroll
+  for (int k = 0; k < F / 2; k++) out[k] = half2v{(_Float16)0.0f, (_Float16)0.0f};
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const _Float16 w = wp[c >> 1][c & 1];
+    const half2v ww = {w, w};
+#pragma unroll
+    for (int k = 0; k < F / 2; k++) out[k] = __builtin_elementwise_fma(ww, __builtin_bit_cast(half2v, vw[c][k]), out[k]);
+  }
+}
+
+template <int F, int NDENSE, int... J>
+__device__ __forceinline__ void encode_all_levels(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv, float px, float py,
+                                                  float pz, half2v* out, std::integer_sequence<int, J...>) {
+  (encode_level2<F, (J < NDENSE)>(table, lv[J], px, py, pz, out + J * (F / 2)), ...);
+}
+
+// all 32 features of one sample in canonical order (feature F*l + f), as four half8 = the k rows [8s, 8s+8) of the first
+// layer; render_queue64 turns them into MFMA B fragments with v_permlane32_swap
+template <int F, int NDENSE>
+__device__ __forceinline__ void encode_sample(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv, float px, float py,
+                                              float pz, half8 f[4]) {
+  px = clamp01(px);
+  py = clamp01(py);
+  pz = clamp01(pz);
+  half2v out[16];
+  encode_all_levels<F, NDENSE>(table, lv, px, py, pz, out, std::make_integer_sequence<int, 32 / F>{});
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      f[s][2 * k] = out[4 * s + k][0];
+      f[s][2 * k + 1] = out[4 * s + k][1];
+    }
+}
+
+// lanes 32..63 of a <-> lanes 0..31 of b (gfx950 v_permlane32_swap), for every dword of a half8
+__device__ __forceinline__ void swap_halves(half8& a, half8& b) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 x = __builtin_bit_cast(u32x4, a), y = __builtin_bit_cast(u32x4, b);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x[k], y[k], false, false); // {x.lo | y.lo, x.hi | y.hi}
+    x[k] = r[0];
+    y[k] = r[1];
+  }
+  a = __builtin_bit_cast(half8, x);
+  b = __builtin_bit_cast(half8, y);
+}
+
 // stage the level table into LDS (call with all threads of the block, then __syncthreads)
 __device__ __forceinline__ void stage_levels(const FieldDev& fd, LevelDev* lds_levels) {
   static_assert(sizeof(LevelDev) == 32, "LevelDev must be two 16-byte words");
@@ -481,6 +600,94 @@ __device__ __forceinline__ MlpOut mlp_forward(const half8* __restrict__ wl, int 
     a = mfma(wl[23 * 64 + lane], hf[3], a);
     out.rgb = a;
   }
+  return out;
+}
+
+// Both MLPs for TWO column groups of 32 samples (render_queue64: the wave's lanes 0..31 and 32..63 each own a sample):
+// every weight fragment is read from LDS once and used for both groups; the groups' chains are independent, so one
+// group's MFMAs run while the other group's accumulators are being packed.  Fragments: the `frags64` set (prv_api.cpp:
+// first-layer k rows in canonical feature order; the density layer's unit 0 and the colour layer's units 0..2 repeated in
+// the padding rows 20 / 20..22, which land in lane half 1: register 8 / registers 8..10).
+struct MlpOut2 {
+  f32x16 densA, rgbA, densB, rgbB;
+};
+
+__device__ __forceinline__ MlpOut2 mlp_forward2(const half8* __restrict__ wl, int lane, const half8 fA[2], const half8 fB[2], half8 shA,
+                                                half8 shB) {
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  MlpOut2 out;
+  half8 hA[4], hB[4];
+  // per layer: group A's MFMAs, group B's MFMAs, then the packs -- B's MFMAs are in the pipe while A's accumulators are
+  // converted; at most two 32x32 accumulators per group are live (PRV_MLP2_ORDER=1: A fully before B, fewer live registers)
+#ifndef PRV_MLP2_ORDER
+#define PRV_MLP2_ORDER 0
+#endif
+  auto layer64 = [&](int f0, const half8 in0A, const half8 in1A, const half8 in0B, const half8 in1B) { // K = 32 -> 64 units
+    const half8 w0 = wl[(f0 + 0) * 64 + lane], w1 = wl[(f0 + 1) * 64 + lane], w2 = wl[(f0 + 2) * 64 + lane], w3 = wl[(f0 + 3) * 64 + lane];
+    f32x16 a0 = mfma(w0, in0A, zero), a1 = mfma(w2, in0A, zero);
+    a0 = mfma(w1, in1A, a0);
+    a1 = mfma(w3, in1A, a1);
+#if PRV_MLP2_ORDER
+    hA[0] = pack8<true>(a0, 0); hA[1] = pack8<true>(a0, 8); hA[2] = pack8<true>(a1, 0); hA[3] = pack8<true>(a1, 8);
+#endif
+    f32x16 b0 = mfma(w0, in0B, zero), b1 = mfma(w2, in0B, zero);
+    b0 = mfma(w1, in1B, b0);
+    b1 = mfma(w3, in1B, b1);
+#if !PRV_MLP2_ORDER
+    hA[0] = pack8<true>(a0, 0); hA[1] = pack8<true>(a0, 8); hA[2] = pack8<true>(a1, 0); hA[3] = pack8<true>(a1, 8);
+#endif
+    hB[0] = pack8<true>(b0, 0); hB[1] = pack8<true>(b0, 8); hB[2] = pack8<true>(b1, 0); hB[3] = pack8<true>(b1, 8);
+  };
+  auto layer16 = [&](int f0, f32x16& a, f32x16& b) { // K = 64 -> 16 units (+ copies in the padding rows)
+    a = zero;
+    b = zero;
+#if PRV_MLP2_ORDER
+#pragma unroll
+    for (int s = 0; s < 4; s++) a = mfma(wl[(f0 + s) * 64 + lane], hA[s], a);
+#pragma unroll
+    for (int s = 0; s < 4; s++) b = mfma(wl[(f0 + s) * 64 + lane], hB[s], b);
+#else
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const half8 w = wl[(f0 + s) * 64 + lane];
+      a = mfma(w, hA[s], a);
+      b = mfma(w, hB[s], b);
+    }
+#endif
+  };
+  layer64(0, fA[0], fA[1], fB[0], fB[1]);  // density layer 1: 32 -> 64
+  layer16(4, out.densA, out.densB);         // density layer 2: 64 -> 16
+  const half8 dfA = pack8<false>(out.densA, 0), dfB = pack8<false>(out.densB, 0);
+  layer64(8, dfA, shA, dfB, shB);           // colour layer 1: [density out 16 | SH 16] -> 64
+  { // colour layer 2: 64 -> 64
+    f32x16 a0 = zero, a1 = zero, b0 = zero, b1 = zero;
+#if PRV_MLP2_ORDER
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      a0 = mfma(wl[(12 + s) * 64 + lane], hA[s], a0);
+      a1 = mfma(wl[(16 + s) * 64 + lane], hA[s], a1);
+    }
+    hA[0] = pack8<true>(a0, 0); hA[1] = pack8<true>(a0, 8); hA[2] = pack8<true>(a1, 0); hA[3] = pack8<true>(a1, 8);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      b0 = mfma(wl[(12 + s) * 64 + lane], hB[s], b0);
+      b1 = mfma(wl[(16 + s) * 64 + lane], hB[s], b1);
+    }
+    hB[0] = pack8<true>(b0, 0); hB[1] = pack8<true>(b0, 8); hB[2] = pack8<true>(b1, 0); hB[3] = pack8<true>(b1, 8);
+#else
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const half8 w0 = wl[(12 + s) * 64 + lane], w1 = wl[(16 + s) * 64 + lane];
+      a0 = mfma(w0, hA[s], a0);
+      a1 = mfma(w1, hA[s], a1);
+      b0 = mfma(w0, hB[s], b0);
+      b1 = mfma(w1, hB[s], b1);
+    }
+    hA[0] = pack8<true>(a0, 0); hA[1] = pack8<true>(a0, 8); hA[2] = pack8<true>(a1, 0); hA[3] = pack8<true>(a1, 8);
+    hB[0] = pack8<true>(b0, 0); hB[1] = pack8<true>(b0, 8); hB[2] = pack8<true>(b1, 0); hB[3] = pack8<true>(b1, 8);
+#endif
+  }
+  layer16(20, out.rgbA, out.rgbB);          // colour layer 3: 64 -> 16 (3 used)
   return out;
 }
 

@@ -311,6 +311,231 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
 }
 
 
+// ------------------------------------------------------------------ K_B64 render from the queue, 64 ray slots per wave
+// The successor of render_queue_kernel (kept above for A/B runs: PRV_RENDER64=0).  One lane = one ray slot and one whole
+// sample per round: the lane picks its next live sample, gathers ALL levels itself (encode_sample: dense levels with
+// no clamps and one-add neighbours, (1-w, w) pairs from one v_cvt_pk each), and two v_permlane32_swap per k-step turn
+// the wave's 64 feature vectors into the MFMA B operands of two 32-sample column groups (lanes 0..31 = group A, lanes
+// 32..63 = group B).  mlp_forward2 runs both groups off one LDS read of every weight fragment.  What the 32-slot kernel
+// computed twice (in both lanes of a pair: sample selection, position, compositing) is computed once per sample here.
+// Arithmetic per sample is unchanged: features bit-identical, the same MFMAs on the same operands, the same compositing.
+// A group refills when all its 32 slots are idle (whole-group lockstep, as before).
+#ifndef PRV_R64_WAVES
+#define PRV_R64_WAVES 0 // dev: 4 = ask for 4 waves per SIMD (<= 128 VGPRs, the compiler spills); 0 = let it choose (3 waves)
+#endif
+template <int F, int NDENSE>
+__global__ __launch_bounds__(256)
+#if PRV_R64_WAVES
+__attribute__((amdgpu_waves_per_eu(PRV_R64_WAVES, PRV_R64_WAVES)))
+#endif
+void render_queue64_kernel(RenderParams P) {
+  __shared__ half8 wl[kNumFrags * 64];
+  __shared__ uint32_t mv[4][32][6]; // tail merges: {record, next sample, T, r, g, b} of the rays that change slots, per wave
+  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = P.field.frags64[i];
+  __syncthreads();
+  // every lane gathers every level, so the level constants are wave-uniform: they are read straight from the kernel
+  // arguments (scalar loads, SGPR operands) instead of LDS -> VGPRs
+  const LevelDev* __restrict__ lvl = P.field.levels;
+
+  const int lane = threadIdx.x & 63, r = lane & 31, g = lane >> 5; // g: the lane's group (A = 0, B = 1) AND its k-row half
+  const uint32_t n_rec = *P.queue_count;
+
+  bool active = false;
+  uint32_t pix = 0, rec_i = 0; // rec_i: the ray's queue record (a ray that changes slots re-reads its constants from it)
+  float o[3] = {0, 0, 0}, d[3] = {0, 0, 1}, t0 = 0.f, dt = 0.f;
+  uint32_t cur = 0, m1 = 0, m2 = 0, m3 = 0, base = 0; // live-sample mask: current word (never 0 while active) + the words behind it
+  float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+  half8 shA = {0, 0, 0, 0, 0, 0, 0, 0}, shB = {0, 0, 0, 0, 0, 0, 0, 0}; // SH rows [8g, 8g+8) of the rays in slots (r, A) and (r, B)
+  bool drained = false;
+  unsigned long long n_eval = 0ull, n_rounds = 0ull;
+  uint32_t q_cur = 0, q_end = 0;
+  const uint32_t n_seg = (uint32_t)P.n_segments;
+  const uint32_t seg_len = ((n_rec + n_seg * kClaim - 1u) / (n_seg * kClaim)) * kClaim;
+  uint32_t seg = n_seg > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % n_seg : 0u;
+  uint32_t seg_tried = 0;
+
+  for (;;) {
+    // ---- tail merge.  A cohort of 32 rays starts in lockstep (adjacent pixels, same depth: their gathers share cache
+    // lines) and thins out as its rays terminate; its last few rays would hold 32 slots' worth of instruction issue.
+    // When one group is down to <= merge_max rays and the other group has that many idle slots, the rays move over
+    // (dynamic state through LDS, constants re-read from the queue record) and the emptied group takes 32 fresh rays
+    // below.  Which lane composites a ray changes, the arithmetic and the sample order do not: pixels are unchanged.
+    if (!drained && P.merge_max > 0) {
+      const unsigned long long act0 = __ballot(active);
+      const uint32_t aA = (uint32_t)act0, aB = (uint32_t)(act0 >> 32);
+      const uint32_t nA = (uint32_t)__popc(aA), nB = (uint32_t)__popc(aB);
+      int src = -1;
+      if (nA != 0u && nB != 0u) {
+        if (nA <= (uint32_t)P.merge_max && nA <= 32u - nB) src = 0;
+        else if (nB <= (uint32_t)P.merge_max && nB <= 32u - nA) src = 1;
+      }
+      if (src >= 0) { // wave-uniform
+        const uint32_t a_src = src == 0 ? aA : aB, a_dst = src == 0 ? aB : aA, n_src = src == 0 ? nA : nB;
+        const uint32_t below = (1u << r) - 1u;
+        uint32_t(*slot)[6] = mv[threadIdx.x >> 6];
+        if (g == src && active) {
+          uint32_t* e = slot[__popc(a_src & below)];
+          e[0] = rec_i;
+          e[1] = base + (uint32_t)__builtin_ctz(cur); // the next sample to take
+          e[2] = __float_as_uint(T);
+          e[3] = __float_as_uint(cr);
+          e[4] = __float_as_uint(cg);
+          e[5] = __float_as_uint(cb);
+          active = false;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t kth = (uint32_t)__popc(~a_dst & below); // rank of slot r among the destination group's idle slots
+        if (!((a_dst >> r) & 1u) && kth < n_src) { // BOTH lanes of the slot: the slot's SH rows go to both halves
+          const uint32_t* e = slot[kth];
+          const uint32_t ri = e[0];
+          const uint4* rec = reinterpret_cast<const uint4*>(P.queue) + (size_t)ri * kRecordWords;
+          const half8 sh = reinterpret_cast<const half8*>(rec)[4 + g];
+          if (src == 0) shB = sh;
+          else shA = sh;
+          if (g != src) { // the destination lane itself takes the ray over
+            const uint32_t next = e[1];
+            T = __uint_as_float(e[2]); cr = __uint_as_float(e[3]); cg = __uint_as_float(e[4]); cb = __uint_as_float(e[5]);
+            const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            o[0] = __uint_as_float(q0.x); o[1] = __uint_as_float(q0.y); o[2] = __uint_as_float(q0.z);
+            t0 = __uint_as_float(q0.w);
+            d[0] = __uint_as_float(q1.x); d[1] = __uint_as_float(q1.y); d[2] = __uint_as_float(q1.z);
+            dt = __uint_as_float(q1.w);
+            cur = q2.x; m1 = q2.y; m2 = q2.z; m3 = q2.w;
+            base = 0u;
+            while (base + 32u <= next) { // the words before the next sample are spent
+              cur = m1; m1 = m2; m2 = m3; m3 = 0u;
+              base += 32u;
+            }
+            cur &= ~0u << (next & 31u);
+            pix = q3.x;
+            rec_i = ri;
+            active = true;
+          }
+        }
+        __builtin_amdgcn_wave_barrier(); // the scratch is reused by the next merge
+      }
+    }
+    // ---- refill: a group whose 32 slots are all idle takes the next records of the wave's claimed range
+    const unsigned long long idle = __ballot(!active);
+    const bool needA = (uint32_t)idle == 0xffffffffu, needB = (uint32_t)(idle >> 32) == 0xffffffffu;
+    if (!drained && (needA || needB)) {
+#pragma unroll
+      for (int grp = 0; grp < 2; grp++) {
+        if (!(grp == 0 ? needA : needB)) continue;
+        while (q_cur == q_end && !drained) {
+          uint32_t claim = 0;
+          if (lane == 0) claim = atomicAdd(P.queue_head + 16u * seg, kClaim);
+          claim = __builtin_amdgcn_readfirstlane(claim);
+          const uint32_t s_lo = min(seg * seg_len, n_rec), s_hi = min(s_lo + seg_len, n_rec);
+          if (claim < s_hi - s_lo) {
+            q_cur = s_lo + claim;
+            q_end = min(q_cur + kClaim, s_hi);
+          } else if (++seg_tried >= n_seg) {
+            drained = true;
+          } else {
+            seg = seg + 1u == n_seg ? 0u : seg + 1u;
+          }
+        }
+        const uint32_t avail = min(32u, q_end - q_cur);
+        if ((uint32_t)r < avail) { // both lane halves: the group's SH rows go to every lane, the ray itself to its own lane
+          const uint4* rec = reinterpret_cast<const uint4*>(P.queue) + (size_t)(q_cur + (uint32_t)r) * kRecordWords;
+          const half8 sh = reinterpret_cast<const half8*>(rec)[4 + g];
+          if (grp == 0) shA = sh;
+          else shB = sh;
+          if (g == grp) {
+            const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            o[0] = __uint_as_float(q0.x); o[1] = __uint_as_float(q0.y); o[2] = __uint_as_float(q0.z);
+            t0 = __uint_as_float(q0.w);
+            d[0] = __uint_as_float(q1.x); d[1] = __uint_as_float(q1.y); d[2] = __uint_as_float(q1.z);
+            dt = __uint_as_float(q1.w);
+            cur = q2.x; m1 = q2.y; m2 = q2.z; m3 = q2.w;
+            base = 0u;
+            while (cur == 0u && base < 96u) { // a queued ray has at least one live sample: normalise so that the current word is not empty
+              cur = m1; m1 = m2; m2 = m3; m3 = 0u;
+              base += 32u;
+            }
+            pix = q3.x;
+            rec_i = q_cur + (uint32_t)r;
+            T = 1.f; cr = 0.f; cg = 0.f; cb = 0.f;
+            active = true;
+          }
+        }
+        q_cur += avail;
+      }
+    }
+    const unsigned long long act = __ballot(active);
+    if (act == 0ull) {
+      if (drained) break;
+      continue;
+    }
+    n_eval += (unsigned long long)__popcll(act);
+    n_rounds += 2ull; // counted in 32-slot units, like the 32-slot kernel: utilisation = evaluated / (32 * rounds)
+
+    // ---- this lane's next live sample, all levels
+    // idle lanes feed whatever their registers hold into their own MFMA column: columns are independent and an idle
+    // lane's results are never read, so the features are deliberately left unset instead of zeroed (16 v_mov per round)
+    half8 f[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) asm volatile("" : "=v"(f[s]));
+    bool last = false;
+    if (active) {
+      const uint32_t i = base + (uint32_t)__builtin_ctz(cur);
+      cur &= cur - 1u;
+      if (cur == 0u) {
+        last = (m1 | m2 | m3) == 0u;
+        while (cur == 0u && !last) {
+          cur = m1; m1 = m2; m2 = m3; m3 = 0u;
+          base += 32u;
+        }
+      }
+      const float t = fmaf((float)i + 0.5f, dt, t0);
+      encode_sample<F, NDENSE>(P.field.table, lvl, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f);
+    }
+    // f[2s] | f[2s+1] = k rows [16s, 16s+8) | [16s+8, 16s+16) of the lane's own sample -> B operands of the two groups
+    swap_halves(f[0], f[1]); // f[0] = group A k-step 0, f[1] = group B k-step 0
+    swap_halves(f[2], f[3]);
+    const half8 fA[2] = {f[0], f[2]}, fB[2] = {f[1], f[3]};
+    const MlpOut2 mo = mlp_forward2(wl, lane, fA, fB, shA, shB);
+    // the lane's own sample: group A's results sit in lane half 0 (rows 0..2 = registers 0..2), group B's copies in the
+    // padding rows 20..22 = lane half 1, registers 8..10
+    const float dens = g ? mo.densB[8] : mo.densA[0];
+    const float lr = g ? mo.rgbB[8] : mo.rgbA[0], lg = g ? mo.rgbB[9] : mo.rgbA[1], lb = g ? mo.rgbB[10] : mo.rgbA[2];
+
+    bool done = false;
+    if (active) {
+      const float sigma = fast_exp(dens + P.field.density_bias);
+      const float alpha = 1.0f - fast_exp(-(sigma * dt));
+      const float wgt = alpha * T;
+      cr = fmaf(wgt, fast_sigmoid(lr), cr);
+      cg = fmaf(wgt, fast_sigmoid(lg), cg);
+      cb = fmaf(wgt, fast_sigmoid(lb), cb);
+      T = T * (1.0f - alpha);
+      done = last || T < P.min_T;
+    }
+    if (done) {
+      float4* out = reinterpret_cast<float4*>(P.out_f32) + pix;
+      float4 v = make_float4(cr, cg, cb, 1.0f - T);
+      if (P.spp_k != 0) {
+        const float4 prev = *out;
+        v.x = prev.x + v.x; v.y = prev.y + v.y; v.z = prev.z + v.z; v.w = prev.w + v.w;
+      }
+      if (P.last_pass) {
+        v.x *= P.inv_spp; v.y *= P.inv_spp; v.z *= P.inv_spp; v.w *= P.inv_spp;
+        if (P.out_u8) P.out_u8[pix] = quantize_rgba8(v.x, v.y, v.z, v.w, P.bg);
+      }
+      *out = v;
+      active = false;
+    }
+  }
+  if (lane == 0 && n_eval) {
+    atomicAdd(P.stat_evaluated, n_eval);
+    atomicAdd(P.stat_evaluated + 1, n_rounds);
+  }
+}
+
+
 // ------------------------------------------------------------------ first-hit ray cast (a13)
 // first occupied cell along (o, d) within max_range, or -1: Amanatides-Woo over the occupancy bits
 __device__ __forceinline__ int32_t first_hit_dda(const FieldDev& fd, const float o[3], const float d[3], float max_range) {
@@ -721,25 +946,22 @@ __global__ __launch_bounds__(256) void repack_level_kernel(const uint16_t* __res
   typedef typename EntryWord<F>::type word_t;
   const word_t* src = reinterpret_cast<const word_t*>(canon) + L.canon_off;
   word_t* dst = reinterpret_cast<word_t*>(phys) + L.phys_off;
-  if (L.hashed && L.dehash) {
-    const uint32_t nv = L.res * L.res * L.res;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nv; i += gridDim.x * 256) {
-      const uint32_t x = i % L.res, y = (i / L.res) % L.res, z = i / (L.res * L.res);
-      const uint32_t hsh = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & (L.n - 1u);
-      dst[x | (y << L.sx) | (z << (2 * L.sx))] = src[hsh];
-      if (x == L.res - 1) dst[(x + 1) | (y << L.sx) | (z << (2 * L.sx))] = src[hsh]; // duplicated border (paired loads)
-    }
+  if (L.hashed && !L.dehash) { // hashed level kept hashed: straight copy
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < L.n; i += gridDim.x * 256) dst[i] = src[i];
     return;
   }
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < L.n; i += gridDim.x * 256) {
-    uint32_t to = i;
-    if (!L.hashed) {
-      const uint32_t x = i % L.res, y = (i / L.res) % L.res, z = i / (L.res * L.res);
-      if (z >= L.res) continue; // canonical padding entries
-      to = x | (y << L.sx) | (z << (2 * L.sx));
-      if (x == L.res - 1) dst[to + 1] = src[i]; // duplicated border entry: the paired load at x = res-1 reads it
-    }
-    dst[to] = src[i];
+  // physically dense level (dense in the canonical table, or a hashed level stored densely): one thread per VERTEX.
+  // The last vertex of every row, the last row of every plane and the last plane are duplicated one step further out,
+  // so vertex + 1 on any axis reads what the min(c + 1, res - 1) clamp would have read (paired x loads of the 32-slot
+  // kernel, clamp-free y / z neighbours of the 64-slot kernel).
+  const uint32_t nv = L.res * L.res * L.res;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nv; i += gridDim.x * 256) {
+    const uint32_t x = i % L.res, y = (i / L.res) % L.res, z = i / (L.res * L.res);
+    const word_t v = src[L.hashed ? ((x ^ (y * 2654435761u) ^ (z * 805459861u)) & (L.n - 1u)) : i];
+    const uint32_t ex = x == L.res - 1 ? 1u : 0u, ey = y == L.res - 1 ? 1u : 0u, ez = z == L.res - 1 ? 1u : 0u;
+    for (uint32_t dz = 0; dz <= ez; dz++)
+      for (uint32_t dy = 0; dy <= ey; dy++)
+        for (uint32_t dx = 0; dx <= ex; dx++) dst[(x + dx) | ((y + dy) << L.sx) | ((z + dz) << (2 * L.sx))] = v;
   }
 }
 
@@ -817,6 +1039,72 @@ __global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const flo
     }
   }
   if (occ_out && h == 0) occ_out[idx] = occupied(fd, p[0], p[1], p[2]) ? 1 : 0;
+}
+
+// the same hook through the 64-slot kernel's machinery: one wave = 64 points, one lane = one point (encode_sample,
+// permlane swaps, mlp_forward2 on the frags64 set)
+template <int F, int NDENSE>
+__global__ __launch_bounds__(256) void debug_field64_kernel(FieldDev fd, const float* __restrict__ pos, const float* __restrict__ dir,
+                                                            int n, uint16_t* __restrict__ feat, float* __restrict__ out36,
+                                                            int32_t* __restrict__ occ_out) {
+  __shared__ half8 wl[kNumFrags * 64];
+  __shared__ LevelDev lvl[kMaxLevels];
+  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = fd.frags64[i];
+  stage_levels(fd, lvl);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r = lane & 31, g = lane >> 5;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int idx = wave * 64 + lane, idxA = wave * 64 + r, idxB = idxA + 32;
+  const bool ok = idx < n;
+  float p[3] = {0.5f, 0.5f, 0.5f};
+  if (ok)
+    for (int a = 0; a < 3; a++) p[a] = pos[idx * 3 + a];
+  auto dir_of = [&](int i, float dd[3]) {
+    dd[0] = 0.f; dd[1] = 0.f; dd[2] = 1.f;
+    if (dir && i < n)
+      for (int a = 0; a < 3; a++) dd[a] = dir[i * 3 + a];
+  };
+  float dA[3], dB[3];
+  dir_of(idxA, dA);
+  dir_of(idxB, dB);
+  half8 f[4];
+  encode_sample<F, NDENSE>(fd.table, lvl, p[0], p[1], p[2], f);
+  if (ok && feat) {
+    typedef uint16_t ushort8 __attribute__((ext_vector_type(8)));
+    uint16_t* dst = feat + (size_t)idx * 32;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const ushort8 u = __builtin_bit_cast(ushort8, f[s]);
+#pragma unroll
+      for (int e = 0; e < 8; e++) dst[8 * s + e] = u[e];
+    }
+  }
+  swap_halves(f[0], f[1]);
+  swap_halves(f[2], f[3]);
+  const half8 fA[2] = {f[0], f[2]}, fB[2] = {f[1], f[3]};
+  const MlpOut2 mo = mlp_forward2(wl, lane, fA, fB, sh_fragment(g, dA[0], dA[1], dA[2]), sh_fragment(g, dB[0], dB[1], dB[2]));
+  if (out36) {
+    if (ok) { // the lane's own point, read where the render kernel reads it
+      float* q = out36 + (size_t)idx * 36;
+      q[0] = fast_exp((g ? mo.densB[8] : mo.densA[0]) + fd.density_bias);
+      q[1] = fast_sigmoid(g ? mo.rgbB[8] : mo.rgbA[0]);
+      q[2] = fast_sigmoid(g ? mo.rgbB[9] : mo.rgbA[1]);
+      q[3] = fast_sigmoid(g ? mo.rgbB[10] : mo.rgbA[2]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { // raw outputs: register i of lane half g = row (i&3) + 8(i>>2) + 4g of column r, both groups
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * g;
+      if (idxA < n) {
+        out36[(size_t)idxA * 36 + 4 + row] = mo.densA[i];
+        out36[(size_t)idxA * 36 + 20 + row] = mo.rgbA[i];
+      }
+      if (idxB < n) {
+        out36[(size_t)idxB * 36 + 4 + row] = mo.densB[i];
+        out36[(size_t)idxB * 36 + 20 + row] = mo.rgbB[i];
+      }
+    }
+  }
+  if (ok && occ_out) occ_out[idx] = occupied(fd, p[0], p[1], p[2]) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ ground-truth splats
@@ -916,12 +1204,34 @@ hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_
 
 // instances: paired loads on the first NPAIR gather steps (host picks the largest instance <= the
 // field's count of leading dense-dense steps)
+// compiled instances of the 64-slot kernel: NDENSE = the largest listed count <= the field's leading dense levels
+// (levels past NDENSE take the generic path, which serves dense levels too)
+static int render64_dense(const FieldDev& fd) {
+  const int n = fd.n_dense_levels;
+  if (fd.n_features == 4) return n >= 5 ? 5 : n >= 3 ? 3 : 0;
+  return n >= 10 ? 10 : n >= 6 ? 6 : 0;
+}
+
 int render_instance_pair_steps(const FieldDev& fd) {
+  if (fd.render64) return render64_dense(fd);
   if (fd.n_features == 4) return fd.n_pair_steps >= 2 ? 2 : 0;
   return fd.n_pair_steps >= 5 ? 5 : 0;
 }
 
 hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s) {
+  if (P.field.render64) {
+    const int nd = render64_dense(P.field);
+    if (P.field.n_features == 4) {
+      if (nd == 5) hipLaunchKernelGGL((render_queue64_kernel<4, 5>), dim3(n_blocks), dim3(256), 0, s, P);
+      else if (nd == 3) hipLaunchKernelGGL((render_queue64_kernel<4, 3>), dim3(n_blocks), dim3(256), 0, s, P);
+      else hipLaunchKernelGGL((render_queue64_kernel<4, 0>), dim3(n_blocks), dim3(256), 0, s, P);
+    } else {
+      if (nd == 10) hipLaunchKernelGGL((render_queue64_kernel<2, 10>), dim3(n_blocks), dim3(256), 0, s, P);
+      else if (nd == 6) hipLaunchKernelGGL((render_queue64_kernel<2, 6>), dim3(n_blocks), dim3(256), 0, s, P);
+      else hipLaunchKernelGGL((render_queue64_kernel<2, 0>), dim3(n_blocks), dim3(256), 0, s, P);
+    }
+    return hipGetLastError();
+  }
   const int np = render_instance_pair_steps(P.field);
   if (P.field.n_features == 4) {
     if (np == 2) hipLaunchKernelGGL((render_queue_kernel<4, 2>), dim3(n_blocks), dim3(256), 0, s, P);
@@ -999,7 +1309,7 @@ hipError_t launch_synth_table(uint16_t* table, size_t n, uint64_t seed, float am
 }
 
 hipError_t launch_repack_level(const uint16_t* canon, uint16_t* phys, const RepackLevel& L, int F, hipStream_t s) {
-  unsigned blocks = ((L.dehash ? L.res * L.res * L.res : L.n) + 255) / 256;
+  unsigned blocks = (((L.hashed && !L.dehash) ? L.n : L.res * L.res * L.res) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks == 0) return hipSuccess;
   if (F == 4)
@@ -1018,6 +1328,20 @@ hipError_t launch_debug_raygen(const CamDev& cam, int W, int H, int spp_k, float
 
 hipError_t launch_debug_field(const FieldDev& fd, const float* pos, const float* dir, int n, uint16_t* feat,
                               float* out36, int32_t* occ, hipStream_t s) {
+  if (fd.render64) {
+    const unsigned blocks64 = (unsigned)((n + 255) / 256);
+    const int nd = render64_dense(fd);
+    if (fd.n_features == 4) {
+      if (nd == 5) hipLaunchKernelGGL((debug_field64_kernel<4, 5>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+      else if (nd == 3) hipLaunchKernelGGL((debug_field64_kernel<4, 3>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+      else hipLaunchKernelGGL((debug_field64_kernel<4, 0>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+    } else {
+      if (nd == 10) hipLaunchKernelGGL((debug_field64_kernel<2, 10>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+      else if (nd == 6) hipLaunchKernelGGL((debug_field64_kernel<2, 6>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+      else hipLaunchKernelGGL((debug_field64_kernel<2, 0>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+    }
+    return hipGetLastError();
+  }
   unsigned blocks = (unsigned)((n + 127) / 128);
   const int np = fd.n_pair_steps;
   if (fd.n_features == 4) {

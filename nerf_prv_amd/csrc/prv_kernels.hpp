@@ -43,6 +43,7 @@ struct RenderParams {
   int spp_k;
   int last_pass;
   int refill_min;
+  int merge_max; // render_queue64: a group down to <= this many rays hands them to the other group's idle slots (0 = never)
   int dbg; // dev-only bits (PRV_DBG env): 1 no table loads, 2 no MLP, 4 no compositing math, 8 slot-occupancy histogram
   float bg[4];
 };

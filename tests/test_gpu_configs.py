@@ -1,6 +1,6 @@
 """BASELINE.json configs[2], [3], [4] on the GPU, each to the parity bar of the rest of the suite:
 
-  configs[3]  synthetic 512^3 field (L=16, F=2, log2T=21: the render_queue_kernel<2,5> instance) -- rows of a full-size
+  configs[3]  synthetic 512^3 field (L=16, F=2, log2T=21: the render_queue64_kernel<2,10> instance) -- rows of a full-size
               view against the oracle, features bit-exact; 1024 candidate views scored in 8 shards of 128 and
               assembled exactly as the all-gather leaves them == the unsharded round, byte for byte
   configs[2]  the reference's 144-view set (Hemisphere/144.txt), a field TRAINED in process, PSNR+coverage-ranked
@@ -39,7 +39,8 @@ def field512(ctx):
 
 def test_field512_runs_the_paired_f2_instance_and_its_features_are_bit_exact(ctx, oracle, field512):
     lay = ctx.model_layout(4)
-    assert lay["kernel_features"] == 2 and lay["n_pair_steps"] >= 5 and lay["kernel_pair_steps"] == 5  # <2,5>
+    assert lay["kernel_features"] == 2 and lay["n_pair_steps"] >= 5 and lay["n_dense_levels"] >= 10
+    assert (lay["kernel_slots"], lay["kernel_pair_steps"]) == (64, 10)  # render_queue64_kernel<2, 10>
     assert lay["table_bytes_canonical"] > 60 * 2 ** 20  # the 64 MiB table of BASELINE.md section 6
     assert lay["n_hashed_levels"] >= 4
     f = oracle.OracleField(oracle.desc(**api.FIELD_512), seed=util.SEED_A)
