@@ -324,6 +324,24 @@ def kernel_figures(m, variant, hbm_bound):
     return out
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; rank 0's stdout carries the ONE JSON line,
+    so while communicators come up the process's fd 1 points at fd 2"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)  # the banner sits in C stdio's buffer (fd 1 is a pipe: fully buffered) until flushed
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def cxx_rccl_check(env, main, timeout_s=90.0):
     """N > 1 only, OUTSIDE the timed region: the same scoring round through the C ABI's own communicator
     (prv_comm_create "rccl" -> ncclCommInitRank; prv_score_views_sharded -> ONE ncclAllGather of the records on the
@@ -383,7 +401,10 @@ def run_rank(args):
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.barrier()  # the communicator (and its banner) comes up here, not inside the timed region
+            torch.cuda.synchronize()
 
     from nerf_prv_amd import api, planner
 
@@ -410,7 +431,8 @@ def run_rank(args):
     extras = {}
     cxx = None
     if use_dist and os.environ.get("PRV_BENCH_NO_CXX_COMM") != "1":  # N > 1 (or PRV_FORCE_DIST=1: one rank, same calls)
-        cxx = cxx_rccl_check(env, main)
+        with stdout_to_stderr():
+            cxx = cxx_rccl_check(env, main)
         if rank == 0:
             same = bool(cxx.get("ok")) and cxx["records"].tobytes() == m["records"].tobytes()
             extras["cxx_rccl_round"] = {"ok": bool(cxx.get("ok")), "records_identical_to_torch_gather": same,
