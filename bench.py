@@ -342,7 +342,7 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
-def cxx_rccl_check(env, main, timeout_s=90.0):
+def cxx_rccl_check(env, main, timeout_s=150.0):
     """N > 1 only, OUTSIDE the timed region: the same scoring round through the C ABI's own communicator
     (prv_comm_create "rccl" -> ncclCommInitRank; prv_score_views_sharded -> ONE ncclAllGather of the records on the
     context's stream; include/prv.h) -- what the C++ planner (prv_planner `shard: views`) runs -- compared with the
@@ -429,17 +429,6 @@ def run_rank(args):
     k, elapsed = args.steps, m["elapsed"]
 
     extras = {}
-    cxx = None
-    if use_dist and os.environ.get("PRV_BENCH_NO_CXX_COMM") != "1":  # N > 1 (or PRV_FORCE_DIST=1: one rank, same calls)
-        with stdout_to_stderr():
-            cxx = cxx_rccl_check(env, main)
-        if rank == 0:
-            same = bool(cxx.get("ok")) and cxx["records"].tobytes() == m["records"].tobytes()
-            extras["cxx_rccl_round"] = {"ok": bool(cxx.get("ok")), "records_identical_to_torch_gather": same,
-                                        "transport": cxx.get("transport"), "ms_per_round": cxx.get("ms_per_round"),
-                                        "error": cxx.get("error"),
-                                        "what": "the same round through prv_score_views_sharded (C ABI: ncclAllGather of the "
-                                                "records inside libprv_hip.so), untimed check"}
     if rank == 0 and not args.no_extras:
         solo = dict(env, world=1, rank=0, use_dist=False)  # side measurements: this GPU alone, no collective
         # (1) the HBM-bound configuration (BASELINE configs[3]'s field) timed in the SAME run
@@ -510,6 +499,19 @@ def run_rank(args):
         tr.close()
         tcams.close()
 
+    # the C ABI's own RCCL round, LAST (all ranks; rank 0 arrives after its side measurements, the others wait in the
+    # rendezvous): whatever happens in here can no longer disturb a measurement
+    cxx = None
+    if use_dist and os.environ.get("PRV_BENCH_NO_CXX_COMM") != "1":  # N > 1 (or PRV_FORCE_DIST=1: one rank, same calls)
+        with stdout_to_stderr():
+            cxx = cxx_rccl_check(env, main)
+        if rank == 0:
+            same = bool(cxx.get("ok")) and cxx["records"].tobytes() == m["records"].tobytes()
+            extras["cxx_rccl_round"] = {"ok": bool(cxx.get("ok")), "records_identical_to_torch_gather": same,
+                                        "transport": cxx.get("transport"), "ms_per_round": cxx.get("ms_per_round"),
+                                        "error": cxx.get("error"),
+                                        "what": "the same round through prv_score_views_sharded (C ABI: ncclAllGather of the "
+                                                "records inside libprv_hip.so), untimed check"}
     if rank == 0:
         roof = kernel_figures(m, variant_of(0), hbm_bound=args.field == "512")
         out = {

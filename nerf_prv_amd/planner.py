@@ -448,17 +448,22 @@ def exchange_members(local, n_members, sizes, group=None, device=None):
     return result
 
 
-def train_ensemble(ctx, n_members, scene_json, n_steps, desc, seed=0x1234, opts=None, group=None, device=None):
+def train_ensemble(ctx, n_members, scene_json, n_steps, desc, seed=0x1234, opts=None, group=None, device=None, comm=None):
     """one NBV iteration's training (main.cpp:2041-2043: train_by_instantNGP once per ensemble member) over the
     GPUs of the job: this rank trains its members side by side on the scene json's views, the fields are
-    exchanged with ONE all-gather, and slots 0..E-1 of `ctx` hold the whole ensemble on every rank."""
+    exchanged, and slots 0..E-1 of `ctx` hold the whole ensemble on every rank.  comm (api.Comm): the exchange is
+    prv_model_exchange -- device to device over RCCL, no host copy; without it (torch.distributed only, e.g. gloo in the
+    CPU tests) the members travel through one all-gather of host-staged arrays."""
     import torch.distributed as dist
 
     from . import api
     from .compat_server import load_dataset_bytes
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    else:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = [e for e in range(n_members) if member_owner(e, world) == rank]
     cams = ctx.cameras_from_dataset_json(scene_json)
     images = load_dataset_bytes(ctx, scene_json)
@@ -473,7 +478,9 @@ def train_ensemble(ctx, n_members, scene_json, n_steps, desc, seed=0x1234, opts=
     for t in trainers:
         t.close()
     cams.close()
-    if world > 1:
+    if world > 1 and comm is not None:
+        comm.exchange_models(n_members, desc)
+    elif world > 1:
         local = {e: ctx.export_model(e, desc) for e in mine}
         everyone = exchange_members(local, n_members, api.model_sizes(desc), group, device)
         for e in range(n_members):
