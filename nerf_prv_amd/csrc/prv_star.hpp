@@ -32,8 +32,8 @@ inline bool send_all(int fd, const void* p, size_t n) {
   const char* c = (const char*)p;
   while (n > 0) {
     const ssize_t k = ::send(fd, c, n, MSG_NOSIGNAL);
-    if (k < 0 && (errno == EINTR || errno == EAGAIN)) continue;
-    if (k <= 0) return false;
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) return false; // closed, or no progress within the socket's timeout (EAGAIN)
     c += k;
     n -= (size_t)k;
   }
@@ -43,8 +43,8 @@ inline bool recv_all(int fd, void* p, size_t n) {
   char* c = (char*)p;
   while (n > 0) {
     const ssize_t k = ::recv(fd, c, n, 0);
-    if (k < 0 && (errno == EINTR || errno == EAGAIN)) continue;
-    if (k <= 0) return false;
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) return false; // closed, or nothing arrived within the socket's timeout (EAGAIN)
     c += k;
     n -= (size_t)k;
   }
@@ -135,9 +135,16 @@ private:
     if (listen_fd_ >= 0) ::close(listen_fd_);
     listen_fd_ = -1;
   }
+  // no rank waits for ever on a peer that is alive but stuck: a transfer that makes no progress for
+  // $PRV_COMM_TIMEOUT_S (default 600 s) fails, the call returns an error and the caller's error path runs
   static void tune(int fd) {
     int one = 1;
     setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+    const char* e = getenv("PRV_COMM_TIMEOUT_S");
+    const long secs = e && atol(e) > 0 ? atol(e) : 600;
+    timeval tv{(time_t)secs, 0};
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
   }
   bool serve(const addrinfo* res, double timeout_s) {
     listen_fd_ = ::socket(AF_INET, SOCK_STREAM, 0);

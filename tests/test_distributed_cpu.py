@@ -187,3 +187,37 @@ def test_shard_views_of_the_c_abi_matches_the_python_sharding():
                 ids_c, per_c = api.shard_views(n, r, world, interleaved)
                 ids_p, per_p = planner.shard_views(n, r, world, interleaved)
                 assert per_c == per_p and np.array_equal(ids_c, ids_p), (n, world, interleaved, r)
+
+
+def _star_stuck_worker(rank, world, port, q):
+    import ctypes as C
+    import time
+
+    os.environ["PRV_COMM_TIMEOUT_S"] = "2"
+    h = planner.host()
+    star = h.prvh_star_open(rank, world, b"127.0.0.1", port, 60.0)
+    assert star
+    buf = np.zeros(8, np.uint8)
+    out = np.zeros(16, np.uint8)
+    if rank == 0:
+        t0 = time.time()
+        rc = h.prvh_star_all_gather(star, buf.ctypes.data_as(C.c_void_p), 8, out.ctypes.data_as(C.c_void_p))  # rank 1 never sends
+        q.put((rc, time.time() - t0))
+    else:
+        time.sleep(6)  # alive, connected, silent
+    h.prvh_star_close(star)
+
+
+def test_star_gives_up_on_a_silent_peer_instead_of_hanging():
+    """a rank that is connected but never answers makes the collective FAIL after PRV_COMM_TIMEOUT_S, it does not hang
+    the job for ever (the reference's hand-shake polls for ever, main.cpp:1695-1698)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_star_stuck_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rc, took = q.get(timeout=60)
+    for p in procs:
+        p.join(timeout=30)
+    assert rc != 0 and 1.5 < took < 10
