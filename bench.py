@@ -294,6 +294,12 @@ def kernel_figures(m, variant, hbm_bound):
         "mfma_pipe_frac": mfma_pipe_frac,
         "valu_insts_per_round_from_profile": cost["valu_insts_per_round"] if cost else None,
         "valu_issue_frac": valu_frac,
+        # the same bound in samples: what the SIMDs could evaluate if every issue slot carried this kernel's instruction
+        # mix AND every ray slot held a live ray; achieved / ceiling = valu_issue_frac x slot_utilisation.  A leaner
+        # kernel RAISES the ceiling (fewer instructions per sample), so compare rounds by samples/s, not by frac alone.
+        "issue_bound_samples_per_s": VALU_PEAK_GINST * 1e9 / (cost["valu_insts_per_round"] / 32.0) if cost else None,
+        "useful_issue_frac": valu_frac * (samples / max(1.0, 32.0 * rounds)) if cost else None,
+        "samples_per_s_in_kernel": samples / kernel_s,
         "traffic_from_profile": None,
     }
     if traffic:
