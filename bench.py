@@ -235,14 +235,21 @@ class Round:
         st, records, order = self.step(want_stats=True)  # also sizes every workspace
         for _ in range(max(0, warmup - 1)):
             self.step()
-        barrier()
-        ctx.profile_begin()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            _, records, order = self.step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        prof = ctx.profile_end()
+        import gc
+
+        gc.collect()
+        gc.disable()  # as timeit does: a generation-2 pass of the interpreter (tens of ms with torch loaded) is not the workload
+        try:
+            barrier()
+            ctx.profile_begin()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                _, records, order = self.step()
+            barrier()
+            elapsed = time.perf_counter() - t0
+            prof = ctx.profile_end()
+        finally:
+            gc.enable()
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=env["device"])
         tot = torch.tensor([float(st.samples_evaluated), float(st.samples_nominal), float(st.rays)], dtype=torch.float64,
                            device=env["device"])

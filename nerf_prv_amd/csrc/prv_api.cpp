@@ -69,12 +69,14 @@ struct prv_ctx {
   Buffer queue, stage, counters, view_ids, img_f32, partial, records, dbg[6];
   Buffer img_u8[PRV_MAX_MODELS];
   bool profiling = false;
-  std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs
+  std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs of the current profiling window
+  std::vector<hipEvent_t> ev_free;             // recycled events: a profiling window creates none once the pool is warm
   int blocks_per_cu = 4;
   int refill_min = 32;
   std::vector<struct prv_trainer*> trainers; // live trainers of this context (detached by prv_destroy)
   int queue_segments = 8; // ray-queue segments = XCDs (PRV_QUEUE_SEGMENTS: 1 = single shared head)
   int render64 = 1;       // render_queue64_kernel (64 ray slots per wave); PRV_RENDER64=0: the 32-slot kernel
+  int pool_on = -1;       // render_queue64 block-level tail pool (PRV_POOL=0/1; -1 = by table and image size, see render_views)
   int merge_max = -1;     // render_queue64 tail merge threshold (PRV_MERGE_MAX; 0 = off; -1 = by table size, see render_views)
   int dbg_flags = 0;
   size_t stage_budget = (size_t)4 << 30; // staging bytes for multi-sample renders (spp x batch x image)
@@ -429,6 +431,17 @@ int check_device_ptr(prv_ctx* c, const void* p, const char* what) {
   return PRV_OK;
 }
 
+// events of the per-kernel timing are recycled: creating (and destroying) four per step made the runtime grow its
+// signal pool in the middle of a timed region now and then (one 50-90 ms stall in a few hundred steps)
+hipError_t take_event(prv_ctx* c, hipEvent_t* e) {
+  if (!c->ev_free.empty()) {
+    *e = c->ev_free.back();
+    c->ev_free.pop_back();
+    return hipSuccess;
+  }
+  return hipEventCreate(e);
+}
+
 // cameras at the render resolution: focal from camera_angle_x at the json width (run.py:285-286,
 // fov_axis = 0), rescaled to the requested width; principal point at the image centre.
 // Dataset sets (prv_cameras_from_dataset_json) keep their principal point and scale per axis.
@@ -530,8 +543,8 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     memcpy(mp.bg, o->background, sizeof(mp.bg));
     if (c->profiling) {
       hipEvent_t a, b;
-      HIPCHK(c, hipEventCreate(&a));
-      HIPCHK(c, hipEventCreate(&b));
+      HIPCHK(c, take_event(c, &a));
+      HIPCHK(c, take_event(c, &b));
       c->ev_march.push_back(a);
       c->ev_march.push_back(b);
       HIPCHK(c, hipEventRecord(a, c->stream));
@@ -553,16 +566,21 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     rp.spp_k = 0;
     rp.last_pass = mp.last_pass;
     rp.refill_min = c->refill_min;
-    // tail merge pays while the table is cache resident (256^3 field: -3 % launch time, slot utilisation 0.765 -> 0.805)
-    // and costs when every gather goes to HBM (512^3 field: +2 %): merged tails gather incoherently.  Measured:
-    // profiles/r02_k_tail_merge.txt
-    rp.merge_max = c->merge_max >= 0 ? c->merge_max : (m.table_halfs * 2 <= ((size_t)32 << 20) ? 16 : 0);
+    // Tail merge + the block's tail pool raise slot utilisation (0.77 -> 0.93) at the price of incoherent gathers from the
+    // relocated rays.  That pays where the gathers of a fresh cohort are coherent to begin with and the table is cache
+    // resident -- large images of the 256^3 field: launch -8 % -- and costs elsewhere: the 512^3 field is bound by random
+    // HBM requests (+2...5 %), and at the reference's 80x45 candidates neighbouring rays are five finest cells apart
+    // (+3...7 %).  Results are identical either way; the default follows table and image size (PRV_MERGE_MAX / PRV_POOL
+    // override).  Measured: profiles/r02_k_tail_merge.txt, profiles/r02_r_tail_pool.txt
+    const bool coherent = m.table_halfs * 2 <= ((size_t)32 << 20) && npix >= ((size_t)1 << 17);
+    rp.merge_max = c->merge_max >= 0 ? c->merge_max : (coherent ? 16 : 0);
+    rp.pool_on = (c->pool_on >= 0 ? c->pool_on != 0 : coherent) && rp.merge_max > 0;
     rp.dbg = c->dbg_flags;
     memcpy(rp.bg, o->background, sizeof(rp.bg));
     if (c->profiling) {
       hipEvent_t a, b;
-      HIPCHK(c, hipEventCreate(&a));
-      HIPCHK(c, hipEventCreate(&b));
+      HIPCHK(c, take_event(c, &a));
+      HIPCHK(c, take_event(c, &b));
       c->ev_render.push_back(a);
       c->ev_render.push_back(b);
       HIPCHK(c, hipEventRecord(a, c->stream));
@@ -645,6 +663,7 @@ int prv_create(prv_ctx** out, int device_id) try {
   if (const char* s = getenv("PRV_QUEUE_SEGMENTS")) c->queue_segments = std::min(8, std::max(1, atoi(s)));
   if (const char* s = getenv("PRV_RENDER64")) c->render64 = atoi(s) != 0;
   if (const char* s = getenv("PRV_MERGE_MAX")) c->merge_max = std::min(31, std::max(0, atoi(s)));
+  if (const char* s = getenv("PRV_POOL")) c->pool_on = atoi(s) != 0 ? 1 : 0;
   if (const char* s = getenv("PRV_DEHASH_MB")) c->dehash_budget = (size_t)std::max(0, atoi(s)) << 20;
   if (const char* s = getenv("PRV_DBG")) c->dbg_flags = atoi(s);
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
@@ -659,6 +678,7 @@ void prv_destroy(prv_ctx* c) {
   train_detach_all(c); // trainers outliving their context become inert handles
   for (hipEvent_t e : c->ev_render) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_march) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
   for (auto& m : c->models) {
     release(m.table);
     release(m.phys);
@@ -710,7 +730,7 @@ static int drain_events(prv_ctx* c, std::vector<hipEvent_t>& ev, double* ms, int
   }
   if (ms) *ms = tot;
   if (n) *n = (int)(ev.size() / 2);
-  for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ev) c->ev_free.push_back(e);
   ev.clear();
   return PRV_OK;
 }

@@ -320,6 +320,8 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
 // computed twice (in both lanes of a pair: sample selection, position, compositing) is computed once per sample here.
 // Arithmetic per sample is unchanged: features bit-identical, the same MFMAs on the same operands, the same compositing.
 // A group refills when all its 32 slots are idle (whole-group lockstep, as before).
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
 #ifndef PRV_R64_WAVES
 #define PRV_R64_WAVES 0 // dev: 4 = ask for 4 waves per SIMD (<= 128 VGPRs, the compiler spills); 0 = let it choose (3 waves)
 #endif
@@ -331,8 +333,26 @@ __attribute__((amdgpu_waves_per_eu(PRV_R64_WAVES, PRV_R64_WAVES)))
 void render_queue64_kernel(RenderParams P) {
   __shared__ half8 wl[kNumFrags * 64];
   __shared__ uint32_t mv[4][32][6]; // tail merges: {record, next sample, T, r, g, b} of the rays that change slots, per wave
+  constexpr uint32_t kPoolCap = 192;
+  __shared__ uint32_t pool[kPoolCap][6]; // the block's tail pool: rays a group gave up, waiting for an idle slot of ANY of the block's waves
+  __shared__ uint32_t pool_n, pool_lock;
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = P.field.frags64[i];
+  if (threadIdx.x == 0) {
+    pool_n = 0u;
+    pool_lock = 0u;
+  }
   __syncthreads();
+  auto pool_acquire = [&]() {
+    if (lane_id() == 0)
+      while (atomicCAS(&pool_lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto pool_release = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane_id() == 0) atomicExch(&pool_lock, 0u);
+  };
   // every lane gathers every level, so the level constants are wave-uniform: they are read straight from the kernel
   // arguments (scalar loads, SGPR operands) instead of LDS -> VGPRs
   const LevelDev* __restrict__ lvl = P.field.levels;
@@ -417,6 +437,81 @@ void render_queue64_kernel(RenderParams P) {
         __builtin_amdgcn_wave_barrier(); // the scratch is reused by the next merge
       }
     }
+    // ---- the block's tail pool.  What the in-wave merge above cannot place (the sibling group has no room) goes to a
+    // small LDS pool shared by the block's four waves: a group down to <= merge_max rays DEPOSITS them there (and takes 32
+    // fresh rays below); any group with idle slots that is not about to refill ADOPTS from the pool.  Fresh rays still
+    // start as whole 32-ray cohorts; only thinned-out tails travel.  A spin lock (one lane per wave) guards the pool.
+    if (P.pool_on) {
+      const unsigned long long act1 = __ballot(active);
+      const uint32_t below = (1u << r) - 1u;
+      const uint32_t in_pool = *(volatile uint32_t*)&pool_n; // a stale value only delays a decision by a round
+#pragma unroll
+      for (int grp = 0; grp < 2; grp++) {
+        const uint32_t a_g = grp == 0 ? (uint32_t)act1 : (uint32_t)(act1 >> 32), n_g = (uint32_t)__popc(a_g);
+        if (!drained && n_g != 0u && n_g <= (uint32_t)P.merge_max && in_pool + n_g <= kPoolCap) { // deposit
+          pool_acquire();
+          const uint32_t at = *(volatile uint32_t*)&pool_n;
+          const bool fits = at + n_g <= kPoolCap;
+          if (fits && g == grp && active) {
+            uint32_t* e = pool[at + (uint32_t)__popc(a_g & below)];
+            e[0] = rec_i;
+            e[1] = base + (uint32_t)__builtin_ctz(cur);
+            e[2] = __float_as_uint(T);
+            e[3] = __float_as_uint(cr);
+            e[4] = __float_as_uint(cg);
+            e[5] = __float_as_uint(cb);
+            active = false;
+          }
+          if (fits && lane == 0) *(volatile uint32_t*)&pool_n = at + n_g;
+          pool_release();
+        }
+      }
+      const unsigned long long act2 = __ballot(active);
+#pragma unroll
+      for (int grp = 0; grp < 2; grp++) {
+        const uint32_t a_g = grp == 0 ? (uint32_t)act2 : (uint32_t)(act2 >> 32);
+        const uint32_t n_idle = 32u - (uint32_t)__popc(a_g);
+        // adopt into groups that keep running (some slots busy), or into anything once the queue is drained
+        if (n_idle == 0u || (a_g == 0u && !drained) || *(volatile uint32_t*)&pool_n == 0u) continue;
+        pool_acquire();
+        const uint32_t have = *(volatile uint32_t*)&pool_n;
+        const uint32_t take = min(have, n_idle), from = have - take;
+        const uint32_t kth = (uint32_t)__popc(~a_g & below);
+        uint32_t ent[6] = {0, 0, 0, 0, 0, 0};
+        const bool mine = !((a_g >> r) & 1u) && kth < take; // both lanes of the slot
+        if (mine) {
+#pragma unroll
+          for (int q = 0; q < 6; q++) ent[q] = pool[from + kth][q];
+        }
+        if (lane == 0) *(volatile uint32_t*)&pool_n = from;
+        pool_release();
+        if (mine) {
+          const uint4* rec = reinterpret_cast<const uint4*>(P.queue) + (size_t)ent[0] * kRecordWords;
+          const half8 sh = reinterpret_cast<const half8*>(rec)[4 + g];
+          if (grp == 0) shA = sh;
+          else shB = sh;
+          if (g == grp) {
+            const uint32_t next = ent[1];
+            T = __uint_as_float(ent[2]); cr = __uint_as_float(ent[3]); cg = __uint_as_float(ent[4]); cb = __uint_as_float(ent[5]);
+            const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            o[0] = __uint_as_float(q0.x); o[1] = __uint_as_float(q0.y); o[2] = __uint_as_float(q0.z);
+            t0 = __uint_as_float(q0.w);
+            d[0] = __uint_as_float(q1.x); d[1] = __uint_as_float(q1.y); d[2] = __uint_as_float(q1.z);
+            dt = __uint_as_float(q1.w);
+            cur = q2.x; m1 = q2.y; m2 = q2.z; m3 = q2.w;
+            base = 0u;
+            while (base + 32u <= next) {
+              cur = m1; m1 = m2; m2 = m3; m3 = 0u;
+              base += 32u;
+            }
+            cur &= ~0u << (next & 31u);
+            pix = q3.x;
+            rec_i = ent[0];
+            active = true;
+          }
+        }
+      }
+    }
     // ---- refill: a group whose 32 slots are all idle takes the next records of the wave's claimed range
     const unsigned long long idle = __ballot(!active);
     const bool needA = (uint32_t)idle == 0xffffffffu, needB = (uint32_t)(idle >> 32) == 0xffffffffu;
@@ -467,7 +562,9 @@ void render_queue64_kernel(RenderParams P) {
     }
     const unsigned long long act = __ballot(active);
     if (act == 0ull) {
-      if (drained) break;
+      // nothing in this wave: leave once the queue is drained AND the pool is empty (whatever is deposited later comes
+      // from a wave that is still running and will adopt it itself once it has drained)
+      if (drained && (!P.pool_on || *(volatile uint32_t*)&pool_n == 0u)) break;
       continue;
     }
     n_eval += (unsigned long long)__popcll(act);

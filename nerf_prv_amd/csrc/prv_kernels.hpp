@@ -44,6 +44,7 @@ struct RenderParams {
   int last_pass;
   int refill_min;
   int merge_max; // render_queue64: a group down to <= this many rays hands them to the other group's idle slots (0 = never)
+  int pool_on;   // render_queue64: ... or, failing that, to the block's LDS tail pool (any wave's idle slots adopt them)
   int dbg; // dev-only bits (PRV_DBG env): 1 no table loads, 2 no MLP, 4 no compositing math, 8 slot-occupancy histogram
   float bg[4];
 };

@@ -153,3 +153,24 @@ def test_training_gradients_on_the_full_size_fields(ctx, oracle, which):
         np.testing.assert_allclose(got[big], want[big], rtol=5e-3)
     assert np.array_equal(np.flatnonzero(tg), np.flatnonzero(want_tg.astype(np.float32))) or \
         np.linalg.norm(tg - want_tg) <= 1e-3 * np.linalg.norm(want_tg)
+
+
+def test_tail_merge_and_pool_do_not_change_a_full_size_image(ctx, scene, monkeypatch):
+    """at 800x800 the 64-slot kernel relocates thinned-out cohorts' rays (in-wave merge, the block's LDS pool: on by default
+    for this size): which lane composites a ray changes, not one bit of the image or the sample count"""
+    desc, cams, _ = scene
+    opts = api.render_opts(W, H, S, 1, 1e-4)
+    want, st = ctx.render(0, cams, [1, 6], opts)
+    monkeypatch.setenv("PRV_MERGE_MAX", "0")
+    monkeypatch.setenv("PRV_POOL", "0")
+    plain = api.Context(0)
+    monkeypatch.delenv("PRV_MERGE_MAX")
+    monkeypatch.delenv("PRV_POOL")
+    try:
+        plain.synthetic_model(0, desc, util.SEED_A)
+        pc = plain.cameras_from_matrices(*[scene[2][0], util.FOV_X, W, H, scene[2][1], scene[2][2]])
+        got, st2 = plain.render(0, pc, [1, 6], opts)
+        assert bool((got.cpu() == want.cpu()).all()) and st2.samples_evaluated == st.samples_evaluated
+        pc.close()
+    finally:
+        plain.close()

@@ -270,7 +270,8 @@ def test_view_batches_do_not_change_anything(ctx, oracle, monkeypatch):
 @pytest.mark.parametrize("env", [{"PRV_REFILL_MIN": "8"}, {"PRV_REFILL_MIN": "1"}, {"PRV_QUEUE_SEGMENTS": "1"},
                                  {"PRV_QUEUE_SEGMENTS": "3"}, {"PRV_DEHASH_MB": "64"}, {"PRV_NO_PAIR": "1"},
                                  {"PRV_BLOCKS_PER_CU": "1"}, {"PRV_BLOCKS_PER_CU": "6", "PRV_REFILL_MIN": "16"},
-                                 {"PRV_MERGE_MAX": "0"}, {"PRV_MERGE_MAX": "6"}, {"PRV_MERGE_MAX": "31", "PRV_BLOCKS_PER_CU": "2"},
+                                 {"PRV_MERGE_MAX": "0"}, {"PRV_MERGE_MAX": "6", "PRV_POOL": "0"}, {"PRV_MERGE_MAX": "31", "PRV_BLOCKS_PER_CU": "2"},
+                                 {"PRV_MERGE_MAX": "12", "PRV_POOL": "1"}, {"PRV_MERGE_MAX": "31", "PRV_POOL": "1", "PRV_BLOCKS_PER_CU": "1"},
                                  {"PRV_RENDER64": "0", "PRV_REFILL_MIN": "8"}, {"PRV_RENDER64": "0", "PRV_NO_PAIR": "1"}])
 @pytest.mark.parametrize("which", ["F4", "F2"])
 def test_placement_and_layout_switches_change_speed_only(ctx, oracle, monkeypatch, env, which):
