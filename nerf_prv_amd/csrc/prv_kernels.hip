@@ -380,7 +380,10 @@ void render_queue64_kernel(RenderParams P) {
     // When one group is down to <= merge_max rays and the other group has that many idle slots, the rays move over
     // (dynamic state through LDS, constants re-read from the queue record) and the emptied group takes 32 fresh rays
     // below.  Which lane composites a ray changes, the arithmetic and the sample order do not: pixels are unchanged.
-    if (!drained && P.merge_max > 0) {
+    // (both relocation steps are looked at every fourth iteration: a tail leaves at most three rounds later, the
+    // bookkeeping costs a quarter)
+    const bool relocate = (n_rounds & 6ull) == 0ull;
+    if (relocate && !drained && P.merge_max > 0) {
       const unsigned long long act0 = __ballot(active);
       const uint32_t aA = (uint32_t)act0, aB = (uint32_t)(act0 >> 32);
       const uint32_t nA = (uint32_t)__popc(aA), nB = (uint32_t)__popc(aB);
@@ -441,7 +444,7 @@ void render_queue64_kernel(RenderParams P) {
     // small LDS pool shared by the block's four waves: a group down to <= merge_max rays DEPOSITS them there (and takes 32
     // fresh rays below); any group with idle slots that is not about to refill ADOPTS from the pool.  Fresh rays still
     // start as whole 32-ray cohorts; only thinned-out tails travel.  A spin lock (one lane per wave) guards the pool.
-    if (P.pool_on) {
+    if (P.pool_on && (relocate || drained)) {
       const unsigned long long act1 = __ballot(active);
       const uint32_t below = (1u << r) - 1u;
       const uint32_t in_pool = *(volatile uint32_t*)&pool_n; // a stale value only delays a decision by a round
