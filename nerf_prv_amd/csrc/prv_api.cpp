@@ -57,6 +57,7 @@ struct prv_camset {
 };
 
 static void train_detach_all(struct prv_ctx* c);
+static void comm_detach_all(struct prv_ctx* c);
 
 struct prv_ctx {
   int device = 0;
@@ -74,6 +75,7 @@ struct prv_ctx {
   int blocks_per_cu = 4;
   int refill_min = 32;
   std::vector<struct prv_trainer*> trainers; // live trainers of this context (detached by prv_destroy)
+  std::vector<struct prv_comm*> comms;       // live communicators of this context (detached by prv_destroy)
   int queue_segments = 8; // ray-queue segments = XCDs (PRV_QUEUE_SEGMENTS: 1 = single shared head)
   int render64 = 1;       // render_queue64_kernel (64 ray slots per wave); PRV_RENDER64=0: the 32-slot kernel
   int pool_on = -1;       // render_queue64 block-level tail pool (PRV_POOL=0/1; -1 = by table and image size, see render_views)
@@ -676,6 +678,7 @@ void prv_destroy(prv_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   train_detach_all(c); // trainers outliving their context become inert handles
+  comm_detach_all(c);  // ... and so do communicators
   for (hipEvent_t e : c->ev_render) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_march) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);

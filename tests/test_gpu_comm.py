@@ -216,3 +216,14 @@ def test_planner_views_sharded_trains_its_members_on_their_owners(ctx, tmp_path)
         assert a == b and len(a) == 16 * (4 - it)
         assert np.isfinite(np.frombuffer(a, api.RECORD_DTYPE)["score"]).all()
     assert all(se.count("train_members:") == 3 for _, se in res)  # both ranks went through the training step each iteration
+
+
+def test_communicator_outliving_its_context_is_inert():
+    """destroying the context first (interpreter shutdown order) must not leave the communicator pointing at freed memory"""
+    c2 = api.Context(0)
+    comm = api.Comm(c2, 0, 1, transport="socket")
+    lib, h = c2.lib, comm.handle
+    c2.close()
+    assert lib.prv_comm_barrier(h) == api.L.PRV_E_INVALID  # inert: an error code, no crash
+    lib.prv_comm_destroy(h)
+    comm.handle = None
