@@ -474,9 +474,9 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   const int W = o->width, H = o->height;
   const size_t npix = (size_t)W * H;
   int rc;
-  if ((rc = ensure(c, c->counters, 64 + 8 * 64 + 33 * 8 + 64)) != PRV_OK) return rc; // count | stats | 8 heads | dev histogram
-  uint32_t* q_count = (uint32_t*)c->counters.p;
-  uint32_t* q_head = q_count + 16; // 8 segment heads, one 64-byte line each
+  if ((rc = ensure(c, c->counters, 1024 + 8 * 64)) != PRV_OK) return rc; // stats | 8 heads | dev histogram || 8 region counts
+  uint32_t* q_head = (uint32_t*)c->counters.p + 16;   // 8 region heads, one 64-byte line each (bytes 64..575)
+  uint32_t* q_count = (uint32_t*)c->counters.p + 256; // 8 region counts, one 64-byte line each (bytes 1024..1535)
   unsigned long long* stat = (unsigned long long*)((char*)c->counters.p + 16);
   if (zero_stats) HIPCHK(c, hipMemsetAsync(stat, 0, 16, c->stream));
   if (zero_stats && (c->dbg_flags & 8)) HIPCHK(c, hipMemsetAsync(stat + 72, 0, 33 * 8, c->stream));
@@ -507,7 +507,19 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   if (spp > 1) batch = std::min<size_t>(batch, std::max<size_t>(1, c->stage_budget / (npix * 16 * (size_t)spp)));
   if (batch * npix * (size_t)spp >= (1ull << 32)) batch = ((1ull << 32) - 1) / (npix * (size_t)spp); // 32-bit pixel ids
   if (batch == 0) return fail(c, PRV_E_INVALID, "image x spp too large");
-  if ((rc = ensure(c, c->queue, batch * npix * (size_t)spp * kRecordBytes)) != PRV_OK) return rc;
+  // the queue is n_seg regions: a march block appends to region (linear block id % n_seg), so a region holds at most
+  // ceil(blocks / n_seg) * 256 records -- the same total as one flat queue plus less than one block per region
+  const int n_seg = c->queue_segments;
+  auto march_blocks = [&](int nb) {
+    const int inner = (spp > 1 && spp <= 64 && (spp & (spp - 1)) == 0) ? spp : 1;
+    int pl = 8;
+    for (int v = inner; v > 1; v >>= 1) pl--;
+    const size_t tw = (size_t)1 << ((pl + 1) / 2), th = (size_t)1 << (pl / 2);
+    return ((W + tw - 1) / tw) * ((H + th - 1) / th) * (size_t)nb * (size_t)(inner > 1 ? 1 : spp);
+  };
+  const size_t seg_cap_max = ((march_blocks((int)batch) + n_seg - 1) / n_seg) * 256;
+  if (seg_cap_max * (size_t)n_seg >= (1ull << 32)) return fail(c, PRV_E_INVALID, "image x spp too large");
+  if ((rc = ensure(c, c->queue, seg_cap_max * (size_t)n_seg * kRecordBytes)) != PRV_OK) return rc;
   if (spp > 1 && (rc = ensure(c, c->stage, batch * npix * (size_t)spp * 16)) != PRV_OK) return rc;
 
   const int n_blocks = c->n_cu * c->blocks_per_cu;
@@ -515,7 +527,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     const int nb = (int)std::min(batch, (size_t)n_views - b0);
     float* dst_f32 = out_f32 + b0 * npix * 4;
     uint32_t* dst_u8 = out_u8 ? (uint32_t*)out_u8 + b0 * npix : nullptr;
-    HIPCHK(c, hipMemsetAsync(q_count, 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(q_count, 0, 8 * 64, c->stream));
     HIPCHK(c, hipMemsetAsync(q_head, 0, 8 * 64, c->stream));
     MarchParams mp;
     memset(&mp, 0, sizeof(mp));
@@ -538,6 +550,8 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     mp.tiles_y = (uint32_t)((H + (1 << mp.tile_h_log2) - 1) >> mp.tile_h_log2);
     mp.queue = c->queue.p;
     mp.queue_count = q_count;
+    mp.n_seg = n_seg;
+    mp.seg_cap = (uint32_t)(((march_blocks(nb) + n_seg - 1) / n_seg) * 256);
     mp.out_f32 = spp > 1 ? (float*)c->stage.p : dst_f32;
     mp.out_u8 = spp > 1 ? nullptr : dst_u8;
     mp.inv_spp = 1.0f;
@@ -559,7 +573,8 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     rp.queue = c->queue.p;
     rp.queue_count = q_count;
     rp.queue_head = q_head;
-    rp.n_segments = c->queue_segments;
+    rp.n_segments = n_seg;
+    rp.seg_cap = mp.seg_cap;
     rp.stat_evaluated = stat;
     rp.out_f32 = mp.out_f32;
     rp.out_u8 = mp.out_u8;

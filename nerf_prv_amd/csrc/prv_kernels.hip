@@ -20,7 +20,7 @@
 #include <algorithm>
 
 #ifndef PRV_ABLATE
-#define PRV_ABLATE 0 // dev-only timing ablations: 1 no gather, 2 no MLP, 4 no compositing math (wrong pixels!)
+#define PRV_ABLATE 0 // dev-only timing ablations: 1 no gather, 2 no MLP, 4 no compositing math (wrong pixels!), 8 march without its rejection test
 #endif
 
 namespace prv {
@@ -33,6 +33,7 @@ __device__ __forceinline__ void morton16(uint32_t i, uint32_t& x, uint32_t& y) {
 }
 
 __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
+  __shared__ uint4 stage[4][64 * kRecordWords]; // a wave's live records, written out as ONE contiguous block
   const uint32_t tile = blockIdx.x, vi = blockIdx.y;
   const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
   // Multi-sample launches: with a power-of-two spp the sub-samples of a pixel sit on ADJACENT lanes
@@ -54,10 +55,35 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
   float o[3] = {0, 0, 0}, d[3] = {0, 0, 1}, t0 = 0.f, dt = 0.f;
   uint32_t m[4] = {0, 0, 0, 0};
   bool live = false;
-  if (valid) {
-    const CamDev cam = P.cams[P.view_ids[vi]];
-    float ox, oy;
-    spp_offset(spp_k, ox, oy);
+  bool maybe = valid;
+  const CamDev& cam = P.cams[P.view_ids[vi]];
+  float ox, oy;
+  spp_offset(spp_k, ox, oy);
+  if (valid && !has_lens(cam)) {
+    // Cheap rejection before the exact (IEEE divides, normalisation: ~300 instructions) ray set-up: nine rays in ten
+    // never come near the object and the pass is VALU bound on that set-up.  A live sample lies in an occupied cell,
+    // hence inside [occ_lo, occ_hi]; a slab test of the UNNORMALISED direction, built with reciprocals, against that
+    // box grown by `grow` can only err towards "hit": the direction is off by < 1e-6 rad, i.e. < 1e-6 * far at the
+    // box, and a ray touching the box crosses the grown one over a chord > 2 * grow.  NaNs (0 * inf) drop a slab.
+    const float far = fmaxf(fmaxf(fabsf(cam.c2w[3] - 0.5f), fabsf(cam.c2w[7] - 0.5f)), fabsf(cam.c2w[11] - 0.5f));
+    const float grow = fmaf(far, 1e-5f, 1e-3f);
+    const float x = (((float)px + ox) - cam.cx) * __builtin_amdgcn_rcpf(cam.fx);
+    const float y = (((float)py + oy) - cam.cy) * __builtin_amdgcn_rcpf(cam.fy);
+    float ta = 0.0f, tb = __builtin_inff();
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float* mrow = cam.c2w + a * 4;
+      const float inv = __builtin_amdgcn_rcpf(fmaf(mrow[0], x, fmaf(mrow[1], y, mrow[2])));
+      const float u = ((P.field.occ_lo[a] - grow) - mrow[3]) * inv, w = ((P.field.occ_hi[a] + grow) - mrow[3]) * inv;
+      ta = fmaxf(ta, fminf(u, w));
+      tb = fminf(tb, fmaxf(u, w));
+    }
+    maybe = !(tb < ta);
+  }
+#if PRV_ABLATE & 8
+  maybe = valid; // dev timing only: no rejection test
+#endif
+  if (maybe) {
     raygen(cam, px, py, ox, oy, o, d);
     float t1;
     if (ray_aabb(o, d, t0, t1)) {
@@ -81,7 +107,7 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
         if (!(tb > ta)) {
           g_hi = 0; // misses the occupied region altogether
         } else if (dt > 0.0f) {
-          const float inv_dt = 1.0f / dt;
+          const float inv_dt = __builtin_amdgcn_rcpf(dt); // bounds only (two samples of slack either side): 1 ulp is plenty
           g_lo = max(0, (int)((ta - t0) * inv_dt) - 2) & ~3;
           g_hi = min(P.S, (int)((tb - t0) * inv_dt) + 3);
         }
@@ -89,49 +115,88 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
       // one mask word (32 samples = 8 groups) at a time, so the word is a plain register and a sample's bit goes in
       // with one shift-or instead of a select chain over m[0..3]; the four fine tests of a group are issued
       // together (four loads in flight, one wait)
+      // the coarse test in coarse-cell units: p * Rc = fma(tm, d * Rc, o * Rc).  Rounding differs from occupied_coarse()'s
+      // by ~1e-6 of a cell, the dilated grid covers a whole cell and the 0.99 above leaves 1 % of one: the skip stays
+      // conservative, the masks bit-identical.
+      const int Rc_m1 = (P.field.occ_res >> 2) - 1;
+      const float fRc = (float)(P.field.occ_res >> 2);
+      const float ocx = o[0] * fRc, ocy = o[1] * fRc, ocz = o[2] * fRc, dcx = d[0] * fRc, dcy = d[1] * fRc, dcz = d[2] * fRc;
+      const uint32_t Rc = (uint32_t)(Rc_m1 + 1);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         uint32_t w = 0u;
         const int lo = max(g_lo, 32 * k), hi = min(g_hi, 32 * k + 32);
-        for (int g = lo; g < hi; g += 4) {
+        if (lo < hi) {
+          // the eight coarse tests of this mask word are issued TOGETHER (eight independent loads in flight, one wait): a
+          // test-and-wait per group made the ray's 32 groups 32 dependent memory round trips -- the pass was latency bound
+          uint32_t pass = 0xffu;
           if (coarse_ok) {
-            const float tm = fmaf((float)g + 2.0f, dt, t0);
-            if (!occupied_coarse(P.field, fmaf(tm, d[0], o[0]), fmaf(tm, d[1], o[1]), fmaf(tm, d[2], o[2]))) continue;
-          }
-          bool occ[4];
+            pass = 0u;
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int i = g + q;
-            const float t = fmaf((float)i + 0.5f, dt, t0);
-            occ[q] = occupied(P.field, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2])) && i < P.S;
+            for (int j = 0; j < 8; j++) {
+              const int g = 32 * k + 4 * j;
+              const float tm = fmaf((float)g + 2.0f, dt, t0);
+              const int cx = min(max((int)fmaf(tm, dcx, ocx), 0), Rc_m1), cy = min(max((int)fmaf(tm, dcy, ocy), 0), Rc_m1),
+                        cz = min(max((int)fmaf(tm, dcz, ocz), 0), Rc_m1);
+              const uint32_t bit = (uint32_t)cx + Rc * ((uint32_t)cy + Rc * (uint32_t)cz);
+              pass |= ((P.field.occ_coarse[bit >> 5] >> (bit & 31u)) & 1u) << j;
+            }
           }
+          // groups inside [lo, hi) only (lo is a multiple of 4)
+          pass &= (0xffu << ((lo - 32 * k) >> 2)) & (0xffu >> (7 - ((hi - 1 - 32 * k) >> 2)));
+          while (pass) {
+            const int j = __builtin_ctz(pass);
+            pass &= pass - 1u;
+            const int g = 32 * k + 4 * j;
+            bool occ[4];
 #pragma unroll
-          for (int q = 0; q < 4; q++) w |= (uint32_t)occ[q] << ((g + q) & 31);
+            for (int q = 0; q < 4; q++) {
+              const int i = g + q;
+              const float t = fmaf((float)i + 0.5f, dt, t0);
+              occ[q] = occupied(P.field, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2])) && i < P.S;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) w |= (uint32_t)occ[q] << ((g + q) & 31);
+          }
         }
         m[k] = w;
       }
       live = (m[0] | m[1] | m[2] | m[3]) != 0u;
     }
   }
-  // wave-level compaction: ballot + prefix popcount, one atomic per wave
+  // wave-level compaction: ballot + prefix popcount, one atomic per wave.  The queue is cut into n_seg regions of
+  // seg_cap records and the counter is sharded with it (a block appends to region `linear block id % n_seg`): one
+  // returning atomic word saturates near 90 per microsecond on this chip and ~10^5 waves append per launch -- with a
+  // single counter that alone was 0.15 ms of the 0.84 ms pass.  The render kernel drains region by region.
   const unsigned long long b = __ballot(live);
   const int lane = threadIdx.x & 63;
   uint32_t base = 0;
   if (b != 0ull) {
-    if (lane == (int)__builtin_ctzll(b)) base = atomicAdd(P.queue_count, (uint32_t)__popcll(b));
+    const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) % (uint32_t)P.n_seg;
+    if (lane == (int)__builtin_ctzll(b)) base = shard * P.seg_cap + atomicAdd(P.queue_count + 16u * shard, (uint32_t)__popcll(b));
     base = __shfl(base, (int)__builtin_ctzll(b));
+    // the wave's live records are consecutive in the queue: they are staged in LDS and leave as one contiguous block,
+    // consecutive lanes writing consecutive 16-byte words (a lane storing its own 96-byte record word by word makes
+    // every store instruction touch 64 different lines, six times over)
+    uint4* st = stage[threadIdx.x >> 6];
+    if (live) {
+      uint4* rec = st + (uint32_t)__popcll(b & ((1ull << lane) - 1ull)) * kRecordWords;
+      rec[0] = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(t0));
+      rec[1] = make_uint4(__float_as_uint(d[0]), __float_as_uint(d[1]), __float_as_uint(d[2]), __float_as_uint(dt));
+      rec[2] = make_uint4(m[0], m[1], m[2], m[3]);
+      rec[3] = make_uint4(pix, 0u, 0u, 0u);
+      // direction encoding once per ray, here, so a slot refill in K_B is loads only
+      reinterpret_cast<half8*>(rec)[4] = sh_fragment(0, d[0], d[1], d[2]);
+      reinterpret_cast<half8*>(rec)[5] = sh_fragment(1, d[0], d[1], d[2]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint4* dst = reinterpret_cast<uint4*>(P.queue) + (size_t)base * kRecordWords;
+    const uint32_t n_words = (uint32_t)__popcll(b) * kRecordWords;
+    for (uint32_t i = (uint32_t)lane; i < n_words; i += 64u) dst[i] = st[i];
   }
-  if (live) {
-    uint32_t slot = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-    uint4* rec = reinterpret_cast<uint4*>(P.queue) + (size_t)slot * kRecordWords;
-    rec[0] = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(t0));
-    rec[1] = make_uint4(__float_as_uint(d[0]), __float_as_uint(d[1]), __float_as_uint(d[2]), __float_as_uint(dt));
-    rec[2] = make_uint4(m[0], m[1], m[2], m[3]);
-    rec[3] = make_uint4(pix, 0u, 0u, 0u);
-    // direction encoding once per ray, here, so a slot refill in K_B is loads only
-    reinterpret_cast<half8*>(rec)[4] = sh_fragment(0, d[0], d[1], d[2]);
-    reinterpret_cast<half8*>(rec)[5] = sh_fragment(1, d[0], d[1], d[2]);
-  } else if (valid) {
+  if (!live && valid) {
     // dead ray: contributes exactly zero to its pixel
     float4* out = reinterpret_cast<float4*>(P.out_f32) + pix;
     float4 v = P.spp_k == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *out;
@@ -157,7 +222,6 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
 
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const uint32_t lt_mask = (1u << r) - 1u;
-  const uint32_t n_rec = *P.queue_count;
 
   bool active = false;
   uint32_t pix = 0;
@@ -169,7 +233,6 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
   unsigned long long n_eval = 0ull, n_rounds = 0ull;
   uint32_t q_cur = 0, q_end = 0; // this wave's claimed range of queue records (wave-uniform)
   const uint32_t n_seg = (uint32_t)P.n_segments; // 8 = one per XCD, 1 = a single shared head
-  const uint32_t seg_len = ((n_rec + n_seg * kClaim - 1u) / (n_seg * kClaim)) * kClaim;
   // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this workgroup runs on
   uint32_t seg = n_seg > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % n_seg : 0u;
   uint32_t seg_tried = 0;
@@ -198,10 +261,10 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(P.queue_head + 16u * seg, kClaim);
         base = __builtin_amdgcn_readfirstlane(base);
-        const uint32_t s_lo = min(seg * seg_len, n_rec), s_hi = min(s_lo + seg_len, n_rec);
-        if (base < s_hi - s_lo) {
+        const uint32_t s_lo = seg * P.seg_cap, s_cnt = P.queue_count[16u * seg]; // region `seg` of the queue
+        if (base < s_cnt) {
           q_cur = s_lo + base;
-          q_end = min(q_cur + kClaim, s_hi);
+          q_end = min(q_cur + kClaim, s_lo + s_cnt);
         } else if (++seg_tried >= n_seg) {
           drained = true;
         } else {
@@ -358,7 +421,6 @@ void render_queue64_kernel(RenderParams P) {
   const LevelDev* __restrict__ lvl = P.field.levels;
 
   const int lane = threadIdx.x & 63, r = lane & 31, g = lane >> 5; // g: the lane's group (A = 0, B = 1) AND its k-row half
-  const uint32_t n_rec = *P.queue_count;
 
   bool active = false;
   uint32_t pix = 0, rec_i = 0; // rec_i: the ray's queue record (a ray that changes slots re-reads its constants from it)
@@ -370,7 +432,6 @@ void render_queue64_kernel(RenderParams P) {
   unsigned long long n_eval = 0ull, n_rounds = 0ull;
   uint32_t q_cur = 0, q_end = 0;
   const uint32_t n_seg = (uint32_t)P.n_segments;
-  const uint32_t seg_len = ((n_rec + n_seg * kClaim - 1u) / (n_seg * kClaim)) * kClaim;
   uint32_t seg = n_seg > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % n_seg : 0u;
   uint32_t seg_tried = 0;
 
@@ -526,10 +587,10 @@ void render_queue64_kernel(RenderParams P) {
           uint32_t claim = 0;
           if (lane == 0) claim = atomicAdd(P.queue_head + 16u * seg, kClaim);
           claim = __builtin_amdgcn_readfirstlane(claim);
-          const uint32_t s_lo = min(seg * seg_len, n_rec), s_hi = min(s_lo + seg_len, n_rec);
-          if (claim < s_hi - s_lo) {
+          const uint32_t s_lo = seg * P.seg_cap, s_cnt = P.queue_count[16u * seg]; // region `seg` of the queue
+          if (claim < s_cnt) {
             q_cur = s_lo + claim;
-            q_end = min(q_cur + kClaim, s_hi);
+            q_end = min(q_cur + kClaim, s_lo + s_cnt);
           } else if (++seg_tried >= n_seg) {
             drained = true;
           } else {

@@ -21,7 +21,9 @@ struct MarchParams {
   int tile_w_log2, tile_h_log2; // pixel tile of one 256-thread block
   int spp_inner_log2;           // > 0: sub-samples on adjacent lanes (spp = 2^n), 0: on grid.z
   void* queue;
-  uint32_t* queue_count;
+  uint32_t* queue_count; // n_seg counters, 64 bytes apart: records appended to region s of the queue
+  int n_seg;             // the queue is n_seg regions of seg_cap records; a block appends to region (linear block id % n_seg)
+  uint32_t seg_cap;
   float* out_f32; // n_views*H*W*4
   uint32_t* out_u8; // optional, n_views*H*W
   float inv_spp;
@@ -32,9 +34,10 @@ struct MarchParams {
 struct RenderParams {
   FieldDev field;
   const void* queue;
-  const uint32_t* queue_count;
-  uint32_t* queue_head; // n_segments heads, 64 bytes apart (segment-relative record counts)
+  const uint32_t* queue_count; // n_segments counters, 64 bytes apart: records in region s
+  uint32_t* queue_head; // n_segments heads, 64 bytes apart (region-relative record counts)
   int n_segments;
+  uint32_t seg_cap;     // records per region: region s = [s * seg_cap, s * seg_cap + queue_count[16 s])
   unsigned long long* stat_evaluated;
   float* out_f32;
   uint32_t* out_u8;
