@@ -72,6 +72,9 @@ struct prv_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs of the current profiling window
   std::vector<hipEvent_t> ev_free;             // recycled events: a profiling window creates none once the pool is warm
+  void* pin = nullptr;                         // pinned host staging of the per-call camera upload (no pageable copy, no stream sync)
+  size_t pin_cap = 0;
+  hipEvent_t pin_ev = nullptr; // recorded after the upload: the staging is rewritten only once that copy has run
   int blocks_per_cu = 4;
   int refill_min = 32;
   std::vector<struct prv_trainer*> trainers; // live trainers of this context (detached by prv_destroy)
@@ -466,6 +469,10 @@ CamDev cam_at(const prv_camset* cs, int i, int w, int h) {
   return r;
 }
 
+constexpr size_t kStatOffset = 1024;                        // counters buffer: heads 0..511, counts 512..1023, then the statistics
+constexpr size_t kCountersBytes = kStatOffset + (72 + 33) * 8; // {evaluated, wave rounds}, 70 spare words, 33-bin dev histogram
+
+
 // The render of one batch of views into out_f32 (+ optional out_u8).  Views are dealt to
 // the queue in batches so the queue stays within queue_budget bytes.
 int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, int n_views,
@@ -474,29 +481,41 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   const int W = o->width, H = o->height;
   const size_t npix = (size_t)W * H;
   int rc;
-  if ((rc = ensure(c, c->counters, 1024 + 8 * 64)) != PRV_OK) return rc; // stats | 8 heads | dev histogram || 8 region counts
-  uint32_t* q_head = (uint32_t*)c->counters.p + 16;   // 8 region heads, one 64-byte line each (bytes 64..575)
-  uint32_t* q_count = (uint32_t*)c->counters.p + 256; // 8 region counts, one 64-byte line each (bytes 1024..1535)
-  unsigned long long* stat = (unsigned long long*)((char*)c->counters.p + 16);
-  if (zero_stats) HIPCHK(c, hipMemsetAsync(stat, 0, 16, c->stream));
-  if (zero_stats && (c->dbg_flags & 8)) HIPCHK(c, hipMemsetAsync(stat + 72, 0, 33 * 8, c->stream));
-  if (n_views == 0) return PRV_OK;
+  // counters: 8 region heads (one 64-byte line each) | 8 region counts (same) | stats {evaluated, wave rounds} | dev histogram
+  if ((rc = ensure(c, c->counters, kCountersBytes)) != PRV_OK) return rc;
+  uint32_t* q_head = (uint32_t*)c->counters.p;
+  uint32_t* q_count = (uint32_t*)c->counters.p + 128;
+  unsigned long long* stat = (unsigned long long*)((char*)c->counters.p + kStatOffset);
+  if (n_views == 0) {
+    if (zero_stats) HIPCHK(c, hipMemsetAsync(stat, 0, kCountersBytes - kStatOffset, c->stream));
+    return PRV_OK;
+  }
 
-  // cameras at this resolution, uploaded per call (tiny)
-  std::vector<CamDev> cams(n_views);
-  std::vector<int> ids(n_views);
+  // cameras at this resolution, uploaded per call (tiny): built in pinned memory and sent with one asynchronous copy
+  const size_t up_bytes = (size_t)n_views * (sizeof(CamDev) + sizeof(int));
+  if (c->pin_cap < up_bytes) {
+    if (c->pin_ev) HIPCHK(c, hipEventSynchronize(c->pin_ev));
+    if (c->pin) (void)hipHostFree(c->pin);
+    c->pin = nullptr;
+    c->pin_cap = 0;
+    HIPCHK(c, hipHostMalloc(&c->pin, std::max<size_t>(up_bytes, 8192), hipHostMallocDefault));
+    c->pin_cap = std::max<size_t>(up_bytes, 8192);
+  }
+  if (!c->pin_ev) HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev, hipEventDisableTiming));
+  else HIPCHK(c, hipEventSynchronize(c->pin_ev));
+  CamDev* cams = (CamDev*)c->pin;
+  int* ids = (int*)((char*)c->pin + (size_t)n_views * sizeof(CamDev));
   for (int i = 0; i < n_views; i++) {
     const int v = view_ids ? view_ids[i] : i;
     if (v < 0 || v >= (int)cs->cams.size()) return fail(c, PRV_E_INVALID, "view id %d out of range", v);
     cams[i] = cam_at(cs, v, W, H);
     ids[i] = i;
   }
-  if ((rc = ensure(c, c->view_ids, (size_t)n_views * (sizeof(CamDev) + sizeof(int)))) != PRV_OK) return rc;
+  if ((rc = ensure(c, c->view_ids, up_bytes)) != PRV_OK) return rc;
   CamDev* cams_dev = (CamDev*)c->view_ids.p;
   int* ids_dev = (int*)((char*)c->view_ids.p + (size_t)n_views * sizeof(CamDev));
-  HIPCHK(c, hipMemcpyAsync(cams_dev, cams.data(), (size_t)n_views * sizeof(CamDev), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(ids_dev, ids.data(), (size_t)n_views * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream)); // staging vectors are stack-owned
+  HIPCHK(c, hipMemcpyAsync(c->view_ids.p, c->pin, up_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->pin_ev, c->stream));
 
   // all spp sub-samples of a batch of views go through ONE march + ONE render launch: sub-sample k of
   // view v is image (k*nb + v) of a staging buffer, reduced over k in order afterwards (spp = 1 renders
@@ -527,8 +546,8 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     const int nb = (int)std::min(batch, (size_t)n_views - b0);
     float* dst_f32 = out_f32 + b0 * npix * 4;
     uint32_t* dst_u8 = out_u8 ? (uint32_t*)out_u8 + b0 * npix : nullptr;
-    HIPCHK(c, hipMemsetAsync(q_count, 0, 8 * 64, c->stream));
-    HIPCHK(c, hipMemsetAsync(q_head, 0, 8 * 64, c->stream));
+    // one fill per batch: heads and counts, and with them the statistics when this call starts a new window
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, b0 == 0 && zero_stats ? kCountersBytes : kStatOffset, c->stream));
     MarchParams mp;
     memset(&mp, 0, sizeof(mp));
     mp.field = m.dev;
@@ -612,7 +631,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
 int fetch_stats(prv_ctx* c, const prv_render_opts* o, int n_views, int n_models, prv_stats* st) {
   if (!st) return PRV_OK;
   unsigned long long ev2[2] = {0, 0};
-  HIPCHK(c, hipMemcpyAsync(ev2, (char*)c->counters.p + 16, 16, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(ev2, (char*)c->counters.p + kStatOffset, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const unsigned long long ev = ev2[0];
   st->wave_rounds = ev2[1];
@@ -621,7 +640,7 @@ int fetch_stats(prv_ctx* c, const prv_render_opts* o, int n_views, int n_models,
   st->samples_evaluated = ev;
   if (c->dbg_flags & 8) { // dev: slot-occupancy histogram of the render launches since the stats were cleared
     unsigned long long hist[33];
-    HIPCHK(c, hipMemcpy(hist, (char*)c->counters.p + 16 + 72 * 8, sizeof(hist), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hist, (char*)c->counters.p + kStatOffset + 72 * 8, sizeof(hist), hipMemcpyDeviceToHost));
     unsigned long long tot = 0;
     for (int i = 1; i <= 32; i++) tot += hist[i];
     fprintf(stderr, "slot occupancy per wave-round (active slots: share of rounds):");
@@ -709,6 +728,8 @@ void prv_destroy(prv_ctx* c) {
   release(c->queue);
   release(c->stage);
   release(c->counters);
+  if (c->pin) (void)hipHostFree(c->pin);
+  if (c->pin_ev) (void)hipEventDestroy(c->pin_ev);
   release(c->view_ids);
   release(c->img_f32);
   release(c->partial);
