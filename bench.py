@@ -248,6 +248,7 @@ class Round:
             barrier()
             elapsed = time.perf_counter() - t0
             prof = ctx.profile_end()
+            prof["clock_ghz"] = ctx.render_clock_ghz()  # stamped inside the last step's render launch (prv_debug_render_clock)
         finally:
             gc.enable()
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=env["device"])
@@ -309,6 +310,14 @@ def kernel_figures(m, variant, hbm_bound):
         "samples_per_s_in_kernel": samples / kernel_s,
         "traffic_from_profile": None,
     }
+    clock = prof.get("clock_ghz") or 0.0
+    if clock > 0.0:
+        # measured in this run: one wave of the render launch stamps the shader cycle counter against the constant-rate
+        # reference counter, so the per-clock peaks can be priced at the clock the launch really ran at
+        out["shader_clock_ghz_measured"] = clock
+        out["mfma_pipe_frac_at_measured_clock"] = mfma_pipe_frac * MAX_CLOCK_HZ / (clock * 1e9)
+        if cost:
+            out["valu_issue_frac_at_measured_clock"] = valu_frac * MAX_CLOCK_HZ / (clock * 1e9)
     if traffic:
         per_sample = (traffic["fetch_kib_per_launch"] + traffic["write_kib_per_launch"]) * 1024.0 / traffic["samples_evaluated_per_launch"]
         out["traffic_from_profile"] = {"bytes_per_launch": per_sample * samples, "bytes_per_unit": per_sample, "file": TRAFFIC_FILE,
@@ -333,7 +342,8 @@ def kernel_figures(m, variant, hbm_bound):
         out["note"] = ("17.4 MiB table is L2 / Infinity-Cache resident, so the HBM figure is not a bound here (hbm_algorithmic_frac "
                        "is kept for reference only).  frac = VALU wave-instructions issued per second (wave-rounds counted by the "
                        "kernel in this run x VALU instructions per round from the PMC pass) over 1024 SIMDs x 2.4 GHz / 4 cycles; "
-                       "the clock under load is below 2.4 GHz, so the true issue occupancy is higher than frac")
+                       "the clock under load is below 2.4 GHz (shader_clock_ghz_measured, stamped inside the launch), so the "
+                       "issue occupancy of the cycles that really happened is valu_issue_frac_at_measured_clock")
     return out
 
 

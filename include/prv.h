@@ -380,6 +380,12 @@ typedef struct prv_model_layout {
   int32_t n_dense_levels;         /* leading physically dense levels */
 } prv_model_layout;
 int prv_debug_model_layout(prv_ctx* ctx, int model_slot, prv_model_layout* out);
+/* Shader clock the render launches actually ran at (roofline accounting: the VALU issue peak is per clock and the
+ * clock under this load is well below the 2.4 GHz maximum).  One wave of every render_queue launch stamps the shader
+ * cycle counter and the constant-rate reference counter at its start and end; this returns the two sums since the
+ * statistics were last cleared (a prv_render / prv_score_views call with stats clears them) and the reference rate.
+ * Average clock = shader_cycles / (ref_ticks / ref_hz).  Synchronises the stream. */
+int prv_debug_render_clock(prv_ctx* ctx, uint64_t* shader_cycles, uint64_t* ref_ticks, double* ref_hz);
 /* rays of view i at (w,h): o,d = n*3, t = n*2 (AABB entry/exit; exit<=entry => miss) */
 int prv_debug_raygen(prv_ctx* ctx, const prv_camset* cs, int view, int width, int height,
                      int spp_index, float* o, float* d, float* t);

@@ -155,6 +155,7 @@ SIGNATURES = {
     "prv_score_views_sharded": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, C.POINTER(RenderOpts), _vp, _vp, C.POINTER(Stats)]),
     "prv_model_exchange": (_i, [_vp, _vp, _i, C.POINTER(FieldDesc)]),
     "prv_debug_model_layout": (_i, [_vp, _i, C.POINTER(ModelLayout)]),
+    "prv_debug_render_clock": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "prv_debug_raygen": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "prv_debug_encode": (_i, [_vp, _i, _vp, _i, _vp]),
     "prv_debug_field": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),

@@ -352,6 +352,12 @@ class Context:
         self._chk(self.lib.prv_debug_model_layout(self.handle, slot, C.byref(out)))
         return {k: getattr(out, k) for k, _ in out._fields_}
 
+    def render_clock_ghz(self):
+        """average shader clock of the render launches since the statistics were last cleared (prv_debug_render_clock)"""
+        cyc, ticks, hz = C.c_uint64(), C.c_uint64(), C.c_double()
+        self._chk(self.lib.prv_debug_render_clock(self.handle, C.byref(cyc), C.byref(ticks), C.byref(hz)))
+        return cyc.value / (ticks.value / hz.value) / 1e9 if ticks.value else 0.0
+
     def debug_raygen(self, camset, view, width, height, spp_index=0):
         n = width * height
         o, d, t = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 2), np.float32)

@@ -1481,6 +1481,21 @@ int prv_rank(const prv_score_record* r, const int* ids, int n, int* order) try {
 
 // ------------------------------------------------------------------ stage hooks
 
+int prv_debug_render_clock(prv_ctx* c, uint64_t* shader_cycles, uint64_t* ref_ticks, double* ref_hz) try {
+  if (!c) return PRV_E_INVALID;
+  if (!shader_cycles || !ref_ticks || !ref_hz) return fail(c, PRV_E_INVALID, "NULL output");
+  if (!c->counters.p) return fail(c, PRV_E_STATE, "nothing rendered yet");
+  unsigned long long v[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(v, (char*)c->counters.p + kStatOffset + 16, 16, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int khz = 0;
+  HIPCHK(c, hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+  *shader_cycles = v[0];
+  *ref_ticks = v[1];
+  *ref_hz = (double)khz * 1e3;
+  return PRV_OK;
+} catch (...) { return caught(c); }
+
 int prv_debug_model_layout(prv_ctx* c, int slot, prv_model_layout* out) try {
   if (!c) return PRV_E_INVALID;
   int rc = check_model(c, slot);

@@ -210,6 +210,22 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
 
 // ------------------------------------------------------------------ K_B render from the queue
 
+// One wave per launch stamps the shader cycle counter (s_memtime) and the constant-rate reference counter
+// (s_memrealtime) into the statistics block: {2, 3} accumulate the deltas, {4, 5} hold the start stamps.  The kernels
+// are persistent, so block 0 lives for the whole launch and the ratio is the launch's average shader clock.
+__device__ __forceinline__ void clock_stamp_begin(unsigned long long* stat) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    stat[4] = __builtin_readcyclecounter();
+    stat[5] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+__device__ __forceinline__ void clock_stamp_end(unsigned long long* stat) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    atomicAdd(stat + 2, __builtin_readcyclecounter() - stat[4]);
+    atomicAdd(stat + 3, __builtin_amdgcn_s_memrealtime() - stat[5]);
+  }
+}
+
 template <int F, int NPAIR>
 __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
   __shared__ half8 wl[kNumFrags * 64];
@@ -231,6 +247,7 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
   half8 shf = {0, 0, 0, 0, 0, 0, 0, 0};
   bool drained = false;
   unsigned long long n_eval = 0ull, n_rounds = 0ull;
+  clock_stamp_begin(P.stat_evaluated);
   uint32_t q_cur = 0, q_end = 0; // this wave's claimed range of queue records (wave-uniform)
   const uint32_t n_seg = (uint32_t)P.n_segments; // 8 = one per XCD, 1 = a single shared head
   // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this workgroup runs on
@@ -367,6 +384,7 @@ __global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
     atomicAdd(P.stat_evaluated, n_eval);
     atomicAdd(P.stat_evaluated + 1, n_rounds); // wave-rounds: slot utilisation = evaluated / (32 * rounds)
   }
+  clock_stamp_end(P.stat_evaluated);
   if (P.dbg & 8) {
     __syncthreads();
     if (threadIdx.x < 33 && hist[threadIdx.x]) atomicAdd(P.stat_evaluated + 72 + threadIdx.x, (unsigned long long)hist[threadIdx.x]);
@@ -430,6 +448,7 @@ void render_queue64_kernel(RenderParams P) {
   half8 shA = {0, 0, 0, 0, 0, 0, 0, 0}, shB = {0, 0, 0, 0, 0, 0, 0, 0}; // SH rows [8g, 8g+8) of the rays in slots (r, A) and (r, B)
   bool drained = false;
   unsigned long long n_eval = 0ull, n_rounds = 0ull;
+  clock_stamp_begin(P.stat_evaluated);
   uint32_t q_cur = 0, q_end = 0;
   const uint32_t n_seg = (uint32_t)P.n_segments;
   uint32_t seg = n_seg > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % n_seg : 0u;
@@ -694,6 +713,7 @@ void render_queue64_kernel(RenderParams P) {
     atomicAdd(P.stat_evaluated, n_eval);
     atomicAdd(P.stat_evaluated + 1, n_rounds);
   }
+  clock_stamp_end(P.stat_evaluated);
 }
 
 

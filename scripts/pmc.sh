@@ -12,6 +12,9 @@ S[4]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
 S[5]="FETCH_SIZE"
 S[6]="WRITE_SIZE"
 S[8]="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_WAVES SQ_BUSY_CYCLES"
+S[9]="TA_TA_BUSY_sum TA_BUSY_max TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum"
+S[10]="TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
+S[11]="TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TCP_TCR_TCP_STALL_CYCLES_sum"
 S[7]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum"
 for i in ${SETS//,/ }; do
   timeout 150 rocprofv3 --kernel-trace --pmc ${S[$i]} --output-format csv -d $OUT/p$i -- python3 ${PMC_SCRIPT:-scripts/kbench.py} ${PMC_SCRIPT:+} $( [ -z "$PMC_SCRIPT" ] && echo --reps 1 ) "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed/timeout"
