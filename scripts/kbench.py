@@ -32,9 +32,14 @@ out = torch.empty((args.views, H, W, 4), dtype=torch.float32, device="cuda")
 _, st = ctx.render(0, cams, None, opts, out=out)
 ctx.profile_begin()
 t0 = time.perf_counter()
+clocks = []
 for _ in range(args.reps):
     ctx.render(0, cams, None, opts, out=out, want_stats=False)
+    if os.environ.get("KBENCH_CLOCKS"):
+        clocks.append(ctx.render_clock_ghz())
 torch.cuda.synchronize()
+if clocks:
+    print(args.tag, "clock GHz per rep:", " ".join(f"{c:.3f}" for c in clocks))
 dt = (time.perf_counter() - t0) / args.reps
 p = ctx.profile_end()
 rms, mms = p["render_ms"] / args.reps, p["march_ms"] / args.reps
@@ -43,4 +48,4 @@ print(f"{args.tag} BPC={os.environ.get('PRV_BLOCKS_PER_CU','4')} RM={os.environ.
       f"render={rms:.2f}ms march={mms:.2f}ms wall={dt*1e3:.2f}ms "
       f"kernel_rate={st.samples_evaluated/rms/1e6:.2f} Gsamp/s wall_rate={st.samples_evaluated/dt/1e9:.2f} Gsamp/s "
       f"frac={st.samples_evaluated/rms/1e6*512/8000:.3f} util={st.samples_evaluated/max(1,32*st.wave_rounds):.3f} "
-      f"ns/round/SIMD={rms*1e6/max(1,st.wave_rounds/1024):.0f}")
+      f"ns/round/SIMD={rms*1e6/max(1,st.wave_rounds/1024):.0f} clock={ctx.render_clock_ghz():.3f}GHz")
