@@ -108,6 +108,41 @@ def test_render_pixels_and_sample_counts(ctx, oracle, fields, cams, S, spp):
     assert st.rays == len(ocams) * w * h * spp and st.samples_nominal == st.rays * S
 
 
+def test_march_rejection_on_awkward_cameras(ctx, oracle, fields):
+    """the march pass rejects rays with a reciprocal-only slab test against the occupied cells' (grown) bounding box
+    before the exact set-up (prv_kernels.hip, march_compact_kernel): it may only ever err towards "hit".  Cameras that
+    stress it: inside the object, exactly axis-aligned rays (zero direction components: 0 * inf in the slab test),
+    300 units away, looking away, and a sweep of sideways offsets whose rays graze the box.  Pixels and the count of
+    evaluated samples equal the oracle's, which knows no such test."""
+    d_o, d_p, f = fields
+    w = h = 33  # odd: the central pixel's ray is exactly the optical axis
+    S = 64
+
+    def tm(rot, t):
+        m = np.eye(4)
+        m[:3, :3] = rot
+        m[:3, 3] = t
+        return m
+
+    eye, back = np.eye(3), np.diag([-1.0, 1.0, -1.0])
+    ry = lambda a: np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    cases = [("inside", tm(eye, [0, 0, 0]), util.FOV_X), ("axis", tm(eye, [0, 0, 0.3]), util.FOV_X), ("away", tm(back, [0, 0, 0.3]), util.FOV_X),
+             ("far", tm(eye, [0, 0, 60.0]), 0.02), ("corner", tm(ry(0.6), [0.25, 0.07, 0.28]), 0.5)]
+    cases += [(f"graze{i}", tm(eye, [0.04 * i, 0.02 * i, 0.3]), 0.6) for i in range(1, 8)]
+    scale, offset = 5.0, np.array([0.5, 0.5, 0.5])
+    live_views = 0
+    for name, m, fov in cases:
+        cs = ctx.cameras_from_matrices(m[None], fov, w, h, scale, offset)
+        oc = oracle.cameras_from_transforms(m[None], fov, w, h, scale, offset)[0]
+        img, st = ctx.render(0, cs, None, api.render_opts(w, h, S, 1, 1e-4))
+        want, ne = f.render(oc, w, h, S, 1, 1e-4)
+        util.assert_pixels_close(img[0].cpu().numpy(), want)
+        assert abs(int(st.samples_evaluated) - ne) <= 2, (name, int(st.samples_evaluated), ne)
+        live_views += ne > 0
+        cs.close()
+    assert live_views >= 6  # most of these views do see the object; "away" sees nothing
+
+
 REF_INTR = {"fl_x": 915.60668945312500, "fl_y": 913.32666015625, "cx": 647.14532470703125, "cy": 372.51531982421875,
             "w": 1280, "h": 720, "k1": 0.12042199820280075, "k2": -0.21373499929904938, "p1": -0.0021210000850260258,
             "p2": 7.5e-4}
