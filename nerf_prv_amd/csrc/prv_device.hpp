@@ -545,9 +545,18 @@ struct MlpOut {
   f32x16 rgb;  // colour MLP outputs: rows 0..2 = r,g,b logits in regs 0..2 of lane half 0
 };
 
+// A tap sees the fp16 B fragments a lane holds between the layers (the trainer's forward pass stores them for its
+// backward pass): tap(0, h1[4]), tap(1, &density_out), tap(2, h2[4]), tap(3, h3[4]).  Fragment t, element j of lane
+// half h = unit 32 (t >> 1) + 16 (t & 1) + 8 (j >> 2) + (j & 3) + 4 h of a 64-unit layer; the density output's element
+// j = unit (j & 3) + 8 (j >> 2) + 4 h.
+struct MlpNoTap {
+  __device__ __forceinline__ void operator()(int, const half8*) const {}
+};
+
 // frag order: D1 (mt,s)=4 | D2 s=4 | R1 (mt,s)=4 | R2 (mt,s)=8 | R3 s=4
+template <class Tap = MlpNoTap>
 __device__ __forceinline__ MlpOut mlp_forward(const half8* __restrict__ wl, int lane, half8 f0,
-                                              half8 f1, half8 shfrag) {
+                                              half8 f1, half8 shfrag, Tap tap = Tap()) {
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   MlpOut out;
   half8 hf[4];
@@ -560,6 +569,7 @@ __device__ __forceinline__ MlpOut mlp_forward(const half8* __restrict__ wl, int 
     hf[1] = pack8<true>(a0, 8);
     hf[2] = pack8<true>(a1, 0);
     hf[3] = pack8<true>(a1, 8);
+    tap(0, hf);
   }
   { // density layer 2: 64 -> 16 (rows 16..31 zero padding)
     f32x16 a = mfma(wl[4 * 64 + lane], hf[0], zero);
@@ -569,6 +579,7 @@ __device__ __forceinline__ MlpOut mlp_forward(const half8* __restrict__ wl, int 
     out.dens = a;
   }
   half8 df = pack8<false>(out.dens, 0);
+  tap(1, &df);
   { // colour layer 1: [density out 16 | SH 16] -> 64
     f32x16 a0 = mfma(wl[8 * 64 + lane], df, zero);
     f32x16 a1 = mfma(wl[10 * 64 + lane], df, zero);
@@ -578,6 +589,7 @@ __device__ __forceinline__ MlpOut mlp_forward(const half8* __restrict__ wl, int 
     hf[1] = pack8<true>(a0, 8);
     hf[2] = pack8<true>(a1, 0);
     hf[3] = pack8<true>(a1, 8);
+    tap(2, hf);
   }
   { // colour layer 2: 64 -> 64
     f32x16 a0 = mfma(wl[12 * 64 + lane], hf[0], zero);
@@ -592,6 +604,7 @@ __device__ __forceinline__ MlpOut mlp_forward(const half8* __restrict__ wl, int 
     hf[1] = pack8<true>(a0, 8);
     hf[2] = pack8<true>(a1, 0);
     hf[3] = pack8<true>(a1, 8);
+    tap(3, hf);
   }
   { // colour layer 3: 64 -> 16 (3 used)
     f32x16 a = mfma(wl[20 * 64 + lane], hf[0], zero);

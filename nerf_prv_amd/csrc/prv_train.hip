@@ -153,6 +153,35 @@ __device__ __forceinline__ void train_encode_level(const uint16_t* __restrict__ 
   for (int k = 0; k < F; k++) feat[k] = (float)acc[k];
 }
 
+// the corner entries and weights alone (no table access): what the backward pass needs of a level when the forward
+// pass kept the activations
+template <int F>
+__device__ __forceinline__ void train_level_corners(const LevelCanon& L, float px, float py, float pz, uint32_t cidx[8], float cw[8]) {
+  const float p[3] = {clamp01(px), clamp01(py), clamp01(pz)};
+  uint32_t c0[3];
+  _Float16 wh[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float pos = fmaf(L.scale, p[a], 0.5f);
+    const float fl = floorf(pos);
+    const float w = pos - fl;
+    c0[a] = (uint32_t)(int)fl;
+    wh[a][0] = to_half(1.0f - w);
+    wh[a][1] = (_Float16)w;
+  }
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    uint32_t cc[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) cc[a] = min(c0[a] + ((c >> a) & 1u), L.res - 1u);
+    const uint32_t idx = L.hashed ? ((cc[0] ^ (cc[1] * 2654435761u) ^ (cc[2] * 805459861u)) & (L.size - 1u))
+                                  : (cc[0] + L.res * (cc[1] + L.res * cc[2]));
+    const _Float16 wxy = wh[0][c & 1] * wh[1][(c >> 1) & 1];
+    cidx[c] = L.offset + idx;
+    cw[c] = (float)(wxy * wh[2][c >> 2]);
+  }
+}
+
 // ------------------------------------------------------------------ tile kernel
 
 typedef float f32x16v __attribute__((ext_vector_type(16)));
@@ -171,6 +200,23 @@ __device__ constexpr int kLLds[5] = {0, 2080, 3168, 5248, 9408}; // prefix of n_
 constexpr int kWLds = 10496;
 // activation rows: feat 0..31 | h1 32..95 | in2 96..127 | h2 128..191 | h3 192..255
 constexpr int kAFeat = 0, kAH1 = 32, kAIn2 = 96, kAH2 = 128, kAH3 = 192, kARows = 256;
+// Saved activations (TrainTileParams::act): slot q of lane half h of a forward lane holds 8 halfs; element j is row
+// act_row(q, h, j) of the [row][sample] activation array.  Slots: 0,1 the lane's features (levels h, 2+h, 4+h, ...:
+// the lane pair splits the levels) | 2..5 h1 | 6 density output | 7 SH | 8..11 h2 | 12..15 h3
+template <int F>
+__device__ __forceinline__ int act_row(int q, int h, int j) {
+  const int unit = 32 * ((q & 3) >> 1) + 16 * (q & 1) + 8 * (j >> 2) + (j & 3) + 4 * h; // of a 64-unit layer, fragment q & 3
+  if (q < 2) {
+    const int e = q * 8 + j;
+    return kAFeat + (2 * (e / F) + h) * F + e % F;
+  }
+  if (q < 6) return kAH1 + 32 * (((q - 2) & 3) >> 1) + 16 * ((q - 2) & 1) + 8 * (j >> 2) + (j & 3) + 4 * h;
+  if (q == 6) return kAIn2 + (j & 3) + 8 * (j >> 2) + 4 * h;
+  if (q == 7) return kAIn2 + 16 + 8 * h + j;
+  return (q < 12 ? kAH2 : kAH3) + unit;
+}
+constexpr int kActSlots = 16, kActTileWords = kActSlots * 64; // uint4 per 32-sample tile
+
 // gradient rows: dOrr 0..15 | dH3 16..79 | dH2 80..143 | dOd 144..175 | dH1 176..239 | dFeat 240..271
 constexpr int kGOrr = 0, kGH3 = 16, kGH2 = 80, kGOd = 144, kGH1 = 176, kGFeat = 240, kGRows = 272;
 
@@ -208,8 +254,9 @@ __device__ __forceinline__ f32x16v layer_tile(const _Float16* __restrict__ Wl, i
   return acc;
 }
 
-template <int F, bool FWD>
+template <int F, bool FWD, bool SAVED = false>
 __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
+  static_assert(!(FWD && SAVED), "kept activations are a backward-pass input");
   // weights and activations are fp16 VALUES (working weights, rounded activations): stored as fp16, widened
   // at the operand read; 21 + 17 KB (+ 36 KB of f32 gradients backward) -> 2 backward / 4 forward blocks per CU
   extern __shared__ float lds[];
@@ -220,10 +267,10 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const uint32_t n_samples = *P.sample_count;
-  const uint32_t n_tiles = (n_samples + 31u) / 32u;
-  if (blockIdx.x >= n_tiles) { // nothing to do for this block: its slot of the weight-gradient partials is zero
+  const uint32_t n_tiles = min((n_samples + 31u) / 32u, P.tile_limit);
+  if (P.tile_begin + blockIdx.x >= n_tiles) { // nothing to do for this block: its slot of the weight-gradient partials is zero
     if (!FWD)
-      for (int i = tid; i < PRV_MLP_HALFS; i += 256) P.mlp_grad_partial[(size_t)blockIdx.x * PRV_MLP_HALFS + i] = 0.0f;
+      for (int i = tid; i < PRV_MLP_HALFS; i += 256) P.mlp_grad_partial[(size_t)(P.slot_base + (int)blockIdx.x) * PRV_MLP_HALFS + i] = 0.0f;
     return;
   }
   // level constants: kernel arguments indexed by a per-lane level would be re-fetched from the kernarg
@@ -245,7 +292,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
   f32x16v dw[3];
   for (int q = 0; q < 3; q++) dw[q] = f32x16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (uint32_t tile = P.tile_begin + blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---- phase E: encode (8 threads per sample), SH inputs, gradient seeds
     const int s = tid & 31, g = tid >> 5;
     const uint32_t sid = tile * 32u + (uint32_t)s;
@@ -253,6 +300,38 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
     uint32_t cidx[LPT][8];
     float cw[LPT][8];
     float4 seed = make_float4(0.f, 0.f, 0.f, 0.f);
+    // SAVED: backward pass on tiles whose activations the forward pass kept (launch_train_tiles gives this instance
+    // exactly those): no table gather, no forward layers -- the corner entries and weights (arithmetic only), the seeds,
+    // and 16 KB of activations copied into the [row][sample] array
+    if constexpr (SAVED) {
+      float pos[3] = {0.5f, 0.5f, 0.5f};
+      if (live) {
+        const uint2 sr = P.samples[sid];
+        const TrainRay* ray = P.rays + sr.x;
+        const float t = fmaf((float)sr.y + ray->jitter, ray->dt, ray->t0);
+        for (int a = 0; a < 3; a++) pos[a] = fmaf(t, ray->d[a], ray->o[a]);
+        seed = P.seeds[sid];
+      }
+#pragma unroll
+      for (int q = 0; q < LPT; q++) train_level_corners<F>(lv[g * LPT + q], pos[0], pos[1], pos[2], cidx[q], cw[q]);
+      if (g == 1) {
+        G[(kGOrr + 0) * kTS + s] = seed.y;
+        G[(kGOrr + 1) * kTS + s] = seed.z;
+        G[(kGOrr + 2) * kTS + s] = seed.w;
+#pragma unroll
+        for (int k = 3; k < 16; k++) G[(kGOrr + k) * kTS + s] = 0.0f;
+      }
+      const uint4* src = P.act + (size_t)tile * kActTileWords;
+#pragma unroll
+      for (int i = 0; i < kActSlots / 4; i++) {
+        const int q = wave + 4 * i; // slot of this wave's 64 words: lane = (half, sample)
+        const uint4 v = src[q * 64 + lane];
+        const _Float16* e = reinterpret_cast<const _Float16*>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) A[act_row<F>(q, h, j) * kTS + r] = e[j];
+      }
+      __syncthreads(); STAMP(2);
+    } else {
     {
       float pos[3] = {0.5f, 0.5f, 0.5f}, dir[3] = {0.f, 0.f, 1.f};
       if (live) {
@@ -328,6 +407,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
       __syncthreads(); STAMP(7);
       continue;
     }
+    } // !saved
     // ---- backward: dX chain (straight through the fp16 roundings, ReLU masks from the activations)
     if (wave < 2) { // dH3 = W_r3 dOrr
       const f32x16v a = layer_tile<true, float>(W + kLLds[4], kLStr[4], 64, wave, G + kGOrr * kTS, 16, lane);
@@ -442,7 +522,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
     else if (wave == 1) { ly[0] = 3; kb[0] = 32; ob[0] = 0; ov[0] = 32; ly[1] = 3; kb[1] = 32; ob[1] = 32; ov[1] = 32; ly[2] = 4; kb[2] = 32; ob[2] = 0; ov[2] = 16; }
     else if (wave == 2) { ly[0] = 2; kb[0] = 0; ob[0] = 0; ov[0] = 32; ly[1] = 2; kb[1] = 0; ob[1] = 32; ov[1] = 32; ly[2] = 1; kb[2] = 0; ob[2] = 0; ov[2] = 16; }
     else { ly[0] = 0; kb[0] = 0; ob[0] = 0; ov[0] = 32; ly[1] = 0; kb[1] = 0; ob[1] = 32; ov[1] = 32; ly[2] = 1; kb[2] = 32; ob[2] = 0; ov[2] = 16; }
-    float* part = P.mlp_grad_partial + (size_t)blockIdx.x * PRV_MLP_HALFS;
+    float* part = P.mlp_grad_partial + (size_t)(P.slot_base + (int)blockIdx.x) * PRV_MLP_HALFS;
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       if (r >= ov[q]) continue;
@@ -554,7 +634,23 @@ __global__ __launch_bounds__(256) void train_forward_fast_kernel(TrainTileParams
       }
     }
     const half8 shf = sh_fragment(h, dir[0], dir[1], dir[2]);
-    const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf);
+    // the B fragments the lanes hold between the layers ARE the activations the backward pass needs: kept, 16 bytes
+    // per lane and slot, a wave-instruction = 1 KB contiguous (layout: act_row); the backward tiles then skip the table
+    // gather and the five forward layers
+    uint4* act = P.act != nullptr && tile * 32u + 32u <= P.act_cap ? P.act + (size_t)tile * kActTileWords + lane : nullptr;
+    auto keep = [&](int slot, const half8& v) { act[slot * 64] = __builtin_bit_cast(uint4, v); };
+    if (act) {
+      keep(0, f0);
+      keep(1, f1);
+      keep(7, shf);
+    }
+    const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf, [&](int stage, const half8* v) {
+      if (!act) return;
+      if (stage == 1) keep(6, v[0]);
+      else
+#pragma unroll
+        for (int t = 0; t < 4; t++) keep((stage == 0 ? 2 : stage == 2 ? 8 : 12) + t, v[t]);
+    });
     if (live && h == 0) P.logits[sid] = make_float4(mo.dens[0], mo.rgb[0], mo.rgb[1], mo.rgb[2]);
   }
 }
@@ -953,36 +1049,58 @@ hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int F, bool FWD>
+template <int F, bool FWD, bool SAVED = false>
 static hipError_t launch_tile(const TrainTileParams& P, int n_blocks, hipStream_t s) {
-  hipLaunchKernelGGL((train_tile_kernel<F, FWD>), dim3(n_blocks), dim3(256), train_tile_lds_bytes(FWD), s, P);
+  hipLaunchKernelGGL((train_tile_kernel<F, FWD, SAVED>), dim3(n_blocks), dim3(256), train_tile_lds_bytes(FWD), s, P);
   return hipGetLastError();
 }
 
 // dynamic LDS above 64 KB has to be allowed per kernel, once, outside any stream capture
 hipError_t train_prepare_kernels() {
   hipError_t e;
-#define PRV_ALLOW_LDS(F, FWD)                                                                                         \
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_tile_kernel<F, FWD>),                               \
+#define PRV_ALLOW_LDS(F, FWD, SAVED)                                                                                  \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_tile_kernel<F, FWD, SAVED>),                        \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)train_tile_lds_bytes(FWD))) != hipSuccess) \
     return e;
-  PRV_ALLOW_LDS(4, true)
-  PRV_ALLOW_LDS(4, false)
-  PRV_ALLOW_LDS(2, true)
-  PRV_ALLOW_LDS(2, false)
+  PRV_ALLOW_LDS(4, true, false)
+  PRV_ALLOW_LDS(4, false, false)
+  PRV_ALLOW_LDS(4, false, true)
+  PRV_ALLOW_LDS(2, true, false)
+  PRV_ALLOW_LDS(2, false, false)
+  PRV_ALLOW_LDS(2, false, true)
 #undef PRV_ALLOW_LDS
   return hipSuccess;
 }
 
-hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s, bool finish_reduce) {
+hipError_t launch_train_tiles(const TrainTileParams& P0, bool forward, int n_blocks, hipStream_t s, bool finish_reduce) {
+  TrainTileParams P = P0;
+  P.tile_begin = 0;
+  P.tile_limit = ~0u;
+  P.slot_base = 0;
+  const bool f4 = P.n_features == 4;
+  if (forward) return f4 ? launch_tile<4, true>(P, n_blocks, s) : launch_tile<2, true>(P, n_blocks, s);
   hipError_t e;
-  if (P.n_features == 4) e = forward ? launch_tile<4, true>(P, n_blocks, s) : launch_tile<4, false>(P, n_blocks, s);
-  else e = forward ? launch_tile<2, true>(P, n_blocks, s) : launch_tile<2, false>(P, n_blocks, s);
-  if (e != hipSuccess || forward) return e;
-  // the stage buffer sits behind the slots (n_blocks slots + kDwGroups group sums)
-  float* stage = P.mlp_grad_partial + (size_t)n_blocks * PRV_MLP_HALFS;
+  int n_slots = n_blocks;
+  const uint32_t kept_tiles = P.act ? P.act_cap / 32u : 0u;
+  if (kept_tiles) {
+    // the tiles whose activations the forward pass kept, then (a second, nearly always empty launch on slots of its own)
+    // the tiles beyond the buffer, which recompute their forward pass
+    P.tile_limit = kept_tiles;
+    e = f4 ? launch_tile<4, false, true>(P, n_blocks, s) : launch_tile<2, false, true>(P, n_blocks, s);
+    if (e != hipSuccess) return e;
+    P.tile_begin = kept_tiles;
+    P.tile_limit = ~0u;
+    P.slot_base = n_blocks;
+    e = f4 ? launch_tile<4, false>(P, n_blocks / 2, s) : launch_tile<2, false>(P, n_blocks / 2, s);
+    n_slots = train_dw_slots(n_blocks);
+  } else {
+    e = f4 ? launch_tile<4, false>(P, n_blocks, s) : launch_tile<2, false>(P, n_blocks, s);
+  }
+  if (e != hipSuccess) return e;
+  // the stage buffer sits behind the slots (train_dw_slots(n_blocks) slots + kDwGroups group sums)
+  float* stage = P.mlp_grad_partial + (size_t)train_dw_slots(n_blocks) * PRV_MLP_HALFS;
   hipLaunchKernelGGL(train_reduce_dw_kernel, dim3((PRV_MLP_HALFS + 255) / 256, kDwGroups), dim3(256), 0, s, P.mlp_grad_partial,
-                     n_blocks, stage);
+                     n_slots, stage);
   if (finish_reduce) hipLaunchKernelGGL(train_reduce_dw2_kernel, dim3((PRV_MLP_HALFS + 255) / 256), dim3(256), 0, s, stage, P.mlp_grad);
   return hipGetLastError();
 }

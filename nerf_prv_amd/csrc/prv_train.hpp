@@ -54,7 +54,19 @@ struct TrainTileParams {
   float* mlp_grad;       // canonical, f32
   float* mlp_grad_partial; // n_blocks slots of PRV_MLP_HALFS floats (backward)
   unsigned long long* stamps; // dev only (PRV_TRAIN_ABLATE & 16)
+  // activations of the forward pass, kept for the backward pass (train_forward_fast_kernel writes, the backward tile
+  // kernel reads; NULL or a tile beyond act_cap: the backward pass recomputes them).  16 KB per 32-sample tile:
+  // [tile][slot 0..15][lane half][sample] x 8 halfs -- the B fragments the forward lanes hold, see act_row()
+  uint4* act;
+  uint32_t act_cap; // samples covered by `act` (a multiple of 32)
+  // set by launch_train_tiles: the tiles [tile_begin, min(tile_limit, all)) are this launch's, block b owns slot
+  // slot_base + b of mlp_grad_partial (the backward pass is two launches when activations are kept: the tiles the
+  // buffer covers, and -- nearly always none -- the tiles beyond it, which recompute their forward pass)
+  uint32_t tile_begin, tile_limit;
+  int slot_base;
 };
+// slots of mlp_grad_partial for a backward pass launched with n_blocks blocks (the stage of the reduction sits behind them)
+inline int train_dw_slots(int n_blocks) { return n_blocks + n_blocks / 2; }
 
 struct TrainCompositeParams {
   TrainRay* rays;

@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r02ao
+mkdir -p $O
+python3 scripts/trainablate.py --save /tmp/state.prvf --rays 65536 2>&1 | tail -1
+PRV_TRAIN_ABLATE=16 python3 nerf_prv_amd/build.py --force > $O/build.log 2>&1
+python3 scripts/trainablate.py --load /tmp/state.prvf --rays 65536 --tag "stamps" 2>&1 | tail -4 | tee -a $O/stamps.txt
+python3 scripts/trainablate.py --load /tmp/state.prvf --rays 4096 --tag "stamps4096" 2>&1 | tail -4 | tee -a $O/stamps.txt
+PRV_TRAIN_ABLATE= python3 nerf_prv_amd/build.py --force > /dev/null 2>&1

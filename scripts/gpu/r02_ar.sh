@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r02ar
+mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+grep "passed\|failed" $O/pytest.log | tail -3; grep -B5 "Error\|assert" $O/pytest.log | head -40
+timeout 600 python3 bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err
+python3 -c "
+import json;d=json.load(open('$O/bench.json'));print(round(d['value']/1e9,2),round(d['ms_per_step'],3));print(d['training'])"
+python3 scripts/nbvbench.py > $O/nbv.txt 2>&1; tail -3 $O/nbv.txt

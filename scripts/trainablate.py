@@ -26,7 +26,8 @@ if args.save:
     print("saved; samples/batch", tr.info()["samples_last"])
 else:
     ctx.load_model_file(0, args.load)
-    tr = api.Trainer(ctx, 0, cams, u8, api.train_opts(n_rays=args.rays))
+    # a huge sample target: the first batch casts all n_rays (the adaptive count would start at target / n_samples)
+    tr = api.Trainer(ctx, 0, cams, u8, api.train_opts(n_rays=args.rays, target_samples=1 << 30))
     tr.gradients()
     torch.cuda.synchronize()
     ctx.lib.prv_train_gradients.argtypes  # keep
