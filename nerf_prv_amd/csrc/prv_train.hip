@@ -19,10 +19,14 @@
 #include "prv_train.hpp"
 
 #ifndef PRV_TRAIN_ABLATE
-#define PRV_TRAIN_ABLATE 0 // dev only: 1 no table scatter, 2 no dW MFMAs, 16 phase time stamps of block 0
+#define PRV_TRAIN_ABLATE 0 // dev only: 1 no table scatter, 2 no dW MFMAs, 16 phase time stamps of block 0 (48: summed over its tiles)
 #endif
 #if PRV_TRAIN_ABLATE & 16
+#if PRV_TRAIN_ABLATE & 32 // phase i's time SUMMED over all tiles of block 0 (and over launches): the average under load
+#define STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && threadIdx.x == 0 && P.stamps) P.stamps[(FWD ? 0 : 32) + (i)] += now_ - stamp_prev; stamp_prev = now_; } while (0)
+#else
 #define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && P.stamps) P.stamps[(FWD ? 0 : 32) + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -260,6 +264,9 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
   // weights and activations are fp16 VALUES (working weights, rounded activations): stored as fp16, widened
   // at the operand read; 21 + 17 KB (+ 36 KB of f32 gradients backward) -> 2 backward / 4 forward blocks per CU
   extern __shared__ float lds[];
+#if (PRV_TRAIN_ABLATE & 48) == 48
+  unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
   float* G = lds;                                                  // kGRows * kTS floats (backward only)
   _Float16* W = reinterpret_cast<_Float16*>(lds + (FWD ? 0 : kGRows * kTS)); // kWLds halfs
   _Float16* A = W + kWLds;                                         // kARows * kTS halfs

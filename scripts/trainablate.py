@@ -40,7 +40,10 @@ else:
     print(f"{args.tag}: {dt*1e3:.3f} ms per batch (fwd + composite + bwd + grad clear), samples/batch {tr.info()['samples_last']}")
     st = np.zeros(64, np.uint64)
     ctx.lib.prv_train_debug_stamps(tr.handle, st.ctypes.data_as(__import__("ctypes").c_void_p))
-    if st.any():
+    if st.any() and os.environ.get("STAMP_SUMS"):
+        v = st[32:64].astype(np.float64) / 2400.0 / (n + 1)  # us per launch, block 0, summed over its tiles
+        print("bwd phase sums per launch (us):", " ".join(f"{i}:{x:.1f}" for i, x in enumerate(v) if x > 0), f"total {v.sum():.1f}")
+    elif st.any():
         for name, base in (("fwd", 0), ("bwd", 32)):
             v = st[base:base + 32].astype(np.int64)
             nz = np.flatnonzero(v)
