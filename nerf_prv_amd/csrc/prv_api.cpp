@@ -742,6 +742,7 @@ void prv_destroy(prv_ctx* c) {
 
 int prv_set_stream(prv_ctx* c, void* s) try {
   if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device)); // the calling thread may be a new one (its current device would be 0)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stream = (hipStream_t)s; // NULL is HIP's legacy default stream (what torch uses by default)
   return PRV_OK;
@@ -756,6 +757,7 @@ int prv_set_coverage_weight(prv_ctx* c, double weight) try {
 
 int prv_synchronize(prv_ctx* c) try {
   if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device)); // the calling thread may be a new one (its current device would be 0)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return PRV_OK;
 } catch (...) { return caught(c); }
@@ -776,6 +778,7 @@ static int drain_events(prv_ctx* c, std::vector<hipEvent_t>& ev, double* ms, int
 
 int prv_profile_begin(prv_ctx* c) try {
   if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device)); // the calling thread may be a new one (its current device would be 0)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   drain_events(c, c->ev_render, nullptr, nullptr);
   drain_events(c, c->ev_march, nullptr, nullptr);
@@ -785,6 +788,7 @@ int prv_profile_begin(prv_ctx* c) try {
 
 int prv_profile_end(prv_ctx* c, double* render_ms, int* render_n, double* march_ms, int* march_n) try {
   if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device)); // the calling thread may be a new one (its current device would be 0)
   c->profiling = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int rc = drain_events(c, c->ev_render, render_ms, render_n);
@@ -895,6 +899,7 @@ static int model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64
 
 int prv_model_export(prv_ctx* c, int slot, uint16_t* table, uint16_t* mlp, uint32_t* occ) try {
   if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device)); // the calling thread may be a new one (its current device would be 0)
   int rc = check_model(c, slot);
   if (rc != PRV_OK) return rc;
   const Model& m = c->models[slot];
@@ -1483,6 +1488,7 @@ int prv_rank(const prv_score_record* r, const int* ids, int n, int* order) try {
 
 int prv_debug_render_clock(prv_ctx* c, uint64_t* shader_cycles, uint64_t* ref_ticks, double* ref_hz) try {
   if (!c) return PRV_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device)); // the calling thread may be a new one (its current device would be 0)
   if (!shader_cycles || !ref_ticks || !ref_hz) return fail(c, PRV_E_INVALID, "NULL output");
   if (!c->counters.p) return fail(c, PRV_E_STATE, "nothing rendered yet");
   unsigned long long v[2] = {0, 0};
