@@ -621,7 +621,13 @@ def main():
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, argv))  # before anything touches a GPU
-    sys.exit(run_rank(args))
+    rc = run_rank(args)
+    # Everything is closed and the line is out.  What a normal interpreter exit adds is the static teardown of the HIP /
+    # HSA runtime, which crashed about once in a thousand process exits on this pool when another process shared the GPU
+    # (scripts/gpu/r02_ay.sh; the C++ planner does the same): a finished run's exit code must not depend on it.
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(rc)
 
 
 if __name__ == "__main__":

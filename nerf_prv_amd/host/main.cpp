@@ -687,7 +687,43 @@ int env_int(const char* key, int fallback) {
 
 } // namespace
 
+// PRV_SEGV_TRACE=1 (diagnostics): a crash prints where it happened before the process dies
+#include <csignal>
+#include <execinfo.h>
+#include <unistd.h>
+static void segv_trace(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "prv_planner: fatal signal, backtrace follows\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+
+static int run(int argc, char** argv);
+
+// Every context has been destroyed and every file closed when run() returns.  What is left of a normal exit is the
+// static teardown of the HIP / HSA runtime, and that crashed (SIGSEGV after the last line of output, about once in a
+// thousand runs, only seen while another process was using the same GPU; scripts/gpu/r02_ay.sh): the exit code of a
+// finished planner run must not depend on it, so the streams are flushed and the process leaves with _exit.
+// PRV_PLANNER_EXIT=normal restores the ordinary return from main.
 int main(int argc, char** argv) {
+  if (getenv("PRV_SEGV_TRACE")) {
+    signal(SIGSEGV, segv_trace);
+    signal(SIGBUS, segv_trace);
+    signal(SIGABRT, segv_trace);
+  }
+  const int rc = run(argc, argv);
+  const char* how = getenv("PRV_PLANNER_EXIT");
+  if (how && std::string(how) == "normal") return rc;
+  std::cout.flush();
+  std::cerr.flush();
+  fflush(nullptr);
+  _exit(rc);
+}
+
+static int run(int argc, char** argv) {
   const std::string cfg = argc > 1 ? argv[1] : "../DefaultConfiguration.yaml";
   int mode = -1;
   std::cout << "input mode:" << std::endl;
