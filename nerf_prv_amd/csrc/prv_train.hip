@@ -63,7 +63,8 @@ __device__ __forceinline__ bool occ_bit(const uint32_t* __restrict__ occ, int R,
 __global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) {
   const int lane = threadIdx.x & 63;
   const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (j >= P.state->n_active) return;
+  if (blockIdx.x * 4u >= P.state->n_active) return; // whole block beyond this step's ray budget (block-uniform)
+  const bool in_budget = j < P.state->n_active;
   const uint64_t st = (uint64_t)P.state->step * 8u;
   const uint32_t img = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 0, j) * (uint64_t)P.n_img) >> 24);
   const uint32_t px = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 1, j) * (uint64_t)P.W) >> 24);
@@ -89,14 +90,25 @@ __global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) {
     m0 = __ballot(on[0]);
     m1 = __ballot(on[1]);
   }
+  if (!in_budget) m0 = m1 = 0ull; // a ray of the last block that lies beyond the budget: takes part in the barriers only
   const uint32_t n0 = (uint32_t)__popcll(m0), n_live = n0 + (uint32_t)__popcll(m1);
-  uint32_t offset = 0;
-  if (lane == 0 && n_live) offset = atomicAdd(P.sample_count, n_live);
-  offset = __shfl(offset, 0);
+  // ONE returning atomic per block (its four rays' counts summed through LDS), not one per ray: 2^16 rays appending
+  // to a single counter were a third of this kernel
+  __shared__ uint32_t cnt[4], base;
+  const int wv = threadIdx.x >> 6;
+  if (lane == 0) cnt[wv] = n_live;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    base = tot ? atomicAdd(P.sample_count, tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t offset = base;
+  for (int w = 0; w < wv; w++) offset += cnt[w];
   const unsigned long long below = (1ull << lane) - 1ull;
   if ((m0 >> lane) & 1ull) P.samples[offset + (uint32_t)__popcll(m0 & below)] = make_uint2(j, (uint32_t)lane);
   if ((m1 >> lane) & 1ull) P.samples[offset + n0 + (uint32_t)__popcll(m1 & below)] = make_uint2(j, 64u + (uint32_t)lane);
-  if (lane == 0) {
+  if (lane == 0 && in_budget) {
     float bg[3] = {0.f, 0.f, 0.f};
     if (P.random_bg)
       for (int k = 0; k < 3; k++) bg[k] = (float)rng_u24(P.seed, st + 4 + k, j) * (1.0f / 16777216.0f);
