@@ -270,8 +270,11 @@ __device__ __forceinline__ f32x16v layer_tile(const _Float16* __restrict__ Wl, i
   return acc;
 }
 
-template <int F, bool FWD, bool SAVED = false>
-__global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
+template <int F, bool FWD, int MODE = 0> // MODE 0: recompute the forward pass | 1: kept activations, LDS chain | 2: kept activations, register chain
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(MODE == 2 ? 3 : 2))) // blocks per CU the LDS footprint allows: 2 (74 KB), MODE 2: 3 (53 KB, <= 168 registers)
+void train_tile_kernel(TrainTileParams P) {
+  constexpr bool SAVED = MODE != 0;
   static_assert(!(FWD && SAVED), "kept activations are a backward-pass input");
   // weights and activations are fp16 VALUES (working weights, rounded activations): stored as fp16, widened
   // at the operand read; 21 + 17 KB (+ 36 KB of f32 gradients backward) -> 2 backward / 4 forward blocks per CU
@@ -280,8 +283,8 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
   float* G = lds;                                                  // kGRows * kTS floats (backward only)
-  _Float16* W = reinterpret_cast<_Float16*>(lds + (FWD ? 0 : kGRows * kTS)); // kWLds halfs
-  _Float16* A = W + kWLds;                                         // kARows * kTS halfs
+  _Float16* W = reinterpret_cast<_Float16*>(lds + (FWD ? 0 : kGRows * kTS)); // kWLds halfs (MODE 2: none, its chain reads fragments)
+  _Float16* A = W + (MODE == 2 ? 0 : kWLds);                       // kARows * kTS halfs
   STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
   if (tid < 16 * (int)(sizeof(LevelCanon) / 4))
     reinterpret_cast<uint32_t*>(lv)[tid] = reinterpret_cast<const uint32_t*>(P.levels)[tid];
 #pragma unroll
-  for (int l = 0; l < 5; l++) { // n_out is a power of two per layer: shifts, no divisions; loads independent
+  for (int l = 0; l < (MODE == 2 ? 0 : 5); l++) { // n_out is a power of two per layer: shifts, no divisions; loads independent
     constexpr int kSh[5] = {6, 4, 6, 6, 4};
     const int n = kLIn[l] * kLOut[l];
 #pragma unroll 4
@@ -311,7 +314,14 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
   f32x16v dw[3];
   for (int q = 0; q < 3; q++) dw[q] = f32x16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+  const int lane_outer = lane;
   for (uint32_t tile = P.tile_begin + blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // The lane id is made opaque once per tile: everything derived from it inside the loop (some 70 LDS addresses of the
+    // [row][sample] arrays) is then recomputed per tile instead of being hoisted out of the loop and kept in registers for
+    // the whole kernel, which is what pushed the register-chain instance past 256 of them.
+    int lane = lane_outer;
+    if constexpr (MODE == 2) asm volatile("" : "+v"(lane)); // (the LDS-chain instances are faster with the hoisted form: they have the registers)
+    const int tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
     // ---- phase E: encode (8 threads per sample), SH inputs, gradient seeds
     const int s = tid & 31, g = tid >> 5;
     const uint32_t sid = tile * 32u + (uint32_t)s;
@@ -428,6 +438,108 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
     }
     } // !saved
     // ---- backward: dX chain (straight through the fp16 roundings, ReLU masks from the activations)
+    if constexpr (MODE == 2) {
+      {
+        // Register-resident chain on ONE wave, like the forward pass: a backward layer's accumulator rows are the next
+        // layer's B operand as they stand (the prepacked A fragments carry the K order, prepack_frags_kernel), no LDS round
+        // trip or barrier between the layers.  bf16 MFMAs on split operands: the f32 gradient g = g_hi + g_lo (two bf16,
+        // 16 significant bits), the fp16 weight W = W_hi + W_lo (exact), W g ~ W_hi g_hi + W_lo g_hi + W_hi g_lo in f32
+        // accumulators (the dropped term is below 2^-16 of the product).  60 MFMAs of K = 16 where the LDS form issues
+        // ~350 of K = 2 behind five barriers.  The masked gradients still go to the [row][sample] array: dW and the
+        // scatter below read them there.
+        if (wave == 0) {
+          typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+          const bf16x8* bf = reinterpret_cast<const bf16x8*>(P.bwd_frags);
+          const f32x16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          auto mm3 = [&](int f, const bf16x8& bh, const bf16x8& bl, f32x16v c) {
+            asm volatile("" ::: "memory"); // fragment loads stay with their MFMAs (hoisted to the top they cost 160 registers)
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 ah = bf[f * 64 + lane], al = bf[(kBwdFrags + f) * 64 + lane];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+            return c;
+          };
+          // registers [base, base + 8) of an accumulator -> the high and low bf16 parts of one B operand
+          auto split8 = [&](const f32x16v& acc, int base, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const float v = acc[base + j];
+              const __bf16 hv = (__bf16)v;
+              hi[j] = hv;
+              lo[j] = (__bf16)(v - (float)hv);
+            }
+          };
+          bf16x8 bh[4], bl[4];
+          { // colour logits' seeds: lane half 0 holds outputs 0..7, of which r, g, b carry a gradient
+            f32x16v sd = zero;
+            if (h == 0) {
+              sd[0] = seed.y;
+              sd[1] = seed.z;
+              sd[2] = seed.w;
+            }
+            split8(sd, 0, bh[0], bl[0]);
+          }
+          f32x16v d[2];
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++) { // dH3 = W_r3 dOrr
+            d[mt] = mm3(mt, bh[0], bl[0], zero);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+              const int row = 32 * mt + rho(i, h);
+              d[mt][i] = A[(kAH3 + row) * kTS + r] > (_Float16)0.0f ? d[mt][i] : 0.0f;
+              G[(kGH3 + row) * kTS + r] = d[mt][i];
+            }
+          }
+#pragma unroll
+          for (int st = 0; st < 4; st++) split8(d[st >> 1], 8 * (st & 1), bh[st], bl[st]);
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++) { // dH2 = W_r2 dH3
+            f32x16v c = zero;
+#pragma unroll
+            for (int st = 0; st < 4; st++) c = mm3(2 + 4 * mt + st, bh[st], bl[st], c);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+              const int row = 32 * mt + rho(i, h);
+              c[i] = A[(kAH2 + row) * kTS + r] > (_Float16)0.0f ? c[i] : 0.0f;
+              G[(kGH2 + row) * kTS + r] = c[i];
+            }
+            d[mt] = c;
+          }
+#pragma unroll
+          for (int st = 0; st < 4; st++) split8(d[st >> 1], 8 * (st & 1), bh[st], bl[st]);
+          { // dOd = (W_r1 dH2)[0..15] (+ the density seed on row 0); the SH rows carry no parameters
+            f32x16v c = zero;
+#pragma unroll
+            for (int st = 0; st < 4; st++) c = mm3(10 + st, bh[st], bl[st], c);
+            if (h == 0) c[0] += seed.x; // row 0 = register 0 of lane half 0
+#pragma unroll
+            for (int i = 0; i < 8; i++) G[(kGOd + rho(i, h)) * kTS + r] = c[i]; // registers 0..7 = rows < 16
+            split8(c, 0, bh[0], bl[0]);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++) { // dH1 = W_d2 dOd
+            d[mt] = mm3(14 + mt, bh[0], bl[0], zero);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+              const int row = 32 * mt + rho(i, h);
+              d[mt][i] = A[(kAH1 + row) * kTS + r] > (_Float16)0.0f ? d[mt][i] : 0.0f;
+              G[(kGH1 + row) * kTS + r] = d[mt][i];
+            }
+          }
+#pragma unroll
+          for (int st = 0; st < 4; st++) split8(d[st >> 1], 8 * (st & 1), bh[st], bl[st]);
+          { // dFeat = W_d1 dH1
+            f32x16v c = zero;
+#pragma unroll
+            for (int st = 0; st < 4; st++) c = mm3(16 + st, bh[st], bl[st], c);
+#pragma unroll
+            for (int i = 0; i < 16; i++) G[(kGFeat + rho(i, h)) * kTS + r] = c[i];
+          }
+        }
+        __syncthreads(); STAMP(12);
+      }
+    } else {
     if (wave < 2) { // dH3 = W_r3 dOrr
       const f32x16v a = layer_tile<true, float>(W + kLLds[4], kLStr[4], 64, wave, G + kGOrr * kTS, 16, lane);
 #pragma unroll
@@ -471,6 +583,7 @@ __global__ __launch_bounds__(256) void train_tile_kernel(TrainTileParams P) {
       for (int i = 0; i < 16; i++) G[(kGFeat + rho(i, h)) * kTS + r] = a[i];
     }
     __syncthreads(); STAMP(12);
+    }
     // ---- dW[k][o] += sum_s X[k][s] dOut[o][s]: three 32x32 weight tiles per wave, K = the 32 samples
     if (!(PRV_TRAIN_ABLATE & 2)) {
       // tile q of wave w: {activation row base, gradient row base, valid gradient rows}
@@ -592,7 +705,34 @@ __global__ __launch_bounds__(256) void prepack_frags_kernel(const uint16_t* __re
                                                             uint32_t* sample_count, float lr) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0 && P.state) end_step(P, sample_count, lr, P.beta1, P.beta2); // the step's last kernel: it opens the next one too
-  if (i >= kNumFrags * kFragHalfs) return;
+  if (i >= kNumFrags * kFragHalfs) {
+    // backward fragments: A[row = input unit][K = output unit] of every layer, the fp16 weight split EXACTLY into a bf16
+    // high part (fragments 0..19) and a bf16 low part (20..39); K order = the order in which a lane holds the previous
+    // backward layer's accumulator rows (frag_hidden_k), as in the forward fragments
+    const int ib = i - kNumFrags * kFragHalfs;
+    if (ib >= kBwdFrags * kFragHalfs) return;
+    const int f = ib / kFragHalfs, ln = (ib % kFragHalfs) >> 3, j = ib & 7;
+    const int r = ln & 31, h = ln >> 5;
+    int layer, mt, st;
+    if (f < 2) { layer = 4; mt = f; st = 0; }                        // dH3 = W_r3 dOrr   (K = 16 colour outputs)
+    else if (f < 10) { layer = 3; mt = (f - 2) >> 2; st = (f - 2) & 3; } // dH2 = W_r2 dH3
+    else if (f < 14) { layer = 2; mt = 0; st = f - 10; }              // dIn2 = W_r1 dH2
+    else if (f < 16) { layer = 1; mt = f - 14; st = 0; }              // dH1 = W_d2 dOd    (K = 16 density outputs)
+    else { layer = 0; mt = 0; st = f - 16; }                          // dFeat = W_d1 dH1
+    int o; // output unit on the K dimension
+    if (layer == 4) o = 8 * h + j;                        // colour logits: lane half h holds outputs 8h..8h+7
+    else if (layer == 1) o = (j & 3) + 8 * (j >> 2) + 4 * h; // the density output as its accumulator rows come
+    else o = frag_hidden_k(st, h, j);
+    const int k_in = 32 * mt + r;
+    float w = 0.0f;
+    if (k_in < kLIn[layer] && o < kLOut[layer]) w = (float)__builtin_bit_cast(_Float16, mlp[kLOff[layer] + k_in * kLOut[layer] + o]);
+    const __bf16 hi = (__bf16)w;
+    const __bf16 lo = (__bf16)(w - (float)hi);
+    uint16_t* out = frags + kNumFrags * kFragHalfs;
+    out[ib] = __builtin_bit_cast(uint16_t, hi);
+    out[kBwdFrags * kFragHalfs + ib] = __builtin_bit_cast(uint16_t, lo);
+    return;
+  }
   const int f = i / kFragHalfs, lane = (i % kFragHalfs) >> 3, j = i & 7;
   const int r = lane & 31, h = lane >> 5;
   int layer, mt, st;
@@ -1061,32 +1201,34 @@ __global__ __launch_bounds__(256) void density_refresh_fast_kernel(DensityParams
 
 // ------------------------------------------------------------------ launchers
 
-size_t train_tile_lds_bytes(bool fwd) { return 2u * (size_t)(kWLds + kARows * kTS) + (fwd ? 0u : 4u * (size_t)(kGRows * kTS)); }
+size_t train_tile_lds_bytes(bool fwd, int mode) { return 2u * (size_t)((mode == 2 ? 0 : kWLds) + kARows * kTS) + (fwd ? 0u : 4u * (size_t)(kGRows * kTS)); }
 
 hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s) {
   hipLaunchKernelGGL(train_rays_kernel, dim3((P.n_rays + 3) / 4), dim3(256), 0, s, P);
   return hipGetLastError();
 }
 
-template <int F, bool FWD, bool SAVED = false>
+template <int F, bool FWD, int MODE = 0>
 static hipError_t launch_tile(const TrainTileParams& P, int n_blocks, hipStream_t s) {
-  hipLaunchKernelGGL((train_tile_kernel<F, FWD, SAVED>), dim3(n_blocks), dim3(256), train_tile_lds_bytes(FWD), s, P);
+  hipLaunchKernelGGL((train_tile_kernel<F, FWD, MODE>), dim3(n_blocks), dim3(256), train_tile_lds_bytes(FWD, MODE), s, P);
   return hipGetLastError();
 }
 
 // dynamic LDS above 64 KB has to be allowed per kernel, once, outside any stream capture
 hipError_t train_prepare_kernels() {
   hipError_t e;
-#define PRV_ALLOW_LDS(F, FWD, SAVED)                                                                                  \
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_tile_kernel<F, FWD, SAVED>),                        \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)train_tile_lds_bytes(FWD))) != hipSuccess) \
+#define PRV_ALLOW_LDS(F, FWD, MODE)                                                                                  \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_tile_kernel<F, FWD, MODE>),                         \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)train_tile_lds_bytes(FWD, MODE))) != hipSuccess) \
     return e;
-  PRV_ALLOW_LDS(4, true, false)
-  PRV_ALLOW_LDS(4, false, false)
-  PRV_ALLOW_LDS(4, false, true)
-  PRV_ALLOW_LDS(2, true, false)
-  PRV_ALLOW_LDS(2, false, false)
-  PRV_ALLOW_LDS(2, false, true)
+  PRV_ALLOW_LDS(4, true, 0)
+  PRV_ALLOW_LDS(4, false, 0)
+  PRV_ALLOW_LDS(4, false, 1)
+  PRV_ALLOW_LDS(4, false, 2)
+  PRV_ALLOW_LDS(2, true, 0)
+  PRV_ALLOW_LDS(2, false, 0)
+  PRV_ALLOW_LDS(2, false, 1)
+  PRV_ALLOW_LDS(2, false, 2)
 #undef PRV_ALLOW_LDS
   return hipSuccess;
 }
@@ -1099,21 +1241,27 @@ hipError_t launch_train_tiles(const TrainTileParams& P0, bool forward, int n_blo
   const bool f4 = P.n_features == 4;
   if (forward) return f4 ? launch_tile<4, true>(P, n_blocks, s) : launch_tile<2, true>(P, n_blocks, s);
   hipError_t e;
+  // n_blocks = 3 per CU, what the register-chain instance (53 KB of LDS) can keep resident; the 74 KB instances get two
+  // per CU (a third block would only wait for a slot and stretch the tail).  Slots are numbered as if all were launched.
+  const int n_lds74 = n_blocks / 3 * 2;
   int n_slots = n_blocks;
   const uint32_t kept_tiles = P.act ? P.act_cap / 32u : 0u;
   if (kept_tiles) {
     // the tiles whose activations the forward pass kept, then (a second, nearly always empty launch on slots of its own)
     // the tiles beyond the buffer, which recompute their forward pass
     P.tile_limit = kept_tiles;
-    e = f4 ? launch_tile<4, false, true>(P, n_blocks, s) : launch_tile<2, false, true>(P, n_blocks, s);
+    const int n_first = P.bwd_frags ? n_blocks : n_lds74, n_tail = n_blocks / 3;
+    if (P.bwd_frags) e = f4 ? launch_tile<4, false, 2>(P, n_first, s) : launch_tile<2, false, 2>(P, n_first, s);
+    else e = f4 ? launch_tile<4, false, 1>(P, n_first, s) : launch_tile<2, false, 1>(P, n_first, s);
     if (e != hipSuccess) return e;
     P.tile_begin = kept_tiles;
     P.tile_limit = ~0u;
-    P.slot_base = n_blocks;
-    e = f4 ? launch_tile<4, false>(P, n_blocks / 2, s) : launch_tile<2, false>(P, n_blocks / 2, s);
-    n_slots = train_dw_slots(n_blocks);
+    P.slot_base = n_first; // every slot below n_first + n_tail is written by exactly one block of the two launches
+    e = f4 ? launch_tile<4, false>(P, n_tail, s) : launch_tile<2, false>(P, n_tail, s);
+    n_slots = n_first + n_tail;
   } else {
-    e = f4 ? launch_tile<4, false>(P, n_blocks, s) : launch_tile<2, false>(P, n_blocks, s);
+    e = f4 ? launch_tile<4, false>(P, n_lds74, s) : launch_tile<2, false>(P, n_lds74, s);
+    n_slots = n_lds74;
   }
   if (e != hipSuccess) return e;
   // the stage buffer sits behind the slots (train_dw_slots(n_blocks) slots + kDwGroups group sums)
@@ -1128,7 +1276,7 @@ hipError_t launch_prepack_frags(const uint16_t* mlp, int n_features, uint16_t* f
                                 uint32_t* sample_count, float lr, hipStream_t s) {
   AdamParams P{};
   if (end_of_step) P = *end_of_step; // state != NULL: this launch closes the step and opens the next
-  hipLaunchKernelGGL(prepack_frags_kernel, dim3((kNumFrags * kFragHalfs + 255) / 256), dim3(256), 0, s, mlp, n_features, frags, P,
+  hipLaunchKernelGGL(prepack_frags_kernel, dim3(((kNumFrags + kBwdFrags) * kFragHalfs + 255) / 256), dim3(256), 0, s, mlp, n_features, frags, P,
                      sample_count, lr);
   return hipGetLastError();
 }

@@ -329,12 +329,14 @@ def test_placement_and_layout_switches_change_speed_only(ctx, oracle, monkeypatc
 
 @pytest.mark.parametrize("env", [{"PRV_TRAIN_GRAPH": "0"}, {"PRV_TRAIN_FAST_FWD": "0"},
                                  {"PRV_TRAIN_GRAPH": "0", "PRV_TRAIN_FAST_FWD": "0"}, {"PRV_TRAIN_KEEP_ACT": "0"},
-                                 {"PRV_TRAIN_ACT_CAP": "256"}, {"PRV_TRAIN_ACT_CAP": "256", "PRV_TRAIN_GRAPH": "0"}])
+                                 {"PRV_TRAIN_ACT_CAP": "256"}, {"PRV_TRAIN_ACT_CAP": "256", "PRV_TRAIN_GRAPH": "0"},
+                                 {"PRV_TRAIN_REG_CHAIN": "0"}, {"PRV_TRAIN_REG_CHAIN": "0", "PRV_TRAIN_ACT_CAP": "256"}])
 def test_trainer_switches_hold_the_same_bars(ctx, oracle, monkeypatch, env):
     """the trainer's switches -- plain launches instead of the captured step graph, f32 tile forward instead of the
     f16-MFMA forward, a backward pass that recomputes the forward activations instead of reading the ones the forward
     pass kept, and a kept-activation buffer smaller than the batch (256 of > 500 samples: the backward pass is then two
-    launches, kept tiles + recomputed tiles) -- against the oracle on the same batch and over a few optimiser steps: same
+    launches, kept tiles + recomputed tiles), the LDS / f32-MFMA gradient chain instead of the register-resident bf16-split
+    one -- against the oracle on the same batch and over a few optimiser steps: same
     ray batch, loss and gradients within 1e-3, steps tracking the oracle like the default configuration does"""
     kw = dict(n_levels=8, n_features=4, log2_hashmap=10, base_res=4, finest_res=24, occ_res=16, density_bias=1.0, table_amp=0.5)
     intr = {"fl_x": 20.0, "fl_y": 19.5, "cx": 12.3, "cy": 7.8, "w": 24, "h": 16, "k1": 0.05, "k2": -0.02, "p1": 0.001, "p2": -0.002}
