@@ -272,7 +272,7 @@ __device__ __forceinline__ f32x16v layer_tile(const _Float16* __restrict__ Wl, i
 
 template <int F, bool FWD, int MODE = 0> // MODE 0: recompute the forward pass | 1: kept activations, LDS chain | 2: kept activations, register chain
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(MODE == 2 ? 3 : 2))) // blocks per CU the LDS footprint allows: 2 (74 KB), MODE 2: 3 (53 KB, <= 168 registers)
+__attribute__((amdgpu_waves_per_eu(2))) // two blocks per CU (74 KB of LDS each): at most 256 registers per lane
 void train_tile_kernel(TrainTileParams P) {
   constexpr bool SAVED = MODE != 0;
   static_assert(!(FWD && SAVED), "kept activations are a backward-pass input");
@@ -283,8 +283,9 @@ void train_tile_kernel(TrainTileParams P) {
   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
   float* G = lds;                                                  // kGRows * kTS floats (backward only)
-  _Float16* W = reinterpret_cast<_Float16*>(lds + (FWD ? 0 : kGRows * kTS)); // kWLds halfs (MODE 2: none, its chain reads fragments)
-  _Float16* A = W + (MODE == 2 ? 0 : kWLds);                       // kARows * kTS halfs
+  _Float16* W = reinterpret_cast<_Float16*>(lds + (FWD ? 0 : kGRows * kTS)); // kWLds halfs: [in][out] weights; MODE 2: the 20 backward A fragments
+  _Float16* A = W + kWLds;                                         // kARows * kTS halfs
+  static_assert(kBwdFrags * kFragHalfs <= kWLds, "the backward fragments take the weight array's place");
   STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -300,6 +301,10 @@ void train_tile_kernel(TrainTileParams P) {
   __shared__ LevelCanon lv[16];
   if (tid < 16 * (int)(sizeof(LevelCanon) / 4))
     reinterpret_cast<uint32_t*>(lv)[tid] = reinterpret_cast<const uint32_t*>(P.levels)[tid];
+  if constexpr (MODE == 2) { // fp16 fragments as prepack_frags_kernel left them: 20 KB, 16 bytes per thread and step
+    uint4* dst = reinterpret_cast<uint4*>(W);
+    for (int i = tid; i < kBwdFrags * 64; i += 256) dst[i] = P.bwd_frags[i];
+  }
 #pragma unroll
   for (int l = 0; l < (MODE == 2 ? 0 : 5); l++) { // n_out is a power of two per layer: shifts, no divisions; loads independent
     constexpr int kSh[5] = {6, 4, 6, 6, 4};
@@ -449,12 +454,18 @@ void train_tile_kernel(TrainTileParams P) {
         // scatter below read them there.
         if (wave == 0) {
           typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-          const bf16x8* bf = reinterpret_cast<const bf16x8*>(P.bwd_frags);
+          const half8* wf = reinterpret_cast<const half8*>(W);
           const f32x16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
           auto mm3 = [&](int f, const bf16x8& bh, const bf16x8& bl, f32x16v c) {
-            asm volatile("" ::: "memory"); // fragment loads stay with their MFMAs (hoisted to the top they cost 160 registers)
-            __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 ah = bf[f * 64 + lane], al = bf[(kBwdFrags + f) * 64 + lane];
+            const half8 w = wf[f * 64 + lane]; // one LDS read; the split into bf16 high + low parts is exact (11 bits into 8 + 8)
+            bf16x8 ah, al;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const float wv = (float)w[j];
+              const __bf16 hv = (__bf16)wv;
+              ah[j] = hv;
+              al[j] = (__bf16)(wv - (float)hv);
+            }
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
@@ -706,9 +717,8 @@ __global__ __launch_bounds__(256) void prepack_frags_kernel(const uint16_t* __re
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0 && P.state) end_step(P, sample_count, lr, P.beta1, P.beta2); // the step's last kernel: it opens the next one too
   if (i >= kNumFrags * kFragHalfs) {
-    // backward fragments: A[row = input unit][K = output unit] of every layer, the fp16 weight split EXACTLY into a bf16
-    // high part (fragments 0..19) and a bf16 low part (20..39); K order = the order in which a lane holds the previous
-    // backward layer's accumulator rows (frag_hidden_k), as in the forward fragments
+    // backward fragments: A[row = input unit][K = output unit] of every layer, fp16 as stored; K order = the order in
+    // which a lane holds the previous backward layer's accumulator rows (frag_hidden_k), as in the forward fragments
     const int ib = i - kNumFrags * kFragHalfs;
     if (ib >= kBwdFrags * kFragHalfs) return;
     const int f = ib / kFragHalfs, ln = (ib % kFragHalfs) >> 3, j = ib & 7;
@@ -724,13 +734,7 @@ __global__ __launch_bounds__(256) void prepack_frags_kernel(const uint16_t* __re
     else if (layer == 1) o = (j & 3) + 8 * (j >> 2) + 4 * h; // the density output as its accumulator rows come
     else o = frag_hidden_k(st, h, j);
     const int k_in = 32 * mt + r;
-    float w = 0.0f;
-    if (k_in < kLIn[layer] && o < kLOut[layer]) w = (float)__builtin_bit_cast(_Float16, mlp[kLOff[layer] + k_in * kLOut[layer] + o]);
-    const __bf16 hi = (__bf16)w;
-    const __bf16 lo = (__bf16)(w - (float)hi);
-    uint16_t* out = frags + kNumFrags * kFragHalfs;
-    out[ib] = __builtin_bit_cast(uint16_t, hi);
-    out[kBwdFrags * kFragHalfs + ib] = __builtin_bit_cast(uint16_t, lo);
+    frags[kNumFrags * kFragHalfs + ib] = k_in < kLIn[layer] && o < kLOut[layer] ? mlp[kLOff[layer] + k_in * kLOut[layer] + o] : (uint16_t)0;
     return;
   }
   const int f = i / kFragHalfs, lane = (i % kFragHalfs) >> 3, j = i & 7;
@@ -1201,7 +1205,7 @@ __global__ __launch_bounds__(256) void density_refresh_fast_kernel(DensityParams
 
 // ------------------------------------------------------------------ launchers
 
-size_t train_tile_lds_bytes(bool fwd, int mode) { return 2u * (size_t)((mode == 2 ? 0 : kWLds) + kARows * kTS) + (fwd ? 0u : 4u * (size_t)(kGRows * kTS)); }
+size_t train_tile_lds_bytes(bool fwd, int) { return 2u * (size_t)(kWLds + kARows * kTS) + (fwd ? 0u : 4u * (size_t)(kGRows * kTS)); }
 
 hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s) {
   hipLaunchKernelGGL(train_rays_kernel, dim3((P.n_rays + 3) / 4), dim3(256), 0, s, P);
@@ -1241,16 +1245,14 @@ hipError_t launch_train_tiles(const TrainTileParams& P0, bool forward, int n_blo
   const bool f4 = P.n_features == 4;
   if (forward) return f4 ? launch_tile<4, true>(P, n_blocks, s) : launch_tile<2, true>(P, n_blocks, s);
   hipError_t e;
-  // n_blocks = 3 per CU, what the register-chain instance (53 KB of LDS) can keep resident; the 74 KB instances get two
-  // per CU (a third block would only wait for a slot and stretch the tail).  Slots are numbered as if all were launched.
-  const int n_lds74 = n_blocks / 3 * 2;
+  const int n_lds74 = n_blocks;
   int n_slots = n_blocks;
   const uint32_t kept_tiles = P.act ? P.act_cap / 32u : 0u;
   if (kept_tiles) {
     // the tiles whose activations the forward pass kept, then (a second, nearly always empty launch on slots of its own)
     // the tiles beyond the buffer, which recompute their forward pass
     P.tile_limit = kept_tiles;
-    const int n_first = P.bwd_frags ? n_blocks : n_lds74, n_tail = n_blocks / 3;
+    const int n_first = n_blocks, n_tail = n_blocks / 2;
     if (P.bwd_frags) e = f4 ? launch_tile<4, false, 2>(P, n_first, s) : launch_tile<2, false, 2>(P, n_first, s);
     else e = f4 ? launch_tile<4, false, 1>(P, n_first, s) : launch_tile<2, false, 1>(P, n_first, s);
     if (e != hipSuccess) return e;

@@ -64,13 +64,13 @@ struct TrainTileParams {
   // buffer covers, and -- nearly always none -- the tiles beyond it, which recompute their forward pass)
   uint32_t tile_begin, tile_limit;
   int slot_base;
-  // backward-pass A fragments (bf16 high parts, then low parts) of the fp16 weights, rebuilt with the forward ones after
-  // every optimiser step: kBwdFrags x 64 lanes x 8 bf16 each; NULL: the LDS / f32-MFMA chain
+  // backward-pass A fragments of the fp16 weights, rebuilt with the forward ones after every optimiser step:
+  // kBwdFrags x 64 lanes x 8 halfs; NULL: the LDS / f32-MFMA chain
   const uint4* bwd_frags;
 };
 constexpr int kBwdFrags = 20; // R3: 2 row tiles | R2: 2 x 4 k-steps | R1: 4 k-steps | D2: 2 row tiles | D1: 4 k-steps
 // slots of mlp_grad_partial for a backward pass launched with n_blocks blocks (the stage of the reduction sits behind them)
-inline int train_dw_slots(int n_blocks) { return n_blocks + n_blocks / 3; } // first launch + the tail launch (launch_train_tiles)
+inline int train_dw_slots(int n_blocks) { return n_blocks + n_blocks / 2; } // first launch + the tail launch (launch_train_tiles)
 
 struct TrainCompositeParams {
   TrainRay* rays;
