@@ -627,6 +627,10 @@ def main():
     # (scripts/gpu/r02_ay.sh; the C++ planner does the same): a finished run's exit code must not depend on it.
     sys.stdout.flush()
     sys.stderr.flush()
+    # ... unless a profiler is attached: rocprofv3 writes its files from an exit handler, which _exit would skip
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ)
+    if profiled or os.environ.get("PRV_BENCH_EXIT") == "normal":
+        sys.exit(rc)
     os._exit(rc)
 
 

@@ -17,6 +17,7 @@
 // and `train_images: files`, written once as <gt_path>/<N>/rgbaClip_<i>.png (what mode 3 leaves on disk) and read
 // back through each iteration's json exactly as run.py's load_training_data does.
 #include <cstdio>
+#include <cstring>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -717,6 +718,11 @@ int main(int argc, char** argv) {
   const int rc = run(argc, argv);
   const char* how = getenv("PRV_PLANNER_EXIT");
   if (how && std::string(how) == "normal") return rc;
+  // a profiler writes its files from an exit handler, which _exit would skip
+  if (const char* pre = getenv("LD_PRELOAD"))
+    if (std::string(pre).find("rocprof") != std::string::npos) return rc;
+  for (char** e = environ; e && *e; e++)
+    if (strncmp(*e, "ROCPROF", 7) == 0 || strncmp(*e, "ROCP_", 5) == 0 || strncmp(*e, "ROCTRACER", 9) == 0) return rc;
   std::cout.flush();
   std::cerr.flush();
   fflush(nullptr);
