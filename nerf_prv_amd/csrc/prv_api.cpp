@@ -75,7 +75,7 @@ struct prv_ctx {
   void* pin = nullptr;                         // pinned host staging of the per-call camera upload (no pageable copy, no stream sync)
   size_t pin_cap = 0;
   hipEvent_t pin_ev = nullptr; // recorded after the upload: the staging is rewritten only once that copy has run
-  int blocks_per_cu = 4;
+  int blocks_per_cu = -1; // persistent render blocks per CU (PRV_BLOCKS_PER_CU); -1 = by table and image size, see render_views
   int refill_min = 32;
   std::vector<struct prv_trainer*> trainers; // live trainers of this context (detached by prv_destroy)
   std::vector<struct prv_comm*> comms;       // live communicators of this context (detached by prv_destroy)
@@ -541,7 +541,14 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   if ((rc = ensure(c, c->queue, seg_cap_max * (size_t)n_seg * kRecordBytes)) != PRV_OK) return rc;
   if (spp > 1 && (rc = ensure(c, c->stage, batch * npix * (size_t)spp * 16)) != PRV_OK) return rc;
 
-  const int n_blocks = c->n_cu * c->blocks_per_cu;
+  // Persistent render blocks per CU.  More resident waves hide more gather latency but also put more random requests in
+  // flight and draw more power: measured per workload (64-slot kernel, profiles/r02_bm_blocks_per_cu.txt) -- the
+  // cache-resident table at large images is flat from 3 up (3 waves per SIMD is what its registers allow), small images
+  // (incoherent gathers: the reference's 80x45 candidates, 320x320) are 6 % faster with 2, and the HBM-bound 512^3 table
+  // is 10 % faster with ONE wave per SIMD: fewer requests in flight, a better L2 hit rate.
+  int bpc = c->blocks_per_cu;
+  if (bpc <= 0) bpc = m.table_halfs * 2 > ((size_t)32 << 20) ? 1 : npix < ((size_t)1 << 17) ? 2 : 4;
+  const int n_blocks = c->n_cu * bpc;
   for (size_t b0 = 0; b0 < (size_t)n_views; b0 += batch) {
     const int nb = (int)std::min(batch, (size_t)n_views - b0);
     float* dst_f32 = out_f32 + b0 * npix * 4;

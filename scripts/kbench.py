@@ -43,7 +43,7 @@ if clocks:
 dt = (time.perf_counter() - t0) / args.reps
 p = ctx.profile_end()
 rms, mms = p["render_ms"] / args.reps, p["march_ms"] / args.reps
-print(f"{args.tag} BPC={os.environ.get('PRV_BLOCKS_PER_CU','4')} RM={os.environ.get('PRV_REFILL_MIN','8')} "
+print(f"{args.tag} BPC={os.environ.get('PRV_BLOCKS_PER_CU','auto')} RM={os.environ.get('PRV_REFILL_MIN','8')} "
       f"eval_exact={st.samples_evaluated} rounds={st.wave_rounds} eval={st.samples_evaluated/1e6:.1f}M ({100*st.samples_evaluated/st.samples_nominal:.2f}% of nominal) "
       f"render={rms:.2f}ms march={mms:.2f}ms wall={dt*1e3:.2f}ms "
       f"kernel_rate={st.samples_evaluated/rms/1e6:.2f} Gsamp/s wall_rate={st.samples_evaluated/dt/1e9:.2f} Gsamp/s "
