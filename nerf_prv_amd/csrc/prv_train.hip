@@ -627,7 +627,11 @@ void train_tile_kernel(TrainTileParams P) {
     // groups and usually share the line too).
     __syncthreads(); STAMP(13); // the activation rows are dead: their LDS becomes the staging array
     {
-      // staging = the (dead) activation region: 256 rows x 33 halfs = 2112 uint2 -> 8 levels of 32 samples at a time
+      // staging = the (dead) activation region: 256 rows x 33 halfs = 2112 uint2 -> 8 levels of 32 samples at a time.
+      // A sample's 64 (entry, weight) pairs sit 65 pairs apart: the writers (lanes = samples) then hit 32 different banks
+      // (with a stride of 64 all of them hit ONE: half of this kernel's LDS cycles were bank conflicts)
+      constexpr int kStageStride = 65;
+      static_assert(32 * kStageStride * 8 <= kARows * kTS * 2, "the staging array lives in the activation region");
       uint2* stage = reinterpret_cast<uint2*>(A);
       constexpr int NL = 32 / F, NPASS = NL / 8;
       const bool contributes = live && (seed.x != 0.0f || seed.y != 0.0f || seed.z != 0.0f || seed.w != 0.0f);
@@ -640,14 +644,14 @@ void train_tile_kernel(TrainTileParams P) {
           if (l / 8 != pass) continue;
 #pragma unroll
           for (int c = 0; c < 8; c++)
-            stage[(s * 8 + (l & 7)) * 8 + c] = make_uint2(contributes ? cidx[q][c] : 0xffffffffu, __float_as_uint(cw[q][c]));
+            stage[s * kStageStride + (l & 7) * 8 + c] = make_uint2(contributes ? cidx[q][c] : 0xffffffffu, __float_as_uint(cw[q][c]));
         }
         __syncthreads();
         if (!(PRV_TRAIN_ABLATE & 1)) {
           const int k = tid % F;
           constexpr int kItems = 32 * 8 * 8, kPerPass = 256 / F;
           for (int it = tid / F; it < kItems; it += kPerPass) {
-            const uint2 e = stage[it];
+            const uint2 e = stage[(it >> 6) * kStageStride + (it & 63)];
             if (e.x == 0xffffffffu) continue;
             const int ss = it >> 6, l = pass * 8 + ((it >> 3) & 7);
             atomicAdd(P.table_grad + (size_t)e.x * F + k, __uint_as_float(e.y) * G[(kGFeat + l * F + k) * kTS + ss]);
