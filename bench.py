@@ -443,7 +443,7 @@ def run_rank(args):
 
     def variant_of(slot):
         lay = ctx.model_layout(slot)
-        return f"{64 if lay['kernel_slots'] == 64 else ''}<{lay['kernel_features']}, {lay['kernel_pair_steps']}>"
+        return f"64<{lay['kernel_features']}, {lay['kernel_dense_levels']}>"
 
     n_views = args.views_per_gpu * world if args.mode == "weak" else args.views_total
     fkw = field_kw(args.field, args.scene)

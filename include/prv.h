@@ -367,16 +367,15 @@ int prv_train_refresh_occupancy(prv_trainer* t);
 int prv_train_debug_stamps(prv_trainer* t, unsigned long long* out64);
 
 /* ---- stage hooks for parity tests (host in / host out, small n) ---------- */
-/* how a loaded field is laid out for the kernels, and which render_queue_kernel<F, NPAIR> instance prv_render
- * launches for it (tests assert that e.g. the 512^3 / F=2 field really runs the <2,5> instance) */
+/* how a loaded field is laid out for the kernels, and which render_queue64_kernel<F, NDENSE> instance prv_render
+ * launches for it (tests assert that e.g. the 512^3 / F=2 field really runs the <2,10> instance) */
 typedef struct prv_model_layout {
   uint64_t table_bytes_canonical; /* ABI layout: what prv_model_load / export carry */
   uint64_t table_bytes_physical;  /* kernel layout: power-of-two strides on the dense levels, size-aligned levels */
-  int32_t n_pair_steps;           /* leading gather steps whose two levels are dense (x-neighbour pairs in one load) */
   int32_t kernel_features;        /* F of the instance */
-  int32_t kernel_pair_steps;      /* 32-slot kernel: NPAIR of the instance; 64-slot kernel: NDENSE of the instance */
+  int32_t kernel_dense_levels;    /* NDENSE of the instance */
   int32_t n_hashed_levels;
-  int32_t kernel_slots;           /* ray slots per wave of the render kernel: 64 (render_queue64_kernel) or 32 */
+  int32_t kernel_slots;           /* ray slots per wave of the render kernel (64) */
   int32_t n_dense_levels;         /* leading physically dense levels */
 } prv_model_layout;
 int prv_debug_model_layout(prv_ctx* ctx, int model_slot, prv_model_layout* out);

@@ -56,8 +56,8 @@ class Rs2Intrinsics(C.Structure):
 
 
 class ModelLayout(C.Structure):
-    _fields_ = [("table_bytes_canonical", C.c_uint64), ("table_bytes_physical", C.c_uint64), ("n_pair_steps", C.c_int32),
-                ("kernel_features", C.c_int32), ("kernel_pair_steps", C.c_int32), ("n_hashed_levels", C.c_int32),
+    _fields_ = [("table_bytes_canonical", C.c_uint64), ("table_bytes_physical", C.c_uint64),
+                ("kernel_features", C.c_int32), ("kernel_dense_levels", C.c_int32), ("n_hashed_levels", C.c_int32),
                 ("kernel_slots", C.c_int32), ("n_dense_levels", C.c_int32)]
 
 

@@ -76,16 +76,13 @@ struct prv_ctx {
   size_t pin_cap = 0;
   hipEvent_t pin_ev = nullptr; // recorded after the upload: the staging is rewritten only once that copy has run
   int blocks_per_cu = -1; // persistent render blocks per CU (PRV_BLOCKS_PER_CU); -1 = by table and image size, see render_views
-  int refill_min = 32;
   std::vector<struct prv_trainer*> trainers; // live trainers of this context (detached by prv_destroy)
   std::vector<struct prv_comm*> comms;       // live communicators of this context (detached by prv_destroy)
   int queue_segments = 8; // ray-queue segments = XCDs (PRV_QUEUE_SEGMENTS: 1 = single shared head)
-  int render64 = 1;       // render_queue64_kernel (64 ray slots per wave); PRV_RENDER64=0: the 32-slot kernel
   int pool_on = -1;       // render_queue64 block-level tail pool (PRV_POOL=0/1; -1 = by table and image size, see render_views)
   int merge_max = -1;     // render_queue64 tail merge threshold (PRV_MERGE_MAX; 0 = off; -1 = by table size, see render_views)
   int dbg_flags = 0;
   size_t stage_budget = (size_t)4 << 30; // staging bytes for multi-sample renders (spp x batch x image)
-  size_t dehash_budget = 0; // bytes per hashed level allowed for a physically dense copy (0 = keep hashed)
   size_t queue_budget = (size_t)4 << 30; // ray-queue bytes per batch of views (288 GB of HBM: one batch for 64 views at 800x800)
   double coverage_weight = PRV_COVERAGE_WEIGHT_DEFAULT; // method 5: score = -PSNR + weight * mean((1 - alpha)^2)
 };
@@ -302,18 +299,13 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   uint32_t psize[kMaxLevels], sx[kMaxLevels], poff[kMaxLevels];
   int order[kMaxLevels];
   auto ceil_log2 = [](uint32_t v) { uint32_t s = 0; while ((1u << s) < v) s++; return s; };
-  bool dehash[kMaxLevels];
   for (int l = 0; l < d.n_levels; l++) {
     order[l] = l;
-    // a hashed level may be STORED densely (coherent gathers) when that fits the budget
-    const uint32_t sxl = ceil_log2(lv[l].res + 1); // +1: room for the duplicated border vertex / row / plane
-    const uint64_t dense_entries = 1ull << (3 * sxl); // >= pow2 ceiling of (res + 1) << 2sx
-    dehash[l] = lv[l].hashed && sxl <= 9 && dense_entries * ebytes <= c->dehash_budget;
-    if (lv[l].hashed && !dehash[l]) {
+    if (lv[l].hashed) {
       sx[l] = 0;
       psize[l] = lv[l].size;
     } else {
-      sx[l] = sxl;
+      sx[l] = ceil_log2(lv[l].res + 1); // +1: room for the duplicated border vertex / row / plane
       psize[l] = 1u << ceil_log2((lv[l].res + 1u) << (2 * sx[l])); // res + 1 planes: the last one is duplicated
     }
   }
@@ -327,7 +319,7 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   if ((rc = ensure(c, m.phys, ptotal * ebytes)) != PRV_OK) return rc;
   HIPCHK(c, hipMemsetAsync(m.phys.p, 0, ptotal * ebytes, c->stream));
   for (int l = 0; l < d.n_levels; l++) {
-    RepackLevel R{lv[l].offset, poff[l], lv[l].size, lv[l].res, sx[l], lv[l].hashed, dehash[l] ? 1u : 0u};
+    RepackLevel R{lv[l].offset, poff[l], lv[l].size, lv[l].res, sx[l], lv[l].hashed};
     HIPCHK(c, launch_repack_level((const uint16_t*)m.table.p, (uint16_t*)m.phys.p, R, d.n_features, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -338,7 +330,6 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   f.occ_coarse = (d.occ_res % 4 == 0 && d.occ_res >= 8) ? (const uint32_t*)m.occ_coarse.p : nullptr;
   f.frags = (const half8*)m.frags.p;
   f.frags64 = (const half8*)m.frags64.p;
-  f.render64 = c->render64;
   f.n_levels = d.n_levels;
   f.n_features = d.n_features;
   f.occ_res = d.occ_res;
@@ -347,22 +338,15 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
     f.occ_lo[a] = m.occ_lo[a];
     f.occ_hi[a] = m.occ_hi[a];
   }
-  // gather step j = levels (2j, 2j+1) on lane halves (0, 1); leading steps whose two levels are both
-  // physically dense can use the paired loads
-  f.n_pair_steps = 0;
-  while (2 * f.n_pair_steps + 1 < d.n_levels && (!lv[2 * f.n_pair_steps].hashed || dehash[2 * f.n_pair_steps]) &&
-         (!lv[2 * f.n_pair_steps + 1].hashed || dehash[2 * f.n_pair_steps + 1]))
-    f.n_pair_steps++;
-  if (getenv("PRV_NO_PAIR")) f.n_pair_steps = 0;
   f.n_dense_levels = 0;
-  while (f.n_dense_levels < d.n_levels && (!lv[f.n_dense_levels].hashed || dehash[f.n_dense_levels])) f.n_dense_levels++;
-  if (getenv("PRV_NO_PAIR")) f.n_dense_levels = 0;
+  while (f.n_dense_levels < d.n_levels && !lv[f.n_dense_levels].hashed) f.n_dense_levels++;
+  if (getenv("PRV_NO_PAIR")) f.n_dense_levels = 0; // tests: every level through the generic (clamped, 8-load) gather
   for (int l = 0; l < d.n_levels; l++) {
     LevelDev& L = f.levels[l];
     L.scale = lv[l].scale;
     L.res_m1 = lv[l].res - 1;
     if (lv[l].res > 4096) return fail(c, PRV_E_INVALID, "level %d has %u vertices per axis (limit 4096)", l, lv[l].res);
-    if (lv[l].hashed && !dehash[l]) { // the kernel multiplies with v_mul_u32_u24: keep the low 24 bits
+    if (lv[l].hashed) { // the kernel multiplies with v_mul_u32_u24: keep the low 24 bits
       L.my_b = (2654435761u * ebytes) & 0xffffffu;
       L.mz_b = (805459861u * ebytes) & 0xffffffu;
       L.m_b = (lv[l].size - 1u) * ebytes;
@@ -608,7 +592,6 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     rp.inv_spp = 1.0f;
     rp.spp_k = 0;
     rp.last_pass = mp.last_pass;
-    rp.refill_min = c->refill_min;
     // Tail merge + the block's tail pool raise slot utilisation (0.77 -> 0.93) at the price of incoherent gathers from the
     // relocated rays.  That pays where the gathers of a fresh cohort are coherent to begin with and the table is cache
     // resident -- large images of the 256^3 field: launch -8 % -- and costs elsewhere: the 512^3 field is bound by random
@@ -698,16 +681,9 @@ int prv_create(prv_ctx** out, int device_id) try {
   }
   c->stream = c->own_stream;
   if (const char* s = getenv("PRV_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(s));
-  if (const char* s = getenv("PRV_REFILL_MIN")) { // group size: power of two in [1, 32]
-    int g = std::min(32, std::max(1, atoi(s)));
-    while (g & (g - 1)) g &= g - 1;
-    c->refill_min = g;
-  }
   if (const char* s = getenv("PRV_QUEUE_SEGMENTS")) c->queue_segments = std::min(8, std::max(1, atoi(s)));
-  if (const char* s = getenv("PRV_RENDER64")) c->render64 = atoi(s) != 0;
   if (const char* s = getenv("PRV_MERGE_MAX")) c->merge_max = std::min(31, std::max(0, atoi(s)));
   if (const char* s = getenv("PRV_POOL")) c->pool_on = atoi(s) != 0 ? 1 : 0;
-  if (const char* s = getenv("PRV_DEHASH_MB")) c->dehash_budget = (size_t)std::max(0, atoi(s)) << 20;
   if (const char* s = getenv("PRV_DBG")) c->dbg_flags = atoi(s);
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
   *out = c;
@@ -1520,10 +1496,9 @@ int prv_debug_model_layout(prv_ctx* c, int slot, prv_model_layout* out) try {
   compute_levels(m.desc, lv, &total);
   out->table_bytes_canonical = m.table_halfs * 2;
   out->table_bytes_physical = m.phys.bytes;
-  out->n_pair_steps = m.dev.n_pair_steps;
   out->kernel_features = m.dev.n_features;
-  out->kernel_pair_steps = render_instance_pair_steps(m.dev);
-  out->kernel_slots = m.dev.render64 ? 64 : 32;
+  out->kernel_dense_levels = render_instance_dense_levels(m.dev);
+  out->kernel_slots = 64;
   out->n_dense_levels = m.dev.n_dense_levels;
   out->n_hashed_levels = 0;
   for (int l = 0; l < m.desc.n_levels; l++) out->n_hashed_levels += lv[l].hashed ? 1 : 0;

@@ -46,13 +46,11 @@ struct FieldDev {
   const uint16_t* table;  // PHYSICAL layout (see LevelDev), fp16 bit patterns, entries of F halfs
   const uint32_t* occ;    // occ_res^3 bits, x fastest
   const uint32_t* occ_coarse; // (occ_res/4)^3 bits: any occupied fine cell in the 4^3 block OR its 26 neighbours (or null)
-  const half8* frags;     // kNumFrags * 64 half8, MFMA A fragments (prepacked weights)
-  const half8* frags64;   // the same for render_queue64 (canonical first-layer k order, result copies in padding rows)
+  const half8* frags;     // kNumFrags * 64 half8, MFMA A fragments (prepacked weights) in the trainer's order (prv_train.hip)
+  const half8* frags64;   // the render kernel's set (canonical first-layer k order, result copies in padding rows)
   LevelDev levels[kMaxLevels];
   int n_levels, n_features, occ_res;
-  int n_pair_steps; // leading gather steps whose two levels are physically dense (paired loads)
-  int n_dense_levels; // leading levels that are physically dense (render_queue64: clamp-free one-add neighbours)
-  int render64;       // 1: prv_render launches render_queue64_kernel (default), 0: the 32-slot kernel
+  int n_dense_levels; // leading levels that are physically dense (clamp-free one-add neighbours)
   float density_bias;
   float occ_lo[3], occ_hi[3]; // bounding box of the occupied cells, grown by one cell (march pass clips to it)
 };
@@ -286,111 +284,11 @@ template <> struct EntryPair<2> {
   }
 };
 
-// One level, one sample, one lane: 8 corner loads of F halfs and the trilinear blend in
-// packed binary16 (as tiny-cuda-nn does for fp16 tables): weights rounded to fp16,
-// w = fp16(fp16(wx*wy)*wz), acc = fp16 fma(w, v, acc), corners in order dx + 2dy + 4dz.
-// Every op is an IEEE RNE fp16 op (v_pk_mul_f16 / v_pk_fma_f16), so the result is
+// ---------------------------------------------------------------- gather: one lane = one sample, every level
+// One level, one sample, one lane: 8 corner values of F halfs and the trilinear blend in packed binary16 (as
+// tiny-cuda-nn does for fp16 tables): weights rounded to fp16, w = fp16(fp16(wx*wy)*wz), acc = fp16 fma(w, v, acc),
+// corners in order dx + 2dy + 4dz.  Every op is an IEEE RNE fp16 op (v_pk_mul_f16 / v_pk_fma_f16), so the result is
 // bit-identical to the oracle.  out = F/2 packed pairs.
-// PAIR (compile time): the level stores x-neighbours contiguously -> 4 loads of 2 entries instead of 8
-// loads of 1: half the lane-addresses through the texture addresser.  Same values, same blend order.
-template <int F, bool PAIR>
-__device__ __forceinline__ void encode_level(const uint16_t* __restrict__ table, const LevelDev& L,
-                                             float px, float py, float pz, half2v out[F / 2]) {
-  constexpr int ESH = F == 4 ? 3 : 2; // log2(entry bytes)
-  const float pos[3] = {fmaf(L.scale, px, 0.5f), fmaf(L.scale, py, 0.5f), fmaf(L.scale, pz, 0.5f)};
-  uint32_t c0[3], c1[3];
-  half2v wa[3]; // (1-w, w) per axis, fp16
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    const float w1 = __builtin_amdgcn_fractf(pos[a]); // pos >= 0.5: pos - floor(pos), exact
-    wa[a][0] = to_half(1.0f - w1);
-    wa[a][1] = (_Float16)w1;
-    c0[a] = (uint32_t)(int)pos[a];                    // truncation = floor; never exceeds res-1
-    c1[a] = min(c0[a] + 1u, L.res_m1);
-  }
-  const uint32_t tx[2] = {(c0[0] << ESH) & L.m_b, (c1[0] << ESH) & L.m_b};
-  // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): c < 2^12, my_b/mz_b hold the low
-  // 24 bits of the multiplier, and only bits below m_b < 2^24 of the product are kept.
-  const uint32_t ty[2] = {__umul24(c0[1], L.my_b) & L.m_b, __umul24(c1[1], L.my_b) & L.m_b};
-  const uint32_t tz[2] = {(__umul24(c0[2], L.mz_b) & L.m_b) | L.off_b, (__umul24(c1[2], L.mz_b) & L.m_b) | L.off_b};
-  uint32_t vw[8][F / 2]; // corner c = dx + 2dy + 4dz, F/2 packed pairs each
-  if (PAIR) {
-    // physically dense level: nothing wraps (no masks) and the level offset folds into the z term
-    // (v_mad_u32_u24); the three terms occupy disjoint bits, so XOR and + agree with the generic form
-    const uint32_t dx0 = c0[0] << ESH;
-    const uint32_t dy[2] = {(uint32_t)__umul24(c0[1], L.my_b), (uint32_t)__umul24(c1[1], L.my_b)};
-    const uint32_t dz[2] = {(uint32_t)__umul24(c0[2], L.mz_b) + L.off_b, (uint32_t)__umul24(c1[2], L.mz_b) + L.off_b};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const uint32_t byte_off = dx0 ^ dy[q & 1] ^ dz[q >> 1];
-      const EntryPair<F> e = EntryPair<F>::load(reinterpret_cast<const char*>(table) + byte_off);
-#pragma unroll
-      for (int k = 0; k < F / 2; k++) {
-        vw[2 * q][k] = e.w[k];
-        vw[2 * q + 1][k] = e.w[F / 2 + k];
-      }
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const uint32_t byte_off = tx[c & 1] ^ ty[(c >> 1) & 1] ^ tz[c >> 2];
-      const Entry<F> e = Entry<F>::load(reinterpret_cast<const char*>(table) + byte_off);
-#pragma unroll
-      for (int k = 0; k < F / 2; k++) vw[c][k] = e.w[k];
-    }
-  }
-  // pair weights over x for each (dy, dz): (wx0, wx1) * wy[dy] * wz[dz]
-  half2v wp[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const half2v wy = {wa[1][q & 1], wa[1][q & 1]}, wz = {wa[2][q >> 1], wa[2][q >> 1]};
-    wp[q] = (wa[0] * wy) * wz;
-  }
-#pragma unroll
-  for (int k = 0; k < F / 2; k++) out[k] = half2v{(_Float16)0.0f, (_Float16)0.0f};
-#pragma unroll
-  for (int c = 0; c < 8; c++) {
-    const _Float16 w = wp[c >> 1][c & 1];
-    const half2v ww = {w, w};
-#pragma unroll
-    for (int k = 0; k < F / 2; k++) out[k] = __builtin_elementwise_fma(ww, __builtin_bit_cast(half2v, vw[c][k]), out[k]);
-  }
-}
-
-template <int F, int NPAIR, int... J>
-__device__ __forceinline__ void encode_steps(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv, int h,
-                                             float px, float py, float pz, half2v* out,
-                                             std::integer_sequence<int, J...>) {
-  (encode_level<F, (J < NPAIR)>(table, lv[2 * J + h], px, py, pz, out + J * (F / 2)), ...);
-}
-
-// The 16 features one lane half contributes to a sample, as its two MFMA B fragments (k-steps 0,1).
-// Levels are INTERLEAVED over the lane halves: gather step j handles level 2j on half 0 and level
-// 2j+1 on half 1, so both halves of a step are of the same kind wherever the field allows it; the first
-// NPAIR steps (compile time; both levels physically dense) use the paired loads.  Fragment s of half h
-// holds levels 2j+h for j in [s*LH/2, (s+1)*LH/2): the first-layer weights are prepacked with the same
-// map (prv_api.cpp: k_feat).
-template <int F, int NPAIR>
-__device__ __forceinline__ void encode_half(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv,
-                                            int h, float px, float py, float pz, half8& b0, half8& b1) {
-  constexpr int LH = 16 / F; // levels per lane half
-  px = clamp01(px);
-  py = clamp01(py);
-  pz = clamp01(pz);
-  half2v out[8];
-  encode_steps<F, NPAIR>(table, lv, h, px, py, pz, out, std::make_integer_sequence<int, LH>{});
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    b0[2 * k] = out[k][0];
-    b0[2 * k + 1] = out[k][1];
-    b1[2 * k] = out[4 + k][0];
-    b1[2 * k + 1] = out[4 + k][1];
-  }
-}
-
-// ---------------------------------------------------------------- v2 gather: one lane = one sample, every level
-// (render_queue64_kernel: 64 ray slots per wave).  Same arithmetic as encode_level -- positions, cells, fp16 weights and the
-// fp16 fma chain are bit-identical -- with fewer instructions around it:
 //  * DENSE levels (compile time: the leading levels of the field that are physically dense): the physical layout
 //    duplicates the last vertex of every row, the last row of every plane and the last plane, so the +1 neighbours
 //    need no clamp on any axis and are one add away: base, base + my, base + mz, base + my + mz (4 paired loads);

@@ -4,13 +4,12 @@
 //       camera (replaces pyngp's ray init behind run.py:296,304), unit-cube slab test, S
 //       occupancy tests -> 128-bit live-sample mask.  Rays with a non-empty mask are
 //       compacted into the ray queue: wave ballot + popcount prefix, one atomic per wave.
-//  K_B  render_queue  : persistent waves.  A wave owns 32 ray slots; slot r is served by
-//       the lane pair (r, r+32), each lane gathering half of the hash-grid levels of the
-//       slot's next live sample.  The two tiny MLPs run on v_mfma_f32_32x32x16_f16 with the
-//       samples on the MFMA column, weights staged once per block in LDS as prepacked A
-//       fragments, activations never leaving registers.  Front-to-back compositing is
-//       sequential per ray inside one lane (deterministic).  Finished slots are refilled
-//       from the queue with a ballot/prefix-sum claim.
+//  K_B  render_queue64: persistent waves, 64 ray slots per wave: one lane = one ray = one whole sample per round
+//       (all hash-grid levels gathered by the lane itself); v_permlane32_swap turns the wave's 64 feature vectors
+//       into the MFMA B operands of two 32-sample column groups.  The two tiny MLPs run on MFMA with the samples on
+//       the column, weights staged once per block in LDS as prepacked A fragments, activations never leaving
+//       registers.  Front-to-back compositing is sequential per ray inside one lane (deterministic).  A group of 32
+//       slots refills as a whole cohort from the queue; thinned-out tails merge / pool (see the kernel).
 //  K_S* score kernels : per-view reductions in fp64, fixed reduction order (no float
 //       atomics), so rankings are reproducible bit for bit.
 //
@@ -226,181 +225,12 @@ __device__ __forceinline__ void clock_stamp_end(unsigned long long* stat) {
   }
 }
 
-template <int F, int NPAIR>
-__global__ __launch_bounds__(256) void render_queue_kernel(RenderParams P) {
-  __shared__ half8 wl[kNumFrags * 64];
-  __shared__ LevelDev lvl[kMaxLevels];
-  __shared__ unsigned hist[33];
-  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = P.field.frags[i];
-  if (threadIdx.x < 33) hist[threadIdx.x] = 0u;
-  stage_levels(P.field, lvl);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const uint32_t lt_mask = (1u << r) - 1u;
-
-  bool active = false;
-  uint32_t pix = 0;
-  float o[3] = {0, 0, 0}, d[3] = {0, 0, 1}, t0 = 0.f, dt = 0.f;
-  uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-  float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
-  half8 shf = {0, 0, 0, 0, 0, 0, 0, 0};
-  bool drained = false;
-  unsigned long long n_eval = 0ull, n_rounds = 0ull;
-  clock_stamp_begin(P.stat_evaluated);
-  uint32_t q_cur = 0, q_end = 0; // this wave's claimed range of queue records (wave-uniform)
-  const uint32_t n_seg = (uint32_t)P.n_segments; // 8 = one per XCD, 1 = a single shared head
-  // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this workgroup runs on
-  uint32_t seg = n_seg > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % n_seg : 0u;
-  uint32_t seg_tried = 0;
-
-  for (;;) {
-    // ---- refill idle slots from the wave's claimed range: ballot + prefix sum hand-out;
-    //      one atomic on the shared head per kClaim records
-    // Slots are refilled in aligned GROUPS of refill_min slots (a power of two, 32 = the whole wave) and
-    // only when a whole group is idle: rays that start together march in lockstep and share cache lines
-    // (measured: per-slot refills double the L2 requests), smaller groups wait less for their longest ray.
-    const uint32_t idle = (uint32_t)__ballot(!active);
-    uint32_t need = 0u;
-    {
-      const uint32_t g = (uint32_t)P.refill_min;
-      const uint32_t gm = g >= 32u ? 0xffffffffu : ((1u << g) - 1u);
-      for (uint32_t s0 = 0; s0 < 32u; s0 += g)
-        if (((idle >> s0) & gm) == gm) need |= gm << s0;
-    }
-    const uint32_t cnt = (uint32_t)__popc(need);
-    if (!drained && cnt != 0u) {
-      // The queue is cut into n_seg contiguous segments, one per XCD (queue order is tile order, so a
-      // segment is a compact set of views / image regions): a wave drains its own XCD's segment first and
-      // then steals from the next ones.  Each XCD's private L2 then serves one region's table lines
-      // instead of a share of everybody's.  Placement changes speed only, never results.
-      while (q_cur == q_end && !drained) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(P.queue_head + 16u * seg, kClaim);
-        base = __builtin_amdgcn_readfirstlane(base);
-        const uint32_t s_lo = seg * P.seg_cap, s_cnt = P.queue_count[16u * seg]; // region `seg` of the queue
-        if (base < s_cnt) {
-          q_cur = s_lo + base;
-          q_end = min(q_cur + kClaim, s_lo + s_cnt);
-        } else if (++seg_tried >= n_seg) {
-          drained = true;
-        } else {
-          seg = seg + 1u == n_seg ? 0u : seg + 1u;
-        }
-      }
-      const uint32_t avail = min(cnt, q_end - q_cur);
-      const uint32_t prefix = (uint32_t)__popc(need & lt_mask);
-      if (((need >> r) & 1u) && prefix < avail) {
-        const uint4* rec = reinterpret_cast<const uint4*>(P.queue) + (size_t)(q_cur + prefix) * kRecordWords;
-        const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-        shf = reinterpret_cast<const half8*>(rec)[4 + h];
-        o[0] = __uint_as_float(q0.x); o[1] = __uint_as_float(q0.y); o[2] = __uint_as_float(q0.z);
-        t0 = __uint_as_float(q0.w);
-        d[0] = __uint_as_float(q1.x); d[1] = __uint_as_float(q1.y); d[2] = __uint_as_float(q1.z);
-        dt = __uint_as_float(q1.w);
-        m0 = q2.x; m1 = q2.y; m2 = q2.z; m3 = q2.w;
-        pix = q3.x;
-        T = 1.f; cr = 0.f; cg = 0.f; cb = 0.f;
-        active = true;
-      }
-      q_cur += avail;
-    }
-    const uint32_t act = (uint32_t)__ballot(active);
-    if (act == 0u) {
-      if (drained) break;
-      continue;
-    }
-    n_eval += (unsigned long long)__popc(act);
-    n_rounds++;
-    if ((P.dbg & 8) && lane == 0) atomicAdd(&hist[__popc(act)], 1u); // dev: how full the wave's 32 slots are, per round
-
-    // ---- next live sample of every active slot (identical in both lanes of a pair)
-    half8 f0 = {0, 0, 0, 0, 0, 0, 0, 0}, f1 = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool last = false;
-    if (active) {
-      uint32_t i;
-      if (m0) { i = (uint32_t)__builtin_ctz(m0); m0 &= m0 - 1u; }
-      else if (m1) { i = 32u + (uint32_t)__builtin_ctz(m1); m1 &= m1 - 1u; }
-      else if (m2) { i = 64u + (uint32_t)__builtin_ctz(m2); m2 &= m2 - 1u; }
-      else { i = 96u + (uint32_t)__builtin_ctz(m3); m3 &= m3 - 1u; }
-      last = (m0 | m1 | m2 | m3) == 0u;
-      const float t = fmaf((float)i + 0.5f, dt, t0);
-#if PRV_ABLATE & 1
-      f0[0] = to_half(t); f1[3] = to_half(dt);
-#else
-      encode_half<F, NPAIR>(P.field.table, lvl, h, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f0, f1);
-#endif
-    }
-    // ---- both MLPs on the matrix cores (whole wave)
-#if PRV_ABLATE & 2
-    MlpOut mo;
-    for (int q = 0; q < 16; q++) { mo.dens[q] = (float)f0[q & 7]; mo.rgb[q] = (float)f1[q & 7]; }
-#else
-    const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf);
-#endif
-
-    // ---- front-to-back compositing (authoritative in lane half 0)
-    bool term = false;
-#if PRV_ABLATE & 4
-    if (active) {
-      const float alpha = mo.dens[0] * 0.001f + 0.05f;
-      cr += mo.rgb[0]; cg += mo.rgb[1]; cb += mo.rgb[2];
-      T = T * (1.0f - alpha);
-      term = T < P.min_T;
-    }
-#else
-    if (active) {
-      // hardware exp2 / rcp (about 1 ulp each): well inside the 1e-3 pixel tolerance
-      const float sigma = fast_exp(mo.dens[0] + P.field.density_bias);
-      const float alpha = 1.0f - fast_exp(-(sigma * dt));
-      const float wgt = alpha * T;
-      cr = fmaf(wgt, fast_sigmoid(mo.rgb[0]), cr);
-      cg = fmaf(wgt, fast_sigmoid(mo.rgb[1]), cg);
-      cb = fmaf(wgt, fast_sigmoid(mo.rgb[2]), cb);
-      T = T * (1.0f - alpha);
-      term = T < P.min_T;
-    }
-#endif
-    const uint32_t tb = (uint32_t)__ballot(term); // low 32 bits: lane half 0
-    const bool done = active && (last || ((tb >> r) & 1u));
-    if (done) {
-      if (h == 0) {
-        float4* out = reinterpret_cast<float4*>(P.out_f32) + pix;
-        float4 v = make_float4(cr, cg, cb, 1.0f - T);
-        if (P.spp_k != 0) {
-          const float4 prev = *out;
-          v.x = prev.x + v.x; v.y = prev.y + v.y; v.z = prev.z + v.z; v.w = prev.w + v.w;
-        }
-        if (P.last_pass) {
-          v.x *= P.inv_spp; v.y *= P.inv_spp; v.z *= P.inv_spp; v.w *= P.inv_spp;
-          if (P.out_u8) P.out_u8[pix] = quantize_rgba8(v.x, v.y, v.z, v.w, P.bg);
-        }
-        *out = v;
-      }
-      active = false;
-    }
-  }
-  if (lane == 0 && n_eval) {
-    atomicAdd(P.stat_evaluated, n_eval);
-    atomicAdd(P.stat_evaluated + 1, n_rounds); // wave-rounds: slot utilisation = evaluated / (32 * rounds)
-  }
-  clock_stamp_end(P.stat_evaluated);
-  if (P.dbg & 8) {
-    __syncthreads();
-    if (threadIdx.x < 33 && hist[threadIdx.x]) atomicAdd(P.stat_evaluated + 72 + threadIdx.x, (unsigned long long)hist[threadIdx.x]);
-  }
-}
-
-
-// ------------------------------------------------------------------ K_B64 render from the queue, 64 ray slots per wave
-// The successor of render_queue_kernel (kept above for A/B runs: PRV_RENDER64=0).  One lane = one ray slot and one whole
-// sample per round: the lane picks its next live sample, gathers ALL levels itself (encode_sample: dense levels with
-// no clamps and one-add neighbours, (1-w, w) pairs from one v_cvt_pk each), and two v_permlane32_swap per k-step turn
-// the wave's 64 feature vectors into the MFMA B operands of two 32-sample column groups (lanes 0..31 = group A, lanes
-// 32..63 = group B).  mlp_forward2 runs both groups off one LDS read of every weight fragment.  What the 32-slot kernel
-// computed twice (in both lanes of a pair: sample selection, position, compositing) is computed once per sample here.
-// Arithmetic per sample is unchanged: features bit-identical, the same MFMAs on the same operands, the same compositing.
-// A group refills when all its 32 slots are idle (whole-group lockstep, as before).
+// ------------------------------------------------------------------ K_B render from the queue, 64 ray slots per wave
+// One lane = one ray slot and one whole sample per round: the lane picks its next live sample, gathers ALL levels
+// itself (encode_sample: dense levels with no clamps and one-add neighbours, (1-w, w) pairs from one v_cvt_pk each),
+// and two v_permlane32_swap per k-step turn the wave's 64 feature vectors into the MFMA B operands of two 32-sample
+// column groups (lanes 0..31 = group A, lanes 32..63 = group B).  mlp_forward2 runs both groups off one LDS read of
+// every weight fragment.  A group refills when all its 32 slots are idle (whole-group lockstep).
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 #ifndef PRV_R64_WAVES
@@ -1117,28 +947,25 @@ __global__ __launch_bounds__(256) void synth_table_kernel(uint16_t* __restrict__
 }
 
 // canonical (ABI) table -> physical layout of one level.
-//  dense level            : one thread per canonical entry, scattered to power-of-two strides
-//  hashed level           : straight copy
-//  hashed, stored densely : one thread per VERTEX, gathers T[hash(x,y,z)] into a power-of-two-
-//                           strided dense grid (a spatially coherent copy; same values by construction)
+//  dense level  : one thread per vertex, scattered to power-of-two strides (+ the duplicated border)
+//  hashed level : straight copy
 template <int F>
 __global__ __launch_bounds__(256) void repack_level_kernel(const uint16_t* __restrict__ canon,
                                                            uint16_t* __restrict__ phys, RepackLevel L) {
   typedef typename EntryWord<F>::type word_t;
   const word_t* src = reinterpret_cast<const word_t*>(canon) + L.canon_off;
   word_t* dst = reinterpret_cast<word_t*>(phys) + L.phys_off;
-  if (L.hashed && !L.dehash) { // hashed level kept hashed: straight copy
+  if (L.hashed) { // straight copy
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < L.n; i += gridDim.x * 256) dst[i] = src[i];
     return;
   }
-  // physically dense level (dense in the canonical table, or a hashed level stored densely): one thread per VERTEX.
+  // dense level: one thread per VERTEX.
   // The last vertex of every row, the last row of every plane and the last plane are duplicated one step further out,
-  // so vertex + 1 on any axis reads what the min(c + 1, res - 1) clamp would have read (paired x loads of the 32-slot
-  // kernel, clamp-free y / z neighbours of the 64-slot kernel).
+  // so vertex + 1 on any axis reads what the min(c + 1, res - 1) clamp would have read (paired x loads, clamp-free y / z).
   const uint32_t nv = L.res * L.res * L.res;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nv; i += gridDim.x * 256) {
     const uint32_t x = i % L.res, y = (i / L.res) % L.res, z = i / (L.res * L.res);
-    const word_t v = src[L.hashed ? ((x ^ (y * 2654435761u) ^ (z * 805459861u)) & (L.n - 1u)) : i];
+    const word_t v = src[i];
     const uint32_t ex = x == L.res - 1 ? 1u : 0u, ey = y == L.res - 1 ? 1u : 0u, ez = z == L.res - 1 ? 1u : 0u;
     for (uint32_t dz = 0; dz <= ez; dz++)
       for (uint32_t dy = 0; dy <= ey; dy++)
@@ -1165,61 +992,6 @@ __global__ __launch_bounds__(256) void debug_raygen_kernel(CamDev cam, int W, in
   }
   t_out[i * 2] = t0;
   t_out[i * 2 + 1] = t1;
-}
-
-// one wave = 32 points through exactly the production gather + MFMA code
-template <int F, int NPAIR>
-__global__ __launch_bounds__(256) void debug_field_kernel(FieldDev fd, const float* __restrict__ pos,
-                                                          const float* __restrict__ dir, int n,
-                                                          uint16_t* __restrict__ feat,
-                                                          float* __restrict__ out36,
-                                                          int32_t* __restrict__ occ_out) {
-  __shared__ half8 wl[kNumFrags * 64];
-  __shared__ LevelDev lvl[kMaxLevels];
-  for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = fd.frags[i];
-  stage_levels(fd, lvl);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int idx = wave * 32 + r;
-  const bool ok = idx < n;
-  float p[3] = {0.5f, 0.5f, 0.5f}, dd[3] = {0.f, 0.f, 1.f};
-  if (ok) {
-    for (int a = 0; a < 3; a++) {
-      p[a] = pos[idx * 3 + a];
-      dd[a] = dir ? dir[idx * 3 + a] : dd[a];
-    }
-  }
-  half8 f0, f1;
-  encode_half<F, NPAIR>(fd.table, lvl, h, p[0], p[1], p[2], f0, f1);
-  const half8 shf = sh_fragment(h, dd[0], dd[1], dd[2]);
-  const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf);
-  if (!ok) return;
-  if (feat) { // fragment s, element e of half h is canonical feature F*(2*(s*LH/2 + e/F) + h) + e%F
-    constexpr int LHd = 16 / F;
-    uint16_t* dst = feat + (size_t)idx * 32;
-    typedef uint16_t ushort8 __attribute__((ext_vector_type(8)));
-    const ushort8 u0 = __builtin_bit_cast(ushort8, f0), u1 = __builtin_bit_cast(ushort8, f1);
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      dst[F * (2 * (0 * LHd / 2 + e / F) + h) + e % F] = u0[e];
-      dst[F * (2 * (1 * LHd / 2 + e / F) + h) + e % F] = u1[e];
-    }
-  }
-  if (out36) {
-    float* q = out36 + (size_t)idx * 36;
-    if (h == 0) {
-      q[0] = fast_exp(mo.dens[0] + fd.density_bias);
-      for (int k = 0; k < 3; k++) q[1 + k] = fast_sigmoid(mo.rgb[k]);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) { // reg i -> row (i&3) + 8(i>>2) + 4h, rows 0..15
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-      q[4 + row] = mo.dens[i];
-      q[20 + row] = mo.rgb[i];
-    }
-  }
-  if (occ_out && h == 0) occ_out[idx] = occupied(fd, p[0], p[1], p[2]) ? 1 : 0;
 }
 
 // the same hook through the 64-slot kernel's machinery: one wave = 64 points, one lane = one point (encode_sample,
@@ -1383,43 +1155,24 @@ hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_
   return hipGetLastError();
 }
 
-// instances: paired loads on the first NPAIR gather steps (host picks the largest instance <= the
-// field's count of leading dense-dense steps)
-// compiled instances of the 64-slot kernel: NDENSE = the largest listed count <= the field's leading dense levels
+// compiled instances of the render kernel: NDENSE = the largest listed count <= the field's leading dense levels
 // (levels past NDENSE take the generic path, which serves dense levels too)
-static int render64_dense(const FieldDev& fd) {
+int render_instance_dense_levels(const FieldDev& fd) {
   const int n = fd.n_dense_levels;
   if (fd.n_features == 4) return n >= 5 ? 5 : n >= 3 ? 3 : 0;
   return n >= 10 ? 10 : n >= 6 ? 6 : 0;
 }
 
-int render_instance_pair_steps(const FieldDev& fd) {
-  if (fd.render64) return render64_dense(fd);
-  if (fd.n_features == 4) return fd.n_pair_steps >= 2 ? 2 : 0;
-  return fd.n_pair_steps >= 5 ? 5 : 0;
-}
-
 hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s) {
-  if (P.field.render64) {
-    const int nd = render64_dense(P.field);
-    if (P.field.n_features == 4) {
-      if (nd == 5) hipLaunchKernelGGL((render_queue64_kernel<4, 5>), dim3(n_blocks), dim3(256), 0, s, P);
-      else if (nd == 3) hipLaunchKernelGGL((render_queue64_kernel<4, 3>), dim3(n_blocks), dim3(256), 0, s, P);
-      else hipLaunchKernelGGL((render_queue64_kernel<4, 0>), dim3(n_blocks), dim3(256), 0, s, P);
-    } else {
-      if (nd == 10) hipLaunchKernelGGL((render_queue64_kernel<2, 10>), dim3(n_blocks), dim3(256), 0, s, P);
-      else if (nd == 6) hipLaunchKernelGGL((render_queue64_kernel<2, 6>), dim3(n_blocks), dim3(256), 0, s, P);
-      else hipLaunchKernelGGL((render_queue64_kernel<2, 0>), dim3(n_blocks), dim3(256), 0, s, P);
-    }
-    return hipGetLastError();
-  }
-  const int np = render_instance_pair_steps(P.field);
+  const int nd = render_instance_dense_levels(P.field);
   if (P.field.n_features == 4) {
-    if (np == 2) hipLaunchKernelGGL((render_queue_kernel<4, 2>), dim3(n_blocks), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((render_queue_kernel<4, 0>), dim3(n_blocks), dim3(256), 0, s, P);
+    if (nd == 5) hipLaunchKernelGGL((render_queue64_kernel<4, 5>), dim3(n_blocks), dim3(256), 0, s, P);
+    else if (nd == 3) hipLaunchKernelGGL((render_queue64_kernel<4, 3>), dim3(n_blocks), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((render_queue64_kernel<4, 0>), dim3(n_blocks), dim3(256), 0, s, P);
   } else {
-    if (np == 5) hipLaunchKernelGGL((render_queue_kernel<2, 5>), dim3(n_blocks), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((render_queue_kernel<2, 0>), dim3(n_blocks), dim3(256), 0, s, P);
+    if (nd == 10) hipLaunchKernelGGL((render_queue64_kernel<2, 10>), dim3(n_blocks), dim3(256), 0, s, P);
+    else if (nd == 6) hipLaunchKernelGGL((render_queue64_kernel<2, 6>), dim3(n_blocks), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((render_queue64_kernel<2, 0>), dim3(n_blocks), dim3(256), 0, s, P);
   }
   return hipGetLastError();
 }
@@ -1490,7 +1243,7 @@ hipError_t launch_synth_table(uint16_t* table, size_t n, uint64_t seed, float am
 }
 
 hipError_t launch_repack_level(const uint16_t* canon, uint16_t* phys, const RepackLevel& L, int F, hipStream_t s) {
-  unsigned blocks = (((L.hashed && !L.dehash) ? L.n : L.res * L.res * L.res) + 255) / 256;
+  unsigned blocks = ((L.hashed ? L.n : L.res * L.res * L.res) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks == 0) return hipSuccess;
   if (F == 4)
@@ -1509,28 +1262,16 @@ hipError_t launch_debug_raygen(const CamDev& cam, int W, int H, int spp_k, float
 
 hipError_t launch_debug_field(const FieldDev& fd, const float* pos, const float* dir, int n, uint16_t* feat,
                               float* out36, int32_t* occ, hipStream_t s) {
-  if (fd.render64) {
-    const unsigned blocks64 = (unsigned)((n + 255) / 256);
-    const int nd = render64_dense(fd);
-    if (fd.n_features == 4) {
-      if (nd == 5) hipLaunchKernelGGL((debug_field64_kernel<4, 5>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
-      else if (nd == 3) hipLaunchKernelGGL((debug_field64_kernel<4, 3>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
-      else hipLaunchKernelGGL((debug_field64_kernel<4, 0>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
-    } else {
-      if (nd == 10) hipLaunchKernelGGL((debug_field64_kernel<2, 10>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
-      else if (nd == 6) hipLaunchKernelGGL((debug_field64_kernel<2, 6>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
-      else hipLaunchKernelGGL((debug_field64_kernel<2, 0>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
-    }
-    return hipGetLastError();
-  }
-  unsigned blocks = (unsigned)((n + 127) / 128);
-  const int np = fd.n_pair_steps;
+  const unsigned blocks64 = (unsigned)((n + 255) / 256);
+  const int nd = render_instance_dense_levels(fd);
   if (fd.n_features == 4) {
-    if (np >= 2) hipLaunchKernelGGL((debug_field_kernel<4, 2>), dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
-    else hipLaunchKernelGGL((debug_field_kernel<4, 0>), dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+    if (nd == 5) hipLaunchKernelGGL((debug_field64_kernel<4, 5>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+    else if (nd == 3) hipLaunchKernelGGL((debug_field64_kernel<4, 3>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+    else hipLaunchKernelGGL((debug_field64_kernel<4, 0>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
   } else {
-    if (np >= 5) hipLaunchKernelGGL((debug_field_kernel<2, 5>), dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
-    else hipLaunchKernelGGL((debug_field_kernel<2, 0>), dim3(blocks), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+    if (nd == 10) hipLaunchKernelGGL((debug_field64_kernel<2, 10>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+    else if (nd == 6) hipLaunchKernelGGL((debug_field64_kernel<2, 6>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
+    else hipLaunchKernelGGL((debug_field64_kernel<2, 0>), dim3(blocks64), dim3(256), 0, s, fd, pos, dir, n, feat, out36, occ);
   }
   return hipGetLastError();
 }

@@ -45,7 +45,6 @@ struct RenderParams {
   float inv_spp;
   int spp_k;
   int last_pass;
-  int refill_min;
   int merge_max; // render_queue64: a group down to <= this many rays hands them to the other group's idle slots (0 = never)
   int pool_on;   // render_queue64: ... or, failing that, to the block's LDS tail pool (any wave's idle slots adopt them)
   int dbg; // dev-only bits (PRV_DBG env): 1 no table loads, 2 no MLP, 4 no compositing math, 8 slot-occupancy histogram
@@ -69,7 +68,7 @@ struct PsnrParams {
 };
 
 struct RepackLevel { // canonical -> physical copy of one level (entries, not bytes)
-  uint32_t canon_off, phys_off, n, res, sx, hashed, dehash;
+  uint32_t canon_off, phys_off, n, res, sx, hashed;
 };
 hipError_t launch_repack_level(const uint16_t* canon, uint16_t* phys, const RepackLevel& L, int F, hipStream_t s);
 
@@ -77,7 +76,7 @@ hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_
 hipError_t launch_spp_reduce(const float* stage, size_t n_pixels, int spp, const float bg[4], float* out, uint32_t* out_u8,
                              hipStream_t s);
 hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s);
-int render_instance_pair_steps(const FieldDev& fd); // NPAIR of the render_queue_kernel<F, NPAIR> instance launch_render picks
+int render_instance_dense_levels(const FieldDev& fd); // NDENSE of the render_queue64_kernel<F, NDENSE> instance launch_render picks
 struct PreceptPose {
   double w2c[16], c2w[16];
 };

@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libprv_oracle.so")
 MLP_HALFS = 10240
 MAX_LEVELS = 16
+STEP_FIXED_S, STEP_NGP = 0, 1  # prv_oracle.h: ORC_STEP_*
+NGP_MAX_STEPS = 1024
 
 
 class FieldDesc(C.Structure):
@@ -111,6 +113,11 @@ def lib():
                                  C.POINTER(C.c_uint64), C.c_int]
         L.orc_render_rows.argtypes = [C.POINTER(Field), C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_float, vp, C.POINTER(C.c_uint64), C.c_int]
+        L.orc_render_rows_mode.argtypes = [C.POINTER(Field), C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_float, vp, C.POINTER(C.c_uint64), C.c_int]
+        L.orc_march_count_rows.restype = C.c_uint64
+        L.orc_march_count_rows.argtypes = [C.POINTER(Field), C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int]
         L.orc_linear_to_srgb.restype, L.orc_linear_to_srgb.argtypes = C.c_float, [C.c_float]
         L.orc_quantize_rgba8.argtypes = [vp, C.c_size_t, vp, vp]
         L.orc_score_ensemble_rgb.restype = C.c_double
@@ -191,13 +198,18 @@ class OracleField:
             occ[i] = lib().orc_occupied(self.ptr, _p(pos[i]))
         return out, occ
 
-    def render(self, cam, w, h, n_samples=128, spp=1, min_T=1e-4, threads=8, rows=None):
+    def render(self, cam, w, h, n_samples=128, spp=1, min_T=1e-4, threads=8, rows=None, step_mode=STEP_FIXED_S):
         img = np.zeros((h, w, 4), np.float32)
         ne = C.c_uint64()
         y0, y1 = rows if rows else (0, h)
-        lib().orc_render_rows(self.ptr, C.byref(cam), w, h, y0, y1, n_samples, spp, C.c_float(min_T), _p(img),
-                              C.byref(ne), threads)
+        lib().orc_render_rows_mode(self.ptr, C.byref(cam), w, h, y0, y1, step_mode, n_samples, spp, C.c_float(min_T),
+                                   _p(img), C.byref(ne), threads)
         return img, ne.value
+
+    def march_count(self, cam, w, h, n_samples=128, spp=1, threads=8, rows=None, step_mode=STEP_FIXED_S):
+        """samples in occupied cells (no field evaluation, no early termination)"""
+        y0, y1 = rows if rows else (0, h)
+        return int(lib().orc_march_count_rows(self.ptr, C.byref(cam), w, h, y0, y1, step_mode, n_samples, spp, threads))
 
     def close(self):
         if self.ptr:

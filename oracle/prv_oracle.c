@@ -664,20 +664,37 @@ int orc_ray_aabb(const float o[3], const float d[3], float* t0, float* t1) {
   return tmax > tmin;
 }
 
-/* one ray: S uniform samples between AABB entry/exit, occupancy skip, front-to-back
- * compositing, early termination at T < min_T (published instant-ngp render loop with
- * the BASELINE configs' fixed sample count) */
-static void march_ray(const orc_field* f, const float o[3], const float d[3], int S, float min_T,
+/* one ray, front-to-back compositing with early termination at T < min_T, in one of two sampling rules:
+ *  ORC_STEP_FIXED_S : S uniform samples between AABB entry and exit (the BASELINE configs' fixed sample count);
+ *  ORC_STEP_NGP     : what pyngp.Testbed.render does behind run.py:245-247, 304 for aabb_scale = 1 (SURVEY App. E;
+ *                     the published instant-ngp render loop -- the engine itself is not in the reference tree):
+ *                     a fixed step dt = sqrt(3)/1024 from the AABB entry, sample i at t0 + (i + 1/2) dt while that is
+ *                     inside the box (at most ORC_NGP_MAX_STEPS = 1024, the cube's diagonal), every step tested
+ *                     against the occupancy grid, alpha = 1 - exp(-sigma dt) with that same dt.
+ * n_live counts the samples that pass the occupancy test BEFORE early termination (the march count: no field
+ * evaluation needed, see orc_march_count_rows); n_eval the samples actually evaluated and composited. */
+static inline int ray_steps(int step_mode, int S, float t0, float t1, float* dt) {
+  if (step_mode == ORC_STEP_NGP) {
+    *dt = sqrtf(3.0f) / 1024.0f;
+    return ORC_NGP_MAX_STEPS;
+  }
+  *dt = (t1 - t0) / (float)S;
+  return S;
+}
+
+static void march_ray(const orc_field* f, const float o[3], const float d[3], int step_mode, int S, float min_T,
                       float out[4], uint64_t* n_eval) {
   out[0] = out[1] = out[2] = out[3] = 0.0f;
   float t0, t1;
   if (!orc_ray_aabb(o, d, &t0, &t1)) return;
-  float dt = (t1 - t0) / (float)S;
+  float dt;
+  const int n = ray_steps(step_mode, S, t0, t1, &dt);
   float sh[16];
   orc_sh4(d, sh);
   float T = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
-  for (int i = 0; i < S; i++) {
+  for (int i = 0; i < n; i++) {
     float t = fmaf((float)i + 0.5f, dt, t0);
+    if (step_mode == ORC_STEP_NGP && !(t < t1)) break; /* left the box */
     float p[3] = {fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2])};
     if (!orc_occupied(f, p)) continue;
     float sigma, c[3];
@@ -697,12 +714,28 @@ static void march_ray(const orc_field* f, const float o[3], const float d[3], in
   out[3] = 1.0f - T;
 }
 
+/* the march alone: how many samples of the ray lie in occupied cells (no field evaluation, no early termination) */
+static uint64_t march_count_ray(const orc_field* f, const float o[3], const float d[3], int step_mode, int S) {
+  float t0, t1;
+  if (!orc_ray_aabb(o, d, &t0, &t1)) return 0;
+  float dt;
+  const int n = ray_steps(step_mode, S, t0, t1, &dt);
+  uint64_t live = 0;
+  for (int i = 0; i < n; i++) {
+    float t = fmaf((float)i + 0.5f, dt, t0);
+    if (step_mode == ORC_STEP_NGP && !(t < t1)) break;
+    float p[3] = {fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2])};
+    live += orc_occupied(f, p) ? 1u : 0u;
+  }
+  return live;
+}
+
 typedef struct {
   const orc_field* f;
   const orc_camera* cam;
-  int w, h, y0, y1, S, spp, tid, nth;
+  int w, h, y0, y1, step_mode, S, spp, tid, nth;
   float min_T;
-  float* rgba;
+  float* rgba; /* NULL: march count only */
   uint64_t n_eval;
 } render_job;
 
@@ -717,9 +750,14 @@ static void* render_worker(void* arg) {
         float ox, oy, o[3], d[3], px[4];
         orc_spp_offset(k, &ox, &oy);
         orc_raygen(j->cam, x, y, ox, oy, o, d);
-        march_ray(j->f, o, d, j->S, j->min_T, px, &n_eval);
+        if (!j->rgba) {
+          n_eval += march_count_ray(j->f, o, d, j->step_mode, j->S);
+          continue;
+        }
+        march_ray(j->f, o, d, j->step_mode, j->S, j->min_T, px, &n_eval);
         for (int c = 0; c < 4; c++) acc[c] += px[c];
       }
+      if (!j->rgba) continue;
       float* dst = j->rgba + ((size_t)y * j->w + x) * 4;
       for (int c = 0; c < 4; c++) dst[c] = acc[c] * inv_spp;
     }
@@ -727,14 +765,14 @@ static void* render_worker(void* arg) {
   return NULL;
 }
 
-void orc_render_rows(const orc_field* f, const orc_camera* cam, int w, int h, int y0, int y1, int S,
-                     int spp, float min_T, float* rgba, uint64_t* n_evaluated, int n_threads) {
+static uint64_t run_rows(const orc_field* f, const orc_camera* cam, int w, int h, int y0, int y1, int step_mode, int S,
+                         int spp, float min_T, float* rgba, int n_threads) {
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 256) n_threads = 256;
   render_job jobs[256];
   pthread_t th[256];
   for (int t = 0; t < n_threads; t++) {
-    render_job jb = {f, cam, w, h, y0, y1, S, spp, t, n_threads, min_T, rgba, 0};
+    render_job jb = {f, cam, w, h, y0, y1, step_mode, S, spp, t, n_threads, min_T, rgba, 0};
     jobs[t] = jb;
     if (t > 0) pthread_create(&th[t], NULL, render_worker, &jobs[t]);
   }
@@ -744,7 +782,23 @@ void orc_render_rows(const orc_field* f, const orc_camera* cam, int w, int h, in
     pthread_join(th[t], NULL);
     tot += jobs[t].n_eval;
   }
+  return tot;
+}
+
+void orc_render_rows_mode(const orc_field* f, const orc_camera* cam, int w, int h, int y0, int y1, int step_mode, int S,
+                          int spp, float min_T, float* rgba, uint64_t* n_evaluated, int n_threads) {
+  const uint64_t tot = run_rows(f, cam, w, h, y0, y1, step_mode, S, spp, min_T, rgba, n_threads);
   if (n_evaluated) *n_evaluated = tot;
+}
+
+uint64_t orc_march_count_rows(const orc_field* f, const orc_camera* cam, int w, int h, int y0, int y1, int step_mode,
+                              int S, int spp, int n_threads) {
+  return run_rows(f, cam, w, h, y0, y1, step_mode, S, spp, 0.0f, NULL, n_threads);
+}
+
+void orc_render_rows(const orc_field* f, const orc_camera* cam, int w, int h, int y0, int y1, int S,
+                     int spp, float min_T, float* rgba, uint64_t* n_evaluated, int n_threads) {
+  orc_render_rows_mode(f, cam, w, h, y0, y1, ORC_STEP_FIXED_S, S, spp, min_T, rgba, n_evaluated, n_threads);
 }
 
 void orc_render(const orc_field* f, const orc_camera* cam, int w, int h, int S, int spp, float min_T,

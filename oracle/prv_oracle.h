@@ -128,6 +128,21 @@ void orc_render_rows(const orc_field* f, const orc_camera* cam, int w, int h, in
                      int n_samples, int spp, float min_T, float* rgba, uint64_t* n_evaluated,
                      int n_threads);
 
+/* the two sampling rules of the marcher (prv_oracle.c: march_ray):
+ *   ORC_STEP_FIXED_S  n_samples uniform samples between AABB entry and exit (BASELINE configs[1], [3]);
+ *   ORC_STEP_NGP      instant-ngp's rule for aabb_scale = 1, what run.py:245-247, 304 renders with: fixed step
+ *                     dt = sqrt(3)/1024 from the AABB entry, samples at t0 + (i + 1/2) dt inside the box, every step
+ *                     tested against the occupancy grid, no per-ray sample cap below the 1024 steps of the diagonal
+ *                     (the engine is not in the reference tree: parity unpinned). */
+#define ORC_STEP_FIXED_S 0
+#define ORC_STEP_NGP 1
+#define ORC_NGP_MAX_STEPS 1024
+void orc_render_rows_mode(const orc_field* f, const orc_camera* cam, int w, int h, int y0, int y1, int step_mode,
+                          int n_samples, int spp, float min_T, float* rgba, uint64_t* n_evaluated, int n_threads);
+/* the march alone: samples of rows [y0,y1) that lie in occupied cells, before any early termination */
+uint64_t orc_march_count_rows(const orc_field* f, const orc_camera* cam, int w, int h, int y0, int y1, int step_mode,
+                              int n_samples, int spp, int n_threads);
+
 /* ---- image post + scores ---- */
 float orc_linear_to_srgb(float x);
 /* shade over background bg[4], un-premultiply, sRGB, quantise (assumed upstream common.py) */

@@ -11,12 +11,14 @@ instant-ngp.  So the C oracle (oracle/prv_oracle.c) is pinned three ways instead
      strongest pin available; it is still NOT parity with the reference binary.
 
 Run from the repo root:  python tests/golden/gen_golden.py
-Writes golden_cameras.json, golden_scores.json, golden_field.json, golden_render.json.
+Writes golden_cameras.json, golden_scores.json, golden_field.json, golden_render.json, golden_lens.json,
+golden_render_ngp.json (name files on the command line to regenerate only those).
 Nothing here reads /root/reference.
 """
 import json
 import math
 import os
+import sys
 
 import numpy as np
 
@@ -417,16 +419,23 @@ def aabb_np(o, d):
     return f32(tmin), f32(tmax)
 
 
-def march_np(field, o, d, S, min_T):
+def march_np(field, o, d, S, min_T, ngp_step=False):
+    """ngp_step: instant-ngp's rule for aabb_scale 1 -- fixed dt = sqrt(3)/1024 from the AABB entry,
+    samples at t0 + (i + 1/2) dt while inside the box, at most 1024; returns (pixel, evaluated, live)"""
     t0, t1 = aabb_np(o, d)
     if not t1 > t0:
-        return np.zeros(4, np.float32), 0
-    dt = f32((t1 - t0) / f32(S))
-    T, rgb, n = f32(1), np.zeros(3, np.float32), 0
-    for i in range(S):
+        return np.zeros(4, np.float32), 0, 0
+    dt = f32(np.sqrt(f32(3)) / f32(1024)) if ngp_step else f32((t1 - t0) / f32(S))
+    T, rgb, n, live, dead = f32(1), np.zeros(3, np.float32), 0, 0, False
+    for i in range(1024 if ngp_step else S):
         t = f32(np.float64(f32(i) + f32(0.5)) * np.float64(dt) + np.float64(t0))
+        if ngp_step and not t < t1:
+            break
         p = [f32(np.float64(t) * np.float64(d[a]) + np.float64(o[a])) for a in range(3)]
         if not field.occupied(p):
+            continue
+        live += 1
+        if dead:
             continue
         _, sigma, c, _, _ = field.eval(p, d)
         alpha = f32(f32(1) - np.exp(-(f32(sigma * dt)), dtype=np.float32))
@@ -435,8 +444,8 @@ def march_np(field, o, d, S, min_T):
         T = f32(T * f32(f32(1) - alpha))
         n += 1
         if T < f32(min_T):
-            break
-    return np.array([rgb[0], rgb[1], rgb[2], f32(1) - T], np.float32), n
+            dead = True  # the march count (live) keeps running, the compositing is over
+    return np.array([rgb[0], rgb[1], rgb[2], f32(1) - T], np.float32), n, live
 
 
 TINY = dict(n_levels=8, n_features=4, log2_hashmap=9, base_res=4, finest_res=32, occ_res=16, density_bias=3.0,
@@ -480,26 +489,53 @@ def gen_render():
     w = h = 12
     fx = fy = f32(0.5 * w / math.tan(0.5 * 0.8))
     img = np.zeros((h, w, 4), np.float32)
-    n_eval = 0
+    n_eval = n_live = 0
     rays = []
     for y in range(h):
         for x in range(w):
             o, dd = raygen_np(c2w, fx, fy, f32(w / 2), f32(h / 2), x, y)
-            px, n = march_np(fld, o, dd, 32, 1e-4)
+            px, n, nl = march_np(fld, o, dd, 32, 1e-4)
             img[y, x] = px
             n_eval += n
+            n_live += nl
             if (x, y) in ((0, 0), (5, 6), (11, 3)):
                 t0, t1 = aabb_np(o, dd)
                 rays.append({"px": x, "py": y, "o": o.astype(np.float64).tolist(), "d": dd.astype(np.float64).tolist(),
                              "t0": float(t0), "t1": float(t1)})
     return {"desc": d, "seed": seed, "c2w": c2w, "fx": float(fx), "w": w, "h": h, "samples": 32, "min_T": 1e-4,
-            "image": img.astype(np.float64).tolist(), "n_evaluated": n_eval, "rays": rays}
+            "image": img.astype(np.float64).tolist(), "n_evaluated": n_eval, "n_live": n_live, "rays": rays}
+
+
+def gen_render_ngp():
+    """the same tiny scene through instant-ngp's stepping rule (dt = sqrt(3)/1024, no sample cap), from an oblique
+    camera so that rays cross the box at every length up to the diagonal; min_T 0.01 = the engine's default
+    (run.py:235 lowers it to 1e-4 for the evaluation views only)"""
+    d, seed = dict(TINY, density_bias=3.0), 0x5EED0001
+    fld = FieldNP(d, seed)
+    c2w = [0.8, -0.36, -0.48, 1.3, 0.6, 0.48, 0.64, -0.55, 0.0, -0.8, 0.6, -0.2]  # rotation (columns orthonormal), looks at the cube
+    w = h = 10
+    fx = fy = f32(0.5 * w / math.tan(0.5 * 0.7))
+    img = np.zeros((h, w, 4), np.float32)
+    n_eval = n_live = 0
+    per_ray = []
+    for y in range(h):
+        for x in range(w):
+            o, dd = raygen_np(c2w, fx, fy, f32(w / 2), f32(h / 2), x, y)
+            px, n, nl = march_np(fld, o, dd, 0, 1e-2, ngp_step=True)
+            img[y, x] = px
+            n_eval += n
+            n_live += nl
+            per_ray.append([n, nl])
+    return {"desc": d, "seed": seed, "c2w": c2w, "fx": float(fx), "w": w, "h": h, "min_T": 1e-2,
+            "image": img.astype(np.float64).tolist(), "n_evaluated": n_eval, "n_live": n_live, "per_ray": per_ray}
 
 
 def main():
     for name, fn in (("golden_cameras.json", gen_cameras), ("golden_scores.json", gen_scores),
                      ("golden_field.json", gen_field), ("golden_render.json", gen_render),
-                     ("golden_lens.json", gen_lens)):
+                     ("golden_lens.json", gen_lens), ("golden_render_ngp.json", gen_render_ngp)):
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         data = fn()
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(data, f)

@@ -39,8 +39,8 @@ def field512(ctx):
 
 def test_field512_runs_the_paired_f2_instance_and_its_features_are_bit_exact(ctx, oracle, field512):
     lay = ctx.model_layout(4)
-    assert lay["kernel_features"] == 2 and lay["n_pair_steps"] >= 5 and lay["n_dense_levels"] >= 10
-    assert (lay["kernel_slots"], lay["kernel_pair_steps"]) == (64, 10)  # render_queue64_kernel<2, 10>
+    assert lay["kernel_features"] == 2 and lay["n_dense_levels"] >= 10
+    assert (lay["kernel_slots"], lay["kernel_dense_levels"]) == (64, 10)  # render_queue64_kernel<2, 10>
     assert lay["table_bytes_canonical"] > 60 * 2 ** 20  # the 64 MiB table of BASELINE.md section 6
     assert lay["n_hashed_levels"] >= 4
     f = oracle.OracleField(oracle.desc(**api.FIELD_512), seed=util.SEED_A)

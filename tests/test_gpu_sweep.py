@@ -267,33 +267,22 @@ def test_view_batches_do_not_change_anything(ctx, oracle, monkeypatch):
         small.close()
 
 
-@pytest.mark.parametrize("env", [{"PRV_REFILL_MIN": "8"}, {"PRV_REFILL_MIN": "1"}, {"PRV_QUEUE_SEGMENTS": "1"},
-                                 {"PRV_QUEUE_SEGMENTS": "3"}, {"PRV_DEHASH_MB": "64"}, {"PRV_NO_PAIR": "1"},
-                                 {"PRV_BLOCKS_PER_CU": "1"}, {"PRV_BLOCKS_PER_CU": "6", "PRV_REFILL_MIN": "16"},
+@pytest.mark.parametrize("env", [{"PRV_QUEUE_SEGMENTS": "1"}, {"PRV_QUEUE_SEGMENTS": "3"}, {"PRV_NO_PAIR": "1"},
+                                 {"PRV_BLOCKS_PER_CU": "1"}, {"PRV_BLOCKS_PER_CU": "6"},
                                  {"PRV_MERGE_MAX": "0"}, {"PRV_MERGE_MAX": "6", "PRV_POOL": "0"}, {"PRV_MERGE_MAX": "31", "PRV_BLOCKS_PER_CU": "2"},
-                                 {"PRV_MERGE_MAX": "12", "PRV_POOL": "1"}, {"PRV_MERGE_MAX": "31", "PRV_POOL": "1", "PRV_BLOCKS_PER_CU": "1"},
-                                 {"PRV_RENDER64": "0", "PRV_REFILL_MIN": "8"}, {"PRV_RENDER64": "0", "PRV_NO_PAIR": "1"}])
+                                 {"PRV_MERGE_MAX": "12", "PRV_POOL": "1"}, {"PRV_MERGE_MAX": "31", "PRV_POOL": "1", "PRV_BLOCKS_PER_CU": "1"}])
 @pytest.mark.parametrize("which", ["F4", "F2"])
-def test_placement_and_layout_switches_change_speed_only(ctx, oracle, monkeypatch, env, which):
-    """the tuning switches of the render path (slot refill granularity, queue segments per XCD, hashed levels stored
-    densely, paired loads off, resident blocks per CU) decide where and in which order rays are rendered and how the
-    table is laid out in memory -- never the arithmetic: images and counts are bit-identical to the defaults.  That
-    includes the 64-slot kernel's tail merge (PRV_MERGE_MAX: rays change lanes mid-flight).  The 32-slot kernel
-    (PRV_RENDER64=0) is compared with itself: it feeds the first layer's MFMAs the same features in another k order,
-    so its f32 accumulations differ from the 64-slot kernel's in the last bits (checked against each other below)"""
+@pytest.mark.parametrize("step_mode", ["fixed", "ngp"])
+def test_placement_and_layout_switches_change_speed_only(ctx, oracle, monkeypatch, env, which, step_mode):
+    """the tuning switches of the render path (queue segments per XCD, the generic gather for every level, resident
+    blocks per CU, tail merge and tail pool: rays change lanes mid-flight) decide where and in which order rays are
+    rendered -- never the arithmetic: images and counts are bit-identical to the defaults, in both stepping modes"""
     kw = util.SMALL if which == "F4" else util.SMALL_F2
-    if env.get("PRV_RENDER64") == "0":
-        monkeypatch.setenv("PRV_RENDER64", "0")
-        ctx32 = api.Context(0)
-        monkeypatch.delenv("PRV_RENDER64")
-    else:
-        ctx32 = None
-    ctx_default, ctx = ctx, (ctx32 or ctx)
     d_p = api.field_desc(**kw)
     pts = util.fibonacci_hemisphere(5)
     tms, scale, offset = util.hemisphere_transforms(oracle, pts)
     w, h = 56, 44
-    opts = api.render_opts(w, h, 96, 1, 1e-4)
+    opts = api.render_opts(w, h, 96, 1, 1e-4, step_mode=api.L.STEP_NGP if step_mode == "ngp" else api.L.STEP_FIXED_S)
     ctx.synthetic_model(2, d_p, util.SEED_A)
     cs = ctx.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
     want, st0 = ctx.render(2, cs, None, opts)
@@ -312,19 +301,8 @@ def test_placement_and_layout_switches_change_speed_only(ctx, oracle, monkeypatc
         assert st1.samples_evaluated == st0.samples_evaluated > 0
         assert np.array_equal(other.debug_encode(2, np.random.default_rng(1).random((300, 3)).astype(np.float32)), feat0)
         cs.close()
-        if ctx32 is not None:  # the two kernels against each other: same features bit for bit, pixels within the parity bar
-            ctx_default.synthetic_model(2, d_p, util.SEED_A)
-            cs = ctx_default.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
-            ref, st64 = ctx_default.render(2, cs, None, opts)
-            assert ctx_default.model_layout(2)["kernel_slots"] == 64 and ctx32.model_layout(2)["kernel_slots"] == 32
-            util.assert_pixels_close(want.cpu().numpy(), ref.cpu().numpy())
-            assert abs(int(st64.samples_evaluated) - int(st0.samples_evaluated)) <= max(2, st0.samples_evaluated // 100000)
-            assert np.array_equal(ctx_default.debug_encode(2, np.random.default_rng(1).random((300, 3)).astype(np.float32)), feat0)
-            cs.close()
     finally:
         other.close()
-        if ctx32 is not None:
-            ctx32.close()
 
 
 @pytest.mark.parametrize("env", [{"PRV_TRAIN_GRAPH": "0"}, {"PRV_TRAIN_FAST_FWD": "0"},

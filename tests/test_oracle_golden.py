@@ -118,6 +118,30 @@ def test_render_against_numpy(oracle):
         assert float(t[i, 0]) == r["t0"] and float(t[i, 1]) == r["t1"]
 
 
+def test_ngp_step_render_against_numpy(oracle):
+    """instant-ngp's stepping rule (dt = sqrt(3)/1024 from the AABB entry, every step tested against the occupancy grid,
+    no sample cap -- what run.py:304 renders with): the C oracle against the independent numpy
+    restatement, per-ray evaluated and live (march) counts exactly, pixels to float rounding"""
+    g = load("golden_render_ngp.json")
+    f = oracle.OracleField(oracle.desc(**g["desc"]), seed=g["seed"])
+    w, h = g["w"], g["h"]
+    cam = oracle.camera(g["c2w"], g["fx"], g["fx"], w / 2, h / 2)
+    img, n_eval = f.render(cam, w, h, 0, 1, g["min_T"], threads=2, step_mode=oracle.STEP_NGP)
+    assert n_eval == g["n_evaluated"] and f.march_count(cam, w, h, 0, step_mode=oracle.STEP_NGP) == g["n_live"]
+    np.testing.assert_allclose(img, np.array(g["image"]), rtol=1e-5, atol=1e-6)
+    per_ray = np.array(g["per_ray"]).reshape(h, w, 2)
+    assert per_ray[..., 1].max() > 128  # rays with more live samples than the fixed-S mode's mask holds
+    for y in (0, 4, 9):  # row by row: the counts of single rows add up to the golden's
+        _, ne = f.render(cam, w, h, 0, 1, g["min_T"], threads=1, rows=(y, y + 1), step_mode=oracle.STEP_NGP)
+        assert ne == per_ray[y, :, 0].sum()
+        assert f.march_count(cam, w, h, 0, rows=(y, y + 1), step_mode=oracle.STEP_NGP) == per_ray[y, :, 1].sum()
+    # the fixed-S march count of the older fixture
+    g0 = load("golden_render.json")
+    f0 = oracle.OracleField(oracle.desc(**g0["desc"]), seed=g0["seed"])
+    cam0 = oracle.camera(g0["c2w"], g0["fx"], g0["fx"], g0["w"] / 2, g0["h"] / 2)
+    assert f0.march_count(cam0, g0["w"], g0["h"], g0["samples"]) == g0["n_live"]
+
+
 def test_lens_model_against_numpy(oracle):
     """inverse OpenCV lens (dataset cameras of run.py:238-247): the C oracle against the independent numpy
     restatement of tests/golden/gen_golden.py -- bit-exact, and the Newton solve really inverts the model"""
