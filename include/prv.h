@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PRV_ABI_VERSION 2 /* 2: prv_field_desc.per_level_scale */
+#define PRV_ABI_VERSION 3 /* 2: prv_field_desc.per_level_scale; 3: prv_render_opts.step_mode, prv_stats.samples_live */
 
 /* error codes (0 = ok, < 0 = error; message via prv_last_error) */
 #define PRV_OK 0
@@ -72,10 +72,23 @@ typedef struct prv_field_desc {
                             geometry an imported instant-ngp snapshot was trained with; finest_res is then only a label */
 } prv_field_desc;
 
+/* How a ray is sampled.
+ * PRV_STEP_FIXED_S: samples_per_ray (<= 128) uniform samples between the AABB entry and exit -- the fixed sample
+ *   count BASELINE configs[1] and [3] prescribe.
+ * PRV_STEP_NGP: the rule pyngp.Testbed.render applies behind run.py:245-247, 304 for aabb_scale = 1 (the reference's
+ *   ray_casting_aabb_scale, DefaultConfiguration.yaml:36): a fixed step dt = sqrt(3)/1024 from the AABB entry, sample i
+ *   at t0 + (i + 1/2) dt while inside the box (at most PRV_NGP_MAX_STEPS, the cube's diagonal), every step tested against
+ *   the occupancy grid, alpha = 1 - exp(-sigma dt) with that dt; samples_per_ray is ignored.  The engine is not in
+ *   the reference tree: the rule is restated from the published algorithm, without its per-ray start
+ *   jitter (a renderer-side dither the reference's scores do not depend on); parity unpinned. */
+#define PRV_STEP_FIXED_S 0
+#define PRV_STEP_NGP 1
+#define PRV_NGP_MAX_STEPS 1024
+
 /* render options == the knobs run.py sets on the Testbed before render():
  * w,h (run.py:304), screenshot_spp (run.py:48,304), render_min_transmittance
- * (run.py:235), background_color (run.py:94,226).  samples_per_ray is the fixed
- * per-ray sample count of the BASELINE configs. */
+ * (run.py:235; the engine's default is 0.01), background_color (run.py:94,226).  samples_per_ray is the fixed
+ * per-ray sample count of the BASELINE configs (step_mode PRV_STEP_FIXED_S). */
 typedef struct prv_render_opts {
   int32_t width;
   int32_t height;
@@ -83,6 +96,7 @@ typedef struct prv_render_opts {
   int32_t spp;
   float min_transmittance;
   float background[4];
+  int32_t step_mode; /* PRV_STEP_FIXED_S (0) | PRV_STEP_NGP */
 } prv_render_opts;
 
 typedef struct prv_score_record { /* 16 bytes: the unit of the multi-GPU all-gather */
@@ -93,9 +107,10 @@ typedef struct prv_score_record { /* 16 bytes: the unit of the multi-GPU all-gat
 
 typedef struct prv_stats {
   uint64_t rays;              /* primary rays generated (pixels x spp) */
-  uint64_t samples_nominal;   /* rays x samples_per_ray */
+  uint64_t samples_nominal;   /* rays x samples_per_ray (PRV_STEP_NGP: rays x PRV_NGP_MAX_STEPS) */
   uint64_t samples_evaluated; /* field evaluations actually composited */
   uint64_t wave_rounds;       /* render_queue wave iterations (32 sample slots each): slot utilisation */
+  uint64_t samples_live;      /* samples in occupied cells, before early termination: the march pass's own count */
 } prv_stats;
 
 /* ---- context ------------------------------------------------------------- */

@@ -20,6 +20,9 @@ PRV_E_INTERNAL = -6
 SCORE_ENSEMBLE_RGB = 2
 SCORE_ENSEMBLE_RGB_DENSITY = 3
 SCORE_PSNR_COVERAGE = 5
+STEP_FIXED_S = 0  # prv.h: samples_per_ray uniform samples between the AABB hits (BASELINE configs[1], [3])
+STEP_NGP = 1      # instant-ngp's rule, what run.py:304 renders with: dt = sqrt(3)/1024, every step tested, no cap
+NGP_MAX_STEPS = 1024
 
 MAX_MODELS = 8
 MLP_HALFS = 10240
@@ -47,6 +50,7 @@ class RenderOpts(C.Structure):
         ("spp", C.c_int32),
         ("min_transmittance", C.c_float),
         ("background", C.c_float * 4),
+        ("step_mode", C.c_int32),
     ]
 
 
@@ -67,7 +71,7 @@ class ScoreRecord(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples_nominal", C.c_uint64), ("samples_evaluated", C.c_uint64),
-                ("wave_rounds", C.c_uint64)]
+                ("wave_rounds", C.c_uint64), ("samples_live", C.c_uint64)]
 
 
 class Intrinsics(C.Structure):

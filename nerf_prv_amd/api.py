@@ -39,9 +39,11 @@ def field_desc(**kw):
     return L.FieldDesc(**d)
 
 
-def render_opts(width, height, samples_per_ray=128, spp=1, min_transmittance=1e-4, background=(0.0, 0.0, 0.0, 0.0)):
+def render_opts(width, height, samples_per_ray=128, spp=1, min_transmittance=1e-4, background=(0.0, 0.0, 0.0, 0.0),
+                step_mode=L.STEP_FIXED_S):
     o = L.RenderOpts()
     o.width, o.height, o.samples_per_ray, o.spp = int(width), int(height), int(samples_per_ray), int(spp)
+    o.step_mode = int(step_mode)
     o.min_transmittance = float(min_transmittance)
     for k in range(4):
         o.background[k] = float(background[k])

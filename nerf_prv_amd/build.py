@@ -21,8 +21,6 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "
              "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall"]
 if os.environ.get("PRV_ABLATE"):
     HIP_FLAGS.append("-DPRV_ABLATE=" + os.environ["PRV_ABLATE"])
-if os.environ.get("PRV_R64_WAVES"):  # dev only: occupancy target of render_queue64_kernel
-    HIP_FLAGS.append("-DPRV_R64_WAVES=" + os.environ["PRV_R64_WAVES"])
 if os.environ.get("PRV_MLP2_ORDER"):  # dev only: MFMA / pack ordering of mlp_forward2
     HIP_FLAGS.append("-DPRV_MLP2_ORDER=" + os.environ["PRV_MLP2_ORDER"])
 if os.environ.get("PRV_TRAIN_ABLATE"):  # dev only: compile-time ablation of the training tile kernel

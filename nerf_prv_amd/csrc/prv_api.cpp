@@ -67,7 +67,7 @@ struct prv_ctx {
   std::string err;
   Model models[PRV_MAX_MODELS];
   // grow-only workspaces
-  Buffer queue, stage, counters, view_ids, img_f32, partial, records, dbg[6];
+  Buffer queue, queue_ext, stage, counters, view_ids, img_f32, partial, records, dbg[6];
   Buffer img_u8[PRV_MAX_MODELS];
   bool profiling = false;
   std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs of the current profiling window
@@ -81,7 +81,6 @@ struct prv_ctx {
   int queue_segments = 8; // ray-queue segments = XCDs (PRV_QUEUE_SEGMENTS: 1 = single shared head)
   int pool_on = -1;       // render_queue64 block-level tail pool (PRV_POOL=0/1; -1 = by table and image size, see render_views)
   int merge_max = -1;     // render_queue64 tail merge threshold (PRV_MERGE_MAX; 0 = off; -1 = by table size, see render_views)
-  int dbg_flags = 0;
   size_t stage_budget = (size_t)4 << 30; // staging bytes for multi-sample renders (spp x batch x image)
   size_t queue_budget = (size_t)4 << 30; // ray-queue bytes per batch of views (288 GB of HBM: one batch for 64 views at 800x800)
   double coverage_weight = PRV_COVERAGE_WEIGHT_DEFAULT; // method 5: score = -PSNR + weight * mean((1 - alpha)^2)
@@ -400,7 +399,9 @@ int check_opts(prv_ctx* c, const prv_render_opts* o) {
   if (!o) return fail(c, PRV_E_INVALID, "render options are NULL");
   if (o->width < 1 || o->height < 1 || o->width > 16384 || o->height > 16384)
     return fail(c, PRV_E_INVALID, "bad image size %dx%d", o->width, o->height);
-  if (o->samples_per_ray < 1 || o->samples_per_ray > kMaxSamples)
+  if (o->step_mode != PRV_STEP_FIXED_S && o->step_mode != PRV_STEP_NGP)
+    return fail(c, PRV_E_INVALID, "step_mode must be PRV_STEP_FIXED_S (0) or PRV_STEP_NGP (1), got %d", o->step_mode);
+  if (o->step_mode == PRV_STEP_FIXED_S && (o->samples_per_ray < 1 || o->samples_per_ray > kMaxSamples))
     return fail(c, PRV_E_INVALID, "samples_per_ray must be in [1,%d], got %d", kMaxSamples, o->samples_per_ray);
   if (o->spp < 1 || o->spp > 1024) return fail(c, PRV_E_INVALID, "spp must be in [1,1024], got %d", o->spp);
   return PRV_OK;
@@ -454,7 +455,7 @@ CamDev cam_at(const prv_camset* cs, int i, int w, int h) {
 }
 
 constexpr size_t kStatOffset = 1024;                        // counters buffer: heads 0..511, counts 512..1023, then the statistics
-constexpr size_t kCountersBytes = kStatOffset + (72 + 33) * 8; // {evaluated, wave rounds}, 70 spare words, 33-bin dev histogram
+constexpr size_t kCountersBytes = kStatOffset + 16 * 8; // {evaluated, wave rounds, clock sums and stamps, live samples}, spare words
 
 
 // The render of one batch of views into out_f32 (+ optional out_u8).  Views are dealt to
@@ -505,7 +506,9 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   // view v is image (k*nb + v) of a staging buffer, reduced over k in order afterwards (spp = 1 renders
   // straight into the output).  Batches keep queue and staging within their budgets.
   const int spp = o->spp;
-  size_t batch = std::max<size_t>(1, c->queue_budget / (npix * kRecordBytes * (size_t)spp));
+  const bool ngp = o->step_mode == PRV_STEP_NGP;
+  const size_t slot_bytes = kRecordBytes + (ngp ? kExtBytes : 0); // NGP: every queue slot has its mask-extension slot
+  size_t batch = std::max<size_t>(1, c->queue_budget / (npix * slot_bytes * (size_t)spp));
   batch = std::min<size_t>(batch, (size_t)n_views);
   if (spp > 1) batch = std::min<size_t>(batch, std::max<size_t>(1, c->stage_budget / (npix * 16 * (size_t)spp)));
   if (batch * npix * (size_t)spp >= (1ull << 32)) batch = ((1ull << 32) - 1) / (npix * (size_t)spp); // 32-bit pixel ids
@@ -523,6 +526,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   const size_t seg_cap_max = ((march_blocks((int)batch) + n_seg - 1) / n_seg) * 256;
   if (seg_cap_max * (size_t)n_seg >= (1ull << 32)) return fail(c, PRV_E_INVALID, "image x spp too large");
   if ((rc = ensure(c, c->queue, seg_cap_max * (size_t)n_seg * kRecordBytes)) != PRV_OK) return rc;
+  if (ngp && (rc = ensure(c, c->queue_ext, seg_cap_max * (size_t)n_seg * kExtBytes)) != PRV_OK) return rc;
   if (spp > 1 && (rc = ensure(c, c->stage, batch * npix * (size_t)spp * 16)) != PRV_OK) return rc;
 
   // Persistent render blocks per CU.  More resident waves hide more gather latency but also put more random requests in
@@ -558,7 +562,10 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     mp.tile_h_log2 = pix_log2 / 2;
     mp.tiles_x = (uint32_t)((W + (1 << mp.tile_w_log2) - 1) >> mp.tile_w_log2);
     mp.tiles_y = (uint32_t)((H + (1 << mp.tile_h_log2) - 1) >> mp.tile_h_log2);
+    mp.step_mode = o->step_mode;
     mp.queue = c->queue.p;
+    mp.queue_ext = (uint4*)c->queue_ext.p;
+    mp.stat = stat;
     mp.queue_count = q_count;
     mp.n_seg = n_seg;
     mp.seg_cap = (uint32_t)(((march_blocks(nb) + n_seg - 1) / n_seg) * 256);
@@ -581,6 +588,8 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     memset(&rp, 0, sizeof(rp));
     rp.field = m.dev;
     rp.queue = c->queue.p;
+    rp.queue_ext = (const uint4*)c->queue_ext.p;
+    rp.step_mode = o->step_mode;
     rp.queue_count = q_count;
     rp.queue_head = q_head;
     rp.n_segments = n_seg;
@@ -601,7 +610,6 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     const bool coherent = m.table_halfs * 2 <= ((size_t)32 << 20) && npix >= ((size_t)1 << 17);
     rp.merge_max = c->merge_max >= 0 ? c->merge_max : (coherent ? 16 : 0);
     rp.pool_on = (c->pool_on >= 0 ? c->pool_on != 0 : coherent) && rp.merge_max > 0;
-    rp.dbg = c->dbg_flags;
     memcpy(rp.bg, o->background, sizeof(rp.bg));
     if (c->profiling) {
       hipEvent_t a, b;
@@ -620,23 +628,14 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
 
 int fetch_stats(prv_ctx* c, const prv_render_opts* o, int n_views, int n_models, prv_stats* st) {
   if (!st) return PRV_OK;
-  unsigned long long ev2[2] = {0, 0};
-  HIPCHK(c, hipMemcpyAsync(ev2, (char*)c->counters.p + kStatOffset, 16, hipMemcpyDeviceToHost, c->stream));
+  unsigned long long ev[7] = {0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(ev, (char*)c->counters.p + kStatOffset, sizeof(ev), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  const unsigned long long ev = ev2[0];
-  st->wave_rounds = ev2[1];
+  st->wave_rounds = ev[1];
   st->rays = (uint64_t)n_views * n_models * o->width * o->height * o->spp;
-  st->samples_nominal = st->rays * (uint64_t)o->samples_per_ray;
-  st->samples_evaluated = ev;
-  if (c->dbg_flags & 8) { // dev: slot-occupancy histogram of the render launches since the stats were cleared
-    unsigned long long hist[33];
-    HIPCHK(c, hipMemcpy(hist, (char*)c->counters.p + kStatOffset + 72 * 8, sizeof(hist), hipMemcpyDeviceToHost));
-    unsigned long long tot = 0;
-    for (int i = 1; i <= 32; i++) tot += hist[i];
-    fprintf(stderr, "slot occupancy per wave-round (active slots: share of rounds):");
-    for (int i = 1; i <= 32; i++) fprintf(stderr, " %d:%.3f", i, tot ? (double)hist[i] / (double)tot : 0.0);
-    fprintf(stderr, "\n");
-  }
+  st->samples_nominal = st->rays * (uint64_t)(o->step_mode == PRV_STEP_NGP ? kNgpMaxSteps : o->samples_per_ray);
+  st->samples_evaluated = ev[0];
+  st->samples_live = ev[6];
   return PRV_OK;
 }
 
@@ -684,7 +683,6 @@ int prv_create(prv_ctx** out, int device_id) try {
   if (const char* s = getenv("PRV_QUEUE_SEGMENTS")) c->queue_segments = std::min(8, std::max(1, atoi(s)));
   if (const char* s = getenv("PRV_MERGE_MAX")) c->merge_max = std::min(31, std::max(0, atoi(s)));
   if (const char* s = getenv("PRV_POOL")) c->pool_on = atoi(s) != 0 ? 1 : 0;
-  if (const char* s = getenv("PRV_DBG")) c->dbg_flags = atoi(s);
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
   *out = c;
   return PRV_OK;
@@ -709,6 +707,7 @@ void prv_destroy(prv_ctx* c) {
     release(m.mlp);
   }
   release(c->queue);
+  release(c->queue_ext);
   release(c->stage);
   release(c->counters);
   if (c->pin) (void)hipHostFree(c->pin);

@@ -31,8 +31,80 @@ __device__ __forceinline__ void morton16(uint32_t i, uint32_t& x, uint32_t& y) {
   y = ((i >> 1) & 1u) | ((i >> 2) & 2u) | ((i >> 3) & 4u) | ((i >> 4) & 8u);
 }
 
+// instant-ngp's stepping rule (PRV_STEP_NGP; SURVEY App. E, what run.py:245-247, 304 renders with): fixed step
+// dt = sqrt(3)/1024 from the AABB entry, sample i at t0 + (i + 1/2) dt while inside the box, at most 1024 (the diagonal)
+constexpr float kNgpDt = 1.7320508075688772f / 1024.0f; // = sqrtf(3.0f) / 1024.0f, the oracle's value bit for bit
+
+// NGP march of one ray: up to 32 mask words (1024 steps) into the lane's column of the block's LDS scratch `mw`
+// ([word][thread]; only words [k_lo, k_hi) are written, the others are empty).  One DILATED coarse lookup clears a whole
+// 32-step word: its samples lie within 16 dt = 0.027 of the word's middle, less than one coarse cell (4 / occ_res) for
+// occ_res <= 128, so a clear dilated bit there means no sample of the word is in an occupied fine cell.  Masks are
+// bit-identical to testing every step.  Returns the number of live samples; first_nz / last_nz = first / last non-empty word.
+__device__ __forceinline__ uint32_t march_ngp(const FieldDev& fd, const float o[3], const float d[3], float t0, float t1,
+                                              uint32_t (*mw)[256], int& k_lo, int& k_hi, int& first_nz, int& last_nz) {
+  const float dt = kNgpDt;
+  first_nz = 32;
+  last_nz = -1;
+  k_lo = k_hi = 0;
+  // only samples inside the (one-cell-grown) bounding box of the occupied cells can be live
+  float ta = t0, tb = t1;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float inv = 1.0f / d[a];
+    const float u = (fd.occ_lo[a] - o[a]) * inv, w = (fd.occ_hi[a] - o[a]) * inv;
+    ta = fmaxf(ta, fminf(u, w));
+    tb = fminf(tb, fmaxf(u, w));
+  }
+  if (!(tb > ta)) return 0u;
+  const float inv_dt = 1024.0f / 1.7320508075688772f;
+  const int g_lo = max(0, (int)((ta - t0) * inv_dt) - 2);
+  const int g_hi = min(kNgpMaxSteps, (int)((tb - t0) * inv_dt) + 3); // the exact `t < t1` test below ends the ray
+  if (g_lo >= g_hi) return 0u;
+  k_lo = g_lo >> 5;
+  k_hi = (g_hi + 31) >> 5;
+  const bool coarse_ok = fd.occ_coarse != nullptr && 16.0f * dt <= 0.99f * 4.0f / (float)fd.occ_res;
+  const int Rc_m1 = (fd.occ_res >> 2) - 1;
+  const float fRc = (float)(fd.occ_res >> 2);
+  const uint32_t Rc = (uint32_t)(Rc_m1 + 1);
+  uint32_t n_live = 0u;
+  for (int k = k_lo; k < k_hi; k++) {
+    uint32_t w = 0u;
+    bool pass = true;
+    if (coarse_ok) {
+      const float tm = fmaf((float)(32 * k + 16), dt, t0);
+      const int cx = min(max((int)(fmaf(tm, d[0], o[0]) * fRc), 0), Rc_m1), cy = min(max((int)(fmaf(tm, d[1], o[1]) * fRc), 0), Rc_m1),
+                cz = min(max((int)(fmaf(tm, d[2], o[2]) * fRc), 0), Rc_m1);
+      const uint32_t bit = (uint32_t)cx + Rc * ((uint32_t)cy + Rc * (uint32_t)cz);
+      pass = (fd.occ_coarse[bit >> 5] >> (bit & 31u)) & 1u;
+    }
+    if (pass) {
+#pragma unroll
+      for (int q0 = 0; q0 < 32; q0 += 8) { // eight fine tests issued together (eight loads in flight, one wait)
+        bool occ[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int i = 32 * k + q0 + q;
+          const float t = fmaf((float)i + 0.5f, dt, t0);
+          occ[q] = occupied(fd, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2])) && t < t1;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) w |= (uint32_t)occ[q] << (q0 + q);
+      }
+    }
+    mw[k][threadIdx.x] = w;
+    if (w != 0u) {
+      if (first_nz == 32) first_nz = k;
+      last_nz = k;
+      n_live += (uint32_t)__popc(w);
+    }
+  }
+  return n_live;
+}
+
+template <bool NGP>
 __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
   __shared__ uint4 stage[4][64 * kRecordWords]; // a wave's live records, written out as ONE contiguous block
+  __shared__ uint32_t mw[NGP ? 32 : 1][256];    // NGP: the lanes' mask words ([word][thread]: conflict-free columns)
   const uint32_t tile = blockIdx.x, vi = blockIdx.y;
   const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
   // Multi-sample launches: with a power-of-two spp the sub-samples of a pixel sit on ADJACENT lanes
@@ -53,6 +125,8 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
 
   float o[3] = {0, 0, 0}, d[3] = {0, 0, 1}, t0 = 0.f, dt = 0.f;
   uint32_t m[4] = {0, 0, 0, 0};
+  uint32_t n_live = 0u;                              // live samples of this ray (statistics: the march count)
+  int k_lo = 0, k_hi = 0, first_nz = 32, last_nz = -1; // NGP: written words of mw, first / last non-empty word
   bool live = false;
   bool maybe = valid;
   const CamDev& cam = P.cams[P.view_ids[vi]];
@@ -85,7 +159,12 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
   if (maybe) {
     raygen(cam, px, py, ox, oy, o, d);
     float t1;
-    if (ray_aabb(o, d, t0, t1)) {
+    if (!ray_aabb(o, d, t0, t1)) {
+    } else if constexpr (NGP) {
+      dt = kNgpDt;
+      n_live = march_ngp(P.field, o, d, t0, t1, mw, k_lo, k_hi, first_nz, last_nz);
+      live = first_nz < 32;
+    } else {
       dt = (t1 - t0) / (float)P.S;
       // Two-level test, bit-identical to testing every sample: samples g..g+3 all lie within 1.5*dt of
       // the point at parameter g+2; when that is less than one coarse cell and the DILATED coarse bit
@@ -161,6 +240,7 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
         m[k] = w;
       }
       live = (m[0] | m[1] | m[2] | m[3]) != 0u;
+      n_live = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
     }
   }
   // wave-level compaction: ballot + prefix popcount, one atomic per wave.  The queue is cut into n_seg regions of
@@ -179,11 +259,25 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
     // every store instruction touch 64 different lines, six times over)
     uint4* st = stage[threadIdx.x >> 6];
     if (live) {
-      uint4* rec = st + (uint32_t)__popcll(b & ((1ull << lane) - 1ull)) * kRecordWords;
+      const uint32_t prefix = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+      uint4* rec = st + prefix * kRecordWords;
+      uint32_t chunk_info = 1u << 16; // {first step of chunk 0 (a multiple of 32), number of 128-step mask chunks << 16}
+      if constexpr (NGP) {
+        // the record carries the 128 steps from the first non-empty word on; the chunks behind it (up to 7 more) go to
+        // the record's slot of the extension buffer, which the render kernel reads only when a ray gets that far
+        auto word = [&](int k) { return (k >= k_lo && k < k_hi) ? mw[k][threadIdx.x] : 0u; };
+#pragma unroll
+        for (int q = 0; q < 4; q++) m[q] = word(first_nz + q);
+        const int n_chunks = ((last_nz - first_nz) >> 2) + 1;
+        chunk_info = (uint32_t)(32 * first_nz) | ((uint32_t)n_chunks << 16);
+        uint4* ext = P.queue_ext + (size_t)(base + prefix) * kExtChunks;
+        for (int j = 1; j < n_chunks; j++)
+          ext[j - 1] = make_uint4(word(first_nz + 4 * j), word(first_nz + 4 * j + 1), word(first_nz + 4 * j + 2), word(first_nz + 4 * j + 3));
+      }
       rec[0] = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(t0));
       rec[1] = make_uint4(__float_as_uint(d[0]), __float_as_uint(d[1]), __float_as_uint(d[2]), __float_as_uint(dt));
       rec[2] = make_uint4(m[0], m[1], m[2], m[3]);
-      rec[3] = make_uint4(pix, 0u, 0u, 0u);
+      rec[3] = make_uint4(pix, chunk_info, 0u, 0u);
       // direction encoding once per ray, here, so a slot refill in K_B is loads only
       reinterpret_cast<half8*>(rec)[4] = sh_fragment(0, d[0], d[1], d[2]);
       reinterpret_cast<half8*>(rec)[5] = sh_fragment(1, d[0], d[1], d[2]);
@@ -194,6 +288,12 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
     uint4* dst = reinterpret_cast<uint4*>(P.queue) + (size_t)base * kRecordWords;
     const uint32_t n_words = (uint32_t)__popcll(b) * kRecordWords;
     for (uint32_t i = (uint32_t)lane; i < n_words; i += 64u) dst[i] = st[i];
+  }
+  if (b != 0ull) { // statistics: the march count (live samples before any early termination), one atomic per wave
+    uint32_t tot = n_live;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) tot += (uint32_t)__shfl_xor((int)tot, sh);
+    if (lane == 0) atomicAdd(P.stat + 6, (unsigned long long)tot);
   }
   if (!live && valid) {
     // dead ray: contributes exactly zero to its pixel
@@ -233,15 +333,8 @@ __device__ __forceinline__ void clock_stamp_end(unsigned long long* stat) {
 // every weight fragment.  A group refills when all its 32 slots are idle (whole-group lockstep).
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
-#ifndef PRV_R64_WAVES
-#define PRV_R64_WAVES 0 // dev: 4 = ask for 4 waves per SIMD (<= 128 VGPRs, the compiler spills); 0 = let it choose (3 waves)
-#endif
-template <int F, int NDENSE>
-__global__ __launch_bounds__(256)
-#if PRV_R64_WAVES
-__attribute__((amdgpu_waves_per_eu(PRV_R64_WAVES, PRV_R64_WAVES)))
-#endif
-void render_queue64_kernel(RenderParams P) {
+template <int F, int NDENSE, bool NGP>
+__global__ __launch_bounds__(256) void render_queue64_kernel(RenderParams P) {
   __shared__ half8 wl[kNumFrags * 64];
   __shared__ uint32_t mv[4][32][6]; // tail merges: {record, next sample, T, r, g, b} of the rays that change slots, per wave
   constexpr uint32_t kPoolCap = 192;
@@ -273,7 +366,10 @@ void render_queue64_kernel(RenderParams P) {
   bool active = false;
   uint32_t pix = 0, rec_i = 0; // rec_i: the ray's queue record (a ray that changes slots re-reads its constants from it)
   float o[3] = {0, 0, 0}, d[3] = {0, 0, 1}, t0 = 0.f, dt = 0.f;
-  uint32_t cur = 0, m1 = 0, m2 = 0, m3 = 0, base = 0; // live-sample mask: current word (never 0 while active) + the words behind it
+  // live-sample mask: the current 32-step word (never 0 while active), the words of its 128-step chunk behind it, and
+  // the step index of the current word's bit 0.  PRV_STEP_NGP: further chunks are fetched from the extension buffer
+  // when this one is spent (next_chunk below); nothing about them lives in registers.
+  uint32_t cur = 0, m1 = 0, m2 = 0, m3 = 0, base = 0;
   float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f;
   half8 shA = {0, 0, 0, 0, 0, 0, 0, 0}, shB = {0, 0, 0, 0, 0, 0, 0, 0}; // SH rows [8g, 8g+8) of the rays in slots (r, A) and (r, B)
   bool drained = false;
@@ -283,6 +379,60 @@ void render_queue64_kernel(RenderParams P) {
   const uint32_t n_seg = (uint32_t)P.n_segments;
   uint32_t seg = n_seg > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % n_seg : 0u;
   uint32_t seg_tried = 0;
+  const uint4* __restrict__ queue = reinterpret_cast<const uint4*>(P.queue);
+
+  // the lane takes over the ray of queue record ri, its mask walk positioned at sample `next` (a live sample of the
+  // ray, or 0 for a fresh ray: then at its first live sample).  Constants come from the record, the dynamic state
+  // (T and the colour sums) from the caller.
+  auto take_ray = [&](uint32_t ri, uint32_t next) {
+    const uint4* rec = queue + (size_t)ri * kRecordWords;
+    const uint4 q0 = rec[0], q1 = rec[1], q3 = rec[3];
+    uint4 mk = rec[2];
+    o[0] = __uint_as_float(q0.x); o[1] = __uint_as_float(q0.y); o[2] = __uint_as_float(q0.z);
+    t0 = __uint_as_float(q0.w);
+    d[0] = __uint_as_float(q1.x); d[1] = __uint_as_float(q1.y); d[2] = __uint_as_float(q1.z);
+    dt = __uint_as_float(q1.w);
+    pix = q3.x;
+    rec_i = ri;
+    base = 0u;
+    if constexpr (NGP) {
+      const uint32_t base0 = q3.y & 0xffffu; // first step of the record's own chunk
+      base = base0;
+      if (next >= base0 + 128u) { // the sample lies in a later chunk
+        const uint32_t j = (next - base0) >> 7;
+        mk = P.queue_ext[(size_t)ri * kExtChunks + (j - 1u)];
+        base = base0 + 128u * j;
+      }
+    }
+    cur = mk.x; m1 = mk.y; m2 = mk.z; m3 = mk.w;
+    while (base + 32u <= next) { // the words before the sample are spent
+      cur = m1; m1 = m2; m2 = m3; m3 = 0u;
+      base += 32u;
+    }
+    if (next > base) cur &= ~0u << (next & 31u); // chunks start at multiples of 32: next & 31 == next - base
+    while (cur == 0u && (m1 | m2 | m3) != 0u) { // fresh FIXED_S rays: the current word must not be empty
+      cur = m1; m1 = m2; m2 = m3; m3 = 0u;
+      base += 32u;
+    }
+    active = true;
+  };
+  // PRV_STEP_NGP, the chunk in the registers is spent: fetch the ray's next non-empty chunk; false = that was the last
+  auto next_chunk = [&]() -> bool {
+    const uint32_t info = queue[(size_t)rec_i * kRecordWords + 3].y;
+    const uint32_t base0 = info & 0xffffu, n_chunks = info >> 16;
+    for (uint32_t j = ((base - base0) >> 7) + 1u; j < n_chunks; j++) {
+      const uint4 mk = P.queue_ext[(size_t)rec_i * kExtChunks + (j - 1u)];
+      if ((mk.x | mk.y | mk.z | mk.w) == 0u) continue; // a gap between two occupied stretches
+      cur = mk.x; m1 = mk.y; m2 = mk.z; m3 = mk.w;
+      base = base0 + 128u * j;
+      while (cur == 0u) {
+        cur = m1; m1 = m2; m2 = m3; m3 = 0u;
+        base += 32u;
+      }
+      return true;
+    }
+    return false;
+  };
 
   for (;;) {
     // ---- tail merge.  A cohort of 32 rays starts in lockstep (adjacent pixels, same depth: their gathers share cache
@@ -323,28 +473,12 @@ void render_queue64_kernel(RenderParams P) {
         if (!((a_dst >> r) & 1u) && kth < n_src) { // BOTH lanes of the slot: the slot's SH rows go to both halves
           const uint32_t* e = slot[kth];
           const uint32_t ri = e[0];
-          const uint4* rec = reinterpret_cast<const uint4*>(P.queue) + (size_t)ri * kRecordWords;
-          const half8 sh = reinterpret_cast<const half8*>(rec)[4 + g];
+          const half8 sh = reinterpret_cast<const half8*>(queue + (size_t)ri * kRecordWords)[4 + g];
           if (src == 0) shB = sh;
           else shA = sh;
           if (g != src) { // the destination lane itself takes the ray over
-            const uint32_t next = e[1];
             T = __uint_as_float(e[2]); cr = __uint_as_float(e[3]); cg = __uint_as_float(e[4]); cb = __uint_as_float(e[5]);
-            const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-            o[0] = __uint_as_float(q0.x); o[1] = __uint_as_float(q0.y); o[2] = __uint_as_float(q0.z);
-            t0 = __uint_as_float(q0.w);
-            d[0] = __uint_as_float(q1.x); d[1] = __uint_as_float(q1.y); d[2] = __uint_as_float(q1.z);
-            dt = __uint_as_float(q1.w);
-            cur = q2.x; m1 = q2.y; m2 = q2.z; m3 = q2.w;
-            base = 0u;
-            while (base + 32u <= next) { // the words before the next sample are spent
-              cur = m1; m1 = m2; m2 = m3; m3 = 0u;
-              base += 32u;
-            }
-            cur &= ~0u << (next & 31u);
-            pix = q3.x;
-            rec_i = ri;
-            active = true;
+            take_ray(ri, e[1]);
           }
         }
         __builtin_amdgcn_wave_barrier(); // the scratch is reused by the next merge
@@ -399,28 +533,12 @@ void render_queue64_kernel(RenderParams P) {
         if (lane == 0) *(volatile uint32_t*)&pool_n = from;
         pool_release();
         if (mine) {
-          const uint4* rec = reinterpret_cast<const uint4*>(P.queue) + (size_t)ent[0] * kRecordWords;
-          const half8 sh = reinterpret_cast<const half8*>(rec)[4 + g];
+          const half8 sh = reinterpret_cast<const half8*>(queue + (size_t)ent[0] * kRecordWords)[4 + g];
           if (grp == 0) shA = sh;
           else shB = sh;
           if (g == grp) {
-            const uint32_t next = ent[1];
             T = __uint_as_float(ent[2]); cr = __uint_as_float(ent[3]); cg = __uint_as_float(ent[4]); cb = __uint_as_float(ent[5]);
-            const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-            o[0] = __uint_as_float(q0.x); o[1] = __uint_as_float(q0.y); o[2] = __uint_as_float(q0.z);
-            t0 = __uint_as_float(q0.w);
-            d[0] = __uint_as_float(q1.x); d[1] = __uint_as_float(q1.y); d[2] = __uint_as_float(q1.z);
-            dt = __uint_as_float(q1.w);
-            cur = q2.x; m1 = q2.y; m2 = q2.z; m3 = q2.w;
-            base = 0u;
-            while (base + 32u <= next) {
-              cur = m1; m1 = m2; m2 = m3; m3 = 0u;
-              base += 32u;
-            }
-            cur &= ~0u << (next & 31u);
-            pix = q3.x;
-            rec_i = ent[0];
-            active = true;
+            take_ray(ent[0], ent[1]);
           }
         }
       }
@@ -448,26 +566,12 @@ void render_queue64_kernel(RenderParams P) {
         }
         const uint32_t avail = min(32u, q_end - q_cur);
         if ((uint32_t)r < avail) { // both lane halves: the group's SH rows go to every lane, the ray itself to its own lane
-          const uint4* rec = reinterpret_cast<const uint4*>(P.queue) + (size_t)(q_cur + (uint32_t)r) * kRecordWords;
-          const half8 sh = reinterpret_cast<const half8*>(rec)[4 + g];
+          const half8 sh = reinterpret_cast<const half8*>(queue + (size_t)(q_cur + (uint32_t)r) * kRecordWords)[4 + g];
           if (grp == 0) shA = sh;
           else shB = sh;
           if (g == grp) {
-            const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-            o[0] = __uint_as_float(q0.x); o[1] = __uint_as_float(q0.y); o[2] = __uint_as_float(q0.z);
-            t0 = __uint_as_float(q0.w);
-            d[0] = __uint_as_float(q1.x); d[1] = __uint_as_float(q1.y); d[2] = __uint_as_float(q1.z);
-            dt = __uint_as_float(q1.w);
-            cur = q2.x; m1 = q2.y; m2 = q2.z; m3 = q2.w;
-            base = 0u;
-            while (cur == 0u && base < 96u) { // a queued ray has at least one live sample: normalise so that the current word is not empty
-              cur = m1; m1 = m2; m2 = m3; m3 = 0u;
-              base += 32u;
-            }
-            pix = q3.x;
-            rec_i = q_cur + (uint32_t)r;
             T = 1.f; cr = 0.f; cg = 0.f; cb = 0.f;
-            active = true;
+            take_ray(q_cur + (uint32_t)r, 0u);
           }
         }
         q_cur += avail;
@@ -481,7 +585,7 @@ void render_queue64_kernel(RenderParams P) {
       continue;
     }
     n_eval += (unsigned long long)__popcll(act);
-    n_rounds += 2ull; // counted in 32-slot units, like the 32-slot kernel: utilisation = evaluated / (32 * rounds)
+    n_rounds += 2ull; // counted in 32-slot units: utilisation = evaluated / (32 * rounds)
 
     // ---- this lane's next live sample, all levels
     // idle lanes feed whatever their registers hold into their own MFMA column: columns are independent and an idle
@@ -498,6 +602,9 @@ void render_queue64_kernel(RenderParams P) {
         while (cur == 0u && !last) {
           cur = m1; m1 = m2; m2 = m3; m3 = 0u;
           base += 32u;
+        }
+        if constexpr (NGP) {
+          if (last) last = !next_chunk();
         }
       }
       const float t = fmaf((float)i + 0.5f, dt, t0);
@@ -1151,7 +1258,8 @@ hipError_t launch_spp_reduce(const float* stage, size_t n_pixels, int spp, const
 
 hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_t s) {
   dim3 grid((unsigned)(P.tiles_x * P.tiles_y), (unsigned)n_views, (unsigned)(P.spp_inner_log2 > 0 ? 1 : n_spp));
-  hipLaunchKernelGGL(march_compact_kernel, grid, dim3(256), 0, s, P);
+  if (P.step_mode == PRV_STEP_NGP) hipLaunchKernelGGL(march_compact_kernel<true>, grid, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(march_compact_kernel<false>, grid, dim3(256), 0, s, P);
   return hipGetLastError();
 }
 
@@ -1163,17 +1271,23 @@ int render_instance_dense_levels(const FieldDev& fd) {
   return n >= 10 ? 10 : n >= 6 ? 6 : 0;
 }
 
-hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s) {
+template <bool NGP>
+static void launch_render_mode(const RenderParams& P, int n_blocks, hipStream_t s) {
   const int nd = render_instance_dense_levels(P.field);
   if (P.field.n_features == 4) {
-    if (nd == 5) hipLaunchKernelGGL((render_queue64_kernel<4, 5>), dim3(n_blocks), dim3(256), 0, s, P);
-    else if (nd == 3) hipLaunchKernelGGL((render_queue64_kernel<4, 3>), dim3(n_blocks), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((render_queue64_kernel<4, 0>), dim3(n_blocks), dim3(256), 0, s, P);
+    if (nd == 5) hipLaunchKernelGGL((render_queue64_kernel<4, 5, NGP>), dim3(n_blocks), dim3(256), 0, s, P);
+    else if (nd == 3) hipLaunchKernelGGL((render_queue64_kernel<4, 3, NGP>), dim3(n_blocks), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((render_queue64_kernel<4, 0, NGP>), dim3(n_blocks), dim3(256), 0, s, P);
   } else {
-    if (nd == 10) hipLaunchKernelGGL((render_queue64_kernel<2, 10>), dim3(n_blocks), dim3(256), 0, s, P);
-    else if (nd == 6) hipLaunchKernelGGL((render_queue64_kernel<2, 6>), dim3(n_blocks), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((render_queue64_kernel<2, 0>), dim3(n_blocks), dim3(256), 0, s, P);
+    if (nd == 10) hipLaunchKernelGGL((render_queue64_kernel<2, 10, NGP>), dim3(n_blocks), dim3(256), 0, s, P);
+    else if (nd == 6) hipLaunchKernelGGL((render_queue64_kernel<2, 6, NGP>), dim3(n_blocks), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((render_queue64_kernel<2, 0, NGP>), dim3(n_blocks), dim3(256), 0, s, P);
   }
+}
+
+hipError_t launch_render(const RenderParams& P, int n_blocks, hipStream_t s) {
+  if (P.step_mode == PRV_STEP_NGP) launch_render_mode<true>(P, n_blocks, s);
+  else launch_render_mode<false>(P, n_blocks, s);
   return hipGetLastError();
 }
 

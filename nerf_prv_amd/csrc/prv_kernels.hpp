@@ -6,11 +6,18 @@
 namespace prv {
 
 // one queue record = 96 bytes = 6 x uint4:
-//   {o.x o.y o.z t0} {d.x d.y d.z dt} {mask0..3} {pixel, 0, 0, 0} {SH coeffs 0..7 fp16} {SH 8..15 fp16}
+//   {o.x o.y o.z t0} {d.x d.y d.z dt} {mask0..3} {pixel, chunk info, 0, 0} {SH coeffs 0..7 fp16} {SH 8..15 fp16}
+// The mask is one 128-step CHUNK of the ray's live-sample mask.  PRV_STEP_FIXED_S: the only one (chunk info = 1 << 16).
+// PRV_STEP_NGP (up to 1024 steps): the chunk that starts at the ray's first non-empty 32-step word; chunk info = first
+// step of that chunk | number of chunks << 16, and chunks 1..n-1 sit in the record's slot of the extension buffer
+// (kExtChunks x uint4 per queue slot), read by the render kernel only when a ray gets that far.
 constexpr size_t kRecordBytes = 96;
 constexpr int kRecordWords = 6;   // uint4 per record
 constexpr uint32_t kClaim = 64;   // records a wave claims per atomic on the queue head
-constexpr int kMaxSamples = 128; // live-sample mask is 128 bits
+constexpr int kMaxSamples = 128;  // PRV_STEP_FIXED_S: the live-sample mask is one 128-bit chunk
+constexpr int kNgpMaxSteps = PRV_NGP_MAX_STEPS; // PRV_STEP_NGP: dt = sqrt(3)/1024, the cube's diagonal
+constexpr int kExtChunks = kNgpMaxSteps / 128 - 1;
+constexpr size_t kExtBytes = (size_t)kExtChunks * 16;
 
 struct MarchParams {
   FieldDev field;
@@ -20,7 +27,10 @@ struct MarchParams {
   uint32_t tiles_x, tiles_y;
   int tile_w_log2, tile_h_log2; // pixel tile of one 256-thread block
   int spp_inner_log2;           // > 0: sub-samples on adjacent lanes (spp = 2^n), 0: on grid.z
+  int step_mode; // PRV_STEP_FIXED_S | PRV_STEP_NGP
   void* queue;
+  uint4* queue_ext;      // PRV_STEP_NGP: kExtChunks mask chunks per queue slot
+  unsigned long long* stat; // statistics block: [6] += live samples (the march count)
   uint32_t* queue_count; // n_seg counters, 64 bytes apart: records appended to region s of the queue
   int n_seg;             // the queue is n_seg regions of seg_cap records; a block appends to region (linear block id % n_seg)
   uint32_t seg_cap;
@@ -34,6 +44,8 @@ struct MarchParams {
 struct RenderParams {
   FieldDev field;
   const void* queue;
+  const uint4* queue_ext; // PRV_STEP_NGP: the mask chunks behind the record's own (see kRecordBytes)
+  int step_mode;
   const uint32_t* queue_count; // n_segments counters, 64 bytes apart: records in region s
   uint32_t* queue_head; // n_segments heads, 64 bytes apart (region-relative record counts)
   int n_segments;
@@ -47,7 +59,6 @@ struct RenderParams {
   int last_pass;
   int merge_max; // render_queue64: a group down to <= this many rays hands them to the other group's idle slots (0 = never)
   int pool_on;   // render_queue64: ... or, failing that, to the block's LDS tail pool (any wave's idle slots adopt them)
-  int dbg; // dev-only bits (PRV_DBG env): 1 no table loads, 2 no MLP, 4 no compositing math, 8 slot-occupancy histogram
   float bg[4];
 };
 

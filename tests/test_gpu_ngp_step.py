@@ -1,0 +1,171 @@
+"""PRV_STEP_NGP on the GPU: instant-ngp's stepping rule (what run.py:245-247, 304 renders with -- fixed step
+dt = sqrt(3)/1024 from the AABB entry, every step tested against the occupancy grid, no per-ray sample cap)
+through the C ABI, against the CPU oracle's restatement of the same rule (oracle/prv_oracle.c: march_ray) and the
+independent numpy golden (tests/golden/golden_render_ngp.json).  Bars as everywhere: the march count (samples in occupied
+cells) is an integer and must be EXACT; evaluated samples may differ by a ray stopping one sample early or late (hardware
+exp vs expf at T ~ min_T); pixels 1e-3 relative (tests/util.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nerf_prv_amd import api
+from tests import util
+
+pytestmark = pytest.mark.gpu
+NGP = api.L.STEP_NGP
+
+
+@pytest.fixture(scope="module", params=["F4", "F2"])
+def fields(request, ctx, oracle):
+    kw = util.SMALL if request.param == "F4" else util.SMALL_F2
+    d_o, d_p = oracle.desc(**kw), api.field_desc(**kw)
+    f = oracle.OracleField(d_o, seed=util.SEED_A)
+    ctx.synthetic_model(0, d_p, util.SEED_A)
+    return d_o, d_p, f
+
+
+@pytest.fixture(scope="module")
+def cams(ctx, oracle):
+    pts = util.fibonacci_hemisphere(5)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    w, h = 44, 36
+    cs = ctx.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+    ocams = oracle.cameras_from_transforms(tms, util.FOV_X, w, h, scale, offset)
+    return cs, ocams, w, h
+
+
+@pytest.mark.parametrize("min_T,spp", [(1e-2, 1), (1e-4, 1), (1e-2, 4)])
+def test_ngp_step_pixels_and_counts(ctx, oracle, fields, cams, min_T, spp):
+    d_o, d_p, f = fields
+    cs, ocams, w, h = cams
+    opts = api.render_opts(w, h, 0, spp, min_T, step_mode=NGP)
+    img, st = ctx.render(0, cs, None, opts)
+    img = img.cpu().numpy()
+    n_eval = n_live = 0
+    for v, oc in enumerate(ocams):
+        want, ne = f.render(oc, w, h, 0, spp, min_T, step_mode=oracle.STEP_NGP)
+        n_eval += ne
+        n_live += f.march_count(oc, w, h, 0, spp, step_mode=oracle.STEP_NGP)
+        util.assert_pixels_close(img[v], want)
+    assert int(st.samples_live) == n_live > 0  # the march pass's masks: every step's occupancy decision, exactly
+    assert abs(int(st.samples_evaluated) - n_eval) <= max(2, n_eval // 100000)
+    assert st.rays == len(ocams) * w * h * spp and st.samples_nominal == st.rays * api.L.NGP_MAX_STEPS
+    assert n_live > 128 * 10  # rays with more live samples than one mask chunk exist in this scene (checked per ray below)
+
+
+def test_fixed_mode_march_count_is_exact_too(ctx, oracle, fields, cams):
+    d_o, d_p, f = fields
+    cs, ocams, w, h = cams
+    for S in (128, 37):
+        _, st = ctx.render(0, cs, None, api.render_opts(w, h, S, 1, 1e-4))
+        assert int(st.samples_live) == sum(f.march_count(oc, w, h, S) for oc in ocams) > 0
+
+
+def test_ngp_step_against_the_numpy_golden(ctx, oracle):
+    """the fixture's camera sees rays with up to 430 live steps (4 mask chunks); counts per image, pixels per pixel"""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "golden_render_ngp.json")) as fh:
+        g = json.load(fh)
+    ctx.synthetic_model(3, api.field_desc(**g["desc"]), g["seed"])
+    w, h = g["w"], g["h"]
+    c2w = np.array(g["c2w"], np.float64).reshape(3, 4)
+    # the fixture states its camera in the ENGINE frame; prv_cameras_from_matrices takes transform_matrix + scale/offset
+    # (nerf_matrix_to_ngp: columns 1,2 negated, axes cycled) -- invert that here
+    tm = np.eye(4)
+    eng = c2w.copy()
+    eng[:, 1] *= -1
+    eng[:, 2] *= -1
+    tm[:3, :] = eng[[2, 0, 1], :]  # engine (x,y,z) = nerf (y,z,x)
+    fov = 2.0 * np.arctan(0.5 * w / g["fx"])
+    cs = ctx.cameras_from_matrices(tm[None], fov, w, h, 1.0, np.zeros(3))
+    got_c2w, got_intr = cs.get(0)
+    np.testing.assert_allclose(got_c2w, c2w, atol=1e-7)
+    assert abs(got_intr[0] - g["fx"]) <= 1e-5 * g["fx"]
+    img, st = ctx.render(3, cs, None, api.render_opts(w, h, 0, 1, g["min_T"], step_mode=NGP))
+    assert int(st.samples_live) == g["n_live"]
+    assert abs(int(st.samples_evaluated) - g["n_evaluated"]) <= 2
+    util.assert_pixels_close(img[0].cpu().numpy(), np.array(g["image"]))
+    per_ray = np.array(g["per_ray"])
+    assert per_ray[:, 1].max() > 384  # four chunks
+    cs.close()
+
+
+def test_ngp_step_awkward_cameras(ctx, oracle, fields):
+    """camera inside the object, axis-aligned rays, far away, looking away, grazing: the clipped step range and the
+    word-level coarse skip may only ever err towards testing more"""
+    d_o, d_p, f = fields
+    w = h = 33
+
+    def tm(rot, t):
+        m = np.eye(4)
+        m[:3, :3] = rot
+        m[:3, 3] = t
+        return m
+
+    eye, back = np.eye(3), np.diag([-1.0, 1.0, -1.0])
+    ry = lambda a: np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    cases = [("inside", tm(eye, [0, 0, 0]), util.FOV_X), ("axis", tm(eye, [0, 0, 0.3]), util.FOV_X), ("away", tm(back, [0, 0, 0.3]), util.FOV_X),
+             ("far", tm(eye, [0, 0, 60.0]), 0.02), ("corner", tm(ry(0.6), [0.25, 0.07, 0.28]), 0.5),
+             ("diag", tm(ry(0.7853981), [0.2, 0.0, 0.2]), 0.3)]
+    cases += [(f"graze{i}", tm(eye, [0.04 * i, 0.02 * i, 0.3]), 0.6) for i in range(1, 6)]
+    scale, offset = 5.0, np.array([0.5, 0.5, 0.5])
+    for name, m, fov in cases:
+        cs = ctx.cameras_from_matrices(m[None], fov, w, h, scale, offset)
+        oc = oracle.cameras_from_transforms(m[None], fov, w, h, scale, offset)[0]
+        img, st = ctx.render(0, cs, None, api.render_opts(w, h, 0, 1, 1e-2, step_mode=NGP))
+        want, ne = f.render(oc, w, h, 0, 1, 1e-2, step_mode=oracle.STEP_NGP)
+        util.assert_pixels_close(img[0].cpu().numpy(), want)
+        assert int(st.samples_live) == f.march_count(oc, w, h, 0, step_mode=oracle.STEP_NGP), name
+        assert abs(int(st.samples_evaluated) - ne) <= 2, (name, int(st.samples_evaluated), ne)
+        cs.close()
+
+
+def test_ngp_step_transparent_field_walks_every_chunk(ctx, oracle):
+    """a nearly transparent field (BASELINE.md section 6's table amplitude and density bias) never terminates early:
+    every live step of every ray is evaluated, so evaluated == live == the oracle's march count, chunk after chunk"""
+    kw = dict(util.SMALL, table_amp=0.1, density_bias=0.0)
+    f = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
+    ctx.synthetic_model(3, api.field_desc(**kw), util.SEED_A)
+    pts = util.fibonacci_hemisphere(3)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    w, h = 40, 30
+    cs = ctx.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+    ocams = oracle.cameras_from_transforms(tms, util.FOV_X, w, h, scale, offset)
+    img, st = ctx.render(3, cs, None, api.render_opts(w, h, 0, 1, 1e-2, step_mode=NGP))
+    live = sum(f.march_count(oc, w, h, 0, step_mode=oracle.STEP_NGP) for oc in ocams)
+    assert int(st.samples_live) == int(st.samples_evaluated) == live
+    for v, oc in enumerate(ocams):
+        want, _ = f.render(oc, w, h, 0, 1, 1e-2, step_mode=oracle.STEP_NGP)
+        util.assert_pixels_close(img[v].cpu().numpy(), want)
+    cs.close()
+
+
+def test_ngp_step_scores_and_bytes_follow(ctx, oracle, fields, cams):
+    """the scoring round and the PNG bytes in the engine's own stepping mode: same records as scoring the same renders"""
+    d_o, d_p, f = fields
+    cs, ocams, w, h = cams
+    ctx.synthetic_model(1, d_p, util.SEED_B)
+    opts = api.render_opts(w, h, 0, 4, 1e-2, background=(0.0, 0.0, 0.0, 1.0), step_mode=NGP)
+    gt, _ = ctx.render(1, cs, None, opts, want_stats=False)
+    img, _ = ctx.render(0, cs, None, opts, want_stats=False)
+    rec, _ = ctx.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cs, None, opts, gt=gt)
+    assert rec.tobytes() == ctx.score_psnr_images(img, gt, background=(0.0, 0.0, 0.0, 1.0)).tobytes()
+    u8, _ = ctx.render_rgba8(0, cs, None, opts)
+    want8 = oracle.quantize_rgba8(img.cpu().numpy(), (0.0, 0.0, 0.0, 1.0))
+    assert np.array_equal(u8.cpu().numpy(), want8)
+    ens, _ = ctx.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, [0, 1], cs, None, opts)
+    u8b, _ = ctx.render_rgba8(1, cs, None, opts)
+    for v in range(len(ocams)):
+        want = oracle.score_ensemble_rgbdensity([u8[v].cpu().numpy(), u8b[v].cpu().numpy()])
+        assert ens["score"][v] == pytest.approx(want, rel=1e-12)
+
+
+def test_step_mode_is_validated(ctx, fields, cams):
+    cs, ocams, w, h = cams
+    with pytest.raises(api.PrvError) as e:
+        ctx.render(0, cs, None, api.render_opts(w, h, 64, 1, 1e-2, step_mode=7))
+    assert e.value.code == api.L.PRV_E_INVALID
+    with pytest.raises(api.PrvError):  # the fixed mode still needs a sample count
+        ctx.render(0, cs, None, api.render_opts(w, h, 0, 1, 1e-2))
+    ctx.render(0, cs, None, api.render_opts(w, h, 0, 1, 1e-2, step_mode=NGP))  # NGP ignores it

@@ -1,0 +1,79 @@
+"""The bench workload itself against the oracle, at full size: the 64-view hemisphere round bench.py times
+(800x800, 128 samples/ray; BASELINE configs[1]) rendered in ONE call with everything the product path switches on at
+that size -- tail merge, the block's tail pool, queue regions drained per XCD, default blocks per CU -- and compared
+WHOLE VIEW by whole view (the pole view and the lowest view of the set) with the CPU oracle, for
+  * the literal BASELINE.md section 6 scene (table U(-0.1,0.1), no density bias): bench.py's headline,
+  * the denser scene the other full-size tests use (table U(-4,4), bias 3: early termination exercised),
+  * the 512^3 field of configs[3] (L=16, F=2, log2T=21: the HBM-bound instance).
+The march count of the WHOLE 64-view round (samples in occupied cells: an integer per round, 200+ M) must equal the
+oracle's; on the section 6 scene no ray terminates early, so the evaluated-sample count of the round equals it too.
+Pixels: 1e-3 relative (tests/util.py).  Oracle time: ~1.5 s per whole view, ~10 s for the round's march count."""
+import os
+
+import numpy as np
+import pytest
+
+from nerf_prv_amd import api, planner
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+W = H = 800
+S = 128
+N_VIEWS = 64
+THREADS = min(64, os.cpu_count() or 8)
+SCENES = {
+    "baseline256": dict(api.FIELD_256, table_amp=0.1, density_bias=0.0),
+    "default256": dict(api.FIELD_256),
+    "default512": dict(api.FIELD_512),
+}
+
+
+@pytest.fixture(scope="module")
+def round_cams(ctx, oracle):
+    pts = planner.hemisphere_generate(N_VIEWS)  # bench.py's candidate set
+    tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
+    cams = ctx.cameras_from_matrices(tms, util.FOV_X, W, H, scale, offset)
+    ocams = oracle.cameras_from_transforms(tms, util.FOV_X, W, H, scale, offset)
+    yield cams, ocams
+    cams.close()
+
+
+@pytest.fixture(scope="module")
+def round_march_count(oracle, round_cams):
+    """the three scenes share the analytic occupancy grid, hence the march count: computed once"""
+    _, ocams = round_cams
+    f = oracle.OracleField(oracle.desc(**SCENES["baseline256"]), seed=util.SEED_A)
+    per_view = [f.march_count(oc, W, H, S, threads=THREADS) for oc in ocams]
+    f.close()
+    return per_view
+
+
+@pytest.mark.parametrize("scene", list(SCENES))
+def test_whole_views_and_the_rounds_march_count(ctx, oracle, round_cams, round_march_count, scene):
+    cams, ocams = round_cams
+    kw = SCENES[scene]
+    ctx.synthetic_model(6, api.L.FieldDesc(**kw), util.SEED_A)
+    f = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
+    assert np.array_equal(f.params()[2], oracle.OracleField(oracle.desc(**SCENES["baseline256"]), seed=util.SEED_A).params()[2])
+    opts = api.render_opts(W, H, S, 1, 1e-4)
+    img, st = ctx.render(6, cams, None, opts)  # all 64 views, one call: one march + one render launch, as bench.py's step
+    assert st.rays == N_VIEWS * W * H
+    assert int(st.samples_live) == sum(round_march_count)
+    if scene == "baseline256":
+        assert int(st.samples_evaluated) == int(st.samples_live)  # nothing terminates early in the section 6 scene
+    else:
+        assert 0 < int(st.samples_evaluated) < int(st.samples_live)
+    n_eval_views = 0
+    for v in (0, N_VIEWS - 1):  # the pole view and the lowest one
+        want, ne = f.render(ocams[v], W, H, S, 1, 1e-4, threads=THREADS)
+        util.assert_pixels_close(img[v].cpu().numpy(), want)
+        assert want[..., 3].max() > (0.1 if scene == "baseline256" else 0.9)
+        n_eval_views += ne
+        if scene == "baseline256":
+            assert ne == round_march_count[v]
+    # the same two views alone: identical images (a view does not depend on its batch), and their evaluated count
+    two, st2 = ctx.render(6, cams, [0, N_VIEWS - 1], opts)
+    assert bool((two[0] == img[0]).all()) and bool((two[1] == img[N_VIEWS - 1]).all())
+    assert abs(int(st2.samples_evaluated) - n_eval_views) <= max(2, n_eval_views // 100000)
+    f.close()
