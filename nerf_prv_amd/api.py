@@ -50,6 +50,14 @@ def render_opts(width, height, samples_per_ray=128, spp=1, min_transmittance=1e-
     return o
 
 
+def engine_render_opts(width, height, samples_per_ray, spp, min_transmittance, background=(0.0, 0.0, 0.0, 0.0)):
+    """render options as the run.py mirrors (Testbed, the flag-file server) state them: samples_per_ray 0 = the engine's
+    own stepping rule (PRV_STEP_NGP: dt = sqrt(3)/1024, what pyngp renders with behind run.py:304), N > 0 = N uniform
+    samples per ray (PRV_STEP_FIXED_S, the BASELINE configs' rule)"""
+    n = int(samples_per_ray)
+    return render_opts(width, height, n, spp, min_transmittance, background, step_mode=L.STEP_NGP if n == 0 else L.STEP_FIXED_S)
+
+
 def model_sizes(desc):
     lib = L.load()
     t, m, o = C.c_uint64(), C.c_uint64(), C.c_uint64()
@@ -349,7 +357,7 @@ class Context:
 
     # -- stage hooks
     def model_layout(self, slot):
-        """kernel-side layout of a loaded field and the render_queue_kernel<F, NPAIR> instance it runs on"""
+        """kernel-side layout of a loaded field and the render_queue64_kernel<F, NDENSE> instance it runs on"""
         out = L.ModelLayout()
         self._chk(self.lib.prv_debug_model_layout(self.handle, slot, C.byref(out)))
         return {k: getattr(out, k) for k, _ in out._fields_}
@@ -542,7 +550,7 @@ class _NerfSettings:
         self.render_min_transmittance = 0.01  # engine default; run.py:235 sets 1e-4 for evaluation
         self.render_with_lens_distortion = False
         self.sharpen = 0.0
-        self.samples_per_ray = 128
+        self.samples_per_ray = 0  # not a pyngp attribute: 0 = the engine's own stepping (dt = sqrt(3)/1024), N > 0 = N uniform samples per ray
         self.training = _Training()
 
 
@@ -699,7 +707,7 @@ class Testbed:
         if self.fov_axis != 0:
             raise NotImplementedError("fov_axis must be 0 (run.py:285)")
         eff_spp = 1 if self.snap_to_pixel_centers else int(spp)
-        opts = render_opts(width, height, self.nerf.samples_per_ray, eff_spp, self.nerf.render_min_transmittance)
+        opts = engine_render_opts(width, height, self.nerf.samples_per_ray, eff_spp, self.nerf.render_min_transmittance)
         if self._training_view is not None:  # dataset camera: own intrinsics + lens (run.py:242-247)
             if self.render_ground_truth:
                 img = self._ground_truth(self._training_view, width, height)

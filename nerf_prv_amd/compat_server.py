@@ -100,7 +100,7 @@ def train_scene(ctx, slot, scene_json, n_steps, desc, seed=0x1234, opts=None):
 
 
 class CompatServer:
-    def __init__(self, interact_dir, ctx, load_model=None, samples_per_ray=128, screenshot_spp=16, reference_images=None,
+    def __init__(self, interact_dir, ctx, load_model=None, samples_per_ray=0, screenshot_spp=16, reference_images=None,
                  train_desc=None, train_opts=None, train_seed=0x1234):
         self.dir, self.ctx = interact_dir, ctx
         # load_model(scene_json, ctx) -> slot supplies weights from elsewhere; without it the request's
@@ -129,7 +129,7 @@ class CompatServer:
                 ref_transforms = json.load(f)
             cams = self.ctx.cameras_from_json(args["screenshot_transforms"])
             w, h = int(ref_transforms["w"]), int(ref_transforms["h"])  # run.py:304
-            opts = api.render_opts(w, h, self.samples_per_ray, self.spp, 0.01, background=(0.0, 0.0, 0.0, 1.0))
+            opts = api.engine_render_opts(w, h, self.samples_per_ray, self.spp, 0.01, background=(0.0, 0.0, 0.0, 1.0))
             u8, _ = self.ctx.render_rgba8(slot, cams, None, opts)
             u8 = u8.cpu().numpy()
             os.makedirs(args["screenshot_dir"], exist_ok=True)
@@ -146,7 +146,7 @@ class CompatServer:
             cams = self.ctx.cameras_from_dataset_json(args["test_transforms"])
             w, h = cams.size
             gt = self.reference_images(args["test_transforms"])
-            opts = api.render_opts(w, h, self.samples_per_ray, 1, 1e-4, background=(0.0, 0.0, 0.0, 1.0))  # run.py:226-235
+            opts = api.engine_render_opts(w, h, self.samples_per_ray, 1, 1e-4, background=(0.0, 0.0, 0.0, 1.0))  # run.py:226-235
             psnr, ssim = self.ctx.evaluate(slot, cams, None, opts, gt)
             planner.write_metrics(args["save_metrics"], psnr, ssim)
             cams.close()

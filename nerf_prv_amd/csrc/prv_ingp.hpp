@@ -75,6 +75,7 @@ struct Value {
   double number() const { return type == Int ? (double)i : f; }
 };
 
+constexpr size_t kMaxMsgpackItems = (size_t)1 << 20; // values in the tree (~150 B each): real snapshots hold 10^2..10^5
 class Parser {
 public:
   Parser(const uint8_t* p, size_t n) : p_(p), n_(n) {}
@@ -88,7 +89,7 @@ public:
 
 private:
   const uint8_t* p_;
-  size_t n_, at_ = 0;
+  size_t n_, at_ = 0, n_items_ = 0;
   std::string err_;
   bool need(size_t k) { return n_ - at_ >= k; }
   uint64_t be(int k) {
@@ -105,6 +106,11 @@ private:
   }
   bool items(size_t count, bool is_map, Value& out, int depth) {
     if (count > n_ - at_) return false; // every item takes at least a byte: a header can not promise more than the file holds
+    n_items_ += count;
+    if (n_items_ > kMaxMsgpackItems) { // a few MB of one-byte items would otherwise become GBs of tree
+      err_ = "msgpack tree has more than " + std::to_string(kMaxMsgpackItems) + " values";
+      return false;
+    }
     out.type = is_map ? Value::Map : Value::Array;
     for (size_t k = 0; k < count; k++) {
       if (is_map) {
@@ -239,7 +245,11 @@ inline void write_msgpack(const Value& v, std::vector<uint8_t>& o) {
 }
 
 // ---------------------------------------------------------------- gzip (".ingp" = zstr-compressed msgpack)
-inline bool gunzip(const std::vector<uint8_t>& in, std::vector<uint8_t>& out, size_t limit = (size_t)8 << 30) {
+// limit: the largest snapshot this build can represent is a < 4 GiB fp16 table + the density grid; upstream adds the
+// optimiser's two fp32 moments when asked to (4 x the parameters).  2.5 GiB covers every configuration that passes the
+// checks below several times over and keeps a hostile file from inflating into the host's memory.
+constexpr size_t kMaxInflatedBytes = ((size_t)5 << 30) / 2;
+inline bool gunzip(const std::vector<uint8_t>& in, std::vector<uint8_t>& out, size_t limit = kMaxInflatedBytes) {
   z_stream z{};
   if (inflateInit2(&z, 15 + 32) != Z_OK) return false; // zlib or gzip header, auto-detected
   z.next_in = const_cast<Bytef*>(in.data());
@@ -468,13 +478,11 @@ inline int read_snapshot(const std::string& path, Field& out, std::string& err) 
   out.occ.assign((cells + 31) / 32, 0u);
   if (!dg || dg->type != Value::Bin || dg->s.size() < cells * 2) { err = "snapshot.density_grid_binary missing or shorter than density_grid_size^3"; return PRV_E_IO; }
   const uint16_t* g = (const uint16_t*)dg->s.data();
+  // upstream's update_density_grid_mean_and_bitfield: mean = sum(max(v, 0)) / N over ALL N cells of cascade 0 -- the
+  // never-seen cells (-1) add nothing to the sum but do count in the denominator
   double sum = 0.0;
-  uint64_t cnt = 0;
-  for (uint64_t i = 0; i < cells; i++) {
-    const float v = half_to_float(g[i]);
-    if (v >= 0.0f) { sum += v; cnt++; }
-  }
-  const float mean = cnt ? (float)(sum / (double)cnt) : 0.0f;
+  for (uint64_t i = 0; i < cells; i++) sum += (double)std::max(half_to_float(g[i]), 0.0f);
+  const float mean = (float)(sum / (double)cells);
   const float thresh = std::min(kMinOpticalThickness, mean);
   for (uint32_t z = 0; z < R; z++)
     for (uint32_t y = 0; y < R; y++)

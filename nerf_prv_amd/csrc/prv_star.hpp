@@ -7,8 +7,14 @@
 // runs: those gather device buffers with RCCL over xGMI.
 //
 // Topology: rank 0 listens on <addr>:<port> (MASTER_ADDR / MASTER_PORT + 23 by default, PRV_COMM_PORT
-// overrides), every other rank connects (retrying until the listener exists) and introduces itself with its
-// rank.  all_gather: every rank sends its block to rank 0, rank 0 answers with the assembled buffer.
+// overrides) -- bound to THAT address, not to every interface -- and every other rank connects (retrying until it
+// is accepted).  A connection introduces itself with {magic, job nonce, communicator sequence number, rank, world};
+// the nonce is a hash of MASTER_PORT and the job's token ($PRV_COMM_TOKEN, else $TORCHELASTIC_RUN_ID), the sequence
+// number counts the communicators this process has opened.  Rank 0 closes and SKIPS anything that does not present
+// the right nonce / sequence / a free rank (a port scanner, a straggler of another job, a peer's NEXT communicator
+// landing in this listener's backlog) and keeps accepting until every rank has arrived or the timeout expires; a
+// rank is accepted with an acknowledgement, and join() returns only once it has that, so a rejected connection is
+// simply retried.  all_gather: every rank sends its block to rank 0, rank 0 answers with the assembled buffer.
 #pragma once
 #include <arpa/inet.h>
 #include <netdb.h>
@@ -17,6 +23,8 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cstdint>
@@ -146,54 +154,105 @@ private:
     setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
     setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
   }
+  static constexpr uint32_t kMagic = 0x50525653u; // "PRVS"
+  struct Hello {
+    uint32_t magic;
+    uint32_t seq;   // which communicator of the job this is (every rank opens them in the same order)
+    uint64_t nonce; // the job: a hash of MASTER_PORT and the job token
+    int32_t rank, world;
+  };
+  static uint64_t job_nonce() {
+    uint64_t h = 0xcbf29ce484222325ull; // FNV-1a over the strings that name the job
+    auto mix = [&](const char* s) {
+      for (; s && *s; s++) h = (h ^ (uint64_t)(unsigned char)*s) * 0x100000001b3ull;
+      h = (h ^ 0xffu) * 0x100000001b3ull;
+    };
+    mix(getenv("MASTER_PORT"));
+    mix(getenv("PRV_COMM_TOKEN"));
+    mix(getenv("TORCHELASTIC_RUN_ID"));
+    return h;
+  }
+  static uint32_t next_seq() {
+    static std::atomic<uint32_t> n{0};
+    return n.fetch_add(1);
+  }
+  static double since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  static void set_timeouts(int fd, double secs) {
+    if (secs < 0.05) secs = 0.05;
+    timeval tv{(time_t)secs, (suseconds_t)((secs - (double)(time_t)secs) * 1e6)};
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+  }
   bool serve(const addrinfo* res, double timeout_s) {
+    const uint32_t seq = next_seq();
+    const uint64_t nonce = job_nonce();
     listen_fd_ = ::socket(AF_INET, SOCK_STREAM, 0);
     if (listen_fd_ < 0) return fail("socket()");
     int one = 1;
     setsockopt(listen_fd_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-    sockaddr_in any = *(const sockaddr_in*)res->ai_addr;
-    any.sin_addr.s_addr = htonl(INADDR_ANY);
     const auto t0 = std::chrono::steady_clock::now();
-    while (::bind(listen_fd_, (const sockaddr*)&any, sizeof(any)) != 0) { // a previous job's listener may linger briefly
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return fail("bind: " + std::string(strerror(errno)));
+    // the resolved rendezvous address itself (MASTER_ADDR), not INADDR_ANY: nothing outside that interface reaches the job
+    while (::bind(listen_fd_, res->ai_addr, res->ai_addrlen) != 0) { // a previous job's listener may linger briefly
+      if (since(t0) > timeout_s) return fail("bind: " + std::string(strerror(errno)));
       std::this_thread::sleep_for(std::chrono::milliseconds(100));
     }
-    if (::listen(listen_fd_, world) != 0) return fail("listen()");
-    timeval tv{(time_t)timeout_s, 0};
-    setsockopt(listen_fd_, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    if (::listen(listen_fd_, world + 16) != 0) return fail("listen()");
     peers_.assign((size_t)world, -1);
-    for (int k = 1; k < world; k++) {
+    int arrived = 1;
+    while (arrived < world) {
+      const double left = timeout_s - since(t0);
+      if (left <= 0) return fail("accept: the other ranks did not arrive");
+      set_timeouts(listen_fd_, left);
       const int fd = ::accept(listen_fd_, nullptr, nullptr);
-      if (fd < 0) return fail("accept: the other ranks did not arrive");
-      tune(fd);
-      int32_t hello[2] = {0, 0};
-      if (!recv_all(fd, hello, sizeof(hello)) || hello[0] <= 0 || hello[0] >= world || hello[1] != world || peers_[hello[0]] >= 0) {
-        ::close(fd);
-        return fail("a peer introduced itself with a bad rank / world size");
+      if (fd < 0) {
+        if (errno == EINTR) continue;
+        return fail("accept: the other ranks did not arrive");
       }
-      peers_[hello[0]] = fd;
+      set_timeouts(fd, std::min(left, 5.0)); // a connection that says nothing is dropped after 5 s, not waited on
+      Hello h{};
+      const bool good = recv_all(fd, &h, sizeof(h)) && h.magic == kMagic && h.nonce == nonce && h.seq == seq && h.world == world &&
+                        h.rank > 0 && h.rank < world && peers_[(size_t)h.rank] < 0;
+      if (!good) { // not one of this communicator's ranks: drop it, keep waiting for the real ones
+        ::close(fd);
+        continue;
+      }
+      const Hello ack{kMagic, seq, nonce, 0, world};
+      if (!send_all(fd, &ack, sizeof(ack))) {
+        ::close(fd);
+        continue;
+      }
+      tune(fd);
+      peers_[(size_t)h.rank] = fd;
+      arrived++;
     }
     ::close(listen_fd_);
     listen_fd_ = -1;
     return true;
   }
   bool join(const addrinfo* res, double timeout_s) {
+    const uint32_t seq = next_seq();
+    const uint64_t nonce = job_nonce();
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
       const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
       if (fd < 0) return fail("socket()");
       if (::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
-        tune(fd);
-        const int32_t hello[2] = {rank, world};
-        if (!send_all(fd, hello, sizeof(hello))) {
-          ::close(fd);
-          return fail("rank 0 closed the connection");
+        set_timeouts(fd, std::max(1.0, std::min(timeout_s - since(t0), 30.0)));
+        const Hello hello{kMagic, seq, nonce, rank, world};
+        Hello ack{};
+        // accepted = rank 0 answered with this communicator's acknowledgement; a listener that closes the connection
+        // instead (it belongs to an earlier communicator or to another job) is retried
+        if (send_all(fd, &hello, sizeof(hello)) && recv_all(fd, &ack, sizeof(ack)) && ack.magic == kMagic && ack.nonce == nonce &&
+            ack.seq == seq && ack.world == world) {
+          tune(fd);
+          peers_.assign(1, fd);
+          return true;
         }
-        peers_.assign(1, fd);
-        return true;
       }
       ::close(fd);
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return fail("connect: rank 0 is not listening");
+      if (since(t0) > timeout_s) return fail("connect: rank 0 did not accept this rank");
       std::this_thread::sleep_for(std::chrono::milliseconds(50));
     }
   }

@@ -150,7 +150,9 @@ public:
     depth_scale = fs.num("depth_scale");
     render_width = (int)fs.num("render_width");
     render_height = (int)fs.num("render_height");
-    samples_per_ray = fs.has("samples_per_ray") ? (int)fs.num("samples_per_ray") : 128;
+    // 0 (the default: the reference's yaml has no such key) = the engine's own stepping rule, what run.py:304 renders
+    // with (PRV_STEP_NGP); N > 0 = N uniform samples per ray (PRV_STEP_FIXED_S, the BASELINE configs' rule)
+    samples_per_ray = fs.has("samples_per_ray") ? (int)fs.num("samples_per_ray") : 0;
     screenshot_spp = fs.has("screenshot_spp") ? (int)fs.num("screenshot_spp") : 16; // run.py:48
     candidate_divisor = fs.has("candidate_divisor") ? fs.num("candidate_divisor") : 16.0; // main.cpp:1796
     min_transmittance = fs.has("min_transmittance") ? fs.num("min_transmittance") : 0.01;

@@ -163,7 +163,8 @@ struct HipScorer {
     prv_render_opts o{};
     o.width = train_w > 0 ? train_w : w;
     o.height = train_h > 0 ? train_h : h;
-    o.samples_per_ray = 128;
+    o.samples_per_ray = sd->samples_per_ray;
+    o.step_mode = sd->samples_per_ray > 0 ? PRV_STEP_FIXED_S : PRV_STEP_NGP;
     o.spp = 1; // snap_to_pixel_centers (run.py:231)
     o.min_transmittance = 1e-4f; // run.py:235
     o.background[3] = 1.f;       // black, opaque (run.py:226)
@@ -201,6 +202,7 @@ struct HipScorer {
     o.width = sd->render_width > 0 ? sd->render_width : w;
     o.height = sd->render_height > 0 ? sd->render_height : h;
     o.samples_per_ray = sd->samples_per_ray;
+    o.step_mode = sd->samples_per_ray > 0 ? PRV_STEP_FIXED_S : PRV_STEP_NGP;
     o.spp = sd->screenshot_spp;
     o.min_transmittance = (float)sd->min_transmittance;
     o.background[0] = o.background[1] = o.background[2] = 0.f;
@@ -372,6 +374,7 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
     o.width = sd->render_width > 0 ? sd->render_width : w;
     o.height = sd->render_height > 0 ? sd->render_height : h;
     o.samples_per_ray = sd->samples_per_ray;
+    o.step_mode = sd->samples_per_ray > 0 ? PRV_STEP_FIXED_S : PRV_STEP_NGP;
     o.spp = sd->screenshot_spp;
     o.min_transmittance = (float)sd->min_transmittance;
     const int n = prv_camset_count(cams);

@@ -87,6 +87,14 @@ def test_snapshot_loads_and_renders_like_the_same_arrays(ctx, oracle, tmp_path, 
     want, _ = f.render(ocam, w, h, 128, 1, 1e-4, threads=8, rows=rows)
     util.assert_pixels_close(a[2].cpu().numpy()[rows[0]:rows[1]], want[rows[0]:rows[1]])
     assert want[rows[0]:rows[1], :, 3].max() > 0.2
+    # ... and the way run.py:304 renders such a snapshot: the engine's own stepping rule (dt = sqrt(3)/1024, min_T 0.01),
+    # march count exact, rows of a view against the oracle's restatement of that rule
+    ngp = api.engine_render_opts(w, h, 0, 1, 1e-2)
+    c, st_n = ctx.render(0, cams, [2], ngp)
+    assert int(st_n.samples_live) == f.march_count(ocam, w, h, 0, step_mode=oracle.STEP_NGP)
+    want_n, _ = f.render(ocam, w, h, 0, 1, 1e-2, threads=8, rows=rows, step_mode=oracle.STEP_NGP)
+    util.assert_pixels_close(c[0].cpu().numpy()[rows[0]:rows[1]], want_n[rows[0]:rows[1]])
+    assert want_n[rows[0]:rows[1], :, 3].max() > 0.2
     # and out again: the writer's file is the reader's input
     out = tmp_path / "saved.msgpack"
     ctx.save_ingp(0, out)

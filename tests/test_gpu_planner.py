@@ -82,7 +82,7 @@ def test_testbed_screenshot_loop_reads_like_run_py(ctx, tmp_path):
     ctx.synthetic_model(0, small_desc(), SEED)
     cams = ctx.cameras_from_json(rj)
     assert len(cams) == 5 and cams.size == (80, 45)
-    batch, _ = ctx.render(0, cams, None, api.render_opts(80, 45, 128, 2, 0.01))
+    batch, _ = ctx.render(0, cams, None, api.engine_render_opts(80, 45, 0, 2, 0.01))  # the Testbed renders with the engine's own stepping rule
     batch = batch.cpu().numpy()
     for img, b in zip(images, batch):
         want = b + (1.0 - b[..., 3:4]) * np.array([0, 0, 0, 1], np.float32)
@@ -91,7 +91,7 @@ def test_testbed_screenshot_loop_reads_like_run_py(ctx, tmp_path):
     testbed.snap_to_pixel_centers = True  # run.py:231: every sub-sample at the pixel centre == spp 1
     testbed.set_nerf_camera_matrix(np.matrix(ref_transforms["frames"][0]["transform_matrix"])[:-1, :])
     one = testbed.render(80, 45, 8, True)
-    spp1, _ = ctx.render(0, cams, [0], api.render_opts(80, 45, 128, 1, 0.01))
+    spp1, _ = ctx.render(0, cams, [0], api.engine_render_opts(80, 45, 0, 1, 0.01))
     np.testing.assert_array_equal(one[..., :3], spp1[0].cpu().numpy()[..., :3])
     with pytest.raises(ValueError):
         testbed.set_nerf_camera_matrix(np.eye(4))

@@ -77,3 +77,28 @@ def test_whole_views_and_the_rounds_march_count(ctx, oracle, round_cams, round_m
     assert bool((two[0] == img[0]).all()) and bool((two[1] == img[N_VIEWS - 1]).all())
     assert abs(int(st2.samples_evaluated) - n_eval_views) <= max(2, n_eval_views // 100000)
     f.close()
+
+
+@pytest.mark.parametrize("scene", ["default256", "default512"])
+def test_ngp_step_at_full_size(ctx, oracle, round_cams, scene):
+    """the engine's own stepping rule (PRV_STEP_NGP, what run.py:304 renders with) on the full-size fields: the march
+    count of two whole 800x800 views exactly (every step's occupancy decision, ~700 steps per ray), a 48-row band of
+    each against the oracle, the engine's default min_T 0.01"""
+    cams, ocams = round_cams
+    kw = SCENES[scene]
+    ctx.synthetic_model(6, api.L.FieldDesc(**kw), util.SEED_A)
+    f = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
+    views = [0, N_VIEWS - 1]
+    opts = api.engine_render_opts(W, H, 0, 1, 1e-2)
+    img, st = ctx.render(6, cams, views, opts)
+    assert int(st.samples_live) == sum(f.march_count(ocams[v], W, H, 0, threads=THREADS, step_mode=oracle.STEP_NGP) for v in views)
+    assert st.samples_nominal == 2 * W * H * api.L.NGP_MAX_STEPS and 0 < st.samples_evaluated < st.samples_live
+    rows = (H // 2 - 24, H // 2 + 24)
+    n_eval = 0
+    for k, v in enumerate(views):
+        want, ne = f.render(ocams[v], W, H, 0, 1, 1e-2, threads=THREADS, rows=rows, step_mode=oracle.STEP_NGP)
+        util.assert_pixels_close(img[k].cpu().numpy()[rows[0]:rows[1]], want[rows[0]:rows[1]])
+        assert want[rows[0]:rows[1], :, 3].max() > 0.9
+        n_eval += ne
+    assert n_eval > 0
+    f.close()

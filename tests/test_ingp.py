@@ -93,13 +93,46 @@ def upstream_snapshot(f, **over):
 
 def expected_occ(f):
     d = f["density_xyz"].astype(np.float32)
-    mean = d[d >= 0].mean() if (d >= 0).any() else 0.0
-    thresh = min(0.01, float(np.float32(mean)))
+    # upstream's update_density_grid_mean_and_bitfield: the mean of max(v, 0) over ALL cells -- the never-seen (-1) ones
+    # add nothing to the sum but count in the denominator
+    mean = np.float32(np.maximum(d, 0).astype(np.float64).sum() / d.size)
+    thresh = min(0.01, float(mean))
     bits = (d > np.float32(thresh)).reshape(-1)  # z, y, x with x fastest = bit x + R*(y + R*z)
     words = np.zeros((bits.size + 31) // 32, np.uint32)
     idx = np.flatnonzero(bits)
     np.bitwise_or.at(words, idx >> 5, (np.uint32(1) << (idx & 31).astype(np.uint32)))
     return words
+
+
+def test_unseen_cells_count_in_the_density_mean(tmp_path):
+    """a thin field (every optical thickness below 0.01, so the threshold is the MEAN) in which most cells were never
+    seen: upstream divides by all cells, so the threshold is far lower than the mean of the seen cells, and cells between
+    the two are occupied"""
+    rng = np.random.default_rng(11)
+    f = make_field(rng, grid=16)
+    d = (rng.random(16 ** 3) * 0.008).astype(np.float16)
+    d[rng.random(16 ** 3) < 0.7] = -1
+    f["density_xyz"] = d.reshape(16, 16, 16)
+    seen = d[d >= 0].astype(np.float32)
+    all_mean = float(np.maximum(d.astype(np.float32), 0).sum() / d.size)
+    assert all_mean < 0.5 * float(seen.mean()) < 0.01
+    between = int(((d.astype(np.float32) > all_mean) & (d.astype(np.float32) <= seen.mean())).sum())
+    assert between > 100  # cells the wrong denominator would drop
+    p = write(tmp_path, "thin.msgpack", upstream_snapshot(f), False)
+    _, _, _, occ = planner.ingp_read(p)
+    assert np.array_equal(occ, expected_occ(f))
+    assert int(np.unpackbits(occ.view(np.uint8)).sum()) == int((d.astype(np.float32) > np.float32(all_mean)).sum())
+
+
+def test_hostile_snapshots_are_refused_before_they_eat_the_host(tmp_path):
+    """a few MB that promise GBs: a msgpack array of a million-and-one one-byte values (each would become a ~150-byte
+    tree node); a gzip bomb is cut off at the inflated-size cap"""
+    n = (1 << 20) + 1
+    raw = b"\xdd" + n.to_bytes(4, "big") + b"\x00" * n
+    p = tmp_path / "items.msgpack"
+    p.write_bytes(raw)
+    with pytest.raises(Exception, match="values"):
+        planner.ingp_read(p)
 
 
 def write(tmp_path, name, root, zipped):
