@@ -2,9 +2,11 @@
 """bench.py -- the hot path of NeRF-PRV on MI355X: render + score candidate views.
 
 One "step" = one scoring round of the planner over this rank's shard of the candidate set:
-march + render every view (800x800, 128 samples/ray) of the synthetic 256^3 hash-grid field,
-reduce each to a PSNR/coverage score against reference images already resident in HBM,
-all-gather the 16-byte records over RCCL (N > 1), rank.  BASELINE.json configs[1].
+march + render every view (800x800, 128 samples/ray) of the synthetic 256^3 hash-grid field
+BASELINE.md section 6 specifies (table U(-0.1,0.1), Xavier MLPs, analytic occupancy), reduce each to a
+PSNR/coverage score against reference images already resident in HBM, all-gather the 16-byte records over
+RCCL (N > 1: prv_score_views_sharded, the C ABI's own communicator -- what prv_planner runs), rank.
+BASELINE.json configs[1].
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -43,8 +45,18 @@ L2_PEAK_GBS = 34500.0        # aggregate L2, ~34.5 TB/s
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16
 N_SIMD, MAX_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its SIMD's VALU for 4 cycles
 VALU_PEAK_GINST = N_SIMD * MAX_CLOCK_HZ / 4.0 / 1e9  # 614.4 G wave-instructions/s at the 2.4 GHz maximum clock
-ROUND_COST_FILE = os.path.join("profiles", "r02_round_cost.json")  # VALU instructions per wave-round, from the PMC pass
-TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")    # fabric-side bytes per launch, from the PMC passes
+ROUND_COST_FILE = os.path.join("profiles", "r03_round_cost.json")  # VALU instructions per wave-round, from the PMC pass
+TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")    # fabric-side bytes per launch, from the PMC passes
+# The algorithmic floor of the render kernel: wave-instructions one 64-sample wave iteration NEEDS for this algorithm
+# (fp16 table and blend as tiny-cuda-nn defines them, fp16 activations between the MLP layers), counted from the ISA of
+# render_queue64_kernel in DESIGN.md section 3 ("floor").  VALU: blend v_pk_fma_f16 128 | weights 15 per level |
+# level positions 3 per level | cell indices 3 per level | addresses 4 per dense, 26 per hashed level | accumulator ->
+# next B operand 104 v_cvt_pk_f16_f32 + 96 v_pk_max_f16 | 8 v_permlane32_swap | sample position 8 | sample selection 8 |
+# compositing 29.  MFMA: 10,240 MAC x 64 samples / 16,384 MAC per v_mfma_f32_32x32x16_f16 = 40 (48 are issued: the two
+# 64 -> 16 layers fill half of their 32-row tiles).
+def isa_floor(n_levels, n_dense):
+    valu = 128 + 15 * n_levels + 3 * n_levels + 3 * n_levels + 4 * n_dense + 26 * (n_levels - n_dense) + 200 + 8 + 8 + 8 + 29
+    return {"valu_per_64_samples": valu, "mfma_per_64_samples": 40}
 
 
 def parse_args(argv=None):
@@ -59,8 +71,13 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--field", choices=["256", "512"], default="256")
-    ap.add_argument("--scene", choices=["default", "baseline"], default="default",
-                    help="baseline = BASELINE.md section 6 literally: table U(-0.1,0.1), no density bias")
+    ap.add_argument("--scene", choices=["baseline", "dense"], default="baseline",
+                    help="baseline = BASELINE.md section 6 literally: table U(-0.1,0.1), no density bias (the headline); "
+                         "dense = table U(-4,4), density bias 3: an opaque object, early termination exercised")
+    ap.add_argument("--full-loop", action="store_true",
+                    help="BASELINE configs[4] at size, off by default (minutes): prv_planner configs/TrainInLoop.yaml semantics, 5 objects x 20 "
+                         "rounds (mode 21) + the PSNR curve and stopping criterion (mode 4), end-to-end wall-clock in a full_loop sub-object")
+    ap.add_argument("--full-loop-objects", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-training", action="store_true")
@@ -188,9 +205,11 @@ def load_json(rel):
 class Round:
     """one workload (field, scene, view set) on this rank: reference images resident, a scoring round per step()"""
 
-    def __init__(self, env, fkw, n_views, args, slots=(0, 1)):
+    def __init__(self, env, fkw, n_views, args, slots=(0, 1), comm=None):
+        """comm: the C ABI's communicator (api.Comm) -- with it a step IS prv_score_views_sharded, the product's multi-GPU
+        path; without it (one rank, or the torch.distributed fallback) the step scores the shard and gathers in Python"""
         api, planner, torch, np = env["api"], env["planner"], env["torch"], env["np"]
-        self.env, self.args, self.n_views = env, args, n_views
+        self.env, self.args, self.n_views, self.comm = env, args, n_views, comm
         ctx, rank, world = env["ctx"], env["rank"], env["world"]
         self.desc = api.L.FieldDesc(**fkw)
         self.slot = slots[0]
@@ -211,15 +230,35 @@ class Round:
     def step(self, want_stats=False):
         env = self.env
         api, planner, np = env["api"], env["planner"], env["np"]
-        _, st = env["ctx"].score_views(api.L.SCORE_PSNR_COVERAGE, [self.slot], self.cams, self.my_ids, self.opts, gt=self.gt,
-                                       records_dev=self.rec_dev, to_host=False, want_stats=want_stats)
-        if env["use_dist"]:
-            records = planner.gather_records(self.rec_dev, self.per_rank, self.n_views, device=env["device"],
-                                             interleaved=True)  # the ONE collective
-        else:  # one rank: its records are the round's records
-            records = self.rec_dev.cpu().numpy().view(api.RECORD_DTYPE)[: self.n_views].copy()
+        if self.comm is not None:
+            # the product path (include/prv.h "several GPUs"; what prv_planner `shard: views` runs): shard -> render +
+            # score -> ONE ncclAllGather of the 16-byte records on the context's stream -> view order, inside libprv_hip.so
+            records, st = self.comm.score_views(api.L.SCORE_PSNR_COVERAGE, [self.slot], self.cams, self.n_views, self.opts,
+                                                gt_shard=self.gt, interleaved=True, want_stats=want_stats)
+        else:
+            _, st = env["ctx"].score_views(api.L.SCORE_PSNR_COVERAGE, [self.slot], self.cams, self.my_ids, self.opts, gt=self.gt,
+                                           records_dev=self.rec_dev, to_host=False, want_stats=want_stats)
+            if env["use_dist"]:  # fallback only (the C ABI's communicator did not come up): torch.distributed's all-gather
+                records = planner.gather_records(self._rec_for_gather(), self.per_rank, self.n_views, device=env["gather_device"], interleaved=True)
+            else:  # one rank: its records are the round's records
+                records = self.rec_dev.cpu().numpy().view(api.RECORD_DTYPE)[: self.n_views].copy()
         order = api.rank_host(records, np.arange(self.n_views, dtype=np.int32))
         return st, records, order
+
+    def torch_gather_round(self):
+        """the cross-check of the product path: the same shard scored into rec_dev, gathered by torch.distributed"""
+        env = self.env
+        api, planner = env["api"], env["planner"]
+        env["ctx"].score_views(api.L.SCORE_PSNR_COVERAGE, [self.slot], self.cams, self.my_ids, self.opts, gt=self.gt,
+                               records_dev=self.rec_dev, to_host=False)
+        return planner.gather_records(self._rec_for_gather(), self.per_rank, self.n_views, device=env["gather_device"], interleaved=True)
+
+    def _rec_for_gather(self):
+        """the device tensor itself for RCCL; a host copy when torch.distributed runs on gloo (tests: ranks sharing a GPU)"""
+        env = self.env
+        if env.get("gather_device") is not None or not env["use_dist"]:
+            return self.rec_dev
+        return self.rec_dev.cpu().numpy().view(env["api"].RECORD_DTYPE)[: len(self.my_ids)].copy()
 
     def measure(self, steps, warmup):
         """W untimed steps, then EXACTLY `steps` timed ones between barriers; -> dict of raw measurements"""
@@ -251,9 +290,9 @@ class Round:
             prof["clock_ghz"] = ctx.render_clock_ghz()  # stamped inside the last step's render launch (prv_debug_render_clock)
         finally:
             gc.enable()
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=env["device"])
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=env.get("red_device", env["device"]))
         tot = torch.tensor([float(st.samples_evaluated), float(st.samples_nominal), float(st.rays)], dtype=torch.float64,
-                           device=env["device"])
+                           device=env.get("red_device", env["device"]))
         if env["use_dist"]:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -266,12 +305,25 @@ class Round:
         self.gt = None
 
 
-def kernel_figures(m, variant, hbm_bound):
-    """roofline object of the dominant kernel (render_queue) from a Round.measure() result.
+def lib_digest():
+    """sha256 of the libprv_hip.so this run loads: the per-round instruction counts of the committed PMC pass are a
+    property of the BINARY, so the profile file names the binary it was taken from and the line says whether they match"""
+    import hashlib
+
+    h = hashlib.sha256()
+    with open(os.path.join(ROOT, "nerf_prv_amd", "libprv_hip.so"), "rb") as fh:
+        for chunk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()[:16]
+
+
+def kernel_figures(m, variant, hbm_bound, scene, layout):
+    """roofline object of the dominant kernel (render_queue64) from a Round.measure() result.
 
     In-run quantities: launch durations (HIP events on the launch stream), evaluated samples and wave-rounds
     (counted by the kernel itself).  Per-round VALU instruction counts are a property of the binary; they come
-    from the committed PMC pass (SQ_INSTS_VALU / wave-rounds) and are labelled *_from_profile."""
+    from the committed PMC pass (SQ_INSTS_VALU / wave-rounds), are labelled *_from_profile, and carry the digest of the
+    library they were measured on next to this run's (profile_matches_binary)."""
     prof, st, k = m["prof"], m["st"], m["steps"]
     launches = max(1, prof["render_launches"])
     kernel_s = prof["render_ms"] * 1e-3 / launches
@@ -281,10 +333,16 @@ def kernel_figures(m, variant, hbm_bound):
     mfma_tflops = samples * FLOP_PER_SAMPLE / kernel_s / 1e12
     # the MFMA pipe's own occupancy: 24 instructions of 8 passes x 4 cycles per wave-round, padded slots included
     mfma_pipe_frac = rounds * MFMA_PER_ROUND * 32 / (kernel_s * N_SIMD * MAX_CLOCK_HZ)
-    cost = (load_json(ROUND_COST_FILE) or {}).get(variant)
+    key = f"{variant} {scene}"
+    cost = (load_json(ROUND_COST_FILE) or {}).get(key)
     valu_ginst = rounds * cost["valu_insts_per_round"] / kernel_s / 1e9 if cost else None
     valu_frac = valu_ginst / VALU_PEAK_GINST if cost else None
-    traffic = (load_json(TRAFFIC_FILE) or {}).get(variant)
+    traffic = (load_json(TRAFFIC_FILE) or {}).get(key)
+    # the algorithmic floor: instructions this algorithm NEEDS per sample, not the ones issued --
+    # a fatter kernel scores higher on valu_issue_frac and lower here
+    floor = isa_floor(layout["n_levels"], layout["n_dense_levels"])
+    floor_valu_frac = samples / 64.0 * floor["valu_per_64_samples"] / kernel_s / (VALU_PEAK_GINST * 1e9)
+    floor_mfma_frac = samples / 64.0 * floor["mfma_per_64_samples"] * 32 / (kernel_s * N_SIMD * MAX_CLOCK_HZ)
     out = {
         "kernel": "render_queue" + variant.replace("<", "_kernel<", 1),
         "units_per_launch": samples,
@@ -301,7 +359,14 @@ def kernel_figures(m, variant, hbm_bound):
         "mfma_useful_frac": mfma_tflops / MFMA_F16_PEAK_TFLOPS,
         "mfma_pipe_frac": mfma_pipe_frac,
         "valu_insts_per_round_from_profile": cost["valu_insts_per_round"] if cost else None,
+        "profile_lib_sha256": cost.get("lib_sha256") if cost else None,
+        "this_lib_sha256": lib_digest(),
+        "profile_matches_binary": bool(cost and cost.get("lib_sha256") == lib_digest()),
         "valu_issue_frac": valu_frac,
+        "floor": dict(floor, valu_frac=floor_valu_frac, mfma_pipe_frac=floor_mfma_frac,
+                      valu_insts_per_round=floor["valu_per_64_samples"] / 2.0,
+                      note="instructions the algorithm needs per 64-sample wave iteration (ISA count, DESIGN.md section 3) x samples "
+                           "evaluated / launch time / (1024 SIMDs x 2.4 GHz / 4): the issue-bound fraction of USEFUL work"),
         # the same bound in samples: what the SIMDs could evaluate if every issue slot carried this kernel's instruction
         # mix AND every ray slot held a live ray; achieved / ceiling = valu_issue_frac x slot_utilisation.  A leaner
         # kernel RAISES the ceiling (fewer instructions per sample), so compare rounds by samples/s, not by frac alone.
@@ -330,20 +395,25 @@ def kernel_figures(m, variant, hbm_bound):
     else:
         # cache-resident table: HBM is not the binding resource (hbm_algorithmic_frac > 1 would be a cache effect, not a
         # fraction of anything).  The binding resource is SIMD issue: VALU instructions on the 1024 SIMDs.
-        cands = {"valu_issue": valu_frac, "mfma_pipe": mfma_pipe_frac, "l2": alg_gbs / L2_PEAK_GBS}
+        cands = {"valu_issue": valu_frac if valu_frac is not None else floor_valu_frac, "mfma_pipe": mfma_pipe_frac, "l2": alg_gbs / L2_PEAK_GBS}
         bound = max((v, n) for n, v in cands.items() if v is not None)[1]
         if bound == "valu_issue":
-            out.update({"bound": "valu_issue", "achieved": valu_ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s", "frac": valu_frac})
+            # frac = the algorithmic floor's fraction of the issue peak; the issue OCCUPANCY (instructions issued, needed or
+            # not) stays beside it as valu_issue_frac
+            out.update({"bound": "valu_issue", "achieved": floor_valu_frac * VALU_PEAK_GINST, "peak": VALU_PEAK_GINST,
+                        "unit": "G wave-instr/s (algorithmic floor)", "frac": floor_valu_frac})
         elif bound == "mfma_pipe":
             out.update({"bound": "mfma", "achieved": mfma_pipe_frac * N_SIMD * MAX_CLOCK_HZ / 1e9, "peak": N_SIMD * MAX_CLOCK_HZ / 1e9,
                         "unit": "G MFMA-pipe cycles/s", "frac": mfma_pipe_frac})
         else:
             out.update({"bound": "l2", "achieved": alg_gbs, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / L2_PEAK_GBS})
         out["note"] = ("17.4 MiB table is L2 / Infinity-Cache resident, so the HBM figure is not a bound here (hbm_algorithmic_frac "
-                       "is kept for reference only).  frac = VALU wave-instructions issued per second (wave-rounds counted by the "
-                       "kernel in this run x VALU instructions per round from the PMC pass) over 1024 SIMDs x 2.4 GHz / 4 cycles; "
-                       "the clock under load is below 2.4 GHz (shader_clock_ghz_measured, stamped inside the launch), so the "
-                       "issue occupancy of the cycles that really happened is valu_issue_frac_at_measured_clock")
+                       "is kept for reference only); the binding resource is SIMD issue.  frac = VALU wave-instructions the "
+                       "algorithm NEEDS (ISA floor, DESIGN.md section 3) x samples evaluated in this run / launch time, over 1024 "
+                       "SIMDs x 2.4 GHz / 4 cycles.  valu_issue_frac = the same with the instructions actually ISSUED (wave-rounds "
+                       "counted by the kernel in this run x VALU instructions per round from the PMC pass of this binary); the clock "
+                       "under load is below 2.4 GHz (shader_clock_ghz_measured, stamped inside the launch): "
+                       "valu_issue_frac_at_measured_clock prices the cycles that really happened")
     return out
 
 
@@ -365,34 +435,24 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
-def cxx_rccl_check(env, main, timeout_s=150.0):
-    """N > 1 only, OUTSIDE the timed region: the same scoring round through the C ABI's own communicator
-    (prv_comm_create "rccl" -> ncclCommInitRank; prv_score_views_sharded -> ONE ncclAllGather of the records on the
-    context's stream; include/prv.h) -- what the C++ planner (prv_planner `shard: views`) runs -- compared with the
-    records torch.distributed gathered.  Runs on a watchdog thread: a failure or a hang here is REPORTED in the line,
-    it can not take the measurement down."""
+def comm_up(env, timeout_s=150.0):
+    """N > 1: bring up the C ABI's own communicator (prv_comm_create "rccl" -> TCP-star rendezvous + ncclCommInitRank; what
+    prv_planner `shard: views` uses) on a watchdog thread: a failure or a hang here is REPORTED, and the ranks then agree
+    (over torch.distributed) whether the timed region runs on it or on the torch.distributed fallback."""
     import threading
 
     api, ctx, rank, world = env["api"], env["ctx"], env["rank"], env["world"]
-    result = {"ok": False, "stage": "create"}
+    result = {"ok": False, "stage": "create", "comm": None}
 
     def work():
         try:
-            comm = api.Comm(ctx, rank, world, transport="rccl")
-            result["stage"] = "score"
-            rec, _ = comm.score_views(api.L.SCORE_PSNR_COVERAGE, [main.slot], main.cams, main.n_views, main.opts, gt_shard=main.gt,
-                                      interleaved=True)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                rec, _ = comm.score_views(api.L.SCORE_PSNR_COVERAGE, [main.slot], main.cams, main.n_views, main.opts, gt_shard=main.gt,
-                                          interleaved=True)
-            result["ms_per_round"] = (time.perf_counter() - t0) / 3 * 1e3
-            result["records"] = rec
+            comm = api.Comm(ctx, rank, world, transport=os.environ.get("PRV_BENCH_COMM", "rccl"))
+            result["comm"] = comm
+            result["stage"] = "barrier"
+            comm.barrier()
             result["transport"] = comm.transport
             result["stage"] = "done"
             result["ok"] = True
-            comm.barrier()
-            comm.close()
         except Exception as e:  # reported, not raised
             result["error"] = f"{type(e).__name__}: {e}"
 
@@ -403,6 +463,48 @@ def cxx_rccl_check(env, main, timeout_s=150.0):
         result["error"] = f"no answer within {timeout_s:.0f} s (stage: {result['stage']})"
         result["hung"] = True
     return result
+
+
+def full_loop(args):
+    """BASELINE configs[4] at size on this GPU: the C++ planner executable on configs/TrainInLoop.yaml semantics -- per
+    object 20 rounds of (train a fresh 5-member ensemble 2500 steps on the views chosen so far, render + score the
+    remaining candidates of the 144-view set at 80x45 spp 16, EnsembleRGBDensity arg-max; main.cpp:1718-2277), then mode 4:
+    the PSNR-vs-#views curve and the stopping criterion's label (NeRF_fit_curve.cpp:119-206).  A child process (the
+    planner owns its own HIP context); wall-clock is the metric configs[4] names."""
+    import re
+    import tempfile
+
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    if not os.path.exists(exe):
+        return {"error": "prv_planner missing: run __graft_entry__.build()"}
+    work = tempfile.mkdtemp(prefix="prv_full_loop_")
+    cfg = open(os.path.join(ROOT, "configs", "TrainInLoop.yaml")).read()
+    cfg = re.sub(r'pre_path: "[^"]*"', f'pre_path: "{work}/"', cfg)
+    cfg = re.sub(r'model_path: "[^"]*"', f'model_path: "{work}/models/"', cfg)
+    cfg = re.sub(r'viewspace_path: "[^"]*"', f'viewspace_path: "{os.path.join(ROOT, "tests", "golden", "hemisphere")}/"', cfg)
+    cfg += "\nevaluate: 1\ncoverage_view_num_max: 30\ncoverage_view_num_add: 3\n"
+    path = os.path.join(work, "cfg.yaml")
+    with open(path, "w") as fh:
+        fh.write(cfg)
+    names = [f"object_{k}" for k in range(args.full_loop_objects)]
+    out = {"objects": len(names), "rounds_per_object": 20, "config": "configs/TrainInLoop.yaml (144-view set, 5 members x 2500 steps per round, "
+           "candidates 80x45 spp 16, engine stepping rule)", "work_dir": work}
+    t_all = time.perf_counter()
+    for mode, key in ((21, "view_planning_s"), (4, "psnr_curve_and_stopping_criterion_s")):
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=3600)
+        out[key] = time.perf_counter() - t0
+        if r.returncode != 0:
+            out["error"] = f"mode {mode} exited {r.returncode}: {(r.stdout + r.stderr)[-400:]}"
+            return out
+        if mode == 21:
+            chosen = [l for l in r.stdout.splitlines() if l.startswith("chosen_nbvs:")]
+            out["views_chosen_last_object"] = [int(x) for x in chosen[-1].split(":")[1].split()] if chosen else None
+        else:
+            out["labels"] = sum(1 for l in r.stdout.splitlines() if l.startswith("label:"))
+    out["wall_clock_s"] = time.perf_counter() - t_all
+    out["seconds_per_object"] = out["wall_clock_s"] / max(1, len(names))
+    return out
 
 
 def run_rank(args):
@@ -418,14 +520,25 @@ def run_rank(args):
     dry = os.environ.get("PRV_BENCH_DRY_RUN") == "1"
     if dry:
         return dry_run(args, rank, world, np, torch, dist)
+    # tests only (tests/test_gpu_comm.py): PRV_BENCH_SHARED_GPU=1 runs N ranks on ONE GPU -- RCCL refuses ranks that share a
+    # device, so torch.distributed comes up on gloo and the C ABI's communicator on its host-staged socket transport; the
+    # code path (comm_up -> unanimous decision -> prv_score_views_sharded in the timed region -> cross-check) is the same
+    shared_gpu = os.environ.get("PRV_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
+        os.environ.setdefault("PRV_BENCH_COMM", "socket")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    red_device = torch.device("cpu") if shared_gpu else device  # where the small torch.distributed reductions live
     use_dist = world > 1 or os.environ.get("PRV_FORCE_DIST") == "1"  # the latter: exercise RCCL with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         with stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            if shared_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
             dist.barrier()  # the communicator (and its banner) comes up here, not inside the timed region
             torch.cuda.synchronize()
 
@@ -433,7 +546,24 @@ def run_rank(args):
 
     ctx = api.Context(local_rank)  # raises when libprv_hip.so / the GPU is missing: no fallback
     env = dict(api=api, planner=planner, torch=torch, dist=dist, np=np, ctx=ctx, rank=rank, world=world, device=device,
-               use_dist=use_dist)
+               use_dist=use_dist, red_device=red_device, gather_device=None if shared_gpu else device)
+
+    # N > 1: the timed region runs the PRODUCT's collective path -- the C ABI's communicator.  Every rank reports whether
+    # its side came up; one all-reduce (torch.distributed, its own stream) makes the decision unanimous.
+    comm, comm_info, any_hung = None, None, False
+    if use_dist:
+        with stdout_to_stderr():
+            comm_info = comm_up(env)
+        flags = torch.tensor([0.0 if comm_info.get("ok") else 1.0, 1.0 if comm_info.get("hung") else 0.0], device=red_device)
+        dist.all_reduce(flags, op=dist.ReduceOp.SUM)
+        n_failed, n_hung = (int(x) for x in flags.tolist())
+        any_hung = n_hung > 0
+        if n_failed == 0:
+            comm = comm_info["comm"]
+        elif comm_info.get("hung"):
+            # this rank's context has a thread stuck inside a collective: it is abandoned; the fallback measures on a fresh one
+            ctx = api.Context(local_rank)
+            env["ctx"] = ctx
 
     def field_kw(field, scene):
         kw = dict(api.FIELD_256 if field == "256" else api.FIELD_512)
@@ -441,50 +571,78 @@ def run_rank(args):
             kw.update(table_amp=0.1, density_bias=0.0)
         return kw
 
+    def layout_of(slot):
+        lay = ctx.model_layout(slot)
+        lay["n_levels"] = lay["n_dense_levels"] + lay["n_hashed_levels"]
+        return lay
+
     def variant_of(slot):
         lay = ctx.model_layout(slot)
         return f"64<{lay['kernel_features']}, {lay['kernel_dense_levels']}>"
 
     n_views = args.views_per_gpu * world if args.mode == "weak" else args.views_total
     fkw = field_kw(args.field, args.scene)
-    main = Round(env, fkw, n_views, args)
+    main = Round(env, fkw, n_views, args, comm=comm)
     m = main.measure(args.steps, args.warmup)
     k, elapsed = args.steps, m["elapsed"]
 
+    # cross-check, untimed: the records the product path gathered == the records torch.distributed gathers
+    collective = None
+    if use_dist:
+        same = None
+        if comm is not None:
+            other = main.torch_gather_round()
+            same = other.tobytes() == m["records"].tobytes()
+        collective = {"timed_path": "prv_score_views_sharded on prv_comm (C ABI, " + (comm.transport if comm else "-") + ")" if comm is not None
+                      else "torch.distributed all-gather (FALLBACK: the C ABI's communicator did not come up)",
+                      "rccl_ranks": comm.world if comm is not None else 0,
+                      "records_identical_to_torch_gather": same,
+                      "error": None if comm is not None else (comm_info or {}).get("error")}
+
     extras = {}
-    if rank == 0 and not args.no_extras:
-        solo = dict(env, world=1, rank=0, use_dist=False)  # side measurements: this GPU alone, no collective
+    solo_ok = rank == 0 and world == 1 and not args.no_extras  # side measurements only in the N = 1 run
+    if solo_ok:
+        solo = dict(env, world=1, rank=0, use_dist=False)
         # (1) the HBM-bound configuration (BASELINE configs[3]'s field) timed in the SAME run
-        if args.field == "256" and args.scene == "default":
-            r = Round(solo, field_kw("512", "default"), args.views_per_gpu, args, slots=(2, 3))
+        if args.field == "256":
+            r = Round(solo, field_kw("512", args.scene), args.views_per_gpu, args, slots=(2, 3))
             mm = r.measure(max(3, min(10, args.steps)), 2)
+            roof512 = kernel_figures(mm, variant_of(2), True, args.scene, layout_of(2))
             extras["field512"] = {
-                "workload": f"{args.views_per_gpu} views {args.width}x{args.height}, synthetic 512^3 field (L=16 F=2 log2T=21, 64 MiB table)",
+                "workload": f"{args.views_per_gpu} views {args.width}x{args.height}, synthetic 512^3 field (L=16 F=2 log2T=21, 64 MiB table), scene {args.scene}",
                 "value": mm["ev_all"] * mm["steps"] / mm["elapsed"], "unit": "ray-samples/s", "steps": mm["steps"],
                 "ms_per_step": mm["elapsed"] / mm["steps"] * 1e3,
                 "samples_evaluated_per_step": mm["st"].samples_evaluated,
-                "roofline": kernel_figures(mm, variant_of(2), hbm_bound=True),
+                "roofline": roof512,
             }
+            # lifted to top-level keys as well: a parser that keeps only scalars keeps these
+            extras["field512_value"] = extras["field512"]["value"]
+            extras["field512_frac"] = roof512["frac"]
+            extras["field512_avg_launch_ms"] = roof512["avg_launch_ms"]
             r.close()
-        # (2) the scene BASELINE.md section 6 specifies literally (table U(-0.1,0.1), no density bias): rays do not
-        #     terminate early there, every occupied sample is evaluated
-        if args.scene == "default":
-            r = Round(solo, field_kw(args.field, "baseline"), args.views_per_gpu, args, slots=(2, 3))
-            mm = r.measure(max(2, min(5, args.steps)), 1)
-            extras["scene_baseline"] = {
-                "workload": f"{args.views_per_gpu} views, table U(-0.1,0.1), density_bias 0 (BASELINE.md section 6)",
-                "value": mm["ev_all"] * mm["steps"] / mm["elapsed"], "unit": "ray-samples/s", "steps": mm["steps"],
-                "ms_per_step": mm["elapsed"] / mm["steps"] * 1e3,
-                "samples_evaluated_per_step": mm["st"].samples_evaluated,
-                "samples_per_ray": mm["st"].samples_evaluated / max(1, mm["st"].rays),
-                "roofline": kernel_figures(mm, variant_of(2), hbm_bound=args.field == "512"),
-            }
-            r.close()
+        # (2) the other scene: dense (table U(-4,4), density bias 3: an opaque object, rays terminate early) when the
+        #     headline is BASELINE.md section 6's nearly transparent one, and the other way round
+        other = "dense" if args.scene == "baseline" else "baseline"
+        r = Round(solo, field_kw(args.field, other), args.views_per_gpu, args, slots=(2, 3))
+        mm = r.measure(max(2, min(5, args.steps)), 1)
+        extras["scene_" + other] = {
+            "workload": f"{args.views_per_gpu} views, " + ("table U(-4,4), density_bias 3 (opaque object, early termination)" if other == "dense"
+                                                        else "table U(-0.1,0.1), density_bias 0 (BASELINE.md section 6)"),
+            "value": mm["ev_all"] * mm["steps"] / mm["elapsed"], "unit": "ray-samples/s", "steps": mm["steps"],
+            "ms_per_step": mm["elapsed"] / mm["steps"] * 1e3,
+            "samples_evaluated_per_step": mm["st"].samples_evaluated,
+            "samples_per_ray": mm["st"].samples_evaluated / max(1, mm["st"].rays),
+            "roofline": kernel_figures(mm, variant_of(2), args.field == "512", other, layout_of(2)),
+        }
+        r.close()
+        # (3) the reference's OWN scoring round: 540 candidates at 80x45, spp 16, 5 members, EnsembleRGBDensity
+        #     (main.cpp:1796-1806, run.py:48,304, Share_Data.hpp:505-510), in both stepping rules
+        extras["reference_round"] = reference_round(env, field_kw(args.field, "dense"))
 
     # BASELINE config 1 analogue (the reference's CPU render path, main.cpp:98-284): first occupied voxel
     # per ray over the same views; GPU (prv_first_hit) here, the oracle's scalar DDA in cpu_baseline
     first_hit = None
-    if rank == 0 and not args.no_extras:
+    if solo_ok:
         cells = ctx.first_hit(0, main.cams, main.my_ids, args.width, args.height)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -498,10 +656,11 @@ def run_rank(args):
     # the other half of an NBV iteration: in-process training of the field (run.py:185-208), outside the timed
     # region and not part of `value`: a fresh field trained on this rank's reference images
     training = None
-    if rank == 0 and not args.no_training:
+    if rank == 0 and world == 1 and not args.no_training:
         tcams = ctx.cameras_from_matrices(np.asarray(main.tms)[main.my_ids], main.fov_x, args.width, args.height, main.scale,
                                           main.offset)
-        u8, _ = ctx.render_rgba8(1, tcams, None, api.render_opts(args.width, args.height, args.samples, 1, 1e-4,
+        ctx.synthetic_model(5, api.L.FieldDesc(**field_kw(args.field, "dense")), SEED_B)  # an opaque object to learn
+        u8, _ = ctx.render_rgba8(5, tcams, None, api.render_opts(args.width, args.height, args.samples, 1, 1e-4,
                                                                 background=(0, 0, 0, 0)))
         tdesc = api.L.FieldDesc(**dict(fkw, table_amp=1e-4, density_bias=0.0))
         ctx.fresh_model(4, tdesc, 0x1234)
@@ -522,21 +681,10 @@ def run_rank(args):
         tr.close()
         tcams.close()
 
-    # the C ABI's own RCCL round, LAST (all ranks; rank 0 arrives after its side measurements, the others wait in the
-    # rendezvous): whatever happens in here can no longer disturb a measurement
-    cxx = None
-    if use_dist and os.environ.get("PRV_BENCH_NO_CXX_COMM") != "1":  # N > 1 (or PRV_FORCE_DIST=1: one rank, same calls)
-        with stdout_to_stderr():
-            cxx = cxx_rccl_check(env, main)
-        if rank == 0:
-            same = bool(cxx.get("ok")) and cxx["records"].tobytes() == m["records"].tobytes()
-            extras["cxx_rccl_round"] = {"ok": bool(cxx.get("ok")), "records_identical_to_torch_gather": same,
-                                        "transport": cxx.get("transport"), "ms_per_round": cxx.get("ms_per_round"),
-                                        "error": cxx.get("error"),
-                                        "what": "the same round through prv_score_views_sharded (C ABI: ncclAllGather of the "
-                                                "records inside libprv_hip.so), untimed check"}
     if rank == 0:
-        roof = kernel_figures(m, variant_of(0), hbm_bound=args.field == "512")
+        roof = kernel_figures(m, variant_of(0), args.field == "512", args.scene, layout_of(0))
+        scene_words = ("BASELINE.md section 6 scene: table U(-0.1,0.1), Xavier MLPs, no density bias, analytic occupancy (4 spheres)"
+                       if args.scene == "baseline" else "dense scene: table U(-4,4), density bias 3, analytic occupancy (4 spheres)")
         out = {
             "metric": "ray-samples/s (field evaluations composited; candidate views rendered + scored)",
             "value": m["ev_all"] * k / elapsed,
@@ -551,24 +699,29 @@ def run_rank(args):
             "dtype": "f16",
             "dtype_note": "fp16 table, blend and MLP operands (MFMA f16 -> f32 accumulate); f32 rays, positions, compositing",
             "data": "synthetic",
-            "parity": "vs own CPU oracle (oracle/), unpinned: the reference's render arithmetic lives in instant-ngp, absent from its tree",
+            "parity": "vs own CPU oracle (oracle/), unpinned: the reference's render arithmetic lives in instant-ngp, absent from its tree; "
+                      "this workload is gated whole view by whole view in tests/test_gpu_wholeview.py",
             "config": {
                 "workload": f"render+score {len(main.my_ids)} hemisphere views/GPU, {args.width}x{args.height}, "
                             f"{args.samples} samples/ray, synthetic {args.field}^3 hash-grid field "
-                            f"(L={fkw['n_levels']} F={fkw['n_features']} log2T={fkw['log2_hashmap']}"
-                            f"{', scene baseline: table U(-0.1,0.1), no bias' if args.scene == 'baseline' else ''}), "
+                            f"(L={fkw['n_levels']} F={fkw['n_features']} log2T={fkw['log2_hashmap']}; {scene_words}), "
                             "PSNR+coverage score vs resident reference images",
+                "scene": args.scene,
+                "samples_per_ray": args.samples,
                 "views_total": n_views,
                 "parallelism": (f"views sharded {args.views_per_gpu}/GPU" if args.mode == "weak" else
                                 f"{n_views} views sharded over {world} GPUs") + ", interleaved; one all-gather of 16-B records",
             },
-            "rccl_ranks": world if use_dist else 0,
+            "rccl_ranks": (comm.world if comm is not None and comm.transport == "rccl" else (world if use_dist and comm is None and not shared_gpu else 0)),
+            "comm_ranks": comm.world if comm is not None else 0,  # prv_comm_world of the communicator the timed region ran on
+            "collective": collective,
             "nominal_ray_samples_per_s": m["nom_all"] * k / elapsed,
             "rays_per_s": m["rays_all"] * k / elapsed,
             "views_scored_per_s": n_views * k / elapsed,
             "samples_evaluated_per_step_per_gpu": m["st"].samples_evaluated,
+            "samples_live_per_step_per_gpu": m["st"].samples_live,
             "samples_nominal_per_step_per_gpu": m["st"].samples_nominal,
-            "samples_per_ray": m["st"].samples_evaluated / max(1, m["st"].rays),
+            "evaluated_samples_per_ray": m["st"].samples_evaluated / max(1, m["st"].rays),
             "ranking_head": [int(x) for x in m["order"][:8]],
             "roofline": roof,
             "first_hit": first_hit,
@@ -577,15 +730,53 @@ def run_rank(args):
         out.update(extras)
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, fkw, main.tms, main.scale, main.offset, main.fov_x)
+        if args.full_loop and world == 1:
+            out["full_loop"] = full_loop(args)
         print(json.dumps(out), flush=True)
-    if cxx is not None and cxx.get("hung"):
-        os._exit(0)  # a watchdog thread is still stuck inside a collective: the line is out, leave without joining it
+    if any_hung:
+        # a rank has a thread stuck inside a collective on an abandoned context: the line (measured on the fallback) is out;
+        # nobody enters another barrier, and the job does not pretend to have ended cleanly
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(3)
+    if comm is not None:
+        comm.barrier()
+        comm.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     main.close()
     ctx.close()
     return 0
+
+
+def reference_round(env, fkw):
+    """the reference's own scoring round on this GPU: 540 candidate views at 80x45, 16 sub-samples per pixel, a 5-member
+    ensemble, EnsembleRGBDensity -- once with 128 uniform samples per ray, once with the engine's stepping rule"""
+    api, planner, torch, np, ctx = env["api"], env["planner"], env["torch"], env["np"], env["ctx"]
+    n_views, members = 540, 5
+    desc = api.L.FieldDesc(**fkw)
+    for e in range(members):
+        ctx.synthetic_model(2 + e, desc, SEED_A + 16 + e)
+    pts = planner.hemisphere_generate(n_views)
+    fov_x = 2.0 * np.arctan(0.5 * 1280 / 915.60668945312500)
+    tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
+    cams = ctx.cameras_from_matrices(tms, fov_x, 80, 45, scale, offset)
+    slots = list(range(2, 2 + members))
+    out = {"workload": "540 views x 80x45 x 16 spp x 5 members, EnsembleRGBDensity (main.cpp:1796-1806, 2099-2161; run.py:48,304), min_T 0.01"}
+    for name, spr in (("fixed_128", 128), ("ngp_step", 0)):
+        opts = api.engine_render_opts(80, 45, spr, 16, 0.01, background=(0, 0, 0, 1))
+        rec, st = ctx.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, slots, cams, None, opts, want_stats=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            rec, _ = ctx.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, slots, cams, None, opts)
+        dt = (time.perf_counter() - t0) / 3
+        out[name] = {"ms_per_round": dt * 1e3, "views_per_s": n_views / dt, "ray_samples_per_s": st.samples_evaluated / dt,
+                     "evaluated_samples_per_ray": st.samples_evaluated / max(1, st.rays), "live_samples_per_ray": st.samples_live / max(1, st.rays),
+                     "best_view": int(ctx.argmax(rec, np.arange(n_views)))}
+    cams.close()
+    return out
 
 
 def dry_run(args, rank, world, np, torch, dist):

@@ -124,6 +124,14 @@ int prv_abi_version(void);
 /* enqueue all work on this hipStream_t from now on; NULL is HIP's legacy default stream.
  * Until this is called the context uses a private non-blocking stream. */
 int prv_set_stream(prv_ctx* ctx, void* hip_stream);
+/* For a host process that OWNS the GPU runtime (prv_planner) and is about to return from main: ends its use of the GPU
+ * in a defined order.  Every context must have been destroyed (PRV_E_STATE otherwise); synchronises and resets every
+ * device a context was created on (hipDeviceReset), so the HIP runtime's own state -- its streams, signal pools and
+ * worker threads -- is torn down HERE, while the process is still intact, and the static destructors that run after
+ * main find nothing left to race with.  (The reference's boundary had no such step: its GPU work lived in child Python
+ * processes, train_server.py:12.)  A process that shares the runtime with another library (Python + torch) must NOT
+ * call this. */
+int prv_runtime_shutdown(void);
 int prv_synchronize(prv_ctx* ctx);
 int prv_device_count(void);
 /* method 5's ranking key is  -PSNR_dB + weight * mean_pixels((1 - alpha)^2) : the worst-reconstructed and

@@ -96,6 +96,7 @@ SIGNATURES = {
     "prv_last_error": (C.c_char_p, [_vp]),
     "prv_abi_version": (_i, []),
     "prv_set_stream": (_i, [_vp, _vp]),
+    "prv_runtime_shutdown": (_i, []),
     "prv_synchronize": (_i, [_vp]),
     "prv_set_coverage_weight": (_i, [_vp, C.c_double]),
     "prv_device_count": (_i, []),

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -29,6 +30,8 @@ using namespace prv;
 namespace {
 
 thread_local std::string g_create_error;
+std::atomic<int> g_live_contexts{0};        // prv_runtime_shutdown refuses while a context is alive
+std::atomic<unsigned long long> g_devices_used{0}; // bit d: a context was created on device d
 
 struct Buffer {
   void* p = nullptr;
@@ -455,7 +458,7 @@ CamDev cam_at(const prv_camset* cs, int i, int w, int h) {
 }
 
 constexpr size_t kStatOffset = 1024;                        // counters buffer: heads 0..511, counts 512..1023, then the statistics
-constexpr size_t kCountersBytes = kStatOffset + 16 * 8; // {evaluated, wave rounds, clock sums and stamps, live samples}, spare words
+constexpr size_t kCountersBytes = kStatOffset + 72 * 8; // {evaluated, wave rounds, clock sums and stamps}, then 8 live-sample shards a cache line apart
 
 
 // The render of one batch of views into out_f32 (+ optional out_u8).  Views are dealt to
@@ -628,14 +631,15 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
 
 int fetch_stats(prv_ctx* c, const prv_render_opts* o, int n_views, int n_models, prv_stats* st) {
   if (!st) return PRV_OK;
-  unsigned long long ev[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ev[72] = {0};
   HIPCHK(c, hipMemcpyAsync(ev, (char*)c->counters.p + kStatOffset, sizeof(ev), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   st->wave_rounds = ev[1];
   st->rays = (uint64_t)n_views * n_models * o->width * o->height * o->spp;
   st->samples_nominal = st->rays * (uint64_t)(o->step_mode == PRV_STEP_NGP ? kNgpMaxSteps : o->samples_per_ray);
   st->samples_evaluated = ev[0];
-  st->samples_live = ev[6];
+  st->samples_live = 0;
+  for (int s = 0; s < 8; s++) st->samples_live += ev[8 * (1 + s)]; // the march pass's sharded counter
   return PRV_OK;
 }
 
@@ -684,6 +688,8 @@ int prv_create(prv_ctx** out, int device_id) try {
   if (const char* s = getenv("PRV_MERGE_MAX")) c->merge_max = std::min(31, std::max(0, atoi(s)));
   if (const char* s = getenv("PRV_POOL")) c->pool_on = atoi(s) != 0 ? 1 : 0;
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
+  g_live_contexts.fetch_add(1);
+  if (device_id < 64) g_devices_used.fetch_or(1ull << device_id);
   *out = c;
   return PRV_OK;
 } catch (...) { return caught(nullptr); }
@@ -720,6 +726,23 @@ void prv_destroy(prv_ctx* c) {
   for (auto& b : c->img_u8) release(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+  g_live_contexts.fetch_sub(1);
+}
+
+int prv_runtime_shutdown(void) {
+  if (g_live_contexts.load() != 0) {
+    g_create_error = "prv_runtime_shutdown: " + std::to_string(g_live_contexts.load()) + " context(s) are still alive";
+    return PRV_E_STATE;
+  }
+  const unsigned long long used = g_devices_used.exchange(0ull);
+  for (int d = 0; d < 64; d++) {
+    if (!((used >> d) & 1ull)) continue;
+    if (hipSetDevice(d) != hipSuccess) continue;
+    (void)hipDeviceSynchronize();
+    (void)hipDeviceReset();
+  }
+  (void)hipGetLastError();
+  return PRV_OK;
 }
 
 int prv_set_stream(prv_ctx* c, void* s) try {

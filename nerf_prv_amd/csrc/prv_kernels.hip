@@ -289,11 +289,13 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
     const uint32_t n_words = (uint32_t)__popcll(b) * kRecordWords;
     for (uint32_t i = (uint32_t)lane; i < n_words; i += 64u) dst[i] = st[i];
   }
-  if (b != 0ull) { // statistics: the march count (live samples before any early termination), one atomic per wave
+  if (b != 0ull) { // statistics: the march count (live samples before any early termination), one atomic per wave,
+    // on a counter sharded like the queue's (~10^5 atomics on ONE word cost 0.3 ms of a 0.65 ms launch)
     uint32_t tot = n_live;
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) tot += (uint32_t)__shfl_xor((int)tot, sh);
-    if (lane == 0) atomicAdd(P.stat + 6, (unsigned long long)tot);
+    const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 7u;
+    if (lane == 0) atomicAdd(P.stat + 8u * (1u + shard), (unsigned long long)tot); // 64 bytes apart: stat[8], stat[16], ...
   }
   if (!live && valid) {
     // dead ray: contributes exactly zero to its pixel

@@ -30,7 +30,7 @@ struct MarchParams {
   int step_mode; // PRV_STEP_FIXED_S | PRV_STEP_NGP
   void* queue;
   uint4* queue_ext;      // PRV_STEP_NGP: kExtChunks mask chunks per queue slot
-  unsigned long long* stat; // statistics block: [6] += live samples (the march count)
+  unsigned long long* stat; // statistics block: [8 (1 + s)] += live samples (the march count), 8 shards a cache line apart
   uint32_t* queue_count; // n_seg counters, 64 bytes apart: records appended to region s of the queue
   int n_seg;             // the queue is n_seg regions of seg_cap records; a block appends to region (linear block id % n_seg)
   uint32_t seg_cap;

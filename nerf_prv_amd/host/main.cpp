@@ -707,11 +707,12 @@ static void segv_trace(int sig) {
 
 static int run(int argc, char** argv);
 
-// Every context has been destroyed and every file closed when run() returns.  What is left of a normal exit is the
-// static teardown of the HIP / HSA runtime, and that crashed (SIGSEGV after the last line of output, about once in a
-// thousand runs, only seen while another process was using the same GPU; scripts/gpu/r02_ay.sh): the exit code of a
-// finished planner run must not depend on it, so the streams are flushed and the process leaves with _exit.
-// PRV_PLANNER_EXIT=normal restores the ordinary return from main.
+// Every context has been destroyed and every file closed when run() returns.  What a normal exit then adds is the static
+// teardown of the HIP / HSA runtime, and in round 2 that crashed about once in a thousand exits while another process
+// shared the GPU (scripts/gpu/r02_ay.sh).  The runtime is therefore shut down EXPLICITLY, in order, before main
+// returns: prv_runtime_shutdown synchronises and resets the device (hipDeviceReset) while the process is intact, so the
+// runtime's streams, signal pools and worker threads are gone before any static destructor runs; then main returns
+// normally.  PRV_PLANNER_EXIT=quick keeps round 2's way out (flush + _exit) for comparison runs (scripts/gpu/r03_exit.sh).
 int main(int argc, char** argv) {
   if (getenv("PRV_SEGV_TRACE")) {
     signal(SIGSEGV, segv_trace);
@@ -720,7 +721,10 @@ int main(int argc, char** argv) {
   }
   const int rc = run(argc, argv);
   const char* how = getenv("PRV_PLANNER_EXIT");
-  if (how && std::string(how) == "normal") return rc;
+  if (!how || std::string(how) != "quick") {
+    if (!how || std::string(how) != "noreset") (void)prv_runtime_shutdown(); // "noreset": plain return, the round-2 crash's setting
+    return rc;
+  }
   // a profiler writes its files from an exit handler, which _exit would skip
   if (const char* pre = getenv("LD_PRELOAD"))
     if (std::string(pre).find("rocprof") != std::string::npos) return rc;

@@ -10,6 +10,8 @@ ap.add_argument("--samples", type=int, default=128)
 ap.add_argument("--field", default="256")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--bias", type=float, default=None)
+ap.add_argument("--scene", choices=["baseline", "dense"], default="baseline", help="bench.py's scenes: BASELINE.md section 6 literally | opaque object")
+ap.add_argument("--step", choices=["fixed", "ngp"], default="fixed")
 ap.add_argument("--tag", default="")
 ap.add_argument("--width", type=int, default=0)
 ap.add_argument("--height", type=int, default=0)
@@ -21,13 +23,14 @@ import torch
 from nerf_prv_amd import api, planner
 ctx = api.Context(0)
 fd = dict(api.FIELD_256 if args.field == "256" else api.FIELD_512)
+if args.scene == "baseline": fd.update(table_amp=0.1, density_bias=0.0)
 if args.bias is not None: fd["density_bias"] = args.bias
 ctx.synthetic_model(0, api.L.FieldDesc(**fd), 0x5EED0001)
 pts = planner.hemisphere_generate(args.views)
 fov = 2.0 * np.arctan(0.5 * 1280 / 915.60668945312500)
 tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
 cams = ctx.cameras_from_matrices(tms, fov, W, H, scale, offset)
-opts = api.render_opts(W, H, args.samples, args.spp, args.min_t)
+opts = api.engine_render_opts(W, H, args.samples if args.step == "fixed" else 0, args.spp, args.min_t)
 out = torch.empty((args.views, H, W, 4), dtype=torch.float32, device="cuda")
 _, st = ctx.render(0, cams, None, opts, out=out)
 ctx.profile_begin()
@@ -43,7 +46,7 @@ if clocks:
 dt = (time.perf_counter() - t0) / args.reps
 p = ctx.profile_end()
 rms, mms = p["render_ms"] / args.reps, p["march_ms"] / args.reps
-print(f"{args.tag} BPC={os.environ.get('PRV_BLOCKS_PER_CU','auto')} RM={os.environ.get('PRV_REFILL_MIN','8')} "
+print(f"{args.tag} scene={args.scene} step={args.step} BPC={os.environ.get('PRV_BLOCKS_PER_CU','auto')} "
       f"eval_exact={st.samples_evaluated} rounds={st.wave_rounds} eval={st.samples_evaluated/1e6:.1f}M ({100*st.samples_evaluated/st.samples_nominal:.2f}% of nominal) "
       f"render={rms:.2f}ms march={mms:.2f}ms wall={dt*1e3:.2f}ms "
       f"kernel_rate={st.samples_evaluated/rms/1e6:.2f} Gsamp/s wall_rate={st.samples_evaluated/dt/1e9:.2f} Gsamp/s "

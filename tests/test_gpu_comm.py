@@ -227,3 +227,34 @@ def test_communicator_outliving_its_context_is_inert():
     assert lib.prv_comm_barrier(h) == api.L.PRV_E_INVALID  # inert: an error code, no crash
     lib.prv_comm_destroy(h)
     comm.handle = None
+
+
+def test_bench_two_ranks_time_the_product_collective_path(tmp_path):
+    """`python bench.py --gpus 2`: the launcher starts two ranks; each brings up the C ABI's communicator and the TIMED
+    region is prv_score_views_sharded (render + score the shard, ONE all-gather of the records inside libprv_hip.so), with
+    torch.distributed's gather as the untimed cross-check.  On this one-GPU box the ranks share the device
+    (PRV_BENCH_SHARED_GPU=1: gloo + the socket transport, RCCL refuses ranks that share a GPU); an 8-GPU node runs the
+    same code with RCCL and needs no change."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PRV_BENCH_SHARED_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--views-per-gpu", "3",
+           "--width", "96", "--height", "80", "--no-extras", "--no-training", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["config"]["views_total"] == 6 and two["value"] > 0
+    col = two["collective"]
+    assert col["timed_path"].startswith("prv_score_views_sharded") and "socket" in col["timed_path"]
+    assert col["records_identical_to_torch_gather"] is True and col["error"] is None and two["comm_ranks"] == 2
+    # the same six views on one rank: the same ranking
+    one = subprocess.run(cmd[:3] + ["1"] + cmd[4:8] + ["--views-per-gpu", "6"] + cmd[10:], capture_output=True, text=True,
+                         env={k: v for k, v in env.items() if k != "PRV_BENCH_SHARED_GPU"}, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stdout + one.stderr
+    ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert ref["ranking_head"] == two["ranking_head"] and ref["collective"] is None

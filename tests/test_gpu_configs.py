@@ -13,6 +13,7 @@ the bar meaningful on near-black pixels written down in tests/util.py."""
 import json
 import os
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -259,3 +260,41 @@ def test_full_loop_two_objects_two_ranks_then_the_stopping_criterion(ctx, tmp_pa
         assert label[0] in ("Converged 1", "Converged 0") and any(l.startswith("gap 2% ") for l in label)
         assert sum(l.startswith("gradient ") for l in label) == 20
         assert "label: converged" in outs[r][0]
+
+
+def test_full_size_loop_one_object_twenty_rounds_decisions_match_the_oracle(oracle, tmp_path):
+    """configs[4] at size for ONE object: configs/TrainInLoop.yaml as it stands -- 144-view set, every round a fresh
+    5-member ensemble trained 2500 steps on the 1280x720 images of the views chosen so far, the other candidates rendered
+    at 80x45 spp 16 with the engine's stepping rule by every member, EnsembleRGBDensity arg-max (main.cpp:2099-2161), 20
+    rounds -- through the executable, with `save_renders: 1` leaving the PNG tree the reference's run.py leaves
+    (main.cpp:1676-1684).  The checker then plays main.cpp:2105-2160 on those files with the ORACLE's score: every one
+    of the 20 decisions must be the oracle's arg-max over the planner's own renders (ties to the lowest id), and the
+    views must be 21 different ones."""
+    from PIL import Image
+
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    cfg = open(os.path.join(ROOT, "configs", "TrainInLoop.yaml")).read()
+    cfg = cfg.replace('pre_path: "./prv_out/"', f'pre_path: "{tmp_path}/"').replace('model_path: "./models/"', f'model_path: "{tmp_path}/models/"')
+    cfg = cfg.replace('viewspace_path: "./tests/golden/hemisphere/"', f'viewspace_path: "{os.path.join(GOLD, "hemisphere")}/"')
+    assert str(tmp_path) in cfg and "num_of_max_iteration: 20" in cfg and "n_steps: 2500" in cfg and "num_of_views : 144" in cfg
+    path = tmp_path / "cfg.yaml"
+    path.write_text(cfg + "\nsave_renders: 1\n")
+    t0 = time.perf_counter()
+    out = subprocess.run([exe, str(path)], input="21\nsynthetic_object\n-1\n", text=True, capture_output=True, timeout=900)
+    wall = time.perf_counter() - t0
+    assert out.returncode == 0, out.stdout + out.stderr
+    chosen = [int(x) for x in [l for l in out.stdout.splitlines() if l.startswith("chosen_nbvs:")][-1].split(":")[1].split()]
+    assert len(chosen) == 21 and len(set(chosen)) == 21 and chosen[0] == 62  # 144.txt: row 62 is the (0,0,1) view
+    save = tmp_path / "Compare" / "ShapeNet" / "synthetic_object_m3_v1_t0"
+    for it in range(20):
+        scores = {}
+        for v in range(144):
+            if v in chosen[: it + 1]:
+                continue
+            imgs = [np.asarray(Image.open(save / "render" / str(it) / f"ensemble_{e}" / f"rgbaClip_{v}.png").convert("RGBA")) for e in range(5)]
+            assert imgs[0].shape == (45, 80, 4)
+            scores[v] = oracle.score_ensemble_rgbdensity(imgs)
+        ids = np.array(sorted(scores), np.int32)
+        want = oracle.argmax(np.array([scores[int(v)] for v in ids]), ids)
+        assert chosen[it + 1] == want, (it, chosen[it + 1], want)
+    print(f"configs[4], one object: {wall:.1f} s wall-clock for 20 rounds incl. process start and {20 * 5 * 143} PNG writes")

@@ -92,9 +92,9 @@ def test_snapshot_loads_and_renders_like_the_same_arrays(ctx, oracle, tmp_path, 
     ngp = api.engine_render_opts(w, h, 0, 1, 1e-2)
     c, st_n = ctx.render(0, cams, [2], ngp)
     assert int(st_n.samples_live) == f.march_count(ocam, w, h, 0, step_mode=oracle.STEP_NGP)
-    want_n, _ = f.render(ocam, w, h, 0, 1, 1e-2, threads=8, rows=rows, step_mode=oracle.STEP_NGP)
-    util.assert_pixels_close(c[0].cpu().numpy()[rows[0]:rows[1]], want_n[rows[0]:rows[1]])
-    assert want_n[rows[0]:rows[1], :, 3].max() > 0.2
+    wants_n = [f.render(ocam, w, h, 0, 1, t, threads=8, rows=rows, step_mode=oracle.STEP_NGP)[0] for t in util.termination_variants(1e-2)]
+    util.assert_pixels_close_any(c[0].cpu().numpy()[rows[0]:rows[1]], [x[rows[0]:rows[1]] for x in wants_n])
+    assert wants_n[0][rows[0]:rows[1], :, 3].max() > 0.2
     # and out again: the writer's file is the reader's input
     out = tmp_path / "saved.msgpack"
     ctx.save_ingp(0, out)

@@ -55,3 +55,29 @@ def assert_pixels_close(got, want, rtol=PIX_RTOL):
     err = pixel_rel_err(got, want)
     worst = np.unravel_index(np.argmax(err), err.shape)
     assert err.max() <= rtol, f"pixel {worst}: got {np.asarray(got)[worst]!r}, want {np.asarray(want)[worst]!r}, relative error {err.max():.3e} (floor {PIX_FLOOR})"
+
+
+# Early termination is a threshold: a ray stops at the first sample after which T < min_T, and T on the GPU differs from
+# the oracle's in its last bits (MFMA accumulation order, hardware exp2), so a ray whose T lands within a hair of min_T
+# stops one sample earlier or later than the oracle's -- the pixel then differs by that one sample's contribution,
+# at most alpha * min_T.  With min_T = 1e-4 that is far below the pixel bar; with the engine's default 0.01 (run.py:304
+# renders with it) it is not.  Such renders are therefore compared per pixel with the oracle at min_T AND at
+# min_T (1 +- TERMINATION_SLACK): every pixel must match ONE of the three within the usual 1e-3 -- a ray may take either
+# side of a threshold it hits to within 1 % (1e-4 in T: a tenth of what the alpha channel's own bar allows).
+TERMINATION_SLACK = 1e-2
+
+
+def termination_variants(min_T):
+    return [min_T, min_T * (1.0 + TERMINATION_SLACK), min_T * (1.0 - TERMINATION_SLACK)]
+
+
+def assert_pixels_close_any(got, wants, rtol=PIX_RTOL):
+    """got: (..., 4); wants: renders of the same image at the thresholds of termination_variants().  Every PIXEL (all four
+    channels together) must match one of them."""
+    got = np.asarray(got)
+    errs = np.stack([pixel_rel_err(got, w).max(axis=-1) for w in wants])  # (variant, ...)
+    best = errs.min(axis=0)
+    worst = np.unravel_index(np.argmax(best), best.shape)
+    assert best.max() <= rtol, (f"pixel {worst}: got {got[worst]!r}, want {np.asarray(wants[0])[worst]!r} (or its termination variants), "
+                                f"relative error {best.max():.3e}; {int((errs[0] > rtol).sum())} pixels match only a variant")
+    return int((errs[0] > rtol).sum())
