@@ -343,6 +343,15 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   f.n_dense_levels = 0;
   while (f.n_dense_levels < d.n_levels && !lv[f.n_dense_levels].hashed) f.n_dense_levels++;
   if (getenv("PRV_NO_PAIR")) f.n_dense_levels = 0; // tests: every level through the generic (clamped, 8-load) gather
+  // the hashed levels' shared constants (every hashed level has T entries of ebytes): valid for the kernel's shared path
+  // when no hashed level is finer than its table, so that (x << esh) needs no mask
+  f.hash_my_b = (2654435761u * ebytes) & 0xffffffu;
+  f.hash_mz_b = (805459861u * ebytes) & 0xffffffu;
+  f.hash_m_b = (uint32_t)(((1ull << d.log2_hashmap) - 1ull) * ebytes);
+  f.hash_shared = 1;
+  for (int l = 0; l < d.n_levels; l++)
+    if (lv[l].hashed && (lv[l].res > lv[l].size || l < f.n_dense_levels)) f.hash_shared = 0;
+  if (getenv("PRV_NO_PAIR")) f.hash_shared = 0;
   for (int l = 0; l < d.n_levels; l++) {
     LevelDev& L = f.levels[l];
     L.scale = lv[l].scale;

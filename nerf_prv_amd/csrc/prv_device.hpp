@@ -51,6 +51,13 @@ struct FieldDev {
   LevelDev levels[kMaxLevels];
   int n_levels, n_features, occ_res;
   int n_dense_levels; // leading levels that are physically dense (clamp-free one-add neighbours)
+  // Every hashed level has the same table size T and entry size, hence the same three hash constants (LevelDev::my_b,
+  // mz_b, m_b): the render kernel reads THESE for its hashed levels -- three scalar registers for all of them instead of
+  // three per level (the kernel keeps every level's constants in SGPRs and was spilling 45..117 of them).
+  // hash_shared = 1: they are valid for every hashed level and no hashed level is finer than its table (res <= T, so
+  // the x term (x << esh) lies inside the mask by itself).
+  uint32_t hash_my_b, hash_mz_b, hash_m_b;
+  int hash_shared;
   float density_bias;
   float occ_lo[3], occ_hi[3]; // bounding box of the occupied cells, grown by one cell (march pass clips to it)
 };
@@ -299,9 +306,15 @@ __device__ __forceinline__ half2v cvt_pk_f16(float lo, float hi) { // {RNE(lo), 
   return r;
 }
 
-template <int F, bool DENSE>
-__device__ __forceinline__ void encode_level2(const uint16_t* __restrict__ table, const LevelDev& L, float px, float py, float pz,
-                                              half2v out[F / 2]) {
+struct HashConsts { // the field's shared hash constants, wave-uniform (FieldDev::hash_*)
+  uint32_t my_b, mz_b, m_b;
+};
+enum { kLevelDense = 0, kLevelHashedShared = 1, kLevelGeneric = 2 };
+
+template <int F, int KIND>
+__device__ __forceinline__ void encode_level2(const uint16_t* __restrict__ table, const LevelDev& L, const HashConsts& H, float px,
+                                              float py, float pz, half2v out[F / 2]) {
+  constexpr bool DENSE = KIND == kLevelDense;
   constexpr int ESH = F == 4 ? 3 : 2;
   const float pos[3] = {fmaf(L.scale, px, 0.5f), fmaf(L.scale, py, 0.5f), fmaf(L.scale, pz, 0.5f)};
   uint32_t c0[3];
@@ -329,6 +342,24 @@ __device__ __forceinline__ void encode_level2(const uint16_t* __restrict__ table
         vw[2 * q][k] = e.w[k];
         vw[2 * q + 1][k] = e.w[F / 2 + k];
       }
+    }
+  } else if (KIND == kLevelHashedShared) {
+    // hashed level, the field's shared constants: byte offset inside the level = ((x << esh) ^ (y * my) ^ (z * mz)) & m.
+    // The x term needs no mask (res <= T, host-checked), the level's offset goes into a SCALAR base pointer, and the three
+    // terms meet in one v_bitop3_b32 (xor3) per corner: per level 3 add + 3 min + 2 shift + 4 mul24 + 4 and + 8 xor3.
+    uint32_t c1[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) c1[a] = min(c0[a] + 1u, L.res_m1);
+    const char* base = reinterpret_cast<const char*>(table) + L.off_b;
+    const uint32_t tx[2] = {c0[0] << ESH, c1[0] << ESH};
+    const uint32_t ty[2] = {__umul24(c0[1], H.my_b) & H.m_b, __umul24(c1[1], H.my_b) & H.m_b};
+    const uint32_t tz[2] = {__umul24(c0[2], H.mz_b) & H.m_b, __umul24(c1[2], H.mz_b) & H.m_b};
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const uint32_t byte_off = __builtin_amdgcn_bitop3_b32(tx[c & 1], ty[(c >> 1) & 1], tz[c >> 2], 0x96); // a ^ b ^ c
+      const Entry<F> e = Entry<F>::load(base + byte_off);
+#pragma unroll
+      for (int k = 0; k < F / 2; k++) vw[c][k] = e.w[k];
     }
   } else {
     uint32_t c1[3];
@@ -362,22 +393,24 @@ __device__ __forceinline__ void encode_level2(const uint16_t* __restrict__ table
   }
 }
 
+// NDENSE > 0: the field has EXACTLY NDENSE leading dense levels and its hashed levels share their constants
+// (FieldDev::hash_shared; the host picks the instance).  NDENSE = 0: every level through the generic path.
 template <int F, int NDENSE, int... J>
-__device__ __forceinline__ void encode_all_levels(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv, float px, float py,
-                                                  float pz, half2v* out, std::integer_sequence<int, J...>) {
-  (encode_level2<F, (J < NDENSE)>(table, lv[J], px, py, pz, out + J * (F / 2)), ...);
+__device__ __forceinline__ void encode_all_levels(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv, const HashConsts& H,
+                                                  float px, float py, float pz, half2v* out, std::integer_sequence<int, J...>) {
+  (encode_level2<F, (J < NDENSE ? kLevelDense : NDENSE > 0 ? kLevelHashedShared : kLevelGeneric)>(table, lv[J], H, px, py, pz, out + J * (F / 2)), ...);
 }
 
 // all 32 features of one sample in canonical order (feature F*l + f), as four half8 = the k rows [8s, 8s+8) of the first
 // layer; render_queue64 turns them into MFMA B fragments with v_permlane32_swap
 template <int F, int NDENSE>
-__device__ __forceinline__ void encode_sample(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv, float px, float py,
-                                              float pz, half8 f[4]) {
+__device__ __forceinline__ void encode_sample(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv, const HashConsts& H,
+                                              float px, float py, float pz, half8 f[4]) {
   px = clamp01(px);
   py = clamp01(py);
   pz = clamp01(pz);
   half2v out[16];
-  encode_all_levels<F, NDENSE>(table, lv, px, py, pz, out, std::make_integer_sequence<int, 32 / F>{});
+  encode_all_levels<F, NDENSE>(table, lv, H, px, py, pz, out, std::make_integer_sequence<int, 32 / F>{});
 #pragma unroll
   for (int s = 0; s < 4; s++)
 #pragma unroll

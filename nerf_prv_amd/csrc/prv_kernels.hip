@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void render_queue64_kernel(RenderParams P) {
   // every lane gathers every level, so the level constants are wave-uniform: they are read straight from the kernel
   // arguments (scalar loads, SGPR operands) instead of LDS -> VGPRs
   const LevelDev* __restrict__ lvl = P.field.levels;
+  const HashConsts hc = {P.field.hash_my_b, P.field.hash_mz_b, P.field.hash_m_b};
 
   const int lane = threadIdx.x & 63, r = lane & 31, g = lane >> 5; // g: the lane's group (A = 0, B = 1) AND its k-row half
 
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(256) void render_queue64_kernel(RenderParams P) {
         }
       }
       const float t = fmaf((float)i + 0.5f, dt, t0);
-      encode_sample<F, NDENSE>(P.field.table, lvl, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f);
+      encode_sample<F, NDENSE>(P.field.table, lvl, hc, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f);
     }
     // f[2s] | f[2s+1] = k rows [16s, 16s+8) | [16s+8, 16s+16) of the lane's own sample -> B operands of the two groups
     swap_halves(f[0], f[1]); // f[0] = group A k-step 0, f[1] = group B k-step 0
@@ -1130,7 +1131,8 @@ __global__ __launch_bounds__(256) void debug_field64_kernel(FieldDev fd, const f
   dir_of(idxA, dA);
   dir_of(idxB, dB);
   half8 f[4];
-  encode_sample<F, NDENSE>(fd.table, lvl, p[0], p[1], p[2], f);
+  const HashConsts hc = {fd.hash_my_b, fd.hash_mz_b, fd.hash_m_b};
+  encode_sample<F, NDENSE>(fd.table, lvl, hc, p[0], p[1], p[2], f);
   if (ok && feat) {
     typedef uint16_t ushort8 __attribute__((ext_vector_type(8)));
     uint16_t* dst = feat + (size_t)idx * 32;
@@ -1265,12 +1267,14 @@ hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_
   return hipGetLastError();
 }
 
-// compiled instances of the render kernel: NDENSE = the largest listed count <= the field's leading dense levels
-// (levels past NDENSE take the generic path, which serves dense levels too)
+// compiled instances of the render kernel: NDENSE = the field's count of leading dense levels when an instance for
+// exactly that count exists (5 / 3 for F = 4, 10 / 6 for F = 2: the BASELINE fields, instant-ngp's base.json, the test
+// fields) and its hashed levels share their hash constants; any other field runs the generic instance <F, 0>
 int render_instance_dense_levels(const FieldDev& fd) {
   const int n = fd.n_dense_levels;
-  if (fd.n_features == 4) return n >= 5 ? 5 : n >= 3 ? 3 : 0;
-  return n >= 10 ? 10 : n >= 6 ? 6 : 0;
+  if (!fd.hash_shared) return 0;
+  if (fd.n_features == 4) return n == 5 ? 5 : n == 3 ? 3 : 0;
+  return n == 10 ? 10 : n == 6 ? 6 : 0;
 }
 
 template <bool NGP>
