@@ -383,8 +383,10 @@ def kernel_figures(m, variant, hbm_bound, scene, layout):
         out["mfma_pipe_frac_at_measured_clock"] = mfma_pipe_frac * MAX_CLOCK_HZ / (clock * 1e9)
         if cost:
             out["valu_issue_frac_at_measured_clock"] = valu_frac * MAX_CLOCK_HZ / (clock * 1e9)
+    out["traffic"] = None  # fabric-side bytes per launch (FETCH_SIZE + WRITE_SIZE), from the committed PMC passes of this binary
     if traffic:
         per_sample = (traffic["fetch_kib_per_launch"] + traffic["write_kib_per_launch"]) * 1024.0 / traffic["samples_evaluated_per_launch"]
+        out["traffic"] = per_sample * samples
         out["traffic_from_profile"] = {"bytes_per_launch": per_sample * samples, "bytes_per_unit": per_sample, "file": TRAFFIC_FILE,
                                        "note": "FETCH_SIZE + WRITE_SIZE of the committed PMC passes scaled by this run's sample count; not measured in this run"}
     if hbm_bound:
@@ -813,9 +815,10 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, argv))  # before anything touches a GPU
     rc = run_rank(args)
-    # Everything is closed and the line is out.  What a normal interpreter exit adds is the static teardown of the HIP /
-    # HSA runtime, which crashed about once in a thousand process exits on this pool when another process shared the GPU
-    # (scripts/gpu/r02_ay.sh; the C++ planner does the same): a finished run's exit code must not depend on it.
+    # Everything is closed and the line is out.  What a normal interpreter exit adds is the static teardown of torch's and
+    # the HIP / HSA runtime's state in an order this script does not control (round 2 saw about one crash in a thousand
+    # process exits on this pool while another process shared the GPU; the C++ planner, which owns its runtime, now shuts
+    # it down explicitly -- prv_runtime_shutdown -- and returns normally): a finished run's exit code must not depend on it.
     sys.stdout.flush()
     sys.stderr.flush()
     # ... unless a profiler is attached: rocprofv3 writes its files from an exit handler, which _exit would skip

@@ -709,10 +709,10 @@ static int run(int argc, char** argv);
 
 // Every context has been destroyed and every file closed when run() returns.  What a normal exit then adds is the static
 // teardown of the HIP / HSA runtime, and in round 2 that crashed about once in a thousand exits while another process
-// shared the GPU (scripts/gpu/r02_ay.sh).  The runtime is therefore shut down EXPLICITLY, in order, before main
+// shared the GPU (profiles/NOTES.md).  The runtime is therefore shut down EXPLICITLY, in order, before main
 // returns: prv_runtime_shutdown synchronises and resets the device (hipDeviceReset) while the process is intact, so the
 // runtime's streams, signal pools and worker threads are gone before any static destructor runs; then main returns
-// normally.  PRV_PLANNER_EXIT=quick keeps round 2's way out (flush + _exit) for comparison runs (scripts/gpu/r03_exit.sh).
+// normally.  PRV_PLANNER_EXIT=quick keeps round 2's way out (flush + _exit) for comparison runs (scripts/gpu/exit_stress.sh).
 int main(int argc, char** argv) {
   if (getenv("PRV_SEGV_TRACE")) {
     signal(SIGSEGV, segv_trace);

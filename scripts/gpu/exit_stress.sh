@@ -1,12 +1,12 @@
 # exits of prv_planner while another process keeps the GPU busy (round 2 saw ~1 crash in 1000 static teardowns):
-#   usage: scripts/gpu/r03_exit.sh <runs of the default exit> <runs of the plain return>
+#   usage: scripts/gpu/exit_stress.sh <runs of the default exit> <runs of the plain return>
 # default = prv_runtime_shutdown (hipDeviceReset before main returns) then a normal return; noreset = plain return
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 export PRV_SEGV_TRACE=1
 O=gpurun_out/r03exit
 mkdir -p $O
-CFG=$(python3 scripts/gpu/r02_ay.py /tmp/repro | tail -1)
+CFG=$(python3 scripts/gpu/repro_planner_inputs.py /tmp/repro | tail -1)
 echo cfg $CFG
 python3 scripts/kbench.py --reps 100000000 --tag bg > $O/bg.txt 2>&1 &
 BG=$!
