@@ -585,46 +585,6 @@ __device__ __forceinline__ MlpOut2 mlp_forward2(const half8* __restrict__ wl, in
   auto layer16 = [&](int f0, f32x16& a, f32x16& b) { // K = 64 -> 16 units (+ copies in the padding rows)
     a = zero;
     b = zero;
-#if defined(PRV_ABLATE) && (PRV_ABLATE & 48)
-    // TIMING BUILD ONLY (wrong pixels): what the two 64 -> 16 layers would cost on v_mfma_f32_16x16x32_f16 -- per group
-    // 2 column tiles x 2 k-steps of 16 cycles instead of 4 x 32, two weight fragments instead of four; bit 32 adds the
-    // 8 v_permlane16_swap per group and layer that re-lay the [half][32 columns] activations as [k block][16 columns]
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    {
-      half8 xa[4] = {hA[0], hA[1], hA[2], hA[3]}, xb[4] = {hB[0], hB[1], hB[2], hB[3]};
-#if PRV_ABLATE & 32
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      auto swap16 = [](half8& p, half8& q) {
-        u32x4 x = __builtin_bit_cast(u32x4, p), y = __builtin_bit_cast(u32x4, q);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const auto r = __builtin_amdgcn_permlane16_swap(x[k], y[k], false, false);
-          x[k] = r[0];
-          y[k] = r[1];
-        }
-        p = __builtin_bit_cast(half8, x);
-        q = __builtin_bit_cast(half8, y);
-      };
-      swap16(xa[0], xa[1]); swap16(xa[2], xa[3]); swap16(xb[0], xb[1]); swap16(xb[2], xb[3]);
-#endif
-      const half8 w0 = wl[(f0 + 0) * 64 + lane], w1 = wl[(f0 + 1) * 64 + lane];
-      f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa[0], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa[1], a1, 0, 0, 0);
-      b0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xb[0], b0, 0, 0, 0);
-      b1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xb[1], b1, 0, 0, 0);
-      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xa[2], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xa[3], a1, 0, 0, 0);
-      b0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xb[2], b0, 0, 0, 0);
-      b1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xb[3], b1, 0, 0, 0);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        a[k] = a0[k]; a[4 + k] = a1[k]; a[8 + k] = a0[k];
-        b[k] = b0[k]; b[4 + k] = b1[k]; b[8 + k] = b0[k];
-      }
-      return;
-    }
-#endif
 #if PRV_MLP2_ORDER
 #pragma unroll
     for (int s = 0; s < 4; s++) a = mfma(wl[(f0 + s) * 64 + lane], hA[s], a);

@@ -691,18 +691,51 @@ int env_int(const char* key, int fallback) {
 
 } // namespace
 
-// PRV_SEGV_TRACE=1 (diagnostics): a crash prints where it happened before the process dies
+// PRV_SEGV_TRACE=1 (diagnostics): a crash prints where it happened before the process dies -- the phase of the process
+// (running / shutting the runtime down / returning from main / exit handlers), the faulting thread, the fault address, the
+// program counter and the mapping it lies in (a PC in no mapping = code that has been unloaded under a running thread)
 #include <csignal>
 #include <execinfo.h>
+#include <sys/syscall.h>
+#include <ucontext.h>
 #include <unistd.h>
-static void segv_trace(int sig) {
+static volatile int g_phase = 0; // 0 run(), 1 inside prv_runtime_shutdown, 2 main is returning, 3 exit handlers have started
+static void segv_trace(int sig, siginfo_t* info, void* uc_) {
+  char buf[512];
+  const ucontext_t* uc = (const ucontext_t*)uc_;
+  const unsigned long long pc = uc ? (unsigned long long)uc->uc_mcontext.gregs[REG_RIP] : 0ull;
+  const long tid = syscall(SYS_gettid);
+  int n = snprintf(buf, sizeof(buf), "prv_planner: fatal signal %d in phase %d, thread %ld (%s), fault address %p, pc 0x%llx\n", sig,
+                   g_phase, tid, tid == (long)getpid() ? "main" : "not main", info ? info->si_addr : nullptr, pc);
+  (void)!write(2, buf, (size_t)n);
+  if (FILE* maps = fopen("/proc/self/maps", "r")) { // not async-signal-safe; the process is dying anyway
+    bool found = false;
+    while (fgets(buf, sizeof(buf), maps)) {
+      unsigned long long lo = 0, hi = 0;
+      if (sscanf(buf, "%llx-%llx", &lo, &hi) == 2 && pc >= lo && pc < hi) {
+        (void)!write(2, "  pc lies in: ", 14);
+        (void)!write(2, buf, strlen(buf));
+        found = true;
+      }
+    }
+    fclose(maps);
+    if (!found) (void)!write(2, "  pc lies in NO mapping (unloaded code)\n", 40);
+  }
   void* frames[64];
-  const int n = backtrace(frames, 64);
-  const char msg[] = "prv_planner: fatal signal, backtrace follows\n";
-  (void)!write(2, msg, sizeof(msg) - 1);
-  backtrace_symbols_fd(frames, n, 2);
+  const int nf = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, nf, 2);
   signal(sig, SIG_DFL);
   raise(sig);
+}
+static void install_trace() {
+  struct sigaction sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_sigaction = segv_trace;
+  sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+  sigaction(SIGSEGV, &sa, nullptr);
+  sigaction(SIGBUS, &sa, nullptr);
+  sigaction(SIGABRT, &sa, nullptr);
+  atexit([] { g_phase = 3; });
 }
 
 static int run(int argc, char** argv);
@@ -714,15 +747,13 @@ static int run(int argc, char** argv);
 // runtime's streams, signal pools and worker threads are gone before any static destructor runs; then main returns
 // normally.  PRV_PLANNER_EXIT=quick keeps round 2's way out (flush + _exit) for comparison runs (scripts/gpu/exit_stress.sh).
 int main(int argc, char** argv) {
-  if (getenv("PRV_SEGV_TRACE")) {
-    signal(SIGSEGV, segv_trace);
-    signal(SIGBUS, segv_trace);
-    signal(SIGABRT, segv_trace);
-  }
+  if (getenv("PRV_SEGV_TRACE")) install_trace();
   const int rc = run(argc, argv);
   const char* how = getenv("PRV_PLANNER_EXIT");
   if (!how || std::string(how) != "quick") {
+    g_phase = 1;
     if (!how || std::string(how) != "noreset") (void)prv_runtime_shutdown(); // "noreset": plain return, the round-2 crash's setting
+    g_phase = 2;
     return rc;
   }
   // a profiler writes its files from an exit handler, which _exit would skip
