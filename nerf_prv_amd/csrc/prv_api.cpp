@@ -466,6 +466,53 @@ CamDev cam_at(const prv_camset* cs, int i, int w, int h) {
   return r;
 }
 
+// The pixel rectangle that contains every ray of a pinhole view that can meet the occupied cells' box (grown like the march
+// pass's own rejection test): a ray through pixel p meets a convex box only if p lies in the box's projection, which lies
+// in the bounding rectangle of its eight projected corners -- provided all eight are in front of the camera.  The march
+// pass skips whole 256-pixel tiles outside it before any per-ray work (most of an 800x800 view of the bench scene).
+void set_cull_rect(CamDev& cam, const Model& m, int W, int H) {
+  cam.cull[0] = cam.cull[1] = cam.cull[2] = cam.cull[3] = 0; // not set
+  if (cam.lens[0] != 0.f || cam.lens[1] != 0.f || cam.lens[2] != 0.f || cam.lens[3] != 0.f) return;
+  if (!(m.occ_hi[0] > m.occ_lo[0])) { // empty occupancy grid: every tile is dead
+    cam.cull[2] = 1; // x1 > 0 marks "set"; the rectangle [0, 1) x [0, 0) contains no pixel
+    return;
+  }
+  const double o[3] = {cam.c2w[3], cam.c2w[7], cam.c2w[11]};
+  const double far = std::max(std::max(std::fabs(o[0] - 0.5), std::fabs(o[1] - 0.5)), std::fabs(o[2] - 0.5));
+  const double grow = 1e-3 + 1e-5 * far + 1e-4; // the march pass's own margin and a little more
+  // camera coordinates of a point p: M^-1 (p - o) with M = the 3x3 of c2w (rays are o + t M (dx, dy, 1)); a general
+  // inverse, not the transpose: the matrices come from a json and need not be exact rotations
+  const double M[3][3] = {{cam.c2w[0], cam.c2w[1], cam.c2w[2]}, {cam.c2w[4], cam.c2w[5], cam.c2w[6]}, {cam.c2w[8], cam.c2w[9], cam.c2w[10]}};
+  const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                     M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+  if (!(std::fabs(det) > 1e-12)) return;
+  double Mi[3][3];
+  for (int r = 0; r < 3; r++)
+    for (int q = 0; q < 3; q++) {
+      const int r1 = (r + 1) % 3, r2 = (r + 2) % 3, q1 = (q + 1) % 3, q2 = (q + 2) % 3;
+      Mi[q][r] = (M[r1][q1] * M[r2][q2] - M[r1][q2] * M[r2][q1]) / det; // adjugate, transposed
+    }
+  double u0 = 1e300, u1 = -1e300, v0 = 1e300, v1 = -1e300;
+  for (int k = 0; k < 8; k++) {
+    const double p[3] = {((k & 1) ? m.occ_hi[0] + grow : m.occ_lo[0] - grow) - o[0], ((k & 2) ? m.occ_hi[1] + grow : m.occ_lo[1] - grow) - o[1],
+                         ((k & 4) ? m.occ_hi[2] + grow : m.occ_lo[2] - grow) - o[2]};
+    double c[3];
+    for (int a = 0; a < 3; a++) c[a] = Mi[a][0] * p[0] + Mi[a][1] * p[1] + Mi[a][2] * p[2];
+    if (!(c[2] > 1e-3)) return; // a corner beside or behind the camera: no rectangle bounds the projection
+    const double u = cam.fx * c[0] / c[2] + cam.cx, v = cam.fy * c[1] / c[2] + cam.cy;
+    u0 = std::min(u0, u); u1 = std::max(u1, u);
+    v0 = std::min(v0, v); v1 = std::max(v1, v);
+  }
+  if (!(u1 - u0 < 1e7) || !(v1 - v0 < 1e7)) return;
+  // pixel (px, py) casts its rays through [px, px + 1) x [py, py + 1); the rotation's columns are unit to ~1e-7 and the
+  // projection is evaluated in double: two pixels of margin cover the float ray set-up many times over
+  const long x0 = (long)std::floor(u0) - 2, x1 = (long)std::ceil(u1) + 3, y0 = (long)std::floor(v0) - 2, y1 = (long)std::ceil(v1) + 3;
+  cam.cull[0] = (int)std::max<long>(0, std::min<long>(W, x0));
+  cam.cull[1] = (int)std::max<long>(0, std::min<long>(H, y0));
+  cam.cull[2] = (int)std::max<long>(1, std::min<long>(W, x1)); // > 0: set
+  cam.cull[3] = (int)std::max<long>(0, std::min<long>(H, y1));
+}
+
 constexpr size_t kStatOffset = 1024;                        // counters buffer: heads 0..511, counts 512..1023, then the statistics
 constexpr size_t kCountersBytes = kStatOffset + 72 * 8; // {evaluated, wave rounds, clock sums and stamps}, then 8 live-sample shards a cache line apart
 
@@ -473,7 +520,8 @@ constexpr size_t kCountersBytes = kStatOffset + 72 * 8; // {evaluated, wave roun
 // The render of one batch of views into out_f32 (+ optional out_u8).  Views are dealt to
 // the queue in batches so the queue stays within queue_budget bytes.
 int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids, int n_views,
-                 const prv_render_opts* o, float* out_f32, uint8_t* out_u8, bool zero_stats) {
+                 const prv_render_opts* o, float* out_f32, uint8_t* out_u8, bool zero_stats, bool private_output = false) {
+  if (o->spp != 1 || out_u8) private_output = false; // sub-sample staging and byte images are written in full
   const Model& m = c->models[slot];
   const int W = o->width, H = o->height;
   const size_t npix = (size_t)W * H;
@@ -506,6 +554,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     const int v = view_ids ? view_ids[i] : i;
     if (v < 0 || v >= (int)cs->cams.size()) return fail(c, PRV_E_INVALID, "view id %d out of range", v);
     cams[i] = cam_at(cs, v, W, H);
+    set_cull_rect(cams[i], m, W, H);
     ids[i] = i;
   }
   if ((rc = ensure(c, c->view_ids, up_bytes)) != PRV_OK) return rc;
@@ -586,6 +635,27 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     mp.inv_spp = 1.0f;
     mp.last_pass = spp == 1; // staged sub-samples are written raw; scaling / bytes happen in the reduce
     memcpy(mp.bg, o->background, sizeof(mp.bg));
+    // A caller that consumes the image through the views' cull rectangles (prv_score_views, method 5: the image is a private
+    // temporary of the round) gets only the tiles inside them launched and nothing written outside: most of an 800x800
+    // view of the bench scene is dead, and 16 B per dead pixel were a 0.4 ms stream of zeros per 64-view step.
+    if (private_output) {
+      const uint64_t tw = 1ull << mp.tile_w_log2, th = 1ull << mp.tile_h_log2;
+      uint64_t live_max = 0;
+      for (int i = 0; i < nb; i++) {
+        const CamDev& cv = cams[b0 + i];
+        uint64_t w = mp.tiles_x, h = mp.tiles_y;
+        if (cv.cull[2] > 0) {
+          const uint64_t x0 = (uint64_t)cv.cull[0] / tw, y0 = (uint64_t)cv.cull[1] / th;
+          const uint64_t x1 = std::min<uint64_t>(mp.tiles_x, ((uint64_t)cv.cull[2] + tw - 1) / tw);
+          const uint64_t y1 = std::min<uint64_t>(mp.tiles_y, ((uint64_t)std::max(cv.cull[3], 0) + th - 1) / th);
+          w = x1 > x0 ? x1 - x0 : 0;
+          h = y1 > y0 ? y1 - y0 : 0;
+        }
+        live_max = std::max(live_max, w * h);
+      }
+      mp.live_grid = 1;
+      mp.live_tiles_max = (uint32_t)live_max;
+    }
     if (c->profiling) {
       hipEvent_t a, b;
       HIPCHK(c, take_event(c, &a));
@@ -1323,7 +1393,7 @@ static int score_ensemble_dev(prv_ctx* c, int method, const uint8_t* const* imgs
 }
 
 static int score_psnr_dev(prv_ctx* c, const float* rgba, const float* gt, int n_views, size_t npix, const float bg[4],
-                          double coverage_weight, prv_score_record* rec_dev) {
+                          double coverage_weight, prv_score_record* rec_dev, const CamDev* cams_dev = nullptr, int W = 0) {
   const int nblk = score_blocks(npix);
   int rc;
   if ((rc = ensure(c, c->partial, (size_t)n_views * nblk * 3 * sizeof(double))) != PRV_OK) return rc;
@@ -1332,6 +1402,8 @@ static int score_psnr_dev(prv_ctx* c, const float* rgba, const float* gt, int n_
   P.rgba = rgba;
   P.gt = gt;
   P.pixels_per_view = npix;
+  P.cams = cams_dev; // the render of a fused round wrote only inside the views' cull rectangles (render_views: private_output)
+  P.W = W;
   memcpy(P.bg, bg, sizeof(P.bg));
   P.partial = (double*)c->partial.p;
   HIPCHK(c, launch_score_psnr(P, n_views, nblk, c->stream));
@@ -1455,9 +1527,13 @@ int prv_score_views(prv_ctx* c, int method, const int* model_slots, int n_models
     }
     if (n_views && (rc = score_ensemble_dev(c, method, imgs, n_models, n_views, npix, rec)) != PRV_OK) return rc;
   } else {
-    if ((rc = render_views(c, model_slots[0], cs, view_ids, n_views, o, (float*)c->img_f32.p, nullptr, true)) != PRV_OK)
+    // the image is a private temporary of the round: only the tiles inside each view's cull rectangle are rendered and
+    // the score reads it through the same rectangles (view i of this call = camera i of the upload in c->view_ids)
+    const bool priv = o->spp == 1;
+    if ((rc = render_views(c, model_slots[0], cs, view_ids, n_views, o, (float*)c->img_f32.p, nullptr, true, priv)) != PRV_OK)
       return rc;
-    if (n_views && (rc = score_psnr_dev(c, (const float*)c->img_f32.p, gt, n_views, npix, o->background, c->coverage_weight, rec)) != PRV_OK)
+    if (n_views && (rc = score_psnr_dev(c, (const float*)c->img_f32.p, gt, n_views, npix, o->background, c->coverage_weight, rec,
+                                        priv ? (const CamDev*)c->view_ids.p : nullptr, o->width)) != PRV_OK)
       return rc;
   }
   if (rec_dev && n_views)

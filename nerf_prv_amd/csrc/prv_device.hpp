@@ -66,6 +66,10 @@ struct CamDev {  // engine-frame camera
   float c2w[12]; // row-major 3x4
   float fx, fy, cx, cy;
   float lens[4]; // k1, k2, p1, p2 (OpenCV model on normalised coordinates); all zero = pinhole
+  // March pass only (set per render call, prv_api.cpp: set_cull_rect): the pixel rectangle [x0, x1) x [y0, y1) outside
+  // which no ray of this view can meet the field's occupied box -- the bounding rectangle of the box's eight projected
+  // corners, two pixels of margin.  x1 == 0: not set (lens cameras, a corner behind the camera): nothing is culled.
+  int cull[4];
 };
 
 // ---------------------------------------------------------------- small helpers

@@ -105,8 +105,28 @@ template <bool NGP>
 __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
   __shared__ uint4 stage[4][64 * kRecordWords]; // a wave's live records, written out as ONE contiguous block
   __shared__ uint32_t mw[NGP ? 32 : 1][256];    // NGP: the lanes' mask words ([word][thread]: conflict-free columns)
-  const uint32_t tile = blockIdx.x, vi = blockIdx.y;
-  const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+  const uint32_t vi = blockIdx.y;
+  uint32_t tx, ty;
+  if (P.live_grid) {
+    // only the tiles inside the view's cull rectangle are launched (the caller consumes the image through the same
+    // rectangles and never reads a pixel outside them: prv_score_views, method 5): blockIdx.x counts the tiles of THIS
+    // view's rectangle, the grid is as large as the largest rectangle of the batch
+    const CamDev& cv = P.cams[P.view_ids[vi]];
+    uint32_t tx0 = 0, ty0 = 0, tx1 = P.tiles_x, ty1 = P.tiles_y;
+    if (cv.cull[2] > 0) {
+      tx0 = (uint32_t)cv.cull[0] >> P.tile_w_log2;
+      ty0 = (uint32_t)cv.cull[1] >> P.tile_h_log2;
+      tx1 = min(P.tiles_x, ((uint32_t)cv.cull[2] + (1u << P.tile_w_log2) - 1u) >> P.tile_w_log2);
+      ty1 = min(P.tiles_y, ((uint32_t)max(cv.cull[3], 0) + (1u << P.tile_h_log2) - 1u) >> P.tile_h_log2);
+    }
+    const uint32_t w = tx1 > tx0 ? tx1 - tx0 : 0u, h = ty1 > ty0 ? ty1 - ty0 : 0u;
+    if (blockIdx.x >= w * h) return;
+    ty = ty0 + blockIdx.x / w;
+    tx = tx0 + blockIdx.x - (blockIdx.x / w) * w;
+  } else {
+    ty = blockIdx.x / P.tiles_x;
+    tx = blockIdx.x - ty * P.tiles_x;
+  }
   // Multi-sample launches: with a power-of-two spp the sub-samples of a pixel sit on ADJACENT lanes
   // (a wave = 64/spp pixels x spp sub-samples: rays that share nearly every grid cell); otherwise the
   // sub-sample index is on grid.z.
@@ -132,7 +152,13 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
   const CamDev& cam = P.cams[P.view_ids[vi]];
   float ox, oy;
   spp_offset(spp_k, ox, oy);
-  if (valid && !has_lens(cam)) {
+  // whole-tile rejection (block-uniform, before any per-ray work): the tile's pixels against the rectangle outside which no
+  // ray of this view can meet the occupied box (CamDev::cull, computed on the host in double per render call)
+  if (cam.cull[2] > 0) {
+    const int x0 = (int)(tx << P.tile_w_log2), y0 = (int)(ty << P.tile_h_log2);
+    if (x0 + (1 << P.tile_w_log2) <= cam.cull[0] || x0 >= cam.cull[2] || y0 + (1 << P.tile_h_log2) <= cam.cull[1] || y0 >= cam.cull[3]) maybe = false;
+  }
+  if (maybe && !has_lens(cam)) {
     // Cheap rejection before the exact (IEEE divides, normalisation: ~300 instructions) ray set-up: nine rays in ten
     // never come near the object and the pass is VALU bound on that set-up.  A live sample lies in an occupied cell,
     // hence inside [occ_lo, occ_hi]; a slab test of the UNNORMALISED direction, built with reciprocals, against that
@@ -900,8 +926,22 @@ __global__ __launch_bounds__(256) void score_psnr_kernel(PsnrParams P) {
   const float4* img = reinterpret_cast<const float4*>(P.rgba) + (size_t)v * npix;
   const float4* gt = reinterpret_cast<const float4*>(P.gt) + (size_t)v * npix;
   double se = 0.0, cov = 0.0, unc = 0.0;
+  // P.cams (optional): the render wrote only the tiles inside the view's cull rectangle (MarchParams::live_grid); every
+  // pixel outside it is a dead ray's (0, 0, 0, 0) by construction and is not read.  Same pixels per thread in the same
+  // order either way: the sums are bit-identical to scoring a fully written image.
+  int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  if (P.cams && P.cams[v].cull[2] > 0) {
+    c0 = P.cams[v].cull[0]; c1 = P.cams[v].cull[1]; c2 = P.cams[v].cull[2]; c3 = P.cams[v].cull[3];
+  }
   for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
-    const float4 a4 = img[p], r4 = gt[p];
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool inside = true;
+    if (c2 > 0) {
+      const int y = (int)((uint32_t)p / (uint32_t)P.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)P.W);
+      inside = x >= c0 && x < c2 && y >= c1 && y < c3;
+    }
+    if (inside) a4 = img[p];
+    const float4 r4 = gt[p];
     const float ra = 1.0f - a4.w, rg = 1.0f - r4.w;
     const float av[3] = {a4.x, a4.y, a4.z}, rv[3] = {r4.x, r4.y, r4.z};
 #pragma unroll
@@ -1261,7 +1301,8 @@ hipError_t launch_spp_reduce(const float* stage, size_t n_pixels, int spp, const
 }
 
 hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_t s) {
-  dim3 grid((unsigned)(P.tiles_x * P.tiles_y), (unsigned)n_views, (unsigned)(P.spp_inner_log2 > 0 ? 1 : n_spp));
+  dim3 grid((unsigned)(P.live_grid ? P.live_tiles_max : P.tiles_x * P.tiles_y), (unsigned)n_views, (unsigned)(P.spp_inner_log2 > 0 ? 1 : n_spp));
+  if (grid.x == 0) return hipSuccess; // no view of the batch can see the object
   if (P.step_mode == PRV_STEP_NGP) hipLaunchKernelGGL(march_compact_kernel<true>, grid, dim3(256), 0, s, P);
   else hipLaunchKernelGGL(march_compact_kernel<false>, grid, dim3(256), 0, s, P);
   return hipGetLastError();

@@ -27,6 +27,9 @@ struct MarchParams {
   uint32_t tiles_x, tiles_y;
   int tile_w_log2, tile_h_log2; // pixel tile of one 256-thread block
   int spp_inner_log2;           // > 0: sub-samples on adjacent lanes (spp = 2^n), 0: on grid.z
+  int live_grid;                // 1: grid.x = the largest cull rectangle of the batch in tiles (CamDev::cull); pixels outside a
+                                //    view's rectangle are NOT written (the caller consumes the image through the rectangles)
+  uint32_t live_tiles_max;
   int step_mode; // PRV_STEP_FIXED_S | PRV_STEP_NGP
   void* queue;
   uint4* queue_ext;      // PRV_STEP_NGP: kExtChunks mask chunks per queue slot
@@ -73,6 +76,8 @@ struct EnsembleParams {
 struct PsnrParams {
   const float* rgba;
   const float* gt;
+  const CamDev* cams; // optional: view v's cull rectangle bounds what was rendered (see score_psnr_kernel)
+  int W;
   size_t pixels_per_view;
   float bg[4];
   double* partial;

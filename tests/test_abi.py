@@ -54,6 +54,7 @@ def test_no_device_fails_loudly_not_silently():
     h = C.c_void_p()
     assert lib.prv_create(C.byref(h), 0) == _lib.PRV_E_NODEVICE
     assert b"no CPU path" in lib.prv_last_error(None)
+    assert lib.prv_runtime_shutdown() == _lib.PRV_OK  # no context was ever created: nothing to shut down, nothing touched
 
 
 def test_product_never_imports_the_oracle():

@@ -444,6 +444,9 @@ def test_error_behaviour(ctx, fields, cams):
         ctx.cameras_from_json("/nonexistent/transforms.json")
     img, st = ctx.render(0, cs, [], api.render_opts(w, h))  # empty view list is fine
     assert img.shape[0] == 0 and st.rays == 0
+    # the runtime can not be shut down under a live context (and this process shares it with torch: never call it here)
+    assert ctx.lib.prv_runtime_shutdown() == api.L.PRV_E_STATE
+    assert b"still alive" in ctx.lib.prv_last_error(None)
 
 
 def test_ground_truth_splats_byte_exact(ctx, oracle):
