@@ -484,7 +484,9 @@ def full_loop(args):
     cfg = re.sub(r'pre_path: "[^"]*"', f'pre_path: "{work}/"', cfg)
     cfg = re.sub(r'model_path: "[^"]*"', f'model_path: "{work}/models/"', cfg)
     cfg = re.sub(r'viewspace_path: "[^"]*"', f'viewspace_path: "{os.path.join(ROOT, "tests", "golden", "hemisphere")}/"', cfg)
-    cfg += "\nevaluate: 1\ncoverage_view_num_max: 30\ncoverage_view_num_add: 3\n"
+    # final evaluation and the curve's test set on the 64-view set (the reference's is its 100-view file, not shipped with
+    # this repository); mode 4's curve at n = 3, 6, ..., 30 views + the 64-view upper bound
+    cfg += "\nevaluate: 1\nevaluate_views: 64\ncoverage_view_num_max: 30\ncoverage_view_num_add: 3\ncoverage_view_num_full: 64\n"
     path = os.path.join(work, "cfg.yaml")
     with open(path, "w") as fh:
         fh.write(cfg)
