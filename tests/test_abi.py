@@ -83,7 +83,10 @@ def test_headers_are_plain_c(tmp_path):
         "  if (prv_model_sizes(&d, &t, &m, &o) != PRV_OK || m != PRV_MLP_HALFS) return 2;\n"
         "  prvh_view_pose(pos, c, pose); prvh_transform_matrix(pose, tm);\n"
         "  if (prv_create(&ctx, 0) == PRV_OK) prv_destroy(ctx); else printf(\"%s\\n\", prv_last_error(NULL));\n"
-        '  printf("table halfs %llu tm03 %.6f\\n", (unsigned long long)t, tm[3]);\n  return 0;\n}\n')
+        '  printf("table halfs %llu tm03 %.6f\\n", (unsigned long long)t, tm[3]);\n'
+        '  printf("sizes %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(prv_field_desc), sizeof(prv_render_opts), sizeof(prv_score_record), sizeof(prv_stats),\n'
+        "         sizeof(prv_intrinsics), sizeof(prv_rs2_intrinsics), sizeof(prv_train_opts));\n"
+        "  if (prv_runtime_shutdown() != PRV_OK) return 3;\n  return 0;\n}\n")
     inc, libdir = os.path.join(ROOT, "include"), os.path.join(ROOT, "nerf_prv_amd")
     exe = tmp_path / "c_caller"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe), "-L", libdir,
@@ -91,6 +94,16 @@ def test_headers_are_plain_c(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "table halfs" in out.stdout and "tm03 0.25" in out.stdout  # json translation = (z, x, y) of the position
+    # the ctypes mirrors of the ABI's structs are the C compiler's size (a field added on one side only shows up here)
+    import ctypes as C
+
+    from nerf_prv_amd import _lib, api
+
+    c_sizes = [int(x) for x in [l for l in out.stdout.splitlines() if l.startswith("sizes ")][0].split()[1:]]
+    py_sizes = [C.sizeof(t) for t in (_lib.FieldDesc, _lib.RenderOpts, _lib.ScoreRecord, _lib.Stats, _lib.Intrinsics, _lib.Rs2Intrinsics,
+                                      _lib.TrainOpts)]
+    assert c_sizes == py_sizes, (c_sizes, py_sizes)
+    assert api.render_opts(8, 8).step_mode == _lib.STEP_FIXED_S and api.engine_render_opts(8, 8, 0, 1, 0.01).step_mode == _lib.STEP_NGP
 
 
 def test_device_code_keeps_the_rounding_contract(tmp_path):
