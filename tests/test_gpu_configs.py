@@ -110,11 +110,16 @@ def test_1024_views_in_8_shards_equal_the_unsharded_round(ctx, field512):
 
 # ------------------------------------------------------------------ configs[2]: 144 views, trained field
 
-def test_144_view_set_trained_field_psnr_ranked_next_best_view(ctx, oracle):
+@pytest.mark.parametrize("shape", ["small_fixed64", "field256_engine_rule"])
+def test_144_view_set_trained_field_psnr_ranked_next_best_view(ctx, oracle, shape):
     """Hemisphere/144.txt (reference data), a fresh field trained in process on 12 of its views, then every view of the
     set rendered at the reference's candidate size (80x45) and ranked by PRV_SCORE_PSNR_COVERAGE against the ground
     truth's images.  The oracle renders the EXPORTED trained field itself and ranks its own scores: same next-best
-    view, same ranking (views whose oracle scores differ by less than the pixel tolerance's worth of dB may swap)."""
+    view, same ranking (views whose oracle scores differ by less than the pixel tolerance's worth of dB may swap).
+    `field256_engine_rule`: the BASELINE field shape (L=8, F=4, log2T=19, finest 256) rendered the way run.py:304 renders
+    (the engine's stepping rule, min_T 0.01) -- configs[2] with everything but the instant-ngp-trained weights."""
+    if shape == "field256_engine_rule":
+        return _ranked_144_views_full_size_field(ctx, oracle)
     kw = dict(util.SMALL, density_bias=0.0, table_amp=1e-4)
     gt_kw = dict(util.SMALL, density_bias=3.0, table_amp=4.0)
     d_train, d_gt = api.field_desc(**kw), api.field_desc(**gt_kw)
@@ -161,6 +166,57 @@ def test_144_view_set_trained_field_psnr_ranked_next_best_view(ctx, oracle):
         assert abs(want[got_order[p], 0] - want[want_order[p], 0]) <= 2e-3 * abs(want[want_order[p], 0])
     assert len(swapped) <= 8, (len(swapped), "of 144 positions differ")
     assert want[:, 1].max() - want[:, 1].min() > 1.0  # PSNR does separate the views (dB)
+    cams.close()
+    ds.close()
+
+
+def _ranked_144_views_full_size_field(ctx, oracle):
+    kw = dict(api.FIELD_256, density_bias=0.0, table_amp=1e-4)
+    d_train, d_gt = api.field_desc(**kw), api.field_desc(**api.FIELD_256)
+    ctx.synthetic_model(1, d_gt, util.SEED_B)
+    pts = planner.hemisphere_read(os.path.join(GOLD, "hemisphere", "144.txt"), 144)
+    tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
+    train_ids = np.arange(0, 144, 12)
+    tw, th = 320, 180
+    intr = {"fl_x": 915.6 * tw / 1280, "fl_y": 913.3 * th / 720, "cx": 647.1 * tw / 1280, "cy": 372.5 * th / 720, "w": tw, "h": th,
+            "k1": 0.1204, "k2": -0.2137, "p1": -0.0021, "p2": 0.0}
+    ds = ctx.cameras_from_matrices_intr(tms[train_ids], intr, scale, offset)
+    u8, _ = ctx.render_rgba8(1, ds, None, api.render_opts(tw, th, 128, 1, 1e-4, background=(0, 0, 0, 0)))
+    ctx.fresh_model(0, d_train, 0x144)
+    tr = api.Trainer(ctx, 0, ds, u8, api.train_opts(n_rays=4096))
+    losses = tr.steps(1500)
+    tr.close()
+    assert losses[-20:].mean() < 0.2 * losses[:5].mean()
+    w, h = 80, 45
+    cams = ctx.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+    opts = api.engine_render_opts(w, h, 0, 1, 1e-2)  # the engine's own stepping rule and default termination threshold
+    gt, _ = ctx.render(1, cams, None, opts, want_stats=False)
+    rec, _ = ctx.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cams, None, opts, gt=gt)
+    img, st = ctx.render(0, cams, None, opts)
+    t, m, o = ctx.export_model(0, d_train)
+    f = oracle.OracleField(oracle.desc(**kw), params=(t, m, o))
+    ocams = oracle.cameras_from_transforms(tms, util.FOV_X, w, h, scale, offset)
+    gt_np, img_np = gt.cpu().numpy(), img.cpu().numpy()
+    want = np.zeros((144, 3))
+    live = 0
+    for v in range(144):
+        a, _ = f.render(ocams[v], w, h, 0, 1, 1e-2, threads=8, step_mode=oracle.STEP_NGP)
+        live += f.march_count(ocams[v], w, h, 0, step_mode=oracle.STEP_NGP)
+        if v % 8 == 0:  # pixels of every eighth view, with the termination variants min_T 0.01 calls for (tests/util.py)
+            others = [f.render(ocams[v], w, h, 0, 1, t_, threads=8, step_mode=oracle.STEP_NGP)[0] for t_ in util.termination_variants(1e-2)[1:]]
+            util.assert_pixels_close_any(img_np[v], [a] + others)
+        want[v] = oracle.score_view(a, gt_np[v])
+    assert int(st.samples_live) == live  # the trained field's own occupancy grid, marched step for step as the oracle does
+    np.testing.assert_allclose(rec["psnr"], want[:, 1], rtol=2e-3)
+    np.testing.assert_allclose(rec["coverage"], want[:, 2], rtol=2e-3, atol=1e-6)
+    ids = np.arange(144, dtype=np.int32)
+    got_order, want_order = ctx.rank(rec, ids), oracle.rank(want[:, 0], ids)
+    assert got_order[0] == want_order[0] == ctx.argmax(rec, ids)  # the next-best view
+    swapped = np.flatnonzero(got_order != want_order)
+    for p in swapped:  # only views the oracle itself can barely tell apart may trade places
+        assert abs(want[got_order[p], 0] - want[want_order[p], 0]) <= 2e-3 * abs(want[want_order[p], 0])
+    assert len(swapped) <= 12, (len(swapped), "of 144 positions differ")
+    assert want[:, 1].max() - want[:, 1].min() > 1.0
     cams.close()
     ds.close()
 

@@ -169,3 +169,34 @@ def test_step_mode_is_validated(ctx, fields, cams):
     with pytest.raises(api.PrvError):  # the fixed mode still needs a sample count
         ctx.render(0, cs, None, api.render_opts(w, h, 0, 1, 1e-2))
     ctx.render(0, cs, None, api.render_opts(w, h, 0, 1, 1e-2, step_mode=NGP))  # NGP ignores it
+
+
+def test_ngp_step_through_the_lens_cameras_of_the_evaluation_block(ctx, oracle, fields):
+    """run.py:238-247 renders the test views with their own intrinsics and lens (render_with_lens_distortion) and
+    `render_min_transmittance = 1e-4`, through the same engine rule: dataset cameras here, march count exact, pixels vs
+    the oracle; and prv_evaluate's PSNR over them equals the oracle's recipe on the oracle's renders to 1e-3"""
+    from tests.test_gpu_parity import REF_INTR
+
+    d_o, d_p, f = fields
+    ctx.synthetic_model(1, d_p, util.SEED_B)
+    fb = oracle.OracleField(d_o, seed=util.SEED_B)
+    pts = util.fibonacci_hemisphere(4)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    cs = ctx.cameras_from_matrices_intr(tms, REF_INTR, scale, offset)
+    w, h = 64, 36
+    ocams = oracle.cameras_from_dataset(tms, REF_INTR, scale, offset, w, h)
+    opts = api.engine_render_opts(w, h, 0, 1, 1e-4)
+    img, st = ctx.render(0, cs, None, opts)
+    gt, _ = ctx.render(1, cs, None, opts, want_stats=False)
+    live, psnrs = 0, []
+    for v, oc in enumerate(ocams):
+        want, _ = f.render(oc, w, h, 0, 1, 1e-4, step_mode=oracle.STEP_NGP)
+        ref, _ = fb.render(oc, w, h, 0, 1, 1e-4, step_mode=oracle.STEP_NGP)
+        live += f.march_count(oc, w, h, 0, step_mode=oracle.STEP_NGP)
+        util.assert_pixels_close(img[v].cpu().numpy(), want)
+        psnrs.append(oracle.score_view(want, ref, (0.0, 0.0, 0.0, 1.0))[1])
+    assert int(st.samples_live) == live > 0
+    bg_opts = api.engine_render_opts(w, h, 0, 1, 1e-4, background=(0.0, 0.0, 0.0, 1.0))
+    psnr, ssim = ctx.evaluate(0, cs, None, bg_opts, gt)
+    assert psnr == pytest.approx(np.mean(psnrs), rel=1e-3) and 0.0 < ssim <= 1.0
+    cs.close()
