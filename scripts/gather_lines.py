@@ -12,7 +12,7 @@ Layouts:  as built  -- dense levels: power-of-two strides, x fastest; hashed: ((
           brickhash -- hashed levels indexed by a hash of the BRICK coordinate, corners of a brick contiguous.
                        NOT value-preserving: it is a different hash function, i.e. a different field -- no permutation of
                        the canonical table can produce it, because canonical neighbours in y/z are scattered by construction.
-  python scripts/gather_lines.py [256|512]"""
+  python scripts/gather_lines.py [256|512] [cohort shape: 8x4 (as built) | 32x1 | 1x32 | 16x2 | auto]"""
 import os
 import sys
 
@@ -37,8 +37,9 @@ def levels(kw):
     return out, T
 
 
-def cohort_samples(n_views=6, tiles_per_view=40, S=128, W=800, seed=1):
-    """positions [cohort, lane(32), 3] of lockstep samples inside the object"""
+def cohort_samples(n_views=6, tiles_per_view=40, S=128, W=800, seed=1, shape=(8, 4)):
+    """positions [cohort, lane(32), 3] of lockstep samples inside the object; shape = the cohort's pixel block (w, h), or
+    "auto": 32x1 rows or 1x32 columns, whichever runs along the image direction of the table's x axis in that view"""
     rng = np.random.default_rng(seed)
     pts = planner.hemisphere_generate(64)
     tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
@@ -52,9 +53,10 @@ def cohort_samples(n_views=6, tiles_per_view=40, S=128, W=800, seed=1):
         m[:, 2] *= -1
         m[:, 3] = m[:, 3] * scale + offset
         c2w = m[[1, 2, 0], :]  # nerf -> engine frame
+        cw, ch = shape if shape != "auto" else ((32, 1) if abs(np.linalg.inv(c2w[:, :3])[0, 0]) >= abs(np.linalg.inv(c2w[:, :3])[1, 0]) else (1, 32))
         for _ in range(tiles_per_view):
             x0, y0 = rng.integers(250, 550), rng.integers(250, 550)
-            px, py = np.meshgrid(np.arange(8) + x0, np.arange(4) + y0)
+            px, py = np.meshgrid(np.arange(cw) + x0, np.arange(ch) + y0)
             d = np.stack([(px.ravel() + 0.5 - W / 2) / f, (py.ravel() + 0.5 - W / 2) / f, np.ones(32)], 1) @ c2w[:, :3].T
             d /= np.linalg.norm(d, axis=1, keepdims=True)
             o = c2w[:, 3]
@@ -105,8 +107,9 @@ def main():
     kw = dict(api.FIELD_256 if which == "256" else api.FIELD_512)
     lv, T = levels(kw)
     ebytes = kw["n_features"] * 2
-    pos = cohort_samples()
-    print(f"field {which}^3: L={kw['n_levels']} F={kw['n_features']} T=2^{kw['log2_hashmap']}, {len(pos)} cohort-samples of 32 lanes")
+    shape = sys.argv[2] if len(sys.argv) > 2 else "8x4"
+    pos = cohort_samples(shape="auto" if shape == "auto" else tuple(int(v) for v in shape.split("x")))
+    print(f"field {which}^3: L={kw['n_levels']} F={kw['n_features']} T=2^{kw['log2_hashmap']}, {len(pos)} cohort-samples of 32 lanes, cohort = {shape} pixels")
     print(f"{'level':>5} {'res':>5} {'kind':>6} | {'as built: alone':>15} {'cohort':>7} | {'brick: alone':>12} {'cohort':>7}")
     tot = {"built": [0.0, 0.0], "brick": [0.0, 0.0]}
     for l, (s, res, hashed) in enumerate(lv):
