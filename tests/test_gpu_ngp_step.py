@@ -200,3 +200,49 @@ def test_ngp_step_through_the_lens_cameras_of_the_evaluation_block(ctx, oracle, 
     psnr, ssim = ctx.evaluate(0, cs, None, bg_opts, gt)
     assert psnr == pytest.approx(np.mean(psnrs), rel=1e-3) and 0.0 < ssim <= 1.0
     cs.close()
+
+
+@pytest.mark.parametrize("mode", ["fixed", "ngp"])
+def test_tile_rejection_never_drops_a_live_ray_random_cameras(ctx, oracle, fields, mode):
+    """the march pass skips whole 16x16 tiles outside the pixel rectangle of the occupied box's projected corners
+    (prv_api.cpp: set_cull_rect) and the fused PSNR round does not even launch them: 40 random cameras -- near and far,
+    looking at, past and away from the object, rolled, some inside the cube -- must give the oracle's march count exactly
+    (one dropped live ray would show), through prv_render AND through the fused scoring round's private image"""
+    d_o, d_p, f = fields
+    rng = np.random.default_rng(20260)
+    w, h = 96, 72
+    step = oracle.STEP_NGP if mode == "ngp" else oracle.STEP_FIXED_S
+    opts = api.engine_render_opts(w, h, 0 if mode == "ngp" else 96, 1, 1e-4)
+    mats = []
+    for k in range(40):
+        eye = rng.normal(size=3)
+        eye = eye / np.linalg.norm(eye) * rng.choice([0.02, 0.08, 0.15, 0.3, 0.6, 2.5])
+        target = rng.normal(size=3) * rng.choice([0.0, 0.02, 0.08, 0.3])
+        fwd = target - eye
+        fwd /= np.linalg.norm(fwd)
+        up = rng.normal(size=3)
+        right = np.cross(fwd, up)
+        right /= np.linalg.norm(right)
+        up = np.cross(right, fwd)
+        m = np.eye(4)
+        m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, up, -fwd, eye  # NeRF convention: the camera looks down -z
+        mats.append(m)
+    mats = np.array(mats)
+    scale, offset = 5.0, np.array([0.5, 0.5, 0.5])
+    fov = 0.9
+    cs = ctx.cameras_from_matrices(mats, fov, w, h, scale, offset)
+    ocams = oracle.cameras_from_transforms(mats, fov, w, h, scale, offset)
+    want = [f.march_count(oc, w, h, 96, step_mode=step) for oc in ocams]
+    assert sum(1 for x in want if x > 0) >= 15 and sum(1 for x in want if x == 0) >= 3  # both kinds of view occur
+    for v in range(len(ocams)):
+        _, st = ctx.render(0, cs, [v], opts)
+        assert int(st.samples_live) == want[v], (v, int(st.samples_live), want[v])
+    # the fused round (only the tiles inside the rectangles are launched, the score reads through the rectangles):
+    # same records as scoring fully written images
+    ctx.synthetic_model(1, d_p, util.SEED_B)
+    gt, _ = ctx.render(1, cs, None, opts, want_stats=False)
+    img, _ = ctx.render(0, cs, None, opts, want_stats=False)
+    rec, st = ctx.score_views(api.L.SCORE_PSNR_COVERAGE, [0], cs, None, opts, gt=gt, want_stats=True)
+    assert int(st.samples_live) == sum(want)
+    assert rec.tobytes() == ctx.score_psnr_images(img, gt).tobytes()
+    cs.close()
