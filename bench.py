@@ -306,15 +306,12 @@ class Round:
 
 
 def lib_digest():
-    """sha256 of the libprv_hip.so this run loads: the per-round instruction counts of the committed PMC pass are a
-    property of the BINARY, so the profile file names the binary it was taken from and the line says whether they match"""
-    import hashlib
+    """sha256 of the DEVICE code (the .hip_fatbin section) of the libprv_hip.so this run loads: the per-round instruction
+    counts of the committed PMC pass are a property of the gfx950 code objects, so the profile file names the code it was
+    taken from and the line says whether they match (host-side changes to the library do not break the binding)"""
+    from nerf_prv_amd import _lib
 
-    h = hashlib.sha256()
-    with open(os.path.join(ROOT, "nerf_prv_amd", "libprv_hip.so"), "rb") as fh:
-        for chunk in iter(lambda: fh.read(1 << 20), b""):
-            h.update(chunk)
-    return h.hexdigest()[:16]
+    return _lib.device_code_digest()
 
 
 def kernel_figures(m, variant, hbm_bound, scene, layout):
@@ -359,9 +356,9 @@ def kernel_figures(m, variant, hbm_bound, scene, layout):
         "mfma_useful_frac": mfma_tflops / MFMA_F16_PEAK_TFLOPS,
         "mfma_pipe_frac": mfma_pipe_frac,
         "valu_insts_per_round_from_profile": cost["valu_insts_per_round"] if cost else None,
-        "profile_lib_sha256": cost.get("lib_sha256") if cost else None,
-        "this_lib_sha256": lib_digest(),
-        "profile_matches_binary": bool(cost and cost.get("lib_sha256") == lib_digest()),
+        "profile_device_code_sha256": cost.get("device_code_sha256") if cost else None,
+        "this_device_code_sha256": lib_digest(),
+        "profile_matches_binary": bool(cost and cost.get("device_code_sha256") == lib_digest()),
         "valu_issue_frac": valu_frac,
         "floor": dict(floor, valu_frac=floor_valu_frac, mfma_pipe_frac=floor_mfma_frac,
                       valu_insts_per_round=floor["valu_per_64_samples"] / 2.0,

@@ -128,7 +128,8 @@ int prv_set_stream(prv_ctx* ctx, void* hip_stream);
  * in a defined order.  Every context must have been destroyed (PRV_E_STATE otherwise); synchronises and resets every
  * device a context was created on (hipDeviceReset), so the HIP runtime's own state -- its streams, signal pools and
  * worker threads -- is torn down HERE, while the process is still intact, and the static destructors that run after
- * main find nothing left to race with.  (The reference's boundary had no such step: its GPU work lived in child Python
+ * main find nothing left to race with.  (A process in which a communicator loaded librccl is only synchronised, not
+ * reset: that library stays loaded and releases device state of its own after main.)  (The reference's boundary had no such step: its GPU work lived in child Python
  * processes, train_server.py:12.)  A process that shares the runtime with another library (Python + torch) must NOT
  * call this. */
 int prv_runtime_shutdown(void);

@@ -189,3 +189,26 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def device_code_digest(path=None):
+    """sha256 (first 16 hex digits) of the .hip_fatbin section of libprv_hip.so: the gfx950 code objects themselves.  What
+    a PMC pass measures (instructions per wave-round) is a property of the DEVICE code; host-side changes to the library do
+    not touch it, so the profiles name this digest and bench.py compares it with the library it loads."""
+    import hashlib
+    import struct
+
+    path = path or LIB_PATH
+    with open(path, "rb") as fh:
+        data = fh.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        raise ValueError(f"{path} is not a 64-bit ELF file")
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    sections = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+    stroff = sections[shstrndx][4]
+    for name_off, _type, _flags, _addr, off, size, *_ in sections:
+        end = data.index(b"\0", stroff + name_off)
+        if data[stroff + name_off:end] == b".hip_fatbin":
+            return hashlib.sha256(data[off:off + size]).hexdigest()[:16]
+    raise ValueError(f"{path} has no .hip_fatbin section")

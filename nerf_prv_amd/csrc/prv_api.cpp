@@ -32,6 +32,7 @@ namespace {
 thread_local std::string g_create_error;
 std::atomic<int> g_live_contexts{0};        // prv_runtime_shutdown refuses while a context is alive
 std::atomic<unsigned long long> g_devices_used{0}; // bit d: a context was created on device d
+std::atomic<bool> g_rccl_loaded{false};            // librccl was dlopen'ed by a communicator: it stays loaded for the process
 
 struct Buffer {
   void* p = nullptr;
@@ -818,7 +819,9 @@ int prv_runtime_shutdown(void) {
     if (!((used >> d) & 1ull)) continue;
     if (hipSetDevice(d) != hipSuccess) continue;
     (void)hipDeviceSynchronize();
-    (void)hipDeviceReset();
+    // librccl (when a communicator loaded it) stays loaded and keeps device state of its own that its static destructors
+    // release after main: the device is then only synchronised, not reset under it
+    if (!g_rccl_loaded.load()) (void)hipDeviceReset();
   }
   (void)hipGetLastError();
   return PRV_OK;

@@ -18,11 +18,14 @@ rq = next(v for k, v in counters.items() if "render_queue" in k)
 kb = open(kbench_log).read()
 ev, rounds = int(re.search(r"eval_exact=(\d+)", kb).group(1)), int(re.search(r"rounds=(\d+)", kb).group(1))
 
-LIB_SHA = hashlib.sha256(open(os.path.join(ROOT, "nerf_prv_amd", "libprv_hip.so"), "rb").read()).hexdigest()[:16]
+sys.path.insert(0, ROOT)
+from nerf_prv_amd import _lib  # noqa: E402
+
+LIB_SHA = _lib.device_code_digest()  # the gfx950 code objects (.hip_fatbin), not the whole file
 
 
 def update(path, entry):
-    entry = dict(entry, lib_sha256=LIB_SHA)
+    entry = dict(entry, device_code_sha256=LIB_SHA)
     full = os.path.join(ROOT, path)
     data = json.load(open(full)) if os.path.exists(full) else {}
     data[variant] = entry
