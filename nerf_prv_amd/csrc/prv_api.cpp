@@ -371,7 +371,16 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
     }
     L.off_b = poff[l] * ebytes;
     L.myz_b = L.my_b + L.mz_b;
-    L.pad1 = 0;
+    // the render kernel's packed word (prv_device.hpp: LevelDev::pack); the alignment the packing relies on is checked
+    // (a field whose offsets leave no room for it -- hashed tables below 4 KiB -- runs the generic instance, which reads the
+    // unpacked constants)
+    if (lv[l].hashed) {
+      if ((L.off_b & 4095u) != 0u || L.res_m1 > 4095u) f.hash_shared = 0;
+      L.pack = (L.off_b & ~4095u) | (L.res_m1 & 4095u);
+    } else {
+      if ((L.off_b & 31u) != 0u || sx[l] > 31u) f.hash_shared = 0;
+      L.pack = (L.off_b & ~31u) | (sx[l] & 31u);
+    }
   }
   m.loaded = true;
   m.dirty = false;

@@ -38,8 +38,12 @@ struct LevelDev {
   uint32_t my_b, mz_b;
   uint32_t m_b;
   uint32_t off_b;  // byte offset of the level, aligned to its size
-  uint32_t myz_b;  // dense levels: my_b + mz_b (the (y+1, z+1) neighbour of the v2 gather)
-  uint32_t pad1;
+  uint32_t myz_b;  // dense levels: my_b + mz_b
+  // Everything but `scale` in ONE word, for the render kernel (which keeps the level constants in scalar registers and runs
+  // out of them): off_b is a multiple of the level's (power-of-two) size, so its low bits are free --
+  //   dense : off_b | sx      (y stride = ebytes << sx, z stride = ebytes << 2 sx)
+  //   hashed: off_b | res_m1  (res_m1 < 4096; the hash constants are the field's shared three)
+  uint32_t pack;
 };
 
 struct FieldDev {
@@ -330,14 +334,21 @@ __device__ __forceinline__ void encode_level2(const uint16_t* __restrict__ table
     c0[a] = (uint32_t)(int)pos[a];
   }
   uint32_t vw[8][F / 2];
+  // The level's packed word, made opaque once per use: everything derived from it (strides, the scalar base pointers) is
+  // then recomputed by the scalar ALU every round -- a handful of SALU instructions per level -- instead of being hoisted
+  // out of the loop into registers the kernel does not have (it was spilling 40..117 SGPRs, one v_readlane per use).
+  uint32_t pk = L.pack;
+  if (KIND != kLevelGeneric) asm volatile("" : "+s"(pk));
   if (DENSE) {
     // the level constants are wave-uniform here (scalar registers): the level offset and the +y neighbour go into two
     // SCALAR base pointers (SALU adds), so the four paired loads need one vector add between them -- (b, base),
     // (b, base + my), (b + mz, base), (b + mz, base + my)
-    const char* base0 = reinterpret_cast<const char*>(table) + L.off_b;
-    const char* base1 = base0 + L.my_b;
-    const uint32_t b = (c0[0] << ESH) + __umul24(c0[1], L.my_b) + __umul24(c0[2], L.mz_b);
-    const uint32_t bz = b + L.mz_b;
+    const uint32_t sxl = pk & 31u, off = pk & ~31u;
+    const uint32_t my = (uint32_t)(F * 2) << sxl, mz = (uint32_t)(F * 2) << (2u * sxl);
+    const char* base0 = reinterpret_cast<const char*>(table) + off;
+    const char* base1 = base0 + my;
+    const uint32_t b = (c0[0] << ESH) + __umul24(c0[1], my) + __umul24(c0[2], mz);
+    const uint32_t bz = b + mz;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const EntryPair<F> e = EntryPair<F>::load(((q & 1) ? base1 : base0) + ((q >> 1) ? bz : b));
@@ -351,10 +362,11 @@ __device__ __forceinline__ void encode_level2(const uint16_t* __restrict__ table
     // hashed level, the field's shared constants: byte offset inside the level = ((x << esh) ^ (y * my) ^ (z * mz)) & m.
     // The x term needs no mask (res <= T, host-checked), the level's offset goes into a SCALAR base pointer, and the three
     // terms meet in one v_bitop3_b32 (xor3) per corner: per level 3 add + 3 min + 2 shift + 4 mul24 + 4 and + 8 xor3.
+    const uint32_t res_m1 = pk & 4095u;
     uint32_t c1[3];
 #pragma unroll
-    for (int a = 0; a < 3; a++) c1[a] = min(c0[a] + 1u, L.res_m1);
-    const char* base = reinterpret_cast<const char*>(table) + L.off_b;
+    for (int a = 0; a < 3; a++) c1[a] = min(c0[a] + 1u, res_m1);
+    const char* base = reinterpret_cast<const char*>(table) + (pk & ~4095u);
     const uint32_t tx[2] = {c0[0] << ESH, c1[0] << ESH};
     const uint32_t ty[2] = {__umul24(c0[1], H.my_b) & H.m_b, __umul24(c1[1], H.my_b) & H.m_b};
     const uint32_t tz[2] = {__umul24(c0[2], H.mz_b) & H.m_b, __umul24(c1[2], H.mz_b) & H.m_b};

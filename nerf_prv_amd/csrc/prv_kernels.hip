@@ -1151,9 +1151,8 @@ __global__ __launch_bounds__(256) void debug_field64_kernel(FieldDev fd, const f
                                                             int n, uint16_t* __restrict__ feat, float* __restrict__ out36,
                                                             int32_t* __restrict__ occ_out) {
   __shared__ half8 wl[kNumFrags * 64];
-  __shared__ LevelDev lvl[kMaxLevels];
+  const LevelDev* __restrict__ lvl = fd.levels; // wave-uniform kernel arguments, as in the render kernel
   for (int i = threadIdx.x; i < kNumFrags * 64; i += 256) wl[i] = fd.frags64[i];
-  stage_levels(fd, lvl);
   __syncthreads();
   const int lane = threadIdx.x & 63, r = lane & 31, g = lane >> 5;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
