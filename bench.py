@@ -412,7 +412,10 @@ def kernel_figures(m, variant, hbm_bound, scene, layout):
                        "SIMDs x 2.4 GHz / 4 cycles.  valu_issue_frac = the same with the instructions actually ISSUED (wave-rounds "
                        "counted by the kernel in this run x VALU instructions per round from the PMC pass of this binary); the clock "
                        "under load is below 2.4 GHz (shader_clock_ghz_measured, stamped inside the launch): "
-                       "valu_issue_frac_at_measured_clock prices the cycles that really happened")
+                       "valu_issue_frac_at_measured_clock prices the cycles that really happened.  What holds the clock down is the chip's power "
+                       "management: with one / two / three waves per SIMD the same launch runs at 2.38 / 2.04 / 1.90 GHz and the third "
+                       "wave buys 1 % (profiles/r03_t_render_kernel_ablation_and_waves.txt) -- less energy per sample, not more "
+                       "parallelism, is what would make it faster")
     return out
 
 
