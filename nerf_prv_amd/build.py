@@ -21,11 +21,9 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "
              "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-Wall"]
 if os.environ.get("PRV_ABLATE"):
     HIP_FLAGS.append("-DPRV_ABLATE=" + os.environ["PRV_ABLATE"])
-if os.environ.get("PRV_MLP2_ORDER"):  # dev only: MFMA / pack ordering of mlp_forward2
-    HIP_FLAGS.append("-DPRV_MLP2_ORDER=" + os.environ["PRV_MLP2_ORDER"])
 if os.environ.get("PRV_TRAIN_ABLATE"):  # dev only: compile-time ablation of the training tile kernel
     HIP_FLAGS.append("-DPRV_TRAIN_ABLATE=" + os.environ["PRV_TRAIN_ABLATE"])
-if os.environ.get("PRV_EXTRA_HIPFLAGS"):  # dev only: compiler-option experiments (scripts/gpu/r02_ai.sh)
+if os.environ.get("PRV_EXTRA_HIPFLAGS"):  # dev only: compiler-option experiments (scripts/gpu/ab_flags.sh)
     HIP_FLAGS += os.environ["PRV_EXTRA_HIPFLAGS"].split()
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-ffp-contract=off"]
 

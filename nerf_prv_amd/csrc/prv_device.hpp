@@ -578,42 +578,27 @@ __device__ __forceinline__ MlpOut2 mlp_forward2(const half8* __restrict__ wl, in
   MlpOut2 out;
   half8 hA[4], hB[4];
   // per layer: group A's MFMAs, group B's MFMAs, then the packs -- B's MFMAs are in the pipe while A's accumulators are
-  // converted; at most two 32x32 accumulators per group are live (PRV_MLP2_ORDER=1: A fully before B, fewer live registers)
-#ifndef PRV_MLP2_ORDER
-#define PRV_MLP2_ORDER 0
-#endif
+  // converted; at most two 32x32 accumulators per group are live
   auto layer64 = [&](int f0, const half8 in0A, const half8 in1A, const half8 in0B, const half8 in1B) { // K = 32 -> 64 units
     const half8 w0 = wl[(f0 + 0) * 64 + lane], w1 = wl[(f0 + 1) * 64 + lane], w2 = wl[(f0 + 2) * 64 + lane], w3 = wl[(f0 + 3) * 64 + lane];
     f32x16 a0 = mfma(w0, in0A, zero), a1 = mfma(w2, in0A, zero);
     a0 = mfma(w1, in1A, a0);
     a1 = mfma(w3, in1A, a1);
-#if PRV_MLP2_ORDER
-    hA[0] = pack8<true>(a0, 0); hA[1] = pack8<true>(a0, 8); hA[2] = pack8<true>(a1, 0); hA[3] = pack8<true>(a1, 8);
-#endif
     f32x16 b0 = mfma(w0, in0B, zero), b1 = mfma(w2, in0B, zero);
     b0 = mfma(w1, in1B, b0);
     b1 = mfma(w3, in1B, b1);
-#if !PRV_MLP2_ORDER
     hA[0] = pack8<true>(a0, 0); hA[1] = pack8<true>(a0, 8); hA[2] = pack8<true>(a1, 0); hA[3] = pack8<true>(a1, 8);
-#endif
     hB[0] = pack8<true>(b0, 0); hB[1] = pack8<true>(b0, 8); hB[2] = pack8<true>(b1, 0); hB[3] = pack8<true>(b1, 8);
   };
   auto layer16 = [&](int f0, f32x16& a, f32x16& b) { // K = 64 -> 16 units (+ copies in the padding rows)
     a = zero;
     b = zero;
-#if PRV_MLP2_ORDER
-#pragma unroll
-    for (int s = 0; s < 4; s++) a = mfma(wl[(f0 + s) * 64 + lane], hA[s], a);
-#pragma unroll
-    for (int s = 0; s < 4; s++) b = mfma(wl[(f0 + s) * 64 + lane], hB[s], b);
-#else
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       const half8 w = wl[(f0 + s) * 64 + lane];
       a = mfma(w, hA[s], a);
       b = mfma(w, hB[s], b);
     }
-#endif
   };
   layer64(0, fA[0], fA[1], fB[0], fB[1]);  // density layer 1: 32 -> 64
   layer16(4, out.densA, out.densB);         // density layer 2: 64 -> 16
@@ -621,20 +606,6 @@ __device__ __forceinline__ MlpOut2 mlp_forward2(const half8* __restrict__ wl, in
   layer64(8, dfA, shA, dfB, shB);           // colour layer 1: [density out 16 | SH 16] -> 64
   { // colour layer 2: 64 -> 64
     f32x16 a0 = zero, a1 = zero, b0 = zero, b1 = zero;
-#if PRV_MLP2_ORDER
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      a0 = mfma(wl[(12 + s) * 64 + lane], hA[s], a0);
-      a1 = mfma(wl[(16 + s) * 64 + lane], hA[s], a1);
-    }
-    hA[0] = pack8<true>(a0, 0); hA[1] = pack8<true>(a0, 8); hA[2] = pack8<true>(a1, 0); hA[3] = pack8<true>(a1, 8);
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      b0 = mfma(wl[(12 + s) * 64 + lane], hB[s], b0);
-      b1 = mfma(wl[(16 + s) * 64 + lane], hB[s], b1);
-    }
-    hB[0] = pack8<true>(b0, 0); hB[1] = pack8<true>(b0, 8); hB[2] = pack8<true>(b1, 0); hB[3] = pack8<true>(b1, 8);
-#else
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       const half8 w0 = wl[(12 + s) * 64 + lane], w1 = wl[(16 + s) * 64 + lane];
@@ -645,7 +616,6 @@ __device__ __forceinline__ MlpOut2 mlp_forward2(const half8* __restrict__ wl, in
     }
     hA[0] = pack8<true>(a0, 0); hA[1] = pack8<true>(a0, 8); hA[2] = pack8<true>(a1, 0); hA[3] = pack8<true>(a1, 8);
     hB[0] = pack8<true>(b0, 0); hB[1] = pack8<true>(b0, 8); hB[2] = pack8<true>(b1, 0); hB[3] = pack8<true>(b1, 8);
-#endif
   }
   layer16(20, out.rgbA, out.rgbB);          // colour layer 3: 64 -> 16 (3 used)
   return out;
