@@ -105,6 +105,36 @@ def test_ensemble_round_at_reference_candidate_size(ctx, oracle, scene):
         assert (imgs[0][..., 3] == 255).all()  # opaque background: alpha carries nothing
 
 
+@pytest.mark.parametrize("rule", ["fixed", "ngp"])
+def test_reference_size_candidates_match_the_oracle(ctx, oracle, scene, rule):
+    """what the ensemble scores are MADE of: the 80x45, 16-sub-sample candidate renders of run.py:304 (main.cpp:1796-1806)
+    on the full-size field against the oracle's own render, whole images, under both stepping rules -- the float image to
+    1e-3 (termination variants: the engine's min_T = 0.01) and the bytes the scores read to one code"""
+    desc, cams, (tms, scale, offset) = scene
+    w, h, spp, min_T = 80, 45, 16, 1e-2
+    small = ctx.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+    ocams = oracle.cameras_from_transforms(tms, util.FOV_X, w, h, scale, offset)
+    f = oracle.OracleField(oracle.desc(), seed=util.SEED_A)
+    bg = (0, 0, 0, 1)
+    opts = api.engine_render_opts(w, h, 0 if rule == "ngp" else S, spp, min_T, background=bg)
+    mode = oracle.STEP_NGP if rule == "ngp" else oracle.STEP_FIXED_S
+    img, st = ctx.render(0, small, None, opts)
+    u8, _ = ctx.render_rgba8(0, small, None, opts)
+    assert st.rays == 8 * w * h * spp
+    n_codes_off = 0
+    for v in range(8):
+        wants = [f.render(ocams[v], w, h, 0 if rule == "ngp" else S, spp, t, threads=8, step_mode=mode)[0] for t in util.termination_variants(min_T)]
+        util.assert_pixels_close_any(img[v].cpu().numpy(), wants)
+        want8 = oracle.quantize_rgba8(wants[0], bg)
+        d = np.abs(u8[v].cpu().numpy().astype(np.int32) - want8.astype(np.int32))
+        assert d.max() <= 1  # a value on a rounding boundary may land on either code
+        n_codes_off += int((d != 0).sum())
+    assert n_codes_off <= 8 * w * h * 4 // 200  # and hardly any does
+    assert wants[0][..., 3].max() > 0.9
+    f.close()
+    small.close()
+
+
 def test_evaluation_path_psnr_ssim_and_metrics_file(ctx, oracle, scene, tmp_path):
     """run.py:226-277 on the device: spp 8 snapped to pixel centres == spp 1, min_T 1e-4, black opaque
     background; mean PSNR / SSIM over the test views; the metrics file other tools read"""
