@@ -80,6 +80,37 @@ def test_whole_views_and_the_rounds_march_count(ctx, oracle, round_cams, round_m
     f.close()
 
 
+def test_the_scoring_round_end_to_end_against_the_oracle_alone(ctx, oracle, round_cams):
+    """bench.py's step with NOTHING of the GPU's on the checking side: eleven of the round's 64 views of the section 6
+    scene, reference images = the oracle's renders of the second field (seed B; uploaded as the round's gt), scored by
+    the fused GPU round (march + render + PSNR / coverage reduce + rank) -- against the oracle's renders of the first field
+    scored by the oracle's recipe (run.py:257-263, main.cpp:2148).  PSNR to 1e-3 dB, coverage to 1e-5, the same ranking
+    (positions may differ only between views whose scores are closer than the PSNR tolerance)."""
+    cams, ocams = round_cams
+    kw = SCENES["baseline256"]
+    ids = list(range(1, N_VIEWS, 6))
+    ctx.synthetic_model(6, api.L.FieldDesc(**kw), util.SEED_A)
+    fa = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
+    fb = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_B)
+    mine = [fa.render(ocams[v], W, H, S, 1, 1e-4, threads=THREADS)[0] for v in ids]
+    refs = [fb.render(ocams[v], W, H, S, 1, 1e-4, threads=THREADS)[0] for v in ids]
+    fa.close()
+    fb.close()
+    want = np.array([oracle.score_view(a, b) for a, b in zip(mine, refs)])  # (score, psnr, coverage)
+    gt = ctx.torch.from_numpy(np.stack(refs)).cuda()
+    opts = api.render_opts(W, H, S, 1, 1e-4)
+    rec, st = ctx.score_views(api.L.SCORE_PSNR_COVERAGE, [6], cams, ids, opts, gt=gt, want_stats=True)
+    assert st.rays == len(ids) * W * H and np.all(np.isfinite(rec["psnr"]))
+    np.testing.assert_allclose(rec["psnr"], want[:, 1], atol=1e-3)  # measured: 4e-5 dB on PSNRs of 46..58 dB
+    np.testing.assert_allclose(rec["coverage"], want[:, 2], rtol=1e-5)  # measured: 3e-7
+    np.testing.assert_allclose(rec["score"], want[:, 0], atol=1e-3)
+    got_order, want_order = ctx.rank(rec, np.asarray(ids, np.int32)), oracle.rank(want[:, 0], np.asarray(ids, np.int32))
+    score_of = dict(zip(ids, want[:, 0]))
+    for a, b in zip(got_order, want_order):
+        assert a == b or abs(score_of[int(a)] - score_of[int(b)]) < 2e-3
+    assert want[:, 1].max() - want[:, 1].min() > 0.5  # the views do differ: the ranking is not a coin toss
+
+
 @pytest.mark.parametrize("scene", ["default256", "default512"])
 def test_ngp_step_at_full_size(ctx, oracle, round_cams, scene):
     """the engine's own stepping rule (PRV_STEP_NGP, what run.py:304 renders with) on the full-size fields: the march
