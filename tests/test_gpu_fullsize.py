@@ -135,6 +135,36 @@ def test_reference_size_candidates_match_the_oracle(ctx, oracle, scene, rule):
     small.close()
 
 
+def test_ensemble_round_end_to_end_against_the_oracle_alone(ctx, oracle, scene):
+    """the reference's scoring round (main.cpp:2045-2160) with nothing of the GPU's on the checking side: five members,
+    eight candidates at 80x45 with 16 sub-samples; the oracle renders every member's candidates, quantises them as
+    write_image does and scores them with the reference's loops -- against prv_score_views of the same members.  A byte
+    on a rounding boundary may differ by one code between the two renders, so the scores agree closely, not bitwise;
+    the ranking must be the same."""
+    desc, cams, (tms, scale, offset) = scene
+    w, h, spp, min_T, E = 80, 45, 16, 1e-2, 5
+    small = ctx.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+    ocams = oracle.cameras_from_transforms(tms, util.FOV_X, w, h, scale, offset)
+    bg = (0, 0, 0, 1)
+    opts = api.render_opts(w, h, S, spp, min_T, background=bg)
+    imgs = []
+    for e in range(E):
+        ctx.synthetic_model(2 + e, desc, 4000 + e)
+        f = oracle.OracleField(oracle.desc(), seed=4000 + e)
+        imgs.append([oracle.quantize_rgba8(f.render(oc, w, h, S, spp, min_T, threads=8)[0], bg) for oc in ocams])
+        f.close()
+    ids = np.arange(8, dtype=np.int32)
+    for method, n, fn in ((2, 2, oracle.score_ensemble_rgb), (3, 5, oracle.score_ensemble_rgbdensity)):
+        want = np.array([fn([imgs[e][v] for e in range(n)]) for v in range(8)])
+        rec, _ = ctx.score_views(method, list(range(2, 2 + n)), small, None, opts)
+        np.testing.assert_allclose(rec["score"], want, rtol=1e-3)  # measured: 1.5e-4 (sums of logs), 1e-5 (variance + density)
+        got_order, want_order = ctx.rank(rec, ids), oracle.rank(want, ids)
+        for a, b in zip(got_order, want_order):
+            assert a == b or abs(want[a] - want[b]) <= 4e-3 * abs(want[a])
+        assert np.ptp(want) > 0.05 * abs(want).max()  # the candidates do differ
+    small.close()
+
+
 def test_evaluation_path_psnr_ssim_and_metrics_file(ctx, oracle, scene, tmp_path):
     """run.py:226-277 on the device: spp 8 snapped to pixel centres == spp 1, min_T 1e-4, black opaque
     background; mean PSNR / SSIM over the test views; the metrics file other tools read"""
