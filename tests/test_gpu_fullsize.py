@@ -190,6 +190,34 @@ def test_evaluation_path_psnr_ssim_and_metrics_file(ctx, oracle, scene, tmp_path
     assert planner.read_metrics(path) == (mp, ms)
 
 
+def test_evaluation_block_at_the_reference_size_against_the_oracle_alone(ctx, oracle, scene):
+    """run.py:226-277 as the reference runs it, at ITS size: a 1280x720 test view through the dataset's own intrinsics and
+    OpenCV lens (render_with_lens_distortion, run.py:145), the engine's stepping rule, min_T 1e-4, black opaque
+    background -- prv_evaluate's PSNR and SSIM of the full-size field against a reference image rendered by the ORACLE,
+    compared with the oracle's metrics of the oracle's own render.  Nothing of the GPU's on the checking side."""
+    from tests.test_gpu_parity import REF_INTR
+
+    pts = util.fibonacci_hemisphere(4)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    cs = ctx.cameras_from_matrices_intr(tms, REF_INTR, scale, offset)
+    w, h, v = 1280, 720, 2
+    oc = oracle.cameras_from_dataset(tms, REF_INTR, scale, offset)[v]
+    bg = (0.0, 0.0, 0.0, 1.0)
+    fa, fb = oracle.OracleField(oracle.desc(), seed=util.SEED_A), oracle.OracleField(oracle.desc(), seed=util.SEED_B)
+    mine, _ = fa.render(oc, w, h, 0, 1, 1e-4, threads=16, step_mode=oracle.STEP_NGP)
+    ref, _ = fb.render(oc, w, h, 0, 1, 1e-4, threads=16, step_mode=oracle.STEP_NGP)
+    fa.close()
+    fb.close()
+    want_psnr, want_ssim = oracle.score_view(mine, ref, bg)[1], oracle.ssim(mine, ref, bg)
+    gt = ctx.torch.from_numpy(ref[None]).cuda()
+    opts = api.engine_render_opts(w, h, 0, 1, 1e-4, background=bg)  # run.py:231-245: spp 8 SNAPPED to pixel centres = one sub-sample
+    psnr, ssim = ctx.evaluate(0, cs, [v], opts, gt)
+    # measured: PSNR 32.6792700 against 32.6792695, SSIM equal to 1.5e-8
+    assert psnr == pytest.approx(want_psnr, abs=1e-3) and ssim == pytest.approx(want_ssim, abs=1e-5)
+    assert 5.0 < want_psnr < 80.0 and mine[..., 3].max() > 0.9
+    cs.close()
+
+
 @pytest.mark.parametrize("which", ["256", "512"])
 def test_training_gradients_on_the_full_size_fields(ctx, oracle, which):
     """one training batch on the BASELINE fields (256^3: L=8 F=4 T=2^19; 512^3: L=16 F=2 T=2^21) at 128 samples
