@@ -80,6 +80,23 @@ def test_whole_views_and_the_rounds_march_count(ctx, oracle, round_cams, round_m
     f.close()
 
 
+def test_first_hit_of_the_whole_round_is_bit_exact(ctx, oracle, round_cams):
+    """configs[0]'s path at the bench size (a13, main.cpp:238-284 as a ray cast per pixel): the first occupied voxel of
+    every pixel of all 64 views at 800x800 -- 41 M integer voxel ids -- equal to the oracle's, bit for bit"""
+    cams, ocams = round_cams
+    kw = SCENES["baseline256"]
+    ctx.synthetic_model(6, api.L.FieldDesc(**kw), util.SEED_A)
+    f = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
+    got = ctx.first_hit(6, cams, None, W, H).cpu().numpy()
+    hits = 0
+    for v, oc in enumerate(ocams):
+        want = oracle.first_hit_image(f, oc, W, H)
+        assert np.array_equal(got[v], want), v
+        hits += int((want >= 0).sum())
+    assert 0.02 * N_VIEWS * W * H < hits < 0.5 * N_VIEWS * W * H  # the object is seen, and so is the empty space around it
+    f.close()
+
+
 def test_the_scoring_round_end_to_end_against_the_oracle_alone(ctx, oracle, round_cams):
     """bench.py's step with NOTHING of the GPU's on the checking side: eleven of the round's 64 views of the section 6
     scene, reference images = the oracle's renders of the second field (seed B; uploaded as the round's gt), scored by
