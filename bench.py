@@ -496,7 +496,10 @@ def full_loop(args):
     t_all = time.perf_counter()
     for mode, key in ((21, "view_planning_s"), (4, "psnr_curve_and_stopping_criterion_s")):
         t0 = time.perf_counter()
-        r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=3600)
+        # `quick`: the planner's ordered shutdown, then _exit -- its exit code is then the planner's own (one ordinary return in
+        # ~5000 dies inside the HIP runtime's exit handlers after main has returned: DESIGN.md section 10, item 9)
+        r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=3600,
+                           env=dict(os.environ, PRV_PLANNER_EXIT=os.environ.get("PRV_PLANNER_EXIT", "quick")))
         out[key] = time.perf_counter() - t0
         if r.returncode != 0:
             out["error"] = f"mode {mode} exited {r.returncode}: {(r.stdout + r.stderr)[-400:]}"

@@ -209,6 +209,27 @@ def test_planner_executable_shards_objects_over_ranks(ctx, tmp_path):
     assert bad.returncode == 2 and "make no sense" in bad.stderr
 
 
+def test_planner_default_exit_is_an_ordinary_return(tmp_path):
+    """what a user gets without PRV_PLANNER_EXIT (the session sets `quick`, conftest.py): the library is shut down in order
+    (prv_runtime_shutdown: every context destroyed, device synchronised and reset) and main returns; exit code 0, the
+    result on stdout; `quick` (the same shutdown, then _exit) gives the same result and code."""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    lines = {}
+    for how in (None, "quick"):
+        pre = tmp_path / str(how)  # an output tree of its own: the planner resumes a finished one
+        pre.mkdir()
+        cfg = pre / "cfg.yaml"
+        cfg.write_text(YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=3,
+                                   model_source=f"synthetic_seed: {SEED}\npretrained_members: 1"))
+        env = {k: v for k, v in os.environ.items() if k != "PRV_PLANNER_EXIT"}
+        if how:
+            env["PRV_PLANNER_EXIT"] = how
+        out = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300, env=env)
+        assert out.returncode == 0, (how, out.stdout + out.stderr)
+        lines[how] = [l for l in out.stdout.splitlines() if l.startswith("chosen_nbvs:")][-1]
+    assert len(set(lines.values())) == 1
+
+
 def test_planner_executable_error_paths(tmp_path):
     exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
     out = subprocess.run([exe, str(tmp_path / "missing.yaml")], input="21\nx\n-1\n", text=True, capture_output=True)
