@@ -602,7 +602,7 @@ def run_rank(args):
             same = other.tobytes() == m["records"].tobytes()
         collective = {"timed_path": "prv_score_views_sharded on prv_comm (C ABI, " + (comm.transport if comm else "-") + ")" if comm is not None
                       else "torch.distributed all-gather (FALLBACK: the C ABI's communicator did not come up)",
-                      "rccl_ranks": comm.world if comm is not None else 0,
+                      "ranks": comm.world if comm is not None else 0, "transport": comm.transport if comm is not None else None,
                       "records_identical_to_torch_gather": same,
                       "error": None if comm is not None else (comm_info or {}).get("error")}
 
