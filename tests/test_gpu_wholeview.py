@@ -97,15 +97,16 @@ def test_first_hit_of_the_whole_round_is_bit_exact(ctx, oracle, round_cams):
     f.close()
 
 
-def test_the_scoring_round_end_to_end_against_the_oracle_alone(ctx, oracle, round_cams):
+@pytest.mark.parametrize("scene,stride", [("baseline256", 6), ("baseline512", 12)])
+def test_the_scoring_round_end_to_end_against_the_oracle_alone(ctx, oracle, round_cams, scene, stride):
     """bench.py's step with NOTHING of the GPU's on the checking side: eleven of the round's 64 views of the section 6
-    scene, reference images = the oracle's renders of the second field (seed B; uploaded as the round's gt), scored by
+    scene (and six of the same scene on configs[3]'s 512^3 field, the HBM-bound instance), reference images = the oracle's renders of the second field (seed B; uploaded as the round's gt), scored by
     the fused GPU round (march + render + PSNR / coverage reduce + rank) -- against the oracle's renders of the first field
     scored by the oracle's recipe (run.py:257-263, main.cpp:2148).  PSNR to 1e-3 dB, coverage to 1e-5, the same ranking
     (positions may differ only between views whose scores are closer than the PSNR tolerance)."""
     cams, ocams = round_cams
-    kw = SCENES["baseline256"]
-    ids = list(range(1, N_VIEWS, 6))
+    kw = SCENES[scene] if scene in SCENES else dict(api.FIELD_512, table_amp=0.1, density_bias=0.0)  # bench.py's `field512`
+    ids = list(range(1, N_VIEWS, stride))
     ctx.synthetic_model(6, api.L.FieldDesc(**kw), util.SEED_A)
     fa = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
     fb = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_B)
