@@ -129,7 +129,7 @@ def test_reference_size_candidates_match_the_oracle(ctx, oracle, scene, rule):
         d = np.abs(u8[v].cpu().numpy().astype(np.int32) - want8.astype(np.int32))
         assert d.max() <= 1  # a value on a rounding boundary may land on either code
         n_codes_off += int((d != 0).sum())
-    assert n_codes_off <= 8 * w * h * 4 // 200  # and hardly any does
+    assert n_codes_off <= 8 * w * h * 4 // 2000  # and hardly any does (measured: 1 and 0 of 115,200 bytes)
     assert wants[0][..., 3].max() > 0.9
     f.close()
     small.close()
