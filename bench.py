@@ -43,20 +43,44 @@ MFMA_PER_ROUND = 24      # v_mfma_f32_32x32x16_f16 per 32-slot round (prv_device
 HBM_PEAK_GBS = 8000.0        # 8 TB/s spec
 L2_PEAK_GBS = 34500.0        # aggregate L2, ~34.5 TB/s
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16
-N_SIMD, MAX_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its SIMD's VALU for 4 cycles
-VALU_PEAK_GINST = N_SIMD * MAX_CLOCK_HZ / 4.0 / 1e9  # 614.4 G wave-instructions/s at the 2.4 GHz maximum clock
-ROUND_COST_FILE = os.path.join("profiles", "r03_round_cost.json")  # VALU instructions per wave-round, from the PMC pass
-TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")    # fabric-side bytes per launch, from the PMC passes
+N_SIMD, MAX_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs
+# What ONE SIMD spends per wave64 vector instruction, MEASURED on this chip (scripts/valu_rate.hip ->
+# profiles/r04_valu_issue_rate.txt; grid 1, four waves per SIMD, the slowest wave of the launch -- the lowest figures of the
+# table, so the peak below is the most any instruction stream of this mix can get).  gfx950 has THREE issue classes:
+#   c2  2 cycles once two waves share the SIMD (one wave alone: 5): v_fma/mul/add/sub_f32, v_add/sub_u32, v_and/or/xor/mov_b32,
+#       v_bitop3_b32, v_lshrrev_b32, v_ashrrev_i32, v_max_f16, v_accvgpr_*
+#   c4  4 cycles whatever the occupancy: every packed-f16 / packed-f32 / f64 op, every conversion, v_lshlrev_b32, v_max/min_f32,
+#       v_med3, v_fract, v_mad/mul_u32_u24, v_mul_lo_u32, v_add3/lshl_add/and_or/bfe/bfi/perm, v_cmp, v_cndmask, DPP / SDWA forms
+#   c8  8 cycles: v_exp/rcp_f32 (and the other transcendentals), v_permlane32_swap, v_fma_f16, v_fma_mixlo_f16
+# and an MFMA holds the SIMD's vector issue for 8 cycles of its 32 (the "v_mfma + k VALU" rows: 24 fillers + 1 MFMA = 108 cycles).
+# The round-3 line assumed 4 cycles flat; the hardware guide says 2 with >= 2 waves per SIMD -- true for c2 only, and four
+# fifths of this kernel's instructions are c4 (packed-f16 blend, f32 -> f16 conversions, ReLU).
+ISSUE_CYCLES = {"c2": 2.08, "c4": 4.07, "c8": 8.07, "mfma": 8.0}
+ISSUE_RATE_FILE = os.path.join("profiles", "r04_valu_issue_rate.txt")
+ISSUE_PEAK_GCYC = N_SIMD * MAX_CLOCK_HZ / 1e9  # 2457.6 G SIMD issue-cycles/s at the 2.4 GHz maximum clock
+VALU_PEAK_GINST = ISSUE_PEAK_GCYC / ISSUE_CYCLES["c4"]  # wave-instructions/s if every instruction were c4 (kept for the detail object)
+ROUND_COST_FILE = os.path.join("profiles", "r04_round_cost.json")  # VALU instructions per wave-round, from the PMC pass
+TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")    # fabric-side bytes per launch, from the PMC passes
+ISA_CLASSES_FILE = os.path.join("profiles", "r04_isa_classes.json")  # static issue-class histogram of the hot loop (scripts/isa_count.py)
+
+
 # The algorithmic floor of the render kernel: wave-instructions one 64-sample wave iteration NEEDS for this algorithm
 # (fp16 table and blend as tiny-cuda-nn defines them, fp16 activations between the MLP layers), counted from the ISA of
-# render_queue64_kernel in DESIGN.md section 3 ("floor").  VALU: blend v_pk_fma_f16 128 | weights 15 per level |
-# level positions 3 per level | cell indices 3 per level | addresses 4 per dense, 26 per hashed level | accumulator ->
-# next B operand 104 v_cvt_pk_f16_f32 + 96 v_pk_max_f16 | 8 v_permlane32_swap | sample position 8 | sample selection 8 |
-# compositing 29.  MFMA: 10,240 MAC x 64 samples / 16,384 MAC per v_mfma_f32_32x32x16_f16 = 40 (48 are issued: the two
-# 64 -> 16 layers fill half of their 32-row tiles).
+# render_queue64_kernel in DESIGN.md section 3 ("floor"), each with its issue class:
+#   blend 128 v_pk_fma_f16 (c4) | per level: weights 3 v_fract + 3 v_cvt_pk_f16_f32 + 6 v_pk_mul_f16 (c4) + 3 v_sub_f32 (c2),
+#   positions 3 v_fma_f32 (c2), cell indices 3 v_cvt_i32_f32 (c4) | addresses: 4 per dense level (2 v_mul_u32_u24 c4 + 2 v_add c2),
+#   26 per hashed level (x shift + 2 multiplies + 3 clamps c4; 3 increments, 8 v_bitop3, 8 v_and / v_add c2 ... 6 c4 + 20 c2) |
+#   accumulator -> next B operand 104 v_cvt_pk_f16_f32 + 96 v_pk_max_f16 (c4) | 8 v_permlane32_swap (c8) | sample position
+#   8 v_fma_f32 (c2) | sample selection 8 (c4) | compositing 29 (2 v_exp + 1 v_rcp c8, 13 c2, 13 c4).
+# MFMA: 10,240 MAC x 64 samples / 16,384 MAC per v_mfma_f32_32x32x16_f16 = 40 (48 are issued: the two 64 -> 16 layers fill
+# half of their 32-row tiles).
 def isa_floor(n_levels, n_dense):
-    valu = 128 + 15 * n_levels + 3 * n_levels + 3 * n_levels + 4 * n_dense + 26 * (n_levels - n_dense) + 200 + 8 + 8 + 8 + 29
-    return {"valu_per_64_samples": valu, "mfma_per_64_samples": 40}
+    n_hashed = n_levels - n_dense
+    c4 = 128 + 12 * n_levels + 3 * n_levels + 2 * n_dense + 6 * n_hashed + 200 + 8 + 13
+    c2 = 3 * n_levels + 3 * n_levels + 2 * n_dense + 20 * n_hashed + 8 + 13
+    c8 = 8 + 3
+    cyc = c2 * ISSUE_CYCLES["c2"] + c4 * ISSUE_CYCLES["c4"] + c8 * ISSUE_CYCLES["c8"] + 40 * ISSUE_CYCLES["mfma"]
+    return {"valu_per_64_samples": c2 + c4 + c8, "c2": c2, "c4": c4, "c8": c8, "mfma_per_64_samples": 40, "issue_cycles_per_64_samples": cyc}
 
 
 def parse_args(argv=None):
@@ -75,9 +99,11 @@ def parse_args(argv=None):
                     help="baseline = BASELINE.md section 6 literally: table U(-0.1,0.1), no density bias (the headline); "
                          "dense = table U(-4,4), density bias 3: an opaque object, early termination exercised")
     ap.add_argument("--full-loop", action="store_true",
-                    help="BASELINE configs[4] at size, off by default (minutes): prv_planner configs/TrainInLoop.yaml semantics, 5 objects x 20 "
-                         "rounds (mode 21) + the PSNR curve and stopping criterion (mode 4), end-to-end wall-clock in a full_loop sub-object")
-    ap.add_argument("--full-loop-objects", type=int, default=5)
+                    help="BASELINE configs[4] at size (minutes): prv_planner configs/TrainInLoop.yaml semantics, 5 objects x 20 rounds (mode 21) + "
+                         "the PSNR curve and stopping criterion (mode 4), end-to-end wall-clock in the full_loop sub-object.  Without it "
+                         "the default run does ONE object x 20 rounds (under a minute) so that the driver's line carries the figure")
+    ap.add_argument("--full-loop-objects", type=int, default=0, help="0 = 1 by default, 5 with --full-loop")
+    ap.add_argument("--no-full-loop", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-training", action="store_true")
@@ -315,12 +341,16 @@ def lib_digest():
 
 
 def kernel_figures(m, variant, hbm_bound, scene, layout):
-    """roofline object of the dominant kernel (render_queue64) from a Round.measure() result.
+    """-> (roofline, detail) of the dominant kernel (render_queue64) from a Round.measure() result.
 
-    In-run quantities: launch durations (HIP events on the launch stream), evaluated samples and wave-rounds
-    (counted by the kernel itself).  Per-round VALU instruction counts are a property of the binary; they come
-    from the committed PMC pass (SQ_INSTS_VALU / wave-rounds), are labelled *_from_profile, and carry the digest of the
-    library they were measured on next to this run's (profile_matches_binary)."""
+    `roofline` is flat and short, the contract's keys first (kernel, bound, frac, peak, achieved, unit, traffic, then the
+    in-run measurements they come from): a parser that keeps the first couple of dozen scalar keys keeps all of it.  Everything
+    else (the floor's composition, the issue occupancy, the per-clock readings, provenance of the PMC figures) is `detail`.
+
+    In-run quantities: launch durations (HIP events on the launch stream), evaluated samples and wave-rounds (counted by the
+    kernel itself), the shader clock (stamped inside the launch).  Per-round instruction counts are a property of the binary:
+    they come from the committed PMC pass (SQ_INSTS_VALU / wave-rounds) and the static issue-class histogram of the hot loop,
+    are labelled *_from_profile, and carry the digest of the device code they were measured on (profile_matches_binary)."""
     prof, st, k = m["prof"], m["st"], m["steps"]
     launches = max(1, prof["render_launches"])
     kernel_s = prof["render_ms"] * 1e-3 / launches
@@ -331,92 +361,100 @@ def kernel_figures(m, variant, hbm_bound, scene, layout):
     # the MFMA pipe's own occupancy: 24 instructions of 8 passes x 4 cycles per wave-round, padded slots included
     mfma_pipe_frac = rounds * MFMA_PER_ROUND * 32 / (kernel_s * N_SIMD * MAX_CLOCK_HZ)
     key = f"{variant} {scene}"
+    digest = lib_digest()
     cost = (load_json(ROUND_COST_FILE) or {}).get(key)
-    valu_ginst = rounds * cost["valu_insts_per_round"] / kernel_s / 1e9 if cost else None
-    valu_frac = valu_ginst / VALU_PEAK_GINST if cost else None
+    classes = (load_json(ISA_CLASSES_FILE) or {}).get(variant)
     traffic = (load_json(TRAFFIC_FILE) or {}).get(key)
-    # the algorithmic floor: instructions this algorithm NEEDS per sample, not the ones issued --
-    # a fatter kernel scores higher on valu_issue_frac and lower here
-    floor = isa_floor(layout["n_levels"], layout["n_dense_levels"])
-    floor_valu_frac = samples / 64.0 * floor["valu_per_64_samples"] / kernel_s / (VALU_PEAK_GINST * 1e9)
-    floor_mfma_frac = samples / 64.0 * floor["mfma_per_64_samples"] * 32 / (kernel_s * N_SIMD * MAX_CLOCK_HZ)
-    out = {
-        "kernel": "render_queue" + variant.replace("<", "_kernel<", 1),
-        "units_per_launch": samples,
-        "wave_rounds_per_launch": rounds,
-        "slot_utilisation": samples / max(1.0, 32.0 * rounds),
-        "avg_launch_ms": kernel_s * 1e3,
-        "launches": launches,
-        "march_avg_launch_ms": prof["march_ms"] / max(1, prof["march_launches"]),
-        "bytes_per_unit": BYTES_PER_SAMPLE,
-        "algorithmic_gather_GBps": alg_gbs,
-        "hbm_algorithmic_frac": alg_gbs / HBM_PEAK_GBS,
-        "l2_algorithmic_frac": alg_gbs / L2_PEAK_GBS,
-        "mfma_tflops": mfma_tflops,
-        "mfma_useful_frac": mfma_tflops / MFMA_F16_PEAK_TFLOPS,
-        "mfma_pipe_frac": mfma_pipe_frac,
-        "valu_insts_per_round_from_profile": cost["valu_insts_per_round"] if cost else None,
-        "profile_device_code_sha256": cost.get("device_code_sha256") if cost else None,
-        "this_device_code_sha256": lib_digest(),
-        "profile_matches_binary": bool(cost and cost.get("device_code_sha256") == lib_digest()),
-        "valu_issue_frac": valu_frac,
-        "floor": dict(floor, valu_frac=floor_valu_frac, mfma_pipe_frac=floor_mfma_frac,
-                      valu_insts_per_round=floor["valu_per_64_samples"] / 2.0,
-                      note="instructions the algorithm needs per 64-sample wave iteration (ISA count, DESIGN.md section 3) x samples "
-                           "evaluated / launch time / (1024 SIMDs x 2.4 GHz / 4): the issue-bound fraction of USEFUL work"),
-        # the same bound in samples: what the SIMDs could evaluate if every issue slot carried this kernel's instruction
-        # mix AND every ray slot held a live ray; achieved / ceiling = valu_issue_frac x slot_utilisation.  A leaner
-        # kernel RAISES the ceiling (fewer instructions per sample), so compare rounds by samples/s, not by frac alone.
-        "issue_bound_samples_per_s": VALU_PEAK_GINST * 1e9 / (cost["valu_insts_per_round"] / 32.0) if cost else None,
-        "useful_issue_frac": valu_frac * (samples / max(1.0, 32.0 * rounds)) if cost else None,
-        "samples_per_s_in_kernel": samples / kernel_s,
-        "traffic_from_profile": None,
-    }
     clock = prof.get("clock_ghz") or 0.0
-    if clock > 0.0:
-        # measured in this run: one wave of the render launch stamps the shader cycle counter against the constant-rate
-        # reference counter, so the per-clock peaks can be priced at the clock the launch really ran at
-        out["shader_clock_ghz_measured"] = clock
-        out["mfma_pipe_frac_at_measured_clock"] = mfma_pipe_frac * MAX_CLOCK_HZ / (clock * 1e9)
-        if cost:
-            out["valu_issue_frac_at_measured_clock"] = valu_frac * MAX_CLOCK_HZ / (clock * 1e9)
-    out["traffic"] = None  # fabric-side bytes per launch (FETCH_SIZE + WRITE_SIZE), from the committed PMC passes of this binary
+    cycles_per_s = N_SIMD * MAX_CLOCK_HZ
+    # the algorithmic floor: issue cycles this algorithm NEEDS per 64 samples at the measured per-class
+    # costs -- a fatter kernel scores lower here, and higher on issue_busy
+    floor = isa_floor(layout["n_levels"], layout["n_dense_levels"])
+    floor_gcyc = samples / 64.0 * floor["issue_cycles_per_64_samples"] / kernel_s / 1e9
+    floor_frac = floor_gcyc / ISSUE_PEAK_GCYC
+    # the instructions actually ISSUED, priced the same way: the hot loop's static class histogram (two blocks, once per
+    # 64-slot iteration = two wave-rounds) + whatever else the PMC pass counted per round, at the c4 price
+    issued_cyc_per_iter = issued_busy = None
+    if cost and classes:
+        hot = classes["c2"] + classes["c4"] + classes["c8"]
+        rest = max(0.0, 2.0 * cost["valu_insts_per_round"] - hot)
+        issued_cyc_per_iter = (classes["c2"] * ISSUE_CYCLES["c2"] + classes["c4"] * ISSUE_CYCLES["c4"] + classes["c8"] * ISSUE_CYCLES["c8"]
+                               + classes["mfma"] * ISSUE_CYCLES["mfma"] + rest * ISSUE_CYCLES["c4"])
+        issued_busy = rounds / 2.0 * issued_cyc_per_iter / (kernel_s * cycles_per_s)
+    traffic_bytes = None
     if traffic:
         per_sample = (traffic["fetch_kib_per_launch"] + traffic["write_kib_per_launch"]) * 1024.0 / traffic["samples_evaluated_per_launch"]
-        out["traffic"] = per_sample * samples
-        out["traffic_from_profile"] = {"bytes_per_launch": per_sample * samples, "bytes_per_unit": per_sample, "file": TRAFFIC_FILE,
-                                       "note": "FETCH_SIZE + WRITE_SIZE of the committed PMC passes scaled by this run's sample count; not measured in this run"}
+        traffic_bytes = per_sample * samples
     if hbm_bound:
         # table >> L2 + Infinity Cache share: every gather is a memory-side request, the algorithmic bytes ARE the traffic
-        out.update({"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS,
-                    "note": "64 MiB table: fabric-side reads ~= algorithmic bytes (profiles/), random 64-B requests; the gather "
-                            "calibration (profiles/r01_gather_calib.txt) puts the ceiling for this access shape at ~3.8 TB/s"})
+        head = {"bound": "hbm", "frac": alg_gbs / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "achieved": alg_gbs, "unit": "GB/s"}
+        note = ("64 MiB table: fabric-side reads ~= algorithmic bytes (profiles/), random 64-B requests; the gather calibration "
+                "(profiles/r01_gather_calib.txt) puts the ceiling for this access shape at ~3.8 TB/s")
     else:
-        # cache-resident table: HBM is not the binding resource (hbm_algorithmic_frac > 1 would be a cache effect, not a
-        # fraction of anything).  The binding resource is SIMD issue: VALU instructions on the 1024 SIMDs.
-        cands = {"valu_issue": valu_frac if valu_frac is not None else floor_valu_frac, "mfma_pipe": mfma_pipe_frac, "l2": alg_gbs / L2_PEAK_GBS}
-        bound = max((v, n) for n, v in cands.items() if v is not None)[1]
+        # cache-resident table: HBM is not the binding resource (hbm_algorithmic_frac > 1 is a cache effect, not a fraction of
+        # anything).  Candidates: SIMD vector issue, the MFMA pipe, L2 bandwidth -- the largest fraction names the bound.
+        cands = {"valu_issue": issued_busy if issued_busy is not None else floor_frac, "mfma": mfma_pipe_frac, "l2": alg_gbs / L2_PEAK_GBS}
+        bound = max((v, n) for n, v in cands.items())[1]
         if bound == "valu_issue":
-            # frac = the algorithmic floor's fraction of the issue peak; the issue OCCUPANCY (instructions issued, needed or
-            # not) stays beside it as valu_issue_frac
-            out.update({"bound": "valu_issue", "achieved": floor_valu_frac * VALU_PEAK_GINST, "peak": VALU_PEAK_GINST,
-                        "unit": "G wave-instr/s (algorithmic floor)", "frac": floor_valu_frac})
-        elif bound == "mfma_pipe":
-            out.update({"bound": "mfma", "achieved": mfma_pipe_frac * N_SIMD * MAX_CLOCK_HZ / 1e9, "peak": N_SIMD * MAX_CLOCK_HZ / 1e9,
-                        "unit": "G MFMA-pipe cycles/s", "frac": mfma_pipe_frac})
+            head = {"bound": "valu_issue", "frac": floor_frac, "peak": ISSUE_PEAK_GCYC, "achieved": floor_gcyc,
+                    "unit": "G SIMD issue-cycles/s (algorithmic floor at measured per-class issue costs)"}
+        elif bound == "mfma":
+            head = {"bound": "mfma", "frac": mfma_pipe_frac, "peak": ISSUE_PEAK_GCYC, "achieved": mfma_pipe_frac * ISSUE_PEAK_GCYC,
+                    "unit": "G MFMA-pipe cycles/s"}
         else:
-            out.update({"bound": "l2", "achieved": alg_gbs, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / L2_PEAK_GBS})
-        out["note"] = ("17.4 MiB table is L2 / Infinity-Cache resident, so the HBM figure is not a bound here (hbm_algorithmic_frac "
-                       "is kept for reference only); the binding resource is SIMD issue.  frac = VALU wave-instructions the "
-                       "algorithm NEEDS (ISA floor, DESIGN.md section 3) x samples evaluated in this run / launch time, over 1024 "
-                       "SIMDs x 2.4 GHz / 4 cycles.  valu_issue_frac = the same with the instructions actually ISSUED (wave-rounds "
-                       "counted by the kernel in this run x VALU instructions per round from the PMC pass of this binary); the clock "
-                       "under load is below 2.4 GHz (shader_clock_ghz_measured, stamped inside the launch): "
-                       "valu_issue_frac_at_measured_clock prices the cycles that really happened.  What holds the clock down is the chip's power "
-                       "management: with one / two / three waves per SIMD the same launch runs at 2.38 / 2.04 / 1.90 GHz and the third "
-                       "wave buys 1 % (profiles/r03_t_render_kernel_ablation_and_waves.txt) -- less energy per sample, not more "
-                       "parallelism, is what would make it faster")
-    return out
+            head = {"bound": "l2", "frac": alg_gbs / L2_PEAK_GBS, "peak": L2_PEAK_GBS, "achieved": alg_gbs, "unit": "GB/s"}
+        note = ("17.4 MiB table is L2 / Infinity-Cache resident, so HBM is not the bound (hbm_algorithmic_frac is a cache effect); "
+                "the binding resource is SIMD vector issue.  frac = issue cycles the algorithm NEEDS per 64 samples (ISA floor, "
+                "each instruction at its MEASURED issue class: 2 / 4 / 8 cycles, MFMA 8; " + ISSUE_RATE_FILE + ") x samples evaluated in "
+                "this run / launch time, over 1024 SIMDs x 2.4 GHz.  issue_busy_at_measured_clock = the same for the instructions "
+                "actually ISSUED at the clock the launch really held (stamped inside it): the share of SIMD cycles spent issuing")
+    roof = {"kernel": "render_queue" + variant.replace("<", "_kernel<", 1)}
+    roof.update(head)
+    roof.update({
+        "traffic": traffic_bytes,  # fabric-side bytes per launch (FETCH_SIZE + WRITE_SIZE of the committed PMC passes, scaled by this run's samples)
+        "avg_launch_ms": kernel_s * 1e3,
+        "units_per_launch": samples,
+        "bytes_per_unit": BYTES_PER_SAMPLE,
+        "launches": launches,
+        "slot_utilisation": samples / max(1.0, 32.0 * rounds),
+        "samples_per_s_in_kernel": samples / kernel_s,
+        "shader_clock_ghz_measured": clock if clock > 0.0 else None,
+        "issue_busy_at_measured_clock": issued_busy * MAX_CLOCK_HZ / (clock * 1e9) if issued_busy is not None and clock > 0.0 else None,
+        "hbm_algorithmic_frac": alg_gbs / HBM_PEAK_GBS,
+        "mfma_useful_frac": mfma_tflops / MFMA_F16_PEAK_TFLOPS,
+        "mfma_pipe_frac": mfma_pipe_frac,
+        "profile_matches_binary": bool(cost and cost.get("device_code_sha256") == digest),
+        "note": note,
+    })
+    detail = {
+        "kernel": roof["kernel"],
+        "wave_rounds_per_launch": rounds,
+        "march_avg_launch_ms": prof["march_ms"] / max(1, prof["march_launches"]),
+        "algorithmic_gather_GBps": alg_gbs,
+        "l2_algorithmic_frac": alg_gbs / L2_PEAK_GBS,
+        "mfma_tflops": mfma_tflops,
+        "issue_cycles_per_instruction": dict(ISSUE_CYCLES, source=ISSUE_RATE_FILE),
+        "floor": dict(floor, frac=floor_frac,
+                      mfma_pipe_frac=samples / 64.0 * floor["mfma_per_64_samples"] * 32 / (kernel_s * cycles_per_s),
+                      note="instructions the algorithm needs per 64-sample wave iteration (ISA count, DESIGN.md section 3), by issue class"),
+        "issued_from_profile": None,
+        "this_device_code_sha256": digest,
+        "traffic_from_profile": None,
+    }
+    if cost:
+        detail["issued_from_profile"] = {
+            "valu_insts_per_round": cost["valu_insts_per_round"], "hot_loop_classes": classes, "issue_cycles_per_64_slot_iteration": issued_cyc_per_iter,
+            "issue_busy_at_max_clock": issued_busy, "device_code_sha256": cost.get("device_code_sha256"), "file": ROUND_COST_FILE,
+            # what the SIMDs could evaluate if every issue cycle carried this kernel's instruction mix AND every ray slot held a
+            # live ray; a leaner kernel RAISES this ceiling, so compare rounds by samples/s, not by a fraction alone
+            "issue_bound_samples_per_s": cycles_per_s / (issued_cyc_per_iter / 64.0) if issued_cyc_per_iter else None}
+    if clock > 0.0:
+        detail["mfma_pipe_frac_at_measured_clock"] = mfma_pipe_frac * MAX_CLOCK_HZ / (clock * 1e9)
+        detail["floor"]["frac_at_measured_clock"] = floor_frac * MAX_CLOCK_HZ / (clock * 1e9)
+    if traffic:
+        detail["traffic_from_profile"] = {"bytes_per_launch": traffic_bytes, "bytes_per_unit": traffic_bytes / samples, "file": TRAFFIC_FILE,
+                                          "note": "FETCH_SIZE + WRITE_SIZE of the committed PMC passes scaled by this run's sample count; not measured in this run"}
+    return roof, detail
 
 
 class stdout_to_stderr:
@@ -490,16 +528,14 @@ def full_loop(args):
     path = os.path.join(work, "cfg.yaml")
     with open(path, "w") as fh:
         fh.write(cfg)
-    names = [f"object_{k}" for k in range(args.full_loop_objects)]
+    names = [f"object_{k}" for k in range(args.full_loop_objects or (5 if args.full_loop else 1))]
     out = {"objects": len(names), "rounds_per_object": 20, "config": "configs/TrainInLoop.yaml (144-view set, 5 members x 2500 steps per round, "
            "candidates 80x45 spp 16, engine stepping rule)", "work_dir": work}
     t_all = time.perf_counter()
     for mode, key in ((21, "view_planning_s"), (4, "psnr_curve_and_stopping_criterion_s")):
         t0 = time.perf_counter()
-        # `quick`: the planner's ordered shutdown, then _exit -- its exit code is then the planner's own (one ordinary return in
-        # ~5000 dies inside the HIP runtime's exit handlers after main has returned: DESIGN.md section 10, item 9)
-        r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=3600,
-                           env=dict(os.environ, PRV_PLANNER_EXIT=os.environ.get("PRV_PLANNER_EXIT", "quick")))
+        # the planner's default exit (ordered shutdown, flush, _exit): its exit code is the planner's own
+        r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=3600)
         out[key] = time.perf_counter() - t0
         if r.returncode != 0:
             out["error"] = f"mode {mode} exited {r.returncode}: {(r.stdout + r.stderr)[-400:]}"
@@ -614,13 +650,14 @@ def run_rank(args):
         if args.field == "256":
             r = Round(solo, field_kw("512", args.scene), args.views_per_gpu, args, slots=(2, 3))
             mm = r.measure(max(3, min(10, args.steps)), 2)
-            roof512 = kernel_figures(mm, variant_of(2), True, args.scene, layout_of(2))
+            roof512, detail512 = kernel_figures(mm, variant_of(2), True, args.scene, layout_of(2))
             extras["field512"] = {
                 "workload": f"{args.views_per_gpu} views {args.width}x{args.height}, synthetic 512^3 field (L=16 F=2 log2T=21, 64 MiB table), scene {args.scene}",
                 "value": mm["ev_all"] * mm["steps"] / mm["elapsed"], "unit": "ray-samples/s", "steps": mm["steps"],
                 "ms_per_step": mm["elapsed"] / mm["steps"] * 1e3,
                 "samples_evaluated_per_step": mm["st"].samples_evaluated,
                 "roofline": roof512,
+                "roofline_detail": detail512,
             }
             # lifted to top-level keys as well: a parser that keeps only scalars keeps these
             extras["field512_value"] = extras["field512"]["value"]
@@ -631,7 +668,7 @@ def run_rank(args):
         #     headline is BASELINE.md section 6's nearly transparent one, and the other way round
         other = "dense" if args.scene == "baseline" else "baseline"
         r = Round(solo, field_kw(args.field, other), args.views_per_gpu, args, slots=(2, 3))
-        mm = r.measure(max(2, min(5, args.steps)), 1)
+        mm = r.measure(args.steps, 2)  # as many steps as the headline: a 5-step figure carried 0.2 ms of warm-up in round 3
         extras["scene_" + other] = {
             "workload": f"{args.views_per_gpu} views, " + ("table U(-4,4), density_bias 3 (opaque object, early termination)" if other == "dense"
                                                         else "table U(-0.1,0.1), density_bias 0 (BASELINE.md section 6)"),
@@ -639,8 +676,16 @@ def run_rank(args):
             "ms_per_step": mm["elapsed"] / mm["steps"] * 1e3,
             "samples_evaluated_per_step": mm["st"].samples_evaluated,
             "samples_per_ray": mm["st"].samples_evaluated / max(1, mm["st"].rays),
-            "roofline": kernel_figures(mm, variant_of(2), args.field == "512", other, layout_of(2)),
         }
+        extras["scene_" + other]["roofline"], extras["scene_" + other]["roofline_detail"] = kernel_figures(
+            mm, variant_of(2), args.field == "512", other, layout_of(2))
+        # where a step of this scene goes, kernel by kernel (HIP events on the launch stream) -- the round-3 verdict asked what
+        # the 0.3 ms between the render launch and the step were
+        pr = mm["prof"]
+        extras["scene_" + other]["step_breakdown_ms"] = {
+            "render": pr["render_ms"] / mm["steps"], "march": pr["march_ms"] / mm["steps"],
+            "everything_else": mm["elapsed"] / mm["steps"] * 1e3 - (pr["render_ms"] + pr["march_ms"]) / mm["steps"],
+            "note": "everything_else = PSNR / coverage reduce (~0.2 ms), record gather + finalize, launch gaps, host time per step"}
         r.close()
         # (3) the reference's OWN scoring round: 540 candidates at 80x45, spp 16, 5 members, EnsembleRGBDensity
         #     (main.cpp:1796-1806, run.py:48,304, Share_Data.hpp:505-510), in both stepping rules
@@ -689,11 +734,18 @@ def run_rank(args):
         tcams.close()
 
     if rank == 0:
-        roof = kernel_figures(m, variant_of(0), args.field == "512", args.scene, layout_of(0))
+        roof, roof_detail = kernel_figures(m, variant_of(0), args.field == "512", args.scene, layout_of(0))
         scene_words = ("BASELINE.md section 6 scene: table U(-0.1,0.1), Xavier MLPs, no density bias, analytic occupancy (4 spheres)"
                        if args.scene == "baseline" else "dense scene: table U(-4,4), density bias 3, analytic occupancy (4 spheres)")
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
+            cpu = cpu_baseline(args, fkw, main.tms, main.scale, main.offset, main.fov_x)
+        loop = None
+        if world == 1 and not args.no_full_loop:
+            loop = full_loop(args)
         out = {
-            "metric": "ray-samples/s (field evaluations composited; candidate views rendered + scored)",
+            # scene in the metric's name: round 3 switched the default scene, and lines of different scenes do not compare
+            "metric": f"ray-samples/s (field evaluations composited; candidate views rendered + scored; scene {args.scene}, field {args.field}^3)",
             "value": m["ev_all"] * k / elapsed,
             "unit": "ray-samples/s",
             "n_gpus": world,
@@ -704,10 +756,7 @@ def run_rank(args):
             "scaling": args.mode,
             "vs_baseline": None,
             "dtype": "f16",
-            "dtype_note": "fp16 table, blend and MLP operands (MFMA f16 -> f32 accumulate); f32 rays, positions, compositing",
             "data": "synthetic",
-            "parity": "vs own CPU oracle (oracle/), unpinned: the reference's render arithmetic lives in instant-ngp, absent from its tree; "
-                      "this workload is gated whole view by whole view in tests/test_gpu_wholeview.py",
             "config": {
                 "workload": f"render+score {len(main.my_ids)} hemisphere views/GPU, {args.width}x{args.height}, "
                             f"{args.samples} samples/ray, synthetic {args.field}^3 hash-grid field "
@@ -719,6 +768,30 @@ def run_rank(args):
                 "parallelism": (f"views sharded {args.views_per_gpu}/GPU" if args.mode == "weak" else
                                 f"{n_views} views sharded over {world} GPUs") + ", interleaved; one all-gather of 16-B records",
             },
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        # scalars a parser that drops nested objects still keeps
+        lifted = {"roofline_frac": roof["frac"], "roofline_bound": roof["bound"]}
+        for key in ("field512_value", "field512_frac", "field512_avg_launch_ms"):
+            if key in extras:
+                lifted[key] = extras.pop(key)
+        rr = extras.get("reference_round")
+        if rr:
+            lifted.update({"reference_round_ms": rr["ngp_step"]["ms_per_round"], "reference_round_views_per_s": rr["ngp_step"]["views_per_s"],
+                           "reference_round_fixed_128_ms": rr["fixed_128"]["ms_per_round"]})
+        if extras.get("ngp_step"):
+            lifted["ngp_step_samples_per_s"] = extras["ngp_step"]["value"]
+        if training:
+            lifted["training_steps_per_s"] = training["steps_per_s"]
+        if loop and "seconds_per_object" in loop:
+            lifted["full_loop_s_per_object"] = loop["seconds_per_object"]
+            lifted["full_loop_member_step_us"] = loop.get("member_step_us")
+        out.update(lifted)
+        out.update({
+            "dtype_note": "fp16 table, blend and MLP operands (MFMA f16 -> f32 accumulate); f32 rays, positions, compositing",
+            "parity": "vs own CPU oracle (oracle/), unpinned: the reference's render arithmetic lives in instant-ngp, absent from its tree; "
+                      "this workload is gated whole view by whole view in tests/test_gpu_wholeview.py",
             "rccl_ranks": (comm.world if comm is not None and comm.transport == "rccl" else (world if use_dist and comm is None and not shared_gpu else 0)),
             "comm_ranks": comm.world if comm is not None else 0,  # prv_comm_world of the communicator the timed region ran on
             "collective": collective,
@@ -730,15 +803,15 @@ def run_rank(args):
             "samples_nominal_per_step_per_gpu": m["st"].samples_nominal,
             "evaluated_samples_per_ray": m["st"].samples_evaluated / max(1, m["st"].rays),
             "ranking_head": [int(x) for x in m["order"][:8]],
-            "roofline": roof,
+            "roofline_detail": roof_detail,
             "first_hit": first_hit,
             "training": training,
-        }
+        })
         out.update(extras)
-        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, fkw, main.tms, main.scale, main.offset, main.fov_x)
-        if args.full_loop and world == 1:
-            out["full_loop"] = full_loop(args)
+        if loop is not None:
+            out["full_loop"] = loop
+        if cpu is None:
+            del out["cpu_baseline"]
         print(json.dumps(out), flush=True)
     if any_hung:
         # a rank has a thread stuck inside a collective on an abandoned context: the line (measured on the fallback) is out;

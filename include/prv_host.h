@@ -104,6 +104,13 @@ long long prvh_pcd_read(const char* path, float* xyz_out, uint8_t* rgb_out, long
 int prvh_png_size(const char* path, int* width, int* height);
 int prvh_png_read_rgba8(const char* path, int width, int height, uint8_t* out_rgba8);
 int prvh_png_write_rgba8(const char* path, int width, int height, const uint8_t* rgba8);
+/* replaces: the body of the per-view loops main.cpp:2045-2094 (method 2, EnsembleRGB) / 2105-2158 (method 3,
+ * EnsembleRGBDensity) for ONE unchosen view, on the host as the reference has it: files[e] = the screenshot member e's
+ * engine call left (render/<it>/ensemble_<e>/rgbaClip_<v>.png), *score = view_uncertainty in the reference's operation
+ * order (BGRA channel order of cv::imread included).  What `score_path: png` of prv_planner runs; the fused device path
+ * (prv_score_views, include/prv.h) returns the same doubles.  0, -1 bad argument, -18 a file is missing / unreadable /
+ * of another size or the method is not 2 or 3. */
+int prvh_score_view_pngs(int method, const char* const* files, int n_members, double* score);
 
 /* ---- instant-ngp snapshots on the host (nerf_prv_amd/csrc/prv_ingp.hpp; what prv_model_load_ingp / save_ingp of
  * include/prv.h do, minus the GPU): <file>.ingp | .msgpack <-> descriptor + canonical arrays.  desc points at a

@@ -90,6 +90,10 @@ public:
   // keys this build adds (absent from the reference's file; all optional)
   int render_width = 0, render_height = 0, samples_per_ray = 0, screenshot_spp = 0;
   double candidate_divisor = 0, min_transmittance = 0;
+  // score_path: fused (default) = one device-resident scoring round per iteration (prv_score_views);
+  //             png = the reference's own data flow: per member train_by_instantNGP(it, "100", true, e) writes
+  //             render/<it>/ensemble_<e>/rgbaClip_<v>.png, then the planner's loops read the PNGs (main.cpp:2045-2094, 2105-2158)
+  bool score_from_pngs = false;
   // state
   double pvb_wait_seconds = 0.0;
   std::vector<std::vector<double>> pt_sphere;
@@ -156,6 +160,14 @@ public:
     screenshot_spp = fs.has("screenshot_spp") ? (int)fs.num("screenshot_spp") : 16; // run.py:48
     candidate_divisor = fs.has("candidate_divisor") ? fs.num("candidate_divisor") : 16.0; // main.cpp:1796
     min_transmittance = fs.has("min_transmittance") ? fs.num("min_transmittance") : 0.01;
+    if (fs.has("score_path")) {
+      const std::string how = fs.str("score_path");
+      if (how != "fused" && how != "png") {
+        error = "score_path must be 'fused' or 'png', not '" + how + "'";
+        return;
+      }
+      score_from_pngs = how == "png";
+    }
     // constructor overrides (Share_Data.hpp:402-409)
     if (test_name != "") name_of_pcd = test_name;
     if (test_method != -1) method_of_IG = test_method;

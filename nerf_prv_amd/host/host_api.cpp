@@ -152,6 +152,16 @@ int prvh_png_write_rgba8(const char* path, int width, int height, const uint8_t*
   return png_write_rgba8(path, width, height, rgba8);
 } catch (...) { return PRVH_E_INTERNAL; }
 
+int prvh_score_view_pngs(int method, const char* const* files, int n_members, double* score) try {
+  if (!files || n_members < 1 || !score) return -1;
+  std::vector<std::string> f;
+  for (int e = 0; e < n_members; e++) {
+    if (!files[e]) return -1;
+    f.push_back(files[e]);
+  }
+  return ensemble_uncertainty_from_pngs(method, f, score);
+} catch (...) { return PRVH_E_INTERNAL; }
+
 int prvh_write_metrics(const char* path, double psnr, double ssim) try {
   if (!path) return -1;
   char buf[128];

@@ -54,11 +54,23 @@ struct HipScorer {
   uint64_t train_seed = 0x1234;
   bool images_from_files = false; // train_images: files -> the json's file_path PNGs (the reference's data flow)
 
-  // train_by_instantNGP(json/<it>.json, ..., ensemble_id = e) for every member, in process
-  int train_members(const std::string& scene_json) {
-    const bool timing = getenv("PRV_PLANNER_TIMING") != nullptr; // dev: where an iteration's seconds go
-    const double t_start = now_seconds();
-    double t_gt = 0, t_fresh = 0, t_create = 0, t_steps = 0;
+  // load_training_data (run.py:109) of one scene json: dataset cameras + the RGBA8 training images on the device.  Kept
+  // until another scene is asked for: the reference's per-member run.py calls of one iteration (main.cpp:2041-2043) all
+  // name the same json, and every one of them would reload the same files.
+  std::string data_scene;
+  prv_camset* data_cams = nullptr;
+  uint8_t* data_imgs = nullptr;
+  int data_w = 0, data_h = 0;
+  void drop_training_data() {
+    if (data_cams) prv_camset_destroy(data_cams);
+    if (data_imgs) prv_free(ctx, data_imgs);
+    data_cams = nullptr;
+    data_imgs = nullptr;
+    data_scene.clear();
+  }
+  int training_data(const std::string& scene_json) {
+    if (data_cams && data_scene == scene_json) return PRV_OK;
+    drop_training_data();
     prv_camset* ds = nullptr;
     if (prv_cameras_from_dataset_json(ctx, scene_json.c_str(), &ds) != PRV_OK) return -30;
     int w = 0, h = 0;
@@ -66,14 +78,17 @@ struct HipScorer {
     prv_render_opts o{};
     o.width = train_w > 0 ? train_w : w; // training images at the dataset size unless the config shrinks them
     o.height = train_h > 0 ? train_h : h;
-    o.samples_per_ray = 128;
+    // the ground truth is rendered with the rule every other render of this run uses (yaml samples_per_ray; 0 = the
+    // engine's own stepping): the PSNR evaluation compares like with like
+    o.samples_per_ray = sd->samples_per_ray;
+    o.step_mode = sd->samples_per_ray > 0 ? PRV_STEP_FIXED_S : PRV_STEP_NGP;
     o.spp = 1;
     o.min_transmittance = 1e-4f;
     const int n = prv_camset_count(ds);
     uint8_t* imgs = nullptr;
     int rc = prv_malloc(ctx, (void**)&imgs, (size_t)n * o.width * o.height * 4);
     if (rc == PRV_OK && images_from_files) {
-      // load_training_data (run.py:109): every frame's file_path, relative to the json, as RGBA8
+      // every frame's file_path, relative to the json, as RGBA8
       std::string text, err;
       prvjson::Value root;
       if (!prvjson::read_file(scene_json, text) || !prvjson::Parser(text).parse(root, err)) rc = -31;
@@ -94,14 +109,33 @@ struct HipScorer {
     } else if (rc == PRV_OK) {
       rc = prv_render_rgba8(ctx, 6, ds, nullptr, n, &o, imgs, nullptr); // straight alpha over nothing
     }
-    if (timing) {
-      prv_synchronize(ctx);
-      t_gt = now_seconds() - t_start;
+    if (rc != PRV_OK) {
+      std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+      prv_camset_destroy(ds);
+      if (imgs) prv_free(ctx, imgs);
+      return rc;
     }
-    // the members train side by side (prv_train_steps_multi), each from its own seeds; with several ranks a member
-    // is trained by rank e % world and reaches the others through prv_model_exchange below
+    data_scene = scene_json;
+    data_cams = ds;
+    data_imgs = imgs;
+    data_w = o.width;
+    data_h = o.height;
+    return PRV_OK;
+  }
+
+  // `--train --n_steps N` for the listed members on one scene json: a fresh field per member (seed = train_seed + e),
+  // the members stepping side by side (prv_train_steps_multi); with several ranks a member is trained by rank e % world
+  int train_member_list(const std::string& scene_json, const std::vector<int>& members, int steps) {
+    const bool timing = getenv("PRV_PLANNER_TIMING") != nullptr; // dev: where an iteration's seconds go
+    const double t_start = now_seconds();
+    double t_fresh = 0, t_create = 0;
+    int rc = training_data(scene_json);
+    if (rc != PRV_OK) return rc;
+    if (timing) prv_synchronize(ctx);
+    const double t_gt = now_seconds() - t_start;
     std::vector<prv_trainer*> trs;
-    for (int e = 0; rc == PRV_OK && e < n_members; e++) {
+    for (size_t k = 0; rc == PRV_OK && k < members.size(); k++) {
+      const int e = members[k];
       if (e % world != rank) continue;
       double t0 = now_seconds();
       rc = prv_model_fresh(ctx, e, &train_desc, train_seed + (uint64_t)e);
@@ -112,22 +146,101 @@ struct HipScorer {
       to.seed += (uint64_t)e;
       prv_trainer* tr = nullptr;
       t0 = now_seconds();
-      if (rc == PRV_OK) rc = prv_train_create(ctx, e, ds, imgs, o.width, o.height, &to, &tr);
+      if (rc == PRV_OK) rc = prv_train_create(ctx, e, data_cams, data_imgs, data_w, data_h, &to, &tr);
       t_create += now_seconds() - t0;
       if (tr) trs.push_back(tr);
     }
-    double t0 = now_seconds();
-    if (rc == PRV_OK && !trs.empty()) rc = prv_train_steps_multi(trs.data(), (int)trs.size(), train_steps, nullptr);
-    t_steps = now_seconds() - t0;
+    const double t0 = now_seconds();
+    if (rc == PRV_OK && !trs.empty()) rc = prv_train_steps_multi(trs.data(), (int)trs.size(), steps, nullptr);
+    const double t_steps = now_seconds() - t0;
     for (prv_trainer* tr : trs) prv_train_destroy(tr);
-    if (rc == PRV_OK && comm) rc = prv_model_exchange(ctx, comm, n_members, &train_desc);
     if (timing)
-      std::cerr << "train_members: views " << n << " gt " << t_gt << " s, fresh " << t_fresh << " s, create " << t_create
-                << " s, steps " << t_steps << " s, total " << now_seconds() - t_start << " s" << std::endl;
+      std::cerr << "train_members: views " << prv_camset_count(data_cams) << " gt " << t_gt << " s, fresh " << t_fresh << " s, create "
+                << t_create << " s, steps " << t_steps << " s, total " << now_seconds() - t_start << " s" << std::endl;
     if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
-    prv_camset_destroy(ds);
-    if (imgs) prv_free(ctx, imgs);
     return rc;
+  }
+
+  // the whole ensemble of an iteration in one go (the fused path): train, then exchange between ranks
+  int train_members(const std::string& scene_json) {
+    std::vector<int> all(n_members);
+    for (int e = 0; e < n_members; e++) all[e] = e;
+    int rc = train_member_list(scene_json, all, train_steps);
+    if (rc == PRV_OK && comm) rc = prv_model_exchange(ctx, comm, n_members, &train_desc);
+    if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+    drop_training_data(); // the next iteration's json differs
+    return rc;
+  }
+
+  // The engine behind NBV_Net_Labeler::train_by_instantNGP's reference signature: ONE run.py invocation
+  // (run.py:185-208 train, :226-277 evaluate, :284-309 screenshots) through include/prv.h, in process.
+  //   --scene S --n_steps N                        train model slot max(ensemble_id, 0) on S (skipped when the run is
+  //                                                configured with pretrained members: train_steps == 0)
+  //   --screenshot_transforms J --screenshot_dir D  render every frame of J at its w x h, spp = screenshot_spp, opaque
+  //                                                black background (run.py:94), write D/<basename(file_path)>
+  //   --test_transforms T --save_metrics M          render every frame of T (spp 1, min_T 1e-4, run.py:231-235), PSNR /
+  //                                                SSIM against renders of the ground-truth field, "PSNR\t..\nSSIM\t.." -> M
+  int run_py(const RunPyArgs& a) {
+    const int slot = a.ensemble_id >= 0 ? a.ensemble_id : 0;
+    if (train_steps > 0) {
+      const int rc = train_member_list(a.scene, {slot}, a.n_steps > 0 ? std::min(a.n_steps, train_steps) : train_steps);
+      if (rc != PRV_OK) return rc;
+    }
+    if (!a.screenshot_transforms.empty()) {
+      prv_camset* cams = nullptr;
+      if (prv_cameras_from_json(ctx, a.screenshot_transforms.c_str(), &cams) != PRV_OK) {
+        std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+        return -20;
+      }
+      std::string text, err;
+      prvjson::Value root;
+      if (!prvjson::read_file(a.screenshot_transforms, text) || !prvjson::Parser(text).parse(root, err)) return -31;
+      const prv_render_opts o = candidate_opts(cams);
+      const int n = prv_camset_count(cams);
+      const size_t bytes = (size_t)o.width * o.height * 4;
+      uint8_t* dev = nullptr;
+      std::vector<uint8_t> px(bytes);
+      int rc = prv_malloc(ctx, (void**)&dev, (size_t)std::max(1, n) * bytes);
+      if (rc == PRV_OK) rc = prv_render_rgba8(ctx, slot, cams, nullptr, n, &o, dev, nullptr);
+      sd->access_directory(a.screenshot_dir);
+      for (int k = 0; rc == PRV_OK && k < n; k++) {
+        std::string name = root.at("frames").arr[(size_t)k].at("file_path").s; // os.path.basename(f["file_path"]) (run.py:297)
+        name = name.substr(name.find_last_of('/') + 1);
+        if (name.find('.') == std::string::npos) name += ".png";
+        rc = prv_memcpy_d2h(ctx, px.data(), dev + (size_t)k * bytes, bytes);
+        if (rc == PRV_OK && png_write_rgba8(a.screenshot_dir + name, o.width, o.height, px.data()) != 0) rc = PRV_E_IO;
+      }
+      if (dev) prv_free(ctx, dev);
+      prv_camset_destroy(cams);
+      if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+      return rc;
+    }
+    if (!a.test_transforms.empty()) {
+      double psnr = 0, ssim = 0;
+      const int rc = evaluate_on(a.test_transforms, slot, &psnr, &ssim);
+      if (rc != PRV_OK) return rc;
+      char buf[128];
+      snprintf(buf, sizeof(buf), "PSNR\t%.17g\nSSIM\t%.17g", psnr, ssim); // run.py:275-277
+      return write_text(a.save_metrics, buf) ? 0 : PRV_E_IO;
+    }
+    return 0;
+  }
+
+  // the candidate renders' options: the render json's own w x h (run.py:304), screenshot_spp sub-samples, the engine's
+  // stepping rule unless the yaml fixes a sample count, opaque black background (run.py:94)
+  prv_render_opts candidate_opts(const prv_camset* cams) const {
+    int w = 0, h = 0;
+    prv_camset_size(cams, &w, &h);
+    prv_render_opts o{};
+    o.width = sd->render_width > 0 ? sd->render_width : w;
+    o.height = sd->render_height > 0 ? sd->render_height : h;
+    o.samples_per_ray = sd->samples_per_ray;
+    o.step_mode = sd->samples_per_ray > 0 ? PRV_STEP_FIXED_S : PRV_STEP_NGP;
+    o.spp = sd->screenshot_spp;
+    o.min_transmittance = (float)sd->min_transmittance;
+    o.background[0] = o.background[1] = o.background[2] = 0.f;
+    o.background[3] = 1.f;
+    return o;
   }
 
   // `evaluate: 1`: train ONE field on the final view set and score it on the test view set
@@ -156,8 +269,17 @@ struct HipScorer {
     const std::string test_json = sd->gt_path + "/" + std::to_string(eval_views) + ".json";
     sd->access_directory(sd->gt_path);
     write_text(test_json, prvjson::to_styled_string(root));
+    return evaluate_on(test_json, 0, psnr, ssim);
+  }
+
+  // run.py:226-277 for one model slot: every frame of the test json (full-size dataset cameras, lens included) at
+  // spp 1 / min_T 1e-4 over opaque black, against renders of the ground-truth field (slot 6) -> mean PSNR, mean SSIM
+  int evaluate_on(const std::string& test_json, int slot, double* psnr, double* ssim) {
     prv_camset* cams = nullptr;
-    if (prv_cameras_from_dataset_json(ctx, test_json.c_str(), &cams) != PRV_OK) return -41;
+    if (prv_cameras_from_dataset_json(ctx, test_json.c_str(), &cams) != PRV_OK) {
+      std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+      return -41;
+    }
     int w = 0, h = 0;
     prv_camset_size(cams, &w, &h);
     prv_render_opts o{};
@@ -170,11 +292,11 @@ struct HipScorer {
     o.background[3] = 1.f;       // black, opaque (run.py:226)
     const int n = prv_camset_count(cams);
     float* gt = nullptr;
-    rc = prv_malloc(ctx, (void**)&gt, (size_t)n * o.width * o.height * 16);
+    int rc = prv_malloc(ctx, (void**)&gt, (size_t)n * o.width * o.height * 16);
     prv_render_opts og = o;
     og.background[3] = 0.f;
     if (rc == PRV_OK) rc = prv_render(ctx, 6, cams, nullptr, n, &og, gt, nullptr); // the reference images
-    if (rc == PRV_OK) rc = prv_evaluate(ctx, 0, cams, nullptr, n, &o, gt, psnr, ssim);
+    if (rc == PRV_OK) rc = prv_evaluate(ctx, slot, cams, nullptr, n, &o, gt, psnr, ssim);
     if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
     if (gt) prv_free(ctx, gt);
     prv_camset_destroy(cams);
@@ -195,18 +317,8 @@ struct HipScorer {
       std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
       return -20;
     }
-    int w = 0, h = 0;
-    prv_camset_size(cams, &w, &h);
     const int n = prv_camset_count(cams);
-    prv_render_opts o{};
-    o.width = sd->render_width > 0 ? sd->render_width : w;
-    o.height = sd->render_height > 0 ? sd->render_height : h;
-    o.samples_per_ray = sd->samples_per_ray;
-    o.step_mode = sd->samples_per_ray > 0 ? PRV_STEP_FIXED_S : PRV_STEP_NGP;
-    o.spp = sd->screenshot_spp;
-    o.min_transmittance = (float)sd->min_transmittance;
-    o.background[0] = o.background[1] = o.background[2] = 0.f;
-    o.background[3] = 1.f; // run.py:94
+    prv_render_opts o = candidate_opts(cams);
     std::vector<int> slots(n_members);
     for (int e = 0; e < n_members; e++) slots[e] = e;
     std::vector<prv_score_record> rec(n);
@@ -405,7 +517,16 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
       return sc ? sc->evaluate(scene, center, size, p, q) : -42;
     };
   }
+  // train_by_instantNGP's reference signature -> the in-process engine (one run.py invocation per call); the engine
+  // shares the loop's scorer object, so `score_path: png` and the fused path train and render the same members
+  HipScorer* engine_state = labeler.scorer.target<HipScorer>();
+  labeler.engine = [engine_state](const RunPyArgs& a) { return engine_state ? engine_state->run_py(a) : -42; };
+  if (sd->score_from_pngs && comm) {
+    std::cerr << "score_path: png is the reference's single-process data flow; shard: views needs score_path: fused" << std::endl;
+    return -24;
+  }
   const int rc = labeler.nbv_loop(first_view_id, 0);
+  if (engine_state) engine_state->drop_training_data();
   if (scorer.gt_dev) prv_free(ctx, scorer.gt_dev);
   if (labeler.final_psnr >= 0) std::cout << "final PSNR " << labeler.final_psnr << " SSIM " << labeler.final_ssim << std::endl;
   std::cout << "chosen_nbvs:";
@@ -443,7 +564,8 @@ int write_coverage_images(prv_ctx* ctx, const std::shared_ptr<Share_Data>& sd) {
   prv_render_opts o{};
   o.width = w;
   o.height = h;
-  o.samples_per_ray = 128;
+  o.samples_per_ray = sd->samples_per_ray; // the rule of every other render of the run (0 = the engine's own stepping)
+  o.step_mode = sd->samples_per_ray > 0 ? PRV_STEP_FIXED_S : PRV_STEP_NGP;
   o.spp = 1;
   o.min_transmittance = 1e-4f;
   const int count = prv_camset_count(ds);
@@ -740,34 +862,33 @@ static void install_trace() {
 
 static int run(int argc, char** argv);
 
-// Every context has been destroyed and every file closed when run() returns.  What a normal exit then adds is the static
-// teardown of the HIP / HSA runtime, and in round 2 that crashed about once in a thousand exits while another process
-// shared the GPU (profiles/NOTES.md).  The runtime is therefore shut down EXPLICITLY, in order, before main
-// returns: prv_runtime_shutdown synchronises and resets the device (hipDeviceReset) while the process is intact, so the
-// runtime's streams, signal pools and worker threads are gone before any static destructor runs; then main returns
-// normally.  19,300 such exits under a concurrent GPU load: 4 still died -- after main had returned, on a worker thread of
-// the runtime itself (a null call in its exit-time teardown; profiles/NOTES.md).  PRV_PLANNER_EXIT=quick therefore remains:
-// the same ordered shutdown, then flush + _exit, so that the runtime's exit handlers never run.
+// Every context has been destroyed and every file closed when run() returns.  What an ordinary exit then adds is the
+// static teardown of the HIP / HSA runtime, which this process does not control: 4 of 19,300 exits that shut the runtime
+// down in order (prv_runtime_shutdown: synchronise + hipDeviceReset) and then returned from main still died AFTER main
+// had returned, on a worker thread of the runtime itself (profiles/NOTES.md, round 3).  A planner run that finished
+// correctly must not report SIGSEGV, so the DEFAULT exit is: ordered prv_runtime_shutdown, flush every stream, _exit(rc)
+// -- the runtime's exit handlers never run.  PRV_PLANNER_EXIT=normal: the same shutdown, then an ordinary return (static
+// destructors and atexit handlers run; chosen automatically under a profiler, which writes its files from an exit
+// handler); =noreset: a plain return without the shutdown (round 2's behaviour, for the stress script only).
 int main(int argc, char** argv) {
   if (getenv("PRV_SEGV_TRACE")) install_trace();
   const int rc = run(argc, argv);
-  const char* how = getenv("PRV_PLANNER_EXIT");
-  if (!how || std::string(how) != "quick") {
-    g_phase = 1;
-    if (!how || std::string(how) != "noreset") (void)prv_runtime_shutdown(); // "noreset": plain return, the round-2 crash's setting
-    g_phase = 2;
-    return rc;
+  const char* how_c = getenv("PRV_PLANNER_EXIT");
+  std::string how = how_c && *how_c ? how_c : "quick";
+  if (how == "quick") {
+    if (const char* pre = getenv("LD_PRELOAD"))
+      if (std::string(pre).find("rocprof") != std::string::npos) how = "normal";
+    for (char** e = environ; e && *e; e++)
+      if (strncmp(*e, "ROCPROF", 7) == 0 || strncmp(*e, "ROCP_", 5) == 0 || strncmp(*e, "ROCTRACER", 9) == 0) how = "normal";
   }
-  // a profiler writes its files from an exit handler, which _exit would skip
-  if (const char* pre = getenv("LD_PRELOAD"))
-    if (std::string(pre).find("rocprof") != std::string::npos) return rc;
-  for (char** e = environ; e && *e; e++)
-    if (strncmp(*e, "ROCPROF", 7) == 0 || strncmp(*e, "ROCP_", 5) == 0 || strncmp(*e, "ROCTRACER", 9) == 0) return rc;
-  (void)prv_runtime_shutdown(); // the same ordered shutdown; what is skipped is the runtime's own exit-time teardown
+  g_phase = 1;
+  if (how != "noreset") (void)prv_runtime_shutdown();
+  g_phase = 2;
   std::cout.flush();
   std::cerr.flush();
   fflush(nullptr);
-  _exit(rc);
+  if (how == "quick") _exit(rc);
+  return rc;
 }
 
 static int run(int argc, char** argv) {

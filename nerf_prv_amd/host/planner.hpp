@@ -7,9 +7,12 @@
 // from a callback or from the file PRVNet's server would have written).
 #pragma once
 #include <chrono>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <ctime>
 #include <functional>
+#include <iostream>
 #include <memory>
 #include <random>
 #include <set>
@@ -21,6 +24,7 @@
 #include "Share_Data.hpp"
 #include "View_Space.hpp"
 #include "path_planner.hpp"
+#include "png_io.hpp"
 
 namespace prvhost {
 
@@ -103,6 +107,21 @@ using Scorer = std::function<int(int method, int iteration, const std::string& s
                                  const std::string& render_json, const std::vector<int>& candidate_ids,
                                  std::vector<double>& scores)>;
 
+// What train_by_instantNGP hands run.py (the command line composed at main.cpp:1666-1685), as a struct: the in-process
+// engine behind the boundary receives exactly the reference's arguments.  Empty strings = flag absent.
+struct RunPyArgs {
+  int n_steps = 0;                   // --n_steps
+  std::string scene;                 // --scene <json>
+  std::string test_transforms;       // --test_transforms <json>      (evaluation branch)
+  std::string save_metrics;          // --save_metrics <txt>          (evaluation branch)
+  std::string screenshot_transforms; // --screenshot_transforms <json> (candidate branch)
+  std::string screenshot_dir;        // --screenshot_dir <dir>/        (candidate branch)
+  int ensemble_id = -1;              // not a run.py flag: which member this call trains (the reference's members differ
+                                     // by the engine's nondeterminism only; here member e has its own seed)
+};
+// the engine: train --n_steps on --scene, then evaluate or write the screenshots; 0 on success
+using Engine = std::function<int(const RunPyArgs&)>;
+
 // method 4: the number of views PRVNet predicts from the initial images (main.cpp:2165-2192 hands the images to a
 // Python server through <pvb_path>/data and reads view_budget.txt back); <= 0 = no answer
 using BudgetFn = std::function<int(const std::vector<int>& init_view_ids)>;
@@ -110,11 +129,57 @@ using BudgetFn = std::function<int(const std::vector<int>& init_view_ids)>;
 // --test_transforms / --save_metrics): train on the scene json's views, score against the test view set
 using EvalFn = std::function<int(const std::string& scene_json, double* mean_psnr, double* mean_ssim)>;
 
+// The reference's score loops over the PNGs its engine left (main.cpp:2045-2094 EnsembleRGB, 2105-2158
+// EnsembleRGBDensity): one unchosen view's E member images -> view_uncertainty, in the reference's own operation order.
+// cv::imread(..., IMREAD_UNCHANGED) returns BGRA, so the reference's "r, g, b" are the PNG's B, G, R -- bytes 2, 1, 0 of
+// an RGBA pixel -- and the order matters for the last bit of the sum.  Per pixel and channel: mean = (sum over members of
+// the byte) / E, variance = (sum of (byte - mean)^2) / E, doubles, members in ascending order; method 2 adds
+// ln(variance) where variance > 1e-10 (channel by channel into the running sum); method 3 adds (v0 + v1 + v2) / 3 and
+// then (1 - mean alpha/255)^2, as two additions.  0, or -18 (a file is missing, unreadable or of another size).
+inline int ensemble_uncertainty_from_pngs(int method, const std::vector<std::string>& files, double* out) {
+  const int E = (int)files.size();
+  if (E < 1 || (method != EnsembleRGB && method != EnsembleRGBDensity) || !out) return -18;
+  std::vector<std::vector<uint8_t>> img((size_t)E);
+  int w = 0, h = 0;
+  for (int e = 0; e < E; e++) {
+    int iw = 0, ih = 0;
+    if (png_read_rgba8(files[(size_t)e], &iw, &ih, img[(size_t)e]) != 0 || (e > 0 && (iw != w || ih != h))) return -18;
+    w = iw;
+    h = ih;
+  }
+  static const int channel_order[3] = {2, 1, 0}; // the reference's rgba[0], rgba[1], rgba[2] of a BGRA pixel
+  double view_uncertainty = 0.0;
+  for (size_t p = 0; p < (size_t)w * (size_t)h; p++) {
+    double var[3];
+    for (int c = 0; c < 3; c++) {
+      const size_t at = p * 4 + (size_t)channel_order[c];
+      double mean = 0.0, v = 0.0;
+      for (int e = 0; e < E; e++) mean += img[(size_t)e][at];
+      mean /= E;
+      for (int e = 0; e < E; e++) v += (img[(size_t)e][at] - mean) * (img[(size_t)e][at] - mean);
+      var[c] = v / E;
+    }
+    if (method == EnsembleRGB) {
+      for (int c = 0; c < 3; c++)
+        if (var[c] > 1e-10) view_uncertainty += std::log(var[c]);
+    } else {
+      double mean_density = 0.0;
+      for (int e = 0; e < E; e++) mean_density += img[(size_t)e][p * 4 + 3] / 255.0;
+      mean_density /= E;
+      view_uncertainty += (var[0] + var[1] + var[2]) / 3.0;
+      view_uncertainty += (1.0 - mean_density) * (1.0 - mean_density);
+    }
+  }
+  *out = view_uncertainty;
+  return 0;
+}
+
 class NBV_Net_Labeler {
 public:
   std::shared_ptr<Share_Data> share_data;
   std::shared_ptr<View_Space> view_space;
   Scorer scorer;
+  Engine engine;      // the in-process run.py behind train_by_instantNGP's reference signature
   BudgetFn budget_fn; // empty: read <pvb_path>/data/view_budget.txt
   EvalFn evaluator;   // empty: `evaluate: 1` is ignored
   std::vector<int> chosen_nbvs;
@@ -145,19 +210,63 @@ public:
     return write_text(share_data->gt_path + "/" + n + ".json", prvjson::to_styled_string(root)) ? 0 : -1;
   }
 
-  // The boundary (main.cpp:1658-1715).  Reference: compose a run.py command line, write
-  // interact/run_with_c++.py + ready_c++.txt, poll ready_py.txt.  Here: one in-process call.
-  // Only the nbv_test / ensemble branch (the candidate-scoring use, :1676-1684) is on the path.
-  int train_by_instantNGP(const std::string& trian_json_file, const std::vector<int>& candidate_ids,
-                          std::vector<double>& scores) {
+  // THE BOUNDARY, with the reference's own signature and branch structure (main.cpp:1658-1715).  The reference composes a
+  // `python run.py ...` command line, writes interact/run_with_c++.py + ready_c++.txt and polls ready_py.txt once a
+  // second; here the same arguments go to `engine` in process (the C ABI of include/prv.h behind it).  A maintainer
+  // of the reference keeps every call site (main.cpp:1956, 2042, 2102, 2481) and swaps only this body: INTEGRATION.md.
+  //   nbv_test == false              : scene <gt_path>/<train>.json, test <gt_path>/<test>.json -> <gt_path>/<train>.txt
+  //   nbv_test, ensemble_id == -1    : scene <save>/json/<it>.json, test <gt_path>/<test>.json  -> <save>/metrics/<it>.txt
+  //                                    (+ <save>/train_time/<it>.txt, :1707-1711)
+  //   nbv_test, ensemble_id == e >= 0: scene <save>/json/<it>.json, screenshots of <save>/render_json/<it>.json ->
+  //                                    <save>/render/<it>/ensemble_<e>/rgbaClip_<v>.png
+  int train_by_instantNGP(std::string trian_json_file, std::string test_json_file = "100", bool nbv_test = false,
+                          int ensemble_id = -1) {
+    if (!engine) return -17;
+    const double t0 = now_seconds();
+    RunPyArgs a;
+    a.n_steps = share_data->n_steps;
+    a.ensemble_id = ensemble_id;
+    if (!nbv_test) {
+      a.scene = share_data->gt_path + "/" + trian_json_file + ".json";
+      a.test_transforms = share_data->gt_path + "/" + test_json_file + ".json";
+      a.save_metrics = share_data->gt_path + "/" + trian_json_file + ".txt";
+    } else {
+      a.scene = share_data->save_path + "/json/" + trian_json_file + ".json";
+      if (ensemble_id == -1) {
+        a.test_transforms = share_data->gt_path + "/" + test_json_file + ".json";
+        a.save_metrics = share_data->save_path + "/metrics/" + trian_json_file + ".txt";
+      } else {
+        a.screenshot_transforms = share_data->save_path + "/render_json/" + trian_json_file + ".json";
+        a.screenshot_dir = share_data->save_path + "/render/" + trian_json_file + "/ensemble_" + std::to_string(ensemble_id) + "/";
+      }
+    }
+    const int rc = engine(a);
+    const double cost_time = now_seconds() - t0;
+    std::cout << "train and eval with executed time " << cost_time << " s." << std::endl; // :1705
+    if (nbv_test && ensemble_id == -1)
+      write_text(share_data->save_path + "/train_time/" + trian_json_file + ".txt", std::to_string(cost_time) + "\n"); // :1707-1711
+    return rc;
+  }
+
+  // The fused form of the same boundary (`score_path: fused`, the default): every member trained and every candidate of
+  // the iteration rendered + reduced on the device in ONE call; nothing but 16-byte records leaves the GPU.
+  int score_candidates(const std::string& trian_json_file, const std::vector<int>& candidate_ids, std::vector<double>& scores) {
     const double t0 = now_seconds();
     const std::string scene = share_data->save_path + "/json/" + trian_json_file + ".json";
     const std::string render = share_data->save_path + "/render_json/" + trian_json_file + ".json";
     const int rc = scorer(share_data->method_of_IG, std::atoi(trian_json_file.c_str()), scene, render, candidate_ids, scores);
     const double cost_time = now_seconds() - t0;
-    std::string t = std::to_string(cost_time) + "\n";
-    write_text(share_data->save_path + "/train_time/" + trian_json_file + ".txt", t); // :1708-1710
+    write_text(share_data->save_path + "/train_time/" + trian_json_file + ".txt", std::to_string(cost_time) + "\n");
     return rc;
+  }
+
+  // `score_path: png`: the score of one unchosen view from the PNGs the engine calls of this iteration left
+  int view_uncertainty_from_pngs(int method, const std::string& iteration, int view_id, double* out) const {
+    std::vector<std::string> files;
+    for (int e = 0; e < share_data->ensemble_num; e++)
+      files.push_back(share_data->save_path + "/render/" + iteration + "/ensemble_" + std::to_string(e) + "/rgbaClip_" +
+                      std::to_string(view_id) + ".png");
+    return ensemble_uncertainty_from_pngs(method, files, out);
   }
 
   // main.cpp:1718-2277, methods 0-5; chosen views in `chosen_nbvs`
@@ -237,9 +346,27 @@ public:
         case EnsembleRGBDensity:
         case PSNRCoverage: { // :2039-2161: score every unchosen view, keep the arg-max
           std::vector<double> scores(candidates.size(), 0.0);
-          const int rc = train_by_instantNGP(it, candidates, scores);
-          if (rc != 0) return rc;
+          if (sd.score_from_pngs && sd.method_of_IG != PSNRCoverage) {
+            // the reference's data flow, call for call: one engine run per member (:2041-2043, :2101-2103), then the PNGs
+            const double t0 = now_seconds();
+            for (int ensemble_id = 0; ensemble_id < sd.ensemble_num; ensemble_id++) {
+              const int rc = train_by_instantNGP(it, "100", true, ensemble_id);
+              if (rc != 0) return rc;
+            }
+            write_text(sd.save_path + "/train_time/" + it + ".txt", std::to_string(now_seconds() - t0) + "\n");
+            for (size_t k = 0; k < candidates.size(); k++) {
+              const int rc = view_uncertainty_from_pngs(sd.method_of_IG, it, candidates[k], &scores[k]);
+              if (rc != 0) return rc;
+            }
+          } else {
+            const int rc = score_candidates(it, candidates, scores);
+            if (rc != 0) return rc;
+          }
           last_scores = scores;
+          if (getenv("PRV_PLANNER_DUMP_RECORDS")) { // tests: this iteration's scores as raw doubles, either score path
+            sd.access_directory(sd.save_path + "/scores");
+            write_text(sd.save_path + "/scores/" + it + ".bin", std::string((const char*)scores.data(), scores.size() * sizeof(double)));
+          }
           double largest_view_uncertainty = -1e100; // :1971
           int best_view_id = -1;
           for (size_t k = 0; k < candidates.size(); k++) // ascending ids, strict '>' (:2088-2091)

@@ -56,6 +56,7 @@ HOST_SIGNATURES = {
     "prvh_pcd_read": (C.c_longlong, [C.c_char_p, _vp, _vp, C.c_longlong]),
     "prvh_png_size": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
     "prvh_png_read_rgba8": (_i, [C.c_char_p, _i, _i, _vp]),
+    "prvh_score_view_pngs": (_i, [_i, C.POINTER(C.c_char_p), _i, C.POINTER(C.c_double)]),
     "prvh_png_write_rgba8": (_i, [C.c_char_p, _i, _i, _vp]),
     "prvh_ingp_read": (_i, [C.c_char_p, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _vp, _vp, _vp, C.c_char_p, _i]),
     "prvh_ingp_write": (_i, [C.c_char_p, _vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64, C.c_char_p, _i]),
@@ -188,6 +189,17 @@ def png_read(path):
     if rc != 0:
         raise IOError(f"{path}: png error {rc}")
     return out
+
+
+def score_view_pngs(method, files):
+    """main.cpp:2045-2094 (method 2) / 2105-2158 (method 3) for one view: the E member screenshots -> view_uncertainty,
+    on the host in the reference's operation order (prvh_score_view_pngs; what prv_planner's `score_path: png` runs)"""
+    arr = (C.c_char_p * len(files))(*[str(f).encode() for f in files])
+    out = C.c_double()
+    rc = host().prvh_score_view_pngs(int(method), arr, len(files), C.byref(out))
+    if rc != 0:
+        raise IOError(f"score_view_pngs: error {rc}")
+    return out.value
 
 
 def png_write(path, rgba8):

@@ -1,6 +1,7 @@
 # exits of prv_planner while another process keeps the GPU busy (round 2 saw ~1 crash in 1000 static teardowns):
-#   usage: scripts/gpu/exit_stress.sh <runs of the default exit> <runs of the plain return>
-# default = prv_runtime_shutdown (hipDeviceReset before main returns) then a normal return; noreset = plain return
+#   usage: scripts/gpu/exit_stress.sh <runs of the ordinary return> <runs of the plain return>
+# normal = prv_runtime_shutdown (hipDeviceReset before main returns) then an ordinary return (round 3's default; the default
+# is now the same shutdown followed by _exit, which cannot die in the runtime's exit handlers); noreset = plain return
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 export PRV_SEGV_TRACE=1
@@ -14,18 +15,14 @@ sleep 25
 loop() { # mode, runs
   local fail=0 t0=$(date +%s)
   for i in $(seq 1 $2); do
-    if [ "$1" = default ]; then
-      printf "21\nobjA\n-1\n" | nerf_prv_amd/prv_planner $CFG > $O/out.txt 2> $O/err.txt; rc=$?
-    else
-      printf "21\nobjA\n-1\n" | PRV_PLANNER_EXIT=$1 nerf_prv_amd/prv_planner $CFG > $O/out.txt 2> $O/err.txt; rc=$?
-    fi
+    printf "21\nobjA\n-1\n" | PRV_PLANNER_EXIT=$1 nerf_prv_amd/prv_planner $CFG > $O/out.txt 2> $O/err.txt; rc=$?
     if [ $rc -ne 0 ]; then fail=$((fail+1)); echo "$1 run $i rc=$rc"; tail -30 $O/err.txt; cp $O/err.txt $O/err_$1_$i.txt; fi
     if [ $i -eq 1 ]; then grep chosen_nbvs $O/out.txt; fi
     find /tmp/repro -mindepth 1 -maxdepth 1 ! -name models ! -name cfg.yaml -exec rm -rf {} +
   done
   echo "$1: failures $fail / $2 in $(( $(date +%s) - t0 )) s" | tee -a $O/summary.txt
 }
-[ "${1:-0}" -gt 0 ] && loop default $1
+[ "${1:-0}" -gt 0 ] && loop normal $1
 [ "${2:-0}" -gt 0 ] && loop noreset $2
 kill $BG 2>/dev/null; wait $BG 2>/dev/null
 cat $O/summary.txt

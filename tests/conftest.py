@@ -12,21 +12,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session", autouse=True)
-def planner_exit_code_is_the_planners():
-    """The planner executables the tests start leave through PRV_PLANNER_EXIT=quick (ordered shutdown, flush, _exit): with
-    the default -- the same shutdown, then an ordinary return from main -- about one exit in 5000 dies AFTER main has
-    returned, inside the HIP runtime's own exit handlers (profiles/r03_y_planner_exit_crash_diagnostic.txt; DESIGN.md
-    section 10, item 9), and two dozen planner runs per session would turn that into a flaky suite.  The default exit is
-    exercised on purpose by tests/test_gpu_planner.py::test_planner_default_exit_is_an_ordinary_return."""
-    if "PRV_PLANNER_EXIT" in os.environ:
-        yield
-        return
-    os.environ["PRV_PLANNER_EXIT"] = "quick"
-    yield
-    os.environ.pop("PRV_PLANNER_EXIT", None)
-
-
 @pytest.fixture(scope="session")
 def oracle():
     """the CPU oracle binding (checker only)"""

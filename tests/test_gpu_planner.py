@@ -209,13 +209,14 @@ def test_planner_executable_shards_objects_over_ranks(ctx, tmp_path):
     assert bad.returncode == 2 and "make no sense" in bad.stderr
 
 
-def test_planner_default_exit_is_an_ordinary_return(tmp_path):
-    """what a user gets without PRV_PLANNER_EXIT (the session sets `quick`, conftest.py): the library is shut down in order
-    (prv_runtime_shutdown: every context destroyed, device synchronised and reset) and main returns; exit code 0, the
-    result on stdout; `quick` (the same shutdown, then _exit) gives the same result and code."""
+def test_planner_exit_modes_agree(tmp_path):
+    """the default exit (what every other test of this file gets: ordered prv_runtime_shutdown, flush, _exit -- so a finished
+    run's exit code never depends on the HIP runtime's own exit handlers) and the opt-in ordinary return
+    (PRV_PLANNER_EXIT=normal: the same shutdown, then main returns) give the same result and code 0, with everything
+    written to stdout flushed either way."""
     exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
     lines = {}
-    for how in (None, "quick"):
+    for how in (None, "normal"):
         pre = tmp_path / str(how)  # an output tree of its own: the planner resumes a finished one
         pre.mkdir()
         cfg = pre / "cfg.yaml"
@@ -228,6 +229,83 @@ def test_planner_default_exit_is_an_ordinary_return(tmp_path):
         assert out.returncode == 0, (how, out.stdout + out.stderr)
         lines[how] = [l for l in out.stdout.splitlines() if l.startswith("chosen_nbvs:")][-1]
     assert len(set(lines.values())) == 1
+
+
+@pytest.mark.parametrize("method", [3, 2])
+def test_reference_signature_png_path_equals_the_fused_round(tmp_path, method):
+    """One planner run per score path on the same members (synthetic seeds, not retrained: training is not bit-reproducible
+    across runs, rendering is).  `score_path: png` is the reference's own data flow behind its own signature --
+    train_by_instantNGP(it, "100", true, e) per member (main.cpp:2041-2043) -> render/<it>/ensemble_<e>/rgbaClip_<v>.png ->
+    the loops that read the PNGs (main.cpp:2045-2094, 2105-2158); `fused` is ONE prv_score_views round.  Same scores bit
+    for bit (method 3; method 2 sums logarithms: the device's log and glibc's may differ in the last place, compared to
+    1e-13 relative), same chosen views, and the PNG tree is the reference's."""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    got = {}
+    for how in ("png", "fused"):
+        pre = tmp_path / how
+        pre.mkdir()
+        cfg = pre / "cfg.yaml"
+        cfg.write_text(YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=method,
+                                   model_source=f"synthetic_seed: {SEED}\npretrained_members: 1\nscore_path: {how}"))
+        out = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=600,
+                             env=dict(os.environ, PRV_PLANNER_DUMP_RECORDS="1"))
+        assert out.returncode == 0, out.stdout + out.stderr
+        save = pre / "Compare" / "ShapeNet" / f"objA_m{method}_v1_t0"
+        scores = [np.frombuffer((save / "scores" / f"{it}.bin").read_bytes(), np.float64) for it in range(3)]
+        chosen = [l for l in out.stdout.splitlines() if l.startswith("chosen_nbvs:")][-1]
+        got[how] = (scores, chosen, save, out.stdout)
+    E = 5 if method == 3 else 2  # Share_Data.hpp:505-510
+    for it in range(3):
+        a, b = got["png"][0][it], got["fused"][0][it]
+        assert a.shape == b.shape == (4 - it,)
+        if method == 3:
+            assert a.tobytes() == b.tobytes(), (it, a, b)
+        else:
+            np.testing.assert_allclose(a, b, rtol=1e-13, atol=0)
+    assert got["png"][1] == got["fused"][1]
+    save = got["png"][2]
+    # the reference's tree: one directory per member and iteration, one PNG per unchosen view, named by view id
+    chosen = [int(x) for x in got["png"][1].split(":")[1].split()]
+    for it in range(3):
+        for e in range(E):
+            names = sorted(os.listdir(save / "render" / str(it) / f"ensemble_{e}"))
+            assert names == sorted(f"rgbaClip_{v}.png" for v in range(5) if v not in chosen[: it + 1])
+    assert got["png"][3].count("train and eval with executed time") == 3 * E  # main.cpp:1705, once per engine call
+    assert (save / "train_time" / "0.txt").exists()
+    # the fused records' scores are what the fused path's scores file holds
+    rec = np.frombuffer((got["fused"][2] / "records" / "0.bin").read_bytes(), api.RECORD_DTYPE)
+    assert rec["score"].tobytes() == got["fused"][0][0].tobytes()
+
+
+def test_reference_signature_trains_one_member_per_call(tmp_path):
+    """score_path: png with training in the loop: every engine call trains ITS member (fresh field, n_steps) on the
+    iteration's json and leaves that member's PNGs; the decision of every iteration is re-derived from the PNGs on disk by
+    the oracle's restatement of main.cpp:2105-2158 (the checker), and equals the planner's."""
+    from PIL import Image
+
+    from oracle import oracle as orc
+
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    pre = tmp_path
+    cfg = pre / "cfg.yaml"
+    cfg.write_text(YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=3,
+                               model_source="n_steps: 60\ntrain_rays: 1024\ntrain_width: 160\ntrain_height: 90\nscore_path: png"))
+    out = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    chosen = [int(x) for x in [l for l in out.stdout.splitlines() if l.startswith("chosen_nbvs:")][-1].split(":")[1].split()]
+    save = pre / "Compare" / "ShapeNet" / "objA_m3_v1_t0"
+    for it in range(3):
+        cands = [v for v in range(5) if v not in chosen[: it + 1]]
+        scores = []
+        for v in cands:
+            imgs = np.stack([np.asarray(Image.open(save / "render" / str(it) / f"ensemble_{e}" / f"rgbaClip_{v}.png").convert("RGBA"))
+                             for e in range(5)])
+            scores.append(orc.score_ensemble_rgbdensity([im for im in imgs]))
+        assert cands[int(np.argmax(scores))] == chosen[it + 1], (it, scores, chosen)
+    members_differ = any(
+        open(save / "render" / "0" / "ensemble_0" / f"rgbaClip_{v}.png", "rb").read() !=
+        open(save / "render" / "0" / "ensemble_1" / f"rgbaClip_{v}.png", "rb").read() for v in range(1, 5))
+    assert members_differ  # each call trained its own member from its own seed
 
 
 def test_planner_executable_error_paths(tmp_path):

@@ -572,3 +572,30 @@ def test_malformed_point_cloud_headers_are_refused(tmp_path):
         bad.write_text(text)
         with pytest.raises(IOError):
             planner.pcd_read(bad)
+
+
+def test_png_score_loops_equal_the_oracle_bit_for_bit(oracle, tmp_path):
+    """the host form of the reference's PNG-reading score loops (main.cpp:2045-2094, 2105-2158; prv_planner's
+    `score_path: png`) against the oracle's restatement of the same lines: random member images through real PNG files,
+    both methods, E = 2 and 5, including pixels where every member agrees (variance 0: the log term is skipped)"""
+    rng = np.random.default_rng(7)
+    for method, E in ((2, 2), (3, 5), (2, 5), (3, 2)):
+        imgs = rng.integers(0, 256, (E, 45, 80, 4), dtype=np.uint8)
+        imgs[:, :5] = imgs[0, :5]  # identical rows
+        imgs[:, 5:9, :, 3] = 255   # fully opaque rows: density term 0
+        files = []
+        for e in range(E):
+            f = tmp_path / f"m{method}_{E}_{e}.png"
+            planner.png_write(f, imgs[e])
+            files.append(f)
+        got = planner.score_view_pngs(method, files)
+        want = (oracle.score_ensemble_rgb if method == 2 else oracle.score_ensemble_rgbdensity)([im for im in imgs])
+        assert np.float64(got).tobytes() == np.float64(want).tobytes(), (method, E, got, want)
+    with pytest.raises(IOError):
+        planner.score_view_pngs(3, [tmp_path / "missing.png"])
+    small = tmp_path / "small.png"
+    planner.png_write(small, np.zeros((4, 4, 4), np.uint8))
+    with pytest.raises(IOError):
+        planner.score_view_pngs(3, [files[0], small])  # another size
+    with pytest.raises(IOError):
+        planner.score_view_pngs(5, files)  # PSNR has no PNG loop in the reference
