@@ -23,6 +23,7 @@ against this repository's own CPU oracle (tests/), which is NOT pinned to the re
 (instant-ngp is absent from the reference tree) -- stated in the line as "parity".
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -535,12 +536,23 @@ def full_loop(args):
     for mode, key in ((21, "view_planning_s"), (4, "psnr_curve_and_stopping_criterion_s")):
         t0 = time.perf_counter()
         # the planner's default exit (ordered shutdown, flush, _exit): its exit code is the planner's own
-        r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=3600)
+        r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=3600,
+                           env=dict(os.environ, PRV_PLANNER_TIMING="1"))  # one line per training call on stderr
         out[key] = time.perf_counter() - t0
         if r.returncode != 0:
             out["error"] = f"mode {mode} exited {r.returncode}: {(r.stdout + r.stderr)[-400:]}"
             return out
         if mode == 21:
+            # "train_members: views V gt G s, fresh F s, create C s, steps S s, total T s": S = prv_train_steps_multi of that
+            # round (5 members x 2500 steps side by side)
+            steps_s = [float(x) for x in re.findall(r"train_members: .*? steps ([0-9.eE+-]+) s", r.stderr)]
+            train_s = [float(x) for x in re.findall(r"train_members: .*? total ([0-9.eE+-]+) s", r.stderr)]
+            if steps_s:
+                out["training_calls"] = len(steps_s)
+                out["training_steps_s"] = sum(steps_s)
+                out["training_total_s"] = sum(train_s)
+                out["member_step_us"] = sum(steps_s) / (len(steps_s) * 5 * 2500) * 1e6  # ensemble_num 5 (method 3), n_steps 2500
+                out["round_of_5_member_steps_ms"] = sum(steps_s) / (len(steps_s) * 2500) * 1e3
             chosen = [l for l in r.stdout.splitlines() if l.startswith("chosen_nbvs:")]
             out["views_chosen_last_object"] = [int(x) for x in chosen[-1].split(":")[1].split()] if chosen else None
         else:
@@ -689,7 +701,9 @@ def run_rank(args):
         r.close()
         # (3) the reference's OWN scoring round: 540 candidates at 80x45, spp 16, 5 members, EnsembleRGBDensity
         #     (main.cpp:1796-1806, run.py:48,304, Share_Data.hpp:505-510), in both stepping rules
-        extras["reference_round"] = reference_round(env, field_kw(args.field, "dense"))
+        extras["reference_round"] = reference_round(env, field_kw(args.field, "dense"), layout_of, variant_of)
+        # (4) the headline's views under the engine's own stepping rule
+        extras["ngp_step"] = ngp_step_round(solo, fkw, args, layout_of, variant_of)
 
     # BASELINE config 1 analogue (the reference's CPU render path, main.cpp:98-284): first occupied voxel
     # per ray over the same views; GPU (prv_first_hit) here, the oracle's scalar DDA in cpu_baseline
@@ -741,7 +755,7 @@ def run_rank(args):
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             cpu = cpu_baseline(args, fkw, main.tms, main.scale, main.offset, main.fov_x)
         loop = None
-        if world == 1 and not args.no_full_loop:
+        if world == 1 and not args.no_full_loop and not args.no_extras:
             loop = full_loop(args)
         out = {
             # scene in the metric's name: round 3 switched the default scene, and lines of different scenes do not compare
@@ -803,6 +817,8 @@ def run_rank(args):
             "samples_nominal_per_step_per_gpu": m["st"].samples_nominal,
             "evaluated_samples_per_ray": m["st"].samples_evaluated / max(1, m["st"].rays),
             "ranking_head": [int(x) for x in m["order"][:8]],
+            "ranking_sha256": hashlib.sha256(np.asarray(m["order"], np.int32).tobytes()).hexdigest()[:16],  # the WHOLE integer ranking
+            "records_sha256": hashlib.sha256(m["records"].tobytes()).hexdigest()[:16],  # every gathered 16-byte record of the last step
             "roofline_detail": roof_detail,
             "first_hit": first_hit,
             "training": training,
@@ -830,9 +846,10 @@ def run_rank(args):
     return 0
 
 
-def reference_round(env, fkw):
+def reference_round(env, fkw, layout_of, variant_of):
     """the reference's own scoring round on this GPU: 540 candidate views at 80x45, 16 sub-samples per pixel, a 5-member
-    ensemble, EnsembleRGBDensity -- once with 128 uniform samples per ray, once with the engine's stepping rule"""
+    ensemble, EnsembleRGBDensity -- once with 128 uniform samples per ray, once with the engine's stepping rule; each with
+    its own roofline of the render launches (one per member), measured in the run like the headline's"""
     api, planner, torch, np, ctx = env["api"], env["planner"], env["torch"], env["np"], env["ctx"]
     n_views, members = 540, 5
     desc = api.L.FieldDesc(**fkw)
@@ -844,19 +861,63 @@ def reference_round(env, fkw):
     cams = ctx.cameras_from_matrices(tms, fov_x, 80, 45, scale, offset)
     slots = list(range(2, 2 + members))
     out = {"workload": "540 views x 80x45 x 16 spp x 5 members, EnsembleRGBDensity (main.cpp:1796-1806, 2099-2161; run.py:48,304), min_T 0.01"}
+    reps = 5
     for name, spr in (("fixed_128", 128), ("ngp_step", 0)):
         opts = api.engine_render_opts(80, 45, spr, 16, 0.01, background=(0, 0, 0, 1))
         rec, st = ctx.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, slots, cams, None, opts, want_stats=True)
         torch.cuda.synchronize()
+        ctx.profile_begin()
         t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(reps):
             rec, _ = ctx.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, slots, cams, None, opts)
-        dt = (time.perf_counter() - t0) / 3
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        prof = ctx.profile_end()
+        prof["clock_ghz"] = ctx.render_clock_ghz()
+        # st counts the whole round (all members); a "step" of the figures below is one round
+        m = {"prof": prof, "st": st, "steps": reps}
+        roof, _ = kernel_figures(m, variant_of(2), False, "dense", layout_of(2))
         out[name] = {"ms_per_round": dt * 1e3, "views_per_s": n_views / dt, "ray_samples_per_s": st.samples_evaluated / dt,
                      "evaluated_samples_per_ray": st.samples_evaluated / max(1, st.rays), "live_samples_per_ray": st.samples_live / max(1, st.rays),
-                     "best_view": int(ctx.argmax(rec, np.arange(n_views)))}
+                     "render_ms_per_round": prof["render_ms"] / reps, "march_ms_per_round": prof["march_ms"] / reps,
+                     "render_launches_per_round": prof["render_launches"] // reps,
+                     "best_view": int(ctx.argmax(rec, np.arange(n_views))),
+                     "roofline": {k: roof[k] for k in ("kernel", "bound", "frac", "peak", "achieved", "unit", "avg_launch_ms", "units_per_launch",
+                                                       "slot_utilisation", "samples_per_s_in_kernel", "shader_clock_ghz_measured")}}
     cams.close()
     return out
+
+
+def ngp_step_round(env, fkw, args, layout_of, variant_of):
+    """the headline's 64 views at 800x800 under the ENGINE's stepping rule (dt = sqrt(3)/1024, every step tested against
+    the occupancy grid, no per-ray cap; what run.py:245-247, 304 render with): render only, samples/s over wall time"""
+    api, planner, torch, np, ctx = env["api"], env["planner"], env["torch"], env["np"], env["ctx"]
+    ctx.synthetic_model(2, api.L.FieldDesc(**fkw), SEED_A)
+    pts = planner.hemisphere_generate(args.views_per_gpu)
+    fov_x = 2.0 * np.arctan(0.5 * 1280 / 915.60668945312500)
+    tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
+    cams = ctx.cameras_from_matrices(tms, fov_x, args.width, args.height, scale, offset)
+    opts = api.engine_render_opts(args.width, args.height, 0, 1, 1e-4)
+    out_img = torch.empty((args.views_per_gpu, args.height, args.width, 4), dtype=torch.float32, device=env["device"])
+    _, st = ctx.render(2, cams, None, opts, out=out_img)
+    torch.cuda.synchronize()
+    reps = 3
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.render(2, cams, None, opts, out=out_img, want_stats=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    prof = ctx.profile_end()
+    prof["clock_ghz"] = ctx.render_clock_ghz()
+    roof, _ = kernel_figures({"prof": prof, "st": st, "steps": reps}, variant_of(2), args.field == "512", args.scene, layout_of(2))
+    cams.close()
+    return {"workload": f"{args.views_per_gpu} views {args.width}x{args.height}, engine stepping rule (PRV_STEP_NGP), scene {args.scene}, render only",
+            "value": st.samples_evaluated / dt, "unit": "ray-samples/s", "ms_per_render": dt * 1e3,
+            "samples_evaluated": st.samples_evaluated, "samples_live_march_count": st.samples_live,
+            "evaluated_samples_per_ray": st.samples_evaluated / max(1, st.rays),
+            "roofline": {k: roof[k] for k in ("kernel", "bound", "frac", "avg_launch_ms", "units_per_launch", "slot_utilisation",
+                                              "samples_per_s_in_kernel", "shader_clock_ghz_measured")}}
 
 
 def dry_run(args, rank, world, np, torch, dist):

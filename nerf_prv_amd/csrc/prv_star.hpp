@@ -6,15 +6,20 @@
 // (two ranks sharing one GPU in the tests, CPU-only rendezvous tests).  Not a data path for real multi-GPU
 // runs: those gather device buffers with RCCL over xGMI.
 //
-// Topology: rank 0 listens on <addr>:<port> (MASTER_ADDR / MASTER_PORT + 23 by default, PRV_COMM_PORT
-// overrides) -- bound to THAT address, not to every interface -- and every other rank connects (retrying until it
-// is accepted).  A connection introduces itself with {magic, job nonce, communicator sequence number, rank, world};
-// the nonce is a hash of MASTER_PORT and the job's token ($PRV_COMM_TOKEN, else $TORCHELASTIC_RUN_ID), the sequence
-// number counts the communicators this process has opened.  Rank 0 closes and SKIPS anything that does not present
-// the right nonce / sequence / a free rank (a port scanner, a straggler of another job, a peer's NEXT communicator
-// landing in this listener's backlog) and keeps accepting until every rank has arrived or the timeout expires; a
-// rank is accepted with an acknowledgement, and join() returns only once it has that, so a rejected connection is
-// simply retried.  all_gather: every rank sends its block to rank 0, rank 0 answers with the assembled buffer.
+// Topology: rank 0 listens on <port> (MASTER_PORT + 23 by default, PRV_COMM_PORT overrides) and every other rank connects
+// to <addr>:<port> (MASTER_ADDR), retrying until it is accepted.  Rank 0 binds the rendezvous address itself when that
+// is a literal IP of a local interface (nothing outside that interface reaches the job); when MASTER_ADDR is a NAME
+// that resolves to loopback on this host (Debian's 127.0.1.1 for the own hostname) or an address that is not local
+// (a service / NAT address: EADDRNOTAVAIL) it listens on every interface instead -- remote ranks must be able to reach
+// it, and the hello below keeps strangers out.  A bind error other than "address in use" is reported at once.
+// A connection introduces itself with {magic, job nonce, rank, world}; the nonce is a hash of MASTER_PORT and the job's
+// token ($PRV_COMM_TOKEN, else $TORCHELASTIC_RUN_ID).  Rank 0 closes without a word anything that does not present the
+// magic and the nonce (a port scanner, another job), REFUSES with a reason a rank of this job that cannot be seated
+// (another world size: fatal for the joiner; a rank already seated -- a peer's NEXT communicator landing in this
+// listener's backlog: the joiner retries), and seats everything else with an acknowledgement that carries rank 0's
+// communicator sequence number: rank 0 dictates it, so a rank whose earlier prv_comm_create failed before it got here
+// is not out of step for the rest of the job.  join() returns once it is seated.
+// all_gather: every rank sends its block to rank 0, rank 0 answers with the assembled buffer.
 #pragma once
 #include <arpa/inet.h>
 #include <netdb.h>
@@ -86,7 +91,7 @@ public:
     hints.ai_family = AF_INET;
     hints.ai_socktype = SOCK_STREAM;
     if (getaddrinfo(addr.c_str(), std::to_string(port).c_str(), &hints, &res) != 0 || !res) return fail("cannot resolve " + addr);
-    bool ok = rank == 0 ? serve(res, timeout_s) : join(res, timeout_s);
+    bool ok = rank == 0 ? serve(res, timeout_s, addr) : join(res, timeout_s);
     freeaddrinfo(res);
     return ok;
   }
@@ -155,11 +160,13 @@ private:
     setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
   }
   static constexpr uint32_t kMagic = 0x50525653u; // "PRVS"
+  enum : uint32_t { kSeated = 0, kRetry = 1, kWorldMismatch = 2, kBadRank = 3 };
   struct Hello {
     uint32_t magic;
-    uint32_t seq;   // which communicator of the job this is (every rank opens them in the same order)
+    uint32_t seq;   // joiner -> rank 0: unused (0); rank 0 -> joiner: the communicator's sequence number at rank 0
     uint64_t nonce; // the job: a hash of MASTER_PORT and the job token
     int32_t rank, world;
+    uint32_t verdict, pad; // rank 0's answer: kSeated, or why not
   };
   static uint64_t job_nonce() {
     uint64_t h = 0xcbf29ce484222325ull; // FNV-1a over the strings that name the job
@@ -185,18 +192,37 @@ private:
     setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
     setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
   }
-  bool serve(const addrinfo* res, double timeout_s) {
-    const uint32_t seq = next_seq();
+public:
+  uint32_t seq = 0; // this communicator's sequence number as rank 0 counts them (diagnostics)
+
+private:
+  // rank 0's listening address: see the header comment
+  static bool is_ip_literal(const std::string& a) {
+    in_addr tmp;
+    return inet_pton(AF_INET, a.c_str(), &tmp) == 1;
+  }
+  bool serve(const addrinfo* res, double timeout_s, const std::string& addr_text) {
+    seq = next_seq();
     const uint64_t nonce = job_nonce();
     listen_fd_ = ::socket(AF_INET, SOCK_STREAM, 0);
     if (listen_fd_ < 0) return fail("socket()");
     int one = 1;
     setsockopt(listen_fd_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
     const auto t0 = std::chrono::steady_clock::now();
-    // the resolved rendezvous address itself (MASTER_ADDR), not INADDR_ANY: nothing outside that interface reaches the job
-    while (::bind(listen_fd_, res->ai_addr, res->ai_addrlen) != 0) { // a previous job's listener may linger briefly
-      if (since(t0) > timeout_s) return fail("bind: " + std::string(strerror(errno)));
-      std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    sockaddr_in want{};
+    memcpy(&want, res->ai_addr, std::min(sizeof(want), (size_t)res->ai_addrlen));
+    const bool loopback = (ntohl(want.sin_addr.s_addr) >> 24) == 127;
+    if (loopback && !is_ip_literal(addr_text) && addr_text != "localhost") want.sin_addr.s_addr = htonl(INADDR_ANY);
+    for (;;) {
+      if (::bind(listen_fd_, (const sockaddr*)&want, sizeof(want)) == 0) break;
+      const int err = errno;
+      if (err == EADDRNOTAVAIL && want.sin_addr.s_addr != htonl(INADDR_ANY)) { // not an address of this host: every interface
+        want.sin_addr.s_addr = htonl(INADDR_ANY);
+        continue;
+      }
+      if (err != EADDRINUSE) return fail("bind " + addr_text + ": " + std::string(strerror(err))); // nothing waiting will cure
+      if (since(t0) > timeout_s) return fail("bind " + addr_text + ": " + std::string(strerror(err)) + " (for the whole timeout)");
+      std::this_thread::sleep_for(std::chrono::milliseconds(100)); // a previous job's listener may linger briefly
     }
     if (::listen(listen_fd_, world + 16) != 0) return fail("listen()");
     peers_.assign((size_t)world, -1);
@@ -212,14 +238,15 @@ private:
       }
       set_timeouts(fd, std::min(left, 5.0)); // a connection that says nothing is dropped after 5 s, not waited on
       Hello h{};
-      const bool good = recv_all(fd, &h, sizeof(h)) && h.magic == kMagic && h.nonce == nonce && h.seq == seq && h.world == world &&
-                        h.rank > 0 && h.rank < world && peers_[(size_t)h.rank] < 0;
-      if (!good) { // not one of this communicator's ranks: drop it, keep waiting for the real ones
+      if (!recv_all(fd, &h, sizeof(h)) || h.magic != kMagic || h.nonce != nonce) { // a stranger: not a word
         ::close(fd);
         continue;
       }
-      const Hello ack{kMagic, seq, nonce, 0, world};
-      if (!send_all(fd, &ack, sizeof(ack))) {
+      Hello ack{kMagic, seq, nonce, 0, world, kSeated, 0};
+      if (h.world != world) ack.verdict = kWorldMismatch;
+      else if (h.rank <= 0 || h.rank >= world) ack.verdict = kBadRank;
+      else if (peers_[(size_t)h.rank] >= 0) ack.verdict = kRetry; // that rank sits here already: its NEXT communicator, too early
+      if (!send_all(fd, &ack, sizeof(ack)) || ack.verdict != kSeated) {
         ::close(fd);
         continue;
       }
@@ -232,7 +259,6 @@ private:
     return true;
   }
   bool join(const addrinfo* res, double timeout_s) {
-    const uint32_t seq = next_seq();
     const uint64_t nonce = job_nonce();
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -240,19 +266,27 @@ private:
       if (fd < 0) return fail("socket()");
       if (::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
         set_timeouts(fd, std::max(1.0, std::min(timeout_s - since(t0), 30.0)));
-        const Hello hello{kMagic, seq, nonce, rank, world};
+        const Hello hello{kMagic, 0, nonce, rank, world, 0, 0};
         Hello ack{};
-        // accepted = rank 0 answered with this communicator's acknowledgement; a listener that closes the connection
-        // instead (it belongs to an earlier communicator or to another job) is retried
-        if (send_all(fd, &hello, sizeof(hello)) && recv_all(fd, &ack, sizeof(ack)) && ack.magic == kMagic && ack.nonce == nonce &&
-            ack.seq == seq && ack.world == world) {
-          tune(fd);
-          peers_.assign(1, fd);
-          return true;
+        // seated = rank 0 answered with an acknowledgement; a listener that closes the connection without a word is
+        // not this job's (or died), a kRetry answer is this job's listener of an earlier communicator: try again
+        if (send_all(fd, &hello, sizeof(hello)) && recv_all(fd, &ack, sizeof(ack)) && ack.magic == kMagic && ack.nonce == nonce) {
+          if (ack.verdict == kSeated) {
+            seq = ack.seq;
+            tune(fd);
+            peers_.assign(1, fd);
+            return true;
+          }
+          if (ack.verdict == kWorldMismatch || ack.verdict == kBadRank) {
+            ::close(fd);
+            return fail(ack.verdict == kWorldMismatch
+                            ? "rank 0 refused this rank: it runs a communicator of " + std::to_string(ack.world) + " ranks, this rank expects " + std::to_string(world)
+                            : "rank 0 refused this rank: rank " + std::to_string(rank) + " is outside its world of " + std::to_string(ack.world));
+          }
         }
       }
       ::close(fd);
-      if (since(t0) > timeout_s) return fail("connect: rank 0 did not accept this rank");
+      if (since(t0) > timeout_s) return fail("connect: rank 0 did not seat this rank within the timeout");
       std::this_thread::sleep_for(std::chrono::milliseconds(50));
     }
   }

@@ -155,7 +155,7 @@ def _star_worker(rank, world, port, q):
         h.prvh_star_close(star)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_star_all_gather_and_broadcast_between_processes(world):
     """the rendezvous / socket transport of the C ABI's communicator, without a GPU: every rank ends with the same
     gathered records in rank order, a broadcast from the last rank reaches everyone"""
@@ -176,6 +176,64 @@ def test_star_all_gather_and_broadcast_between_processes(world):
     want_sum = int((np.arange(3_000_001) % 251).sum())
     for rank, rec_bytes, s in got:
         assert rec_bytes == want.tobytes() and s == want_sum
+
+
+def _star_odd_worker(rank, world, port, q, case):
+    """rendezvous cases beyond the happy path; puts (rank, ok, message, seconds)"""
+    import time
+
+    h = planner.host()
+    t0 = time.time()
+    if case == "world_mismatch":  # rank 1 believes in 3 ranks, rank 0 in 2: refused with the reason, at once
+        star = h.prvh_star_open(rank, 3 if rank == 1 else 2, b"127.0.0.1", port, 8.0 if rank == 0 else 30.0)
+    elif case == "failed_first_open":  # rank 1's first communicator never got as far as the rendezvous; the second one must still work
+        if rank == 1:
+            assert not h.prvh_star_open(5, 2, b"127.0.0.1", port, 5.0)  # bad rank: fails before any connection
+        star = h.prvh_star_open(rank, world, b"127.0.0.1", port, 30.0)
+    elif case == "name_and_foreign_address":
+        # rank 0 is given an address that is not one of this host's (a service / NAT address: bind -> EADDRNOTAVAIL):
+        # it listens on every interface instead of spinning until the timeout; rank 1 reaches it through a NAME
+        star = h.prvh_star_open(rank, world, b"192.0.2.1" if rank == 0 else b"localhost", port, 30.0)
+    msg = "" if star else h.prvh_share_data_error().decode()
+    ok = bool(star)
+    if star and case != "world_mismatch":
+        ok = h.prvh_star_barrier(star) == 0
+    q.put((rank, ok, msg, time.time() - t0))
+    if star:
+        h.prvh_star_close(star)
+
+
+@pytest.mark.parametrize("case", ["world_mismatch", "failed_first_open", "name_and_foreign_address"])
+def test_star_rendezvous_corner_cases(case):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_star_odd_worker, args=(r, 2, port, q, case)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (ok, msg, took)) for r, ok, msg, took in (q.get(timeout=90) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=30)
+    if case == "world_mismatch":
+        ok, msg, took = got[1]
+        assert not ok and "refused" in msg and "2 ranks" in msg and took < 5.0, got  # an explicit answer, not a timeout
+        assert not got[0][0] and "did not arrive" in got[0][1]  # rank 0 keeps its seat free until ITS timeout
+    else:
+        assert got[0][0] and got[1][0], got
+
+
+def test_star_reports_a_bind_error_at_once():
+    """a bind failure that waiting cannot cure (here: a privileged port as an ordinary user, or an address family error)
+    is reported immediately with its errno text -- round 3 retried every bind error for the whole timeout"""
+    import time
+
+    if os.geteuid() == 0:
+        pytest.skip("root may bind any port")
+    h = planner.host()
+    t0 = time.time()
+    star = h.prvh_star_open(0, 2, b"127.0.0.1", 1, 30.0)
+    assert not star and time.time() - t0 < 3.0
+    assert "bind" in h.prvh_share_data_error().decode()
 
 
 def test_shard_views_of_the_c_abi_matches_the_python_sharding():

@@ -258,3 +258,65 @@ def test_bench_two_ranks_time_the_product_collective_path(tmp_path):
     assert one.returncode == 0, one.stdout + one.stderr
     ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert ref["ranking_head"] == two["ranking_head"] and ref["collective"] is None
+
+
+def test_bench_eight_ranks_shard_1024_views_of_the_512_field(tmp_path):
+    """BASELINE configs[3]'s layout before the driver's 8-GPU run: `bench.py --gpus 8 --mode strong --views-total 1024
+    --field 512` -- eight fresh rank processes, 128 views each (interleaved), the 512^3 F=2 field, ONE all-gather of the
+    records per round through the C ABI's communicator.  The pool has one GPU, so the eight ranks share it (gloo + the socket
+    transport; small images): the gathered records and the whole integer ranking are byte-identical to ONE process
+    scoring all 1024 views.  The parent (this test) never touches the GPU for it."""
+    import json
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--mode", "strong", "--views-total", "1024",
+            "--field", "512", "--width", "40", "--height", "32", "--no-extras", "--no-training", "--no-cpu-baseline", "--no-full-loop"]
+    out = subprocess.run(base + ["--gpus", "8"], capture_output=True, text=True, env=dict(env, PRV_BENCH_SHARED_GPU="1"), timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    eight = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert eight["n_gpus"] == 8 and eight["comm_ranks"] == 8 and eight["config"]["views_total"] == 1024
+    col = eight["collective"]
+    assert col["timed_path"].startswith("prv_score_views_sharded") and col["transport"] == "socket" and col["ranks"] == 8
+    assert col["records_identical_to_torch_gather"] is True and col["error"] is None
+    one = subprocess.run(base + ["--gpus", "1"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert ref["config"]["views_total"] == 1024 and ref["collective"] is None
+    assert eight["records_sha256"] == ref["records_sha256"]  # 1024 records, byte for byte
+    assert eight["ranking_sha256"] == ref["ranking_sha256"] and eight["ranking_head"] == ref["ranking_head"]
+    assert eight["samples_evaluated_per_step_per_gpu"] > 0
+
+
+def _rccl_shared_device_worker(rank, port, q):
+    c = api.Context(0)
+    try:
+        api.Comm(c, rank, 2, transport="rccl", rendezvous=f"127.0.0.1:{port}")
+        q.put((rank, "created"))
+    except api.PrvError as e:
+        q.put((rank, f"{e.code}: {e}"))
+    finally:
+        c.close()
+
+
+def test_rccl_transport_refuses_two_ranks_on_one_gpu_with_a_reason(tmp_path):
+    """two ranks that sit on the same physical GPU ask for the rccl transport: BOTH get PRV_E_INVALID naming the ranks and
+    the device, promptly -- not a hang inside ncclCommInitRank"""
+    import time
+
+    import torch.multiprocessing as mp
+
+    port = free_port()
+    mctx = mp.get_context("spawn")
+    q = mctx.Queue()
+    t0 = time.time()
+    procs = [mctx.Process(target=_rccl_shared_device_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert time.time() - t0 < 170
+    for r in range(2):
+        assert got[r].startswith(str(api.L.PRV_E_INVALID)) and "ranks 0 and 1 share one GPU" in got[r] and "socket" in got[r], got
