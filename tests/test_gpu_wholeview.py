@@ -152,3 +152,30 @@ def test_ngp_step_at_full_size(ctx, oracle, round_cams, scene):
         n_eval += wants[0][1]
     assert n_eval > 0
     f.close()
+
+
+@pytest.mark.parametrize("scene", ["baseline256", "baseline512"])
+def test_ngp_step_whole_views_of_the_headline_scene(ctx, oracle, round_cams, scene):
+    """the engine's stepping rule on the HEADLINE scene (BASELINE.md section 6 literally; and the same scene on configs[3]'s
+    512^3 field): the 64-view 800x800 round in one call -- its march count (every occupancy decision of every step of 41 M
+    rays: 1.1 G samples in occupied cells) equal to the oracle's as an integer, and four WHOLE views (pole, two in
+    between, the lowest) against the oracle pixel by pixel.  Nothing terminates early in this scene (alpha stays small),
+    so evaluated == live and min_T needs no termination variants."""
+    cams, ocams = round_cams
+    kw = SCENES[scene] if scene in SCENES else dict(api.FIELD_512, table_amp=0.1, density_bias=0.0)
+    ctx.synthetic_model(6, api.L.FieldDesc(**kw), util.SEED_A)
+    f = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
+    opts = api.engine_render_opts(W, H, 0, 1, 1e-2)
+    img, st = ctx.render(6, cams, None, opts)
+    want_march = sum(f.march_count(oc, W, H, 0, threads=THREADS, step_mode=oracle.STEP_NGP) for oc in ocams)
+    assert int(st.samples_live) == want_march and want_march > 1_000_000_000
+    assert int(st.samples_evaluated) == int(st.samples_live)
+    assert st.samples_nominal == N_VIEWS * W * H * api.L.NGP_MAX_STEPS
+    n_eval = 0
+    for v in (0, 21, 42, 63):
+        want, ne = f.render(ocams[v], W, H, 0, 1, 1e-2, threads=THREADS, step_mode=oracle.STEP_NGP)
+        util.assert_pixels_close(img[v].cpu().numpy(), want)
+        assert want[..., 3].max() > 0.1
+        n_eval += ne
+    assert n_eval > 0
+    f.close()
