@@ -97,10 +97,6 @@ typedef struct prvh_loop_result {
 /* ---- PNG files of the boundary (rgbaClip_<i>.png written at main.cpp:1617, screenshots of run.py:309 read at
  * main.cpp:2047, 2107): 8-bit grey / RGB / RGBA, non-interlaced; pixels as RGBA8, top row first.
  * 0, or -1 io, -2 not a PNG, -3 unsupported flavour, -4 corrupt, -5 size mismatch */
-/* the ground-truth cloud file (pcl::io::loadPCDFile<PointXYZRGB>, main.cpp:654): PCD v0.7 ascii / binary, fields
- * x y z [rgb|rgba].  Returns the point count (fills the arrays when capacity suffices: xyz n*3 floats, rgb n*3
- * bytes), or -1 io, -2 bad header, -3 unsupported flavour, -4 truncated */
-long long prvh_pcd_read(const char* path, float* xyz_out, uint8_t* rgb_out, long long capacity);
 int prvh_png_size(const char* path, int* width, int* height);
 int prvh_png_read_rgba8(const char* path, int width, int height, uint8_t* out_rgba8);
 int prvh_png_write_rgba8(const char* path, int width, int height, const uint8_t* rgba8);
@@ -136,10 +132,6 @@ int prvh_star_barrier(prvh_star*);
 
 int prvh_nbv_loop(prvh_share_data* sd, const double center[3], double predicted_size, int first_view_id,
                   int test_id, prvh_score_fn score, void* user, prvh_loop_result* out);
-/* the same with the view budget of method 4 (PVBCoverage, main.cpp:2163-2242) supplied by the caller -- what
- * PRVNet's server answers through <pvb_path>/data/view_budget.txt; <= 0: read that file */
-int prvh_nbv_loop_budget(prvh_share_data* sd, const double center[3], double predicted_size, int first_view_id,
-                         int test_id, prvh_score_fn score, void* user, int view_budget, prvh_loop_result* out);
 
 #ifdef __cplusplus
 }

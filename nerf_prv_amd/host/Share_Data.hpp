@@ -95,7 +95,6 @@ public:
   //             render/<it>/ensemble_<e>/rgbaClip_<v>.png, then the planner's loops read the PNGs (main.cpp:2045-2094, 2105-2158)
   bool score_from_pngs = false;
   // state
-  double pvb_wait_seconds = 0.0;
   std::vector<std::vector<double>> pt_sphere;
   double pt_norm = 0;
   bool ok = false;
@@ -116,7 +115,6 @@ public:
     instant_ngp_path = fs.str("instant_ngp_path");
     orginalviews_path = fs.str("orginalviews_path");
     pvb_path = fs.str("pvb_path");
-    pvb_wait_seconds = fs.has("pvb_wait_seconds") ? fs.num("pvb_wait_seconds") : 0.0; // this build's key: how long method 4 waits for PRVNet's server
     shape_net = fs.str("shape_net");
     name_of_pcd = fs.str("name_of_pcd");
     nbv_net_path = fs.str("nbv_net_path");

@@ -7,7 +7,6 @@
 #include "fit_curve.hpp"
 #include "path_planner.hpp"
 #include "planner.hpp"
-#include "pcd_io.hpp"
 #include "png_io.hpp"
 #include "../csrc/prv_star.hpp"
 #include "../csrc/prv_ingp.hpp"
@@ -114,20 +113,6 @@ int prvh_write_transforms(const char* path, const prvh_intrinsics* in, int candi
     root["frames"].append(view_image);
   }
   return write_text(path, prvjson::to_styled_string(root)) ? 0 : -3;
-} catch (...) { return PRVH_E_INTERNAL; }
-
-long long prvh_pcd_read(const char* path, float* xyz_out, uint8_t* rgb_out, long long capacity) try {
-  if (!path) return -1;
-  std::vector<float> xyz;
-  std::vector<uint8_t> rgb;
-  const int rc = pcd_read(path, xyz, rgb);
-  if (rc != 0) return rc;
-  const long long n = (long long)(xyz.size() / 3);
-  if (xyz_out && rgb_out && capacity >= n) {
-    memcpy(xyz_out, xyz.data(), xyz.size() * sizeof(float));
-    memcpy(rgb_out, rgb.data(), rgb.size());
-  }
-  return n;
 } catch (...) { return PRVH_E_INTERNAL; }
 
 int prvh_png_size(const char* path, int* width, int* height) try {
@@ -291,11 +276,6 @@ void prvh_share_data_intrinsics(const prvh_share_data* h, prvh_intrinsics* o) {
 
 int prvh_nbv_loop(prvh_share_data* h, const double center[3], double predicted_size, int first_view_id, int test_id,
                   prvh_score_fn score, void* user, prvh_loop_result* out) try {
-  return prvh_nbv_loop_budget(h, center, predicted_size, first_view_id, test_id, score, user, 0, out);
-} catch (...) { return PRVH_E_INTERNAL; }
-
-int prvh_nbv_loop_budget(prvh_share_data* h, const double center[3], double predicted_size, int first_view_id, int test_id,
-                         prvh_score_fn score, void* user, int view_budget, prvh_loop_result* out) try {
   if (!h || !center || !out) return -1;
   Scorer s = [score, user](int method, int iteration, const std::string& scene, const std::string& render,
                            const std::vector<int>& ids, std::vector<double>& scores) -> int {
@@ -303,7 +283,6 @@ int prvh_nbv_loop_budget(prvh_share_data* h, const double center[3], double pred
     return score(user, method, iteration, scene.c_str(), render.c_str(), ids.data(), (int)ids.size(), scores.data());
   };
   NBV_Net_Labeler labeler(h->sd, Vec3(center[0], center[1], center[2]), predicted_size, s);
-  if (view_budget > 0) labeler.budget_fn = [view_budget](const std::vector<int>&) { return view_budget; };
   const int rc = labeler.nbv_loop(first_view_id, test_id);
   out->n_chosen = (int)std::min<size_t>(labeler.chosen_nbvs.size(), 1024);
   for (int i = 0; i < out->n_chosen; i++) out->chosen[i] = labeler.chosen_nbvs[i];

@@ -28,7 +28,7 @@ extern "C" {
 }
 #include "planner.hpp"
 #include "fit_curve.hpp"
-#include "pcd_io.hpp"
+#include "extras/pcd_io.hpp" // mode 3 only: the coloured cloud the splat rasteriser turns into rgbaClip images (not exported)
 #include "png_io.hpp"
 
 using namespace prvhost;

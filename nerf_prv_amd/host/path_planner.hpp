@@ -1,5 +1,6 @@
 // path_planner.hpp -- movement cost between views and the visiting order of a view set.
-// Restates get_local_path (View_Space.hpp:206-305) literally and replaces Global_Path_Planner
+// get_local_path (View_Space.hpp:206-305) in vector form (same doubles as the reference formula: the stored tours and
+// movement/<it>.txt depend on them) and, in place of Global_Path_Planner
 // (main.cpp:398-594, a Gurobi MILP with lazy sub-tour cuts) by an exact Held-Karp dynamic
 // programme for up to 20 views and an iterated local search (2-opt + Or-opt + segment swaps) beyond -- flagged
 // inexact, though it reaches the stored Gurobi tour length on every view set the reference ships (N = 3..100).
@@ -19,45 +20,60 @@ namespace prvhost {
 
 enum { ErrorPath = -2, WrongPath = -1, LinePath = 0, CirclePath = 1 }; // View_Space.hpp:201-204
 
-inline double pow2(double x) { return x * x; }
+inline double dot3(const Vec3& u, const Vec3& v) { return u.x * v.x + u.y * v.y + u.z * v.z; }
 
-// straight segment M->N, or M->P + arc PQ on the sphere (O, r) + Q->N when the segment crosses it
-inline std::pair<int, double> get_local_path(const Vec3& M, const Vec3& N, const Vec3& O, double r) {
-  const double x1 = M.x, y1 = M.y, z1 = M.z, x2 = N.x, y2 = N.y, z2 = N.z, x0 = O.x, y0 = O.y, z0 = O.z;
-  const double a = pow2(x2 - x1) + pow2(y2 - y1) + pow2(z2 - z1);
-  const double b = 2.0 * ((x2 - x1) * (x1 - x0) + (y2 - y1) * (y1 - y0) + (z2 - z1) * (z1 - z0));
-  const double c = pow2(x1 - x0) + pow2(y1 - y0) + pow2(z1 - z0) - pow2(r);
-  const double delta = pow2(b) - 4.0 * a * c;
-  if (delta <= 0) return {LinePath, (N - M).norm()}; // :218-223
-  double t3 = (-b - std::sqrt(delta)) / (2.0 * a), t4 = (-b + std::sqrt(delta)) / (2.0 * a);
-  if ((t3 < 0 || t3 > 1) && (t4 < 0 || t4 > 1)) return {LinePath, (N - M).norm()}; // :228-233
-  if ((t3 < 0 || t3 > 1) || (t4 < 0 || t4 > 1)) return {WrongPath, 1e10};         // start or end inside: :234-237
-  if (t3 > t4) std::swap(t3, t4);
-  const double x3 = (x2 - x1) * t3 + x1, y3 = (y2 - y1) * t3 + y1, z3 = (z2 - z1) * t3 + z1;
-  const double x4 = (x2 - x1) * t4 + x1, y4 = (y2 - y1) * t4 + y1, z4 = (z2 - z1) * t4 + z1;
-  const Vec3 P(x3, y3, z3), Q(x4, y4, z4);
-  const double X1 = x3 - x0, X2 = x4 - x0, Y1 = y3 - y0, Y2 = y4 - y0, Z1 = z3 - z0, Z2 = z4 - z0;
-  const double A = Y1 * Z2 - Y2 * Z1, B = Z1 * X2 - Z2 * X1, C = X1 * Y2 - X2 * Y1; // plane MON :255-257
-  const double two_pi = 2.0 * std::acos(-1.0);
-  auto angle = [&](double x, double y, double z) { // :262-276, same for P and Q
-    const double sin_t = -(z - z0) / r * std::sqrt(pow2(A) + pow2(B) + pow2(C)) / std::sqrt(pow2(A) + pow2(B));
-    double t = std::asin(sin_t);
+// The great circle through two points of the sphere (O, r), parametrised as the reference does (View_Space.hpp:255-297):
+// with n = p x q the circle's normal, a point of the circle is O + e1 cos(t) + e2 sin(t), where e1 lies in the xy plane
+// (perpendicular to n's xy part) and e2 = the in-plane direction that climbs in -z.  Only x and y of the basis are ever
+// compared, so only those are kept.
+struct ArcFrame {
+  double n_xy, n_len; // |(n.x, n.y)| and |n|
+  double e1x, e1y, e2x, e2y;
+  double r;
+  ArcFrame(const Vec3& p, const Vec3& q, double radius) : r(radius) {
+    const Vec3 n = p.cross(q);
+    n_xy = std::sqrt(n.x * n.x + n.y * n.y);
+    n_len = std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+    e1x = r * n.y / n_xy;
+    e1y = r * n.x / n_xy; // enters with a minus sign below
+    e2x = r * n.x * n.z / n_xy / n_len;
+    e2y = r * n.y * n.z / n_xy / n_len;
+  }
+  static double wrap(double t) { // one turn up or down into [0, 2 pi)
+    const double two_pi = 2.0 * std::acos(-1.0);
     if (t < 0) t += two_pi;
     if (t >= two_pi) t -= two_pi;
-    const double xt = x0 + r * B / std::sqrt(pow2(A) + pow2(B)) * std::cos(t) +
-                      r * A * C / std::sqrt(pow2(A) + pow2(B)) / std::sqrt(pow2(A) + pow2(B) + pow2(C)) * std::sin(t);
-    const double yt = y0 - r * A / std::sqrt(pow2(A) + pow2(B)) * std::cos(t) +
-                      r * B * C / std::sqrt(pow2(A) + pow2(B)) / std::sqrt(pow2(A) + pow2(B) + pow2(C)) * std::sin(t);
-    if (std::fabs(x - xt) > 1e-6 || std::fabs(y - yt) > 1e-6) {
-      t = std::acos(-1.0) - t;
-      if (t < 0) t += two_pi;
-      if (t >= two_pi) t -= two_pi;
-    }
     return t;
-  };
-  const double theta3 = angle(x3, y3, z3), theta4 = angle(x4, y4, z4);
-  const double L = std::fabs(theta3 - theta4) * r; // :299 (as written: not the shorter arc when > pi)
-  return {CirclePath, (M - P).norm() + L + (Q - N).norm()};
+  }
+  // the circle parameter of a point of the circle: asin of its height above the centre fixes t up to the mirror pi - t;
+  // the branch whose x and y reproduce the point (to 1e-6) is taken (:262-276, 279-293: the same rule for both ends)
+  double parameter(const Vec3& point, const Vec3& centre) const {
+    double t = wrap(std::asin(-(point.z - centre.z) / r * n_len / n_xy));
+    const double xt = centre.x + e1x * std::cos(t) + e2x * std::sin(t);
+    const double yt = centre.y - e1y * std::cos(t) + e2y * std::sin(t);
+    if (std::fabs(point.x - xt) > 1e-6 || std::fabs(point.y - yt) > 1e-6) t = wrap(std::acos(-1.0) - t);
+    return t;
+  }
+};
+
+// straight segment M->N, or M->P + arc PQ on the sphere (O, r) + Q->N when the segment crosses it (View_Space.hpp:206-305).
+// P, Q = the roots of |M + t (N - M) - O|^2 = r^2 in t; no real pair, or both outside [0, 1]: the straight line;
+// exactly one inside: an end point lies inside the obstacle (WrongPath).
+inline std::pair<int, double> get_local_path(const Vec3& M, const Vec3& N, const Vec3& O, double r) {
+  const Vec3 step = N - M, from_centre = M - O;
+  const double qa = dot3(step, step), qb = 2.0 * dot3(step, from_centre), qc = dot3(from_centre, from_centre) - r * r;
+  const double disc = qb * qb - 4.0 * qa * qc;
+  if (disc <= 0) return {LinePath, step.norm()}; // :218-223
+  double t_in = (-qb - std::sqrt(disc)) / (2.0 * qa), t_out = (-qb + std::sqrt(disc)) / (2.0 * qa);
+  const bool in_off = t_in < 0 || t_in > 1, out_off = t_out < 0 || t_out > 1;
+  if (in_off && out_off) return {LinePath, step.norm()}; // :228-233
+  if (in_off || out_off) return {WrongPath, 1e10};       // :234-237
+  if (t_in > t_out) std::swap(t_in, t_out);
+  const Vec3 P = step * t_in + M, Q = step * t_out + M;
+  const Vec3 p = P - O, q = Q - O;
+  const ArcFrame circle(p, q, r);
+  const double arc = std::fabs(circle.parameter(P, O) - circle.parameter(Q, O)) * r; // :299 (as written: not the shorter arc when > pi)
+  return {CirclePath, (M - P).norm() + arc + (Q - N).norm()};
 }
 
 class Global_Path_Planner {

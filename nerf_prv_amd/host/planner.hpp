@@ -122,9 +122,6 @@ struct RunPyArgs {
 // the engine: train --n_steps on --scene, then evaluate or write the screenshots; 0 on success
 using Engine = std::function<int(const RunPyArgs&)>;
 
-// method 4: the number of views PRVNet predicts from the initial images (main.cpp:2165-2192 hands the images to a
-// Python server through <pvb_path>/data and reads view_budget.txt back); <= 0 = no answer
-using BudgetFn = std::function<int(const std::vector<int>& init_view_ids)>;
 // the final evaluation of `evaluate: 1` (main.cpp:1954-1965: train_by_instantNGP(<it>, "100", true) -> run.py's
 // --test_transforms / --save_metrics): train on the scene json's views, score against the test view set
 using EvalFn = std::function<int(const std::string& scene_json, double* mean_psnr, double* mean_ssim)>;
@@ -180,7 +177,6 @@ public:
   std::shared_ptr<View_Space> view_space;
   Scorer scorer;
   Engine engine;      // the in-process run.py behind train_by_instantNGP's reference signature
-  BudgetFn budget_fn; // empty: read <pvb_path>/data/view_budget.txt
   EvalFn evaluator;   // empty: `evaluate: 1` is ignored
   std::vector<int> chosen_nbvs;
   std::vector<double> last_scores;
@@ -298,10 +294,8 @@ public:
     std::mt19937 rng(12345); // the reference seeds rand() with clock() (Share_Data.hpp:514): unreproducible by design
     const double loop_t0 = now_seconds();
     int iteration = 0;
-    std::vector<int> oneshot_views; // methods 1 and 4: the planned tour, consumed front to back
-    bool oneshot_planned = false;
     while (true) {
-      const int n_views = (int)view_space->views.size(); // method 4 swaps the view space
+      const int n_views = (int)view_space->views.size();
       const std::string prefix = "../../../../Coverage_images/ShapeNet/" + sd.name_of_pcd + "/" + std::to_string(sd.num_of_views) + "/rgbaClip_";
       Value now_nbvs_json(root_nbvs), now_render_json(root_render);
       std::vector<int> candidates;
@@ -377,108 +371,8 @@ public:
           next_view_id = best_view_id;
           break;
         }
-        case RandomOneshot: { // :1981-2037: 50 random view sets, keep the most spread one, visit it along the shortest tour
-          if (!oneshot_planned) {
-            std::set<int> best;
-            double largest_pair_dis = -1e100;
-            for (int check = 0; check < 50; check++) {
-              std::set<int> pick{first_view_id};
-              for (int i = 0; i < sd.num_of_max_iteration && (int)pick.size() < n_views; i++) {
-                int v = (int)(rng() % (unsigned)n_views);
-                while (pick.count(v)) v = (int)(rng() % (unsigned)n_views);
-                pick.insert(v);
-              }
-              double dis = 0;
-              for (auto a = pick.begin(); a != pick.end(); ++a)
-                for (auto b = std::next(a); b != pick.end(); ++b)
-                  dis += (view_space->views[*a].init_pos - view_space->views[*b].init_pos).norm();
-              if (dis > largest_pair_dis) {
-                largest_pair_dis = dis;
-                best = pick;
-              }
-            }
-            oneshot_views.assign(best.begin(), best.end());
-            Global_Path_Planner gpp(view_space->views, oneshot_views, first_view_id,
-                                    view_space->object_center_world + Vec3(1e-10, 1e-10, 1e-10), view_space->predicted_size);
-            gpp.solve();
-            oneshot_views = gpp.get_path_id_set();
-            if (oneshot_views.empty()) return -13;
-            oneshot_views.erase(oneshot_views.begin()); // the initial view
-            sd.num_of_max_iteration = (int)oneshot_views.size();
-            oneshot_planned = true;
-          }
-          if (oneshot_views.empty()) return -13;
-          next_view_id = oneshot_views.front();
-          oneshot_views.erase(oneshot_views.begin());
-          break;
-        }
-        case PVBCoverage: { // :2163-2242: PRVNet's view budget N -> the N-view coverage set, visited along the shortest tour
-          if (!oneshot_planned) {
-            int view_budget = -1;
-            if (budget_fn) view_budget = budget_fn(chosen_nbvs);
-            else {
-              if (sd.pvb_wait_seconds > 0.0) { // the hand-shake with PRVNet's infer_server.py (:2165-2185)
-                sd.access_directory(sd.pvb_path + "data/images");
-                for (int id : chosen_nbvs) { // the initial views' images, named by view id
-                  std::ifstream src(sd.gt_path + "/" + std::to_string(sd.num_of_views) + "/rgbaClip_" + std::to_string(id) + ".png", std::ios::binary);
-                  std::ofstream dst(sd.pvb_path + "data/images/" + std::to_string(id) + ".png", std::ios::binary);
-                  if (src.is_open()) dst << src.rdbuf();
-                }
-                write_text(sd.pvb_path + "data/ready_c++.txt", "");
-                const double t0 = now_seconds();
-                bool answered = false;
-                while (now_seconds() - t0 < sd.pvb_wait_seconds) { // the reference polls every 100 ms, forever
-                  if (std::ifstream(sd.pvb_path + "data/ready_py.txt").is_open()) {
-                    answered = true;
-                    break;
-                  }
-                  std::this_thread::sleep_for(std::chrono::milliseconds(100));
-                }
-                if (!answered) return -16; // PRVNet's server did not answer in time
-                std::this_thread::sleep_for(std::chrono::milliseconds(100));
-                std::remove((sd.pvb_path + "data/ready_py.txt").c_str());
-              }
-              std::ifstream fin(sd.pvb_path + "data/view_budget.txt");
-              if (fin.is_open()) fin >> view_budget;
-            }
-            if (view_budget < 2) return -12; // no budget: PRVNet (or its stand-in) has not answered
-            sd.num_of_views = view_budget;
-            std::ifstream fin_sphere(sd.viewspace_path + std::to_string(view_budget) + ".txt");
-            if (!fin_sphere.is_open()) return -14;
-            sd.pt_sphere.assign(view_budget, std::vector<double>(3, 0.0));
-            for (int i = 0; i < view_budget; i++)
-              for (int j = 0; j < 3; j++) fin_sphere >> sd.pt_sphere[i][j];
-            sd.pt_norm = std::sqrt(sd.pt_sphere[0][0] * sd.pt_sphere[0][0] + sd.pt_sphere[0][1] * sd.pt_sphere[0][1] +
-                                   sd.pt_sphere[0][2] * sd.pt_sphere[0][2]);
-            const Vec3 center = view_space->object_center_world;
-            const double size = view_space->predicted_size;
-            view_space = std::make_shared<View_Space>(share_data);
-            view_space->set_view_space(center, size);
-            int now_first_view_id = -1;
-            const int nv = (int)view_space->views.size();
-            for (int i = 0; i < nv; i++) {
-              const Vec3 p = view_space->views[i].init_pos - center;
-              if (std::fabs(p.x) < 1e-6 && std::fabs(p.y) < 1e-6 && std::fabs(p.z - sd.view_space_radius) < 1e-6) now_first_view_id = i;
-              oneshot_views.push_back(i);
-            }
-            if (now_first_view_id == -1) return -15; // "can not find now view id" (:2221)
-            chosen_nbvs.assign(1, now_first_view_id);
-            chosen_nbvs_set = {now_first_view_id};
-            Global_Path_Planner gpp(view_space->views, oneshot_views, now_first_view_id,
-                                    center + Vec3(1e-10, 1e-10, 1e-10), size);
-            gpp.solve();
-            oneshot_views = gpp.get_path_id_set();
-            write_text(sd.save_path + "/view_budget.txt", std::to_string(oneshot_views.size()) + "\n"); // :2233-2234
-            if (oneshot_views.empty()) return -13;
-            oneshot_views.erase(oneshot_views.begin());
-            sd.num_of_max_iteration = (int)oneshot_views.size();
-            oneshot_planned = true;
-          }
-          if (oneshot_views.empty()) return -13;
-          next_view_id = oneshot_views.front();
-          oneshot_views.erase(oneshot_views.begin());
-          break;
-        }
+        // methods 1 (RandomOneshot) and 4 (PVBCoverage, PRVNet's view budget) never render: SURVEY section 2 keeps them out
+        // of this build's scope; they are refused, not silently mapped to something else
         default:
           return -10;
       }

@@ -53,7 +53,6 @@ HOST_SIGNATURES = {
     "prvh_share_data_number": (_d, [_vp, C.c_char_p]),
     "prvh_share_data_views": (_i, [_vp, _vp]),
     "prvh_share_data_intrinsics": (None, [_vp, C.POINTER(Intrinsics)]),
-    "prvh_pcd_read": (C.c_longlong, [C.c_char_p, _vp, _vp, C.c_longlong]),
     "prvh_png_size": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
     "prvh_png_read_rgba8": (_i, [C.c_char_p, _i, _i, _vp]),
     "prvh_score_view_pngs": (_i, [_i, C.POINTER(C.c_char_p), _i, C.POINTER(C.c_double)]),
@@ -66,7 +65,6 @@ HOST_SIGNATURES = {
     "prvh_star_broadcast": (_i, [_vp, _vp, C.c_uint64, _i]),
     "prvh_star_barrier": (_i, [_vp]),
     "prvh_nbv_loop": (_i, [_vp, _vp, _d, _i, _i, SCORE_FN, _vp, C.POINTER(LoopResult)]),
-    "prvh_nbv_loop_budget": (_i, [_vp, _vp, _d, _i, _i, SCORE_FN, _vp, _i, C.POINTER(LoopResult)]),
 }
 
 _host = None
@@ -166,16 +164,6 @@ def read_metrics(path):
     if host().prvh_read_metrics(str(path).encode(), C.byref(p), C.byref(s)) != 0:
         raise IOError(f"cannot read metrics from {path}")
     return p.value, s.value
-
-
-def pcd_read(path):
-    """(xyz float32 [n,3], rgb uint8 [n,3]) of a PCD file (ascii / binary, fields x y z [rgb])"""
-    n = host().prvh_pcd_read(str(path).encode(), None, None, 0)
-    if n < 0:
-        raise IOError(f"{path}: pcd error {n}")
-    xyz, rgb = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.uint8)
-    host().prvh_pcd_read(str(path).encode(), _p(xyz), _p(rgb), n)
-    return xyz, rgb
 
 
 def png_read(path):
@@ -304,9 +292,8 @@ class ShareData:
         host().prvh_share_data_intrinsics(self.h, C.byref(k))
         return k
 
-    def nbv_loop(self, center, predicted_size, score_fn, first_view_id=-1, test_id=0, view_budget=0):
-        """run NBV_Net_Labeler::nbv_loop; score_fn(method, iteration, scene_json, render_json, ids) -> scores;
-        view_budget: method 4's PRVNet answer (0: read <pvb_path>/data/view_budget.txt)"""
+    def nbv_loop(self, center, predicted_size, score_fn, first_view_id=-1, test_id=0):
+        """run NBV_Net_Labeler::nbv_loop; score_fn(method, iteration, scene_json, render_json, ids) -> scores"""
         def cb(user, method, iteration, scene, render, ids, n, scores):
             try:
                 vals = score_fn(method, iteration, scene.decode(), render.decode(), [ids[i] for i in range(n)])
@@ -320,8 +307,7 @@ class ShareData:
         c = np.ascontiguousarray(center, np.float64)
         res = LoopResult()
         keep = SCORE_FN(cb)
-        rc = host().prvh_nbv_loop_budget(self.h, _p(c), float(predicted_size), first_view_id, test_id, keep, None,
-                                         int(view_budget), C.byref(res))
+        rc = host().prvh_nbv_loop(self.h, _p(c), float(predicted_size), first_view_id, test_id, keep, None, C.byref(res))
         if rc != 0:
             raise RuntimeError(f"nbv_loop failed rc={rc}: {getattr(self, 'last_error', '')}")
         return [res.chosen[i] for i in range(res.n_chosen)]
