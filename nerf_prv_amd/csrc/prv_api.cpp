@@ -80,13 +80,16 @@ struct prv_ctx {
   size_t pin_cap = 0;
   hipEvent_t pin_ev = nullptr; // recorded after the upload: the staging is rewritten only once that copy has run
   int blocks_per_cu = -1; // persistent render blocks per CU (PRV_BLOCKS_PER_CU); -1 = by table and image size, see render_views
+  int cell_cache = -1;    // render_queue64 per-lane corner cache (PRV_CELL_CACHE=0/1; -1 = by stepping rule and image size, see render_views)
   std::vector<struct prv_trainer*> trainers; // live trainers of this context (detached by prv_destroy)
   std::vector<struct prv_comm*> comms;       // live communicators of this context (detached by prv_destroy)
   int queue_segments = 8; // ray-queue segments = XCDs (PRV_QUEUE_SEGMENTS: 1 = single shared head)
   int pool_on = -1;       // render_queue64 block-level tail pool (PRV_POOL=0/1; -1 = by table and image size, see render_views)
   int merge_max = -1;     // render_queue64 tail merge threshold (PRV_MERGE_MAX; 0 = off; -1 = by table size, see render_views)
   size_t stage_budget = (size_t)4 << 30; // staging bytes for multi-sample renders (spp x batch x image)
-  size_t queue_budget = (size_t)4 << 30; // ray-queue bytes per batch of views (288 GB of HBM: one batch for 64 views at 800x800)
+  size_t queue_budget = (size_t)8 << 30; // ray-queue bytes per batch of views (288 GB of HBM): one batch for 64 views at 800x800 and for the
+                                         // reference's whole candidate set under the engine's rule (540 x 80x45 x 16 spp x 208 B = 6.5 GB:
+                                         // one launch pair per member instead of two, -3 % per round)
   double coverage_weight = PRV_COVERAGE_WEIGHT_DEFAULT; // method 5: score = -PSNR + weight * mean((1 - alpha)^2)
 };
 
@@ -700,8 +703,20 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     // (+3...7 %).  Results are identical either way; the default follows table and image size (PRV_MERGE_MAX / PRV_POOL
     // override).  Measured: profiles/r02_k_tail_merge.txt, profiles/r02_r_tail_pool.txt
     const bool coherent = m.table_halfs * 2 <= ((size_t)32 << 20) && npix >= ((size_t)1 << 17);
-    rp.merge_max = c->merge_max >= 0 ? c->merge_max : (coherent ? 16 : 0);
-    rp.pool_on = (c->pool_on >= 0 ? c->pool_on != 0 : coherent) && rp.merge_max > 0;
+    // The per-lane corner cache: under the engine's stepping rule a ray's consecutive samples share their cell on the hashed
+    // levels about half of the time, and where the cohort's gathers are incoherent (small images: every corner of every lane
+    // its own cache line) the launch is bound by the L2's request rate -- 9.5 L2 requests per sample, 135 G/s, the ceiling
+    // scripts/gather_calib.hip finds for this footprint (profiles/r04_reference_round_*) -- so a lane whose cell did not
+    // change skips its eight loads of that level.  Costs ~50 VGPRs (two waves per SIMD, which those images run with
+    // anyway) and a few VALU per level; off for large images, whose launch is issue-bound, and for the F = 2 fields (six
+    // hashed levels do not fit the registers).  Cell keys hold 10 bits per axis.  PRV_CELL_CACHE overrides.
+    const bool cached = (c->cell_cache >= 0 ? c->cell_cache != 0 : (ngp && !coherent)) && m.desc.finest_res <= 1023 &&
+                        m.desc.n_features == 4 && m.dev.hash_shared && m.dev.n_dense_levels == 5;
+    rp.cell_cache = cached ? 1 : 0;
+    // With the cache in place the small-image launch is no longer request-bound and fuller slots pay again: relocation on
+    // (merge threshold 24, pool), 0.68 -> 0.95 slot utilisation, -13 % launch time (profiles/r04_cell_cache_ab.txt)
+    rp.merge_max = c->merge_max >= 0 ? c->merge_max : (coherent ? 16 : cached ? 24 : 0);
+    rp.pool_on = (c->pool_on >= 0 ? c->pool_on != 0 : (coherent || cached)) && rp.merge_max > 0;
     memcpy(rp.bg, o->background, sizeof(rp.bg));
     if (c->profiling) {
       hipEvent_t a, b;
@@ -776,6 +791,7 @@ int prv_create(prv_ctx** out, int device_id) try {
   if (const char* s = getenv("PRV_QUEUE_SEGMENTS")) c->queue_segments = std::min(8, std::max(1, atoi(s)));
   if (const char* s = getenv("PRV_MERGE_MAX")) c->merge_max = std::min(31, std::max(0, atoi(s)));
   if (const char* s = getenv("PRV_POOL")) c->pool_on = atoi(s) != 0 ? 1 : 0;
+  if (const char* s = getenv("PRV_CELL_CACHE")) c->cell_cache = atoi(s) != 0 ? 1 : 0;
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
   g_live_contexts.fetch_add(1);
   if (device_id < 64) g_devices_used.fetch_or(1ull << device_id);

@@ -319,6 +319,18 @@ struct HashConsts { // the field's shared hash constants, wave-uniform (FieldDev
 };
 enum { kLevelDense = 0, kLevelHashedShared = 1, kLevelGeneric = 2 };
 
+// The last cell a LANE gathered on one hashed level and its eight corner entries.  Under the engine's stepping rule
+// (dt = sqrt(3)/1024 = 0.43 of the finest cell of a 256^3 field) a ray's consecutive samples stay in the cell about
+// half of the time; where a cohort's gathers are incoherent to begin with (the reference's 80x45 candidates: neighbouring
+// pixels are six finest cells apart, every corner its own cache line) the launch is bound by the L2's request rate
+// (profiles/NOTES.md, round 4), and the loads of a lane whose cell did not change are pure waste.  The cache maps a CELL to
+// its entries, so it stays valid when the lane takes over another ray; values and blend are untouched: same pixels.
+template <int F>
+struct CornerCache {
+  uint32_t key; // x | y << 10 | z << 20 of the cell (levels up to 1023 cells per axis); ~0u = nothing cached
+  uint32_t v[8][F / 2];
+};
+
 template <int F, int KIND>
 __device__ __forceinline__ void encode_level2(const uint16_t* __restrict__ table, const LevelDev& L, const HashConsts& H, float px,
                                               float py, float pz, half2v out[F / 2]) {
@@ -370,12 +382,14 @@ __device__ __forceinline__ void encode_level2(const uint16_t* __restrict__ table
     const uint32_t tx[2] = {c0[0] << ESH, c1[0] << ESH};
     const uint32_t ty[2] = {__umul24(c0[1], H.my_b) & H.m_b, __umul24(c1[1], H.my_b) & H.m_b};
     const uint32_t tz[2] = {__umul24(c0[2], H.mz_b) & H.m_b, __umul24(c1[2], H.mz_b) & H.m_b};
+    {
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const uint32_t byte_off = __builtin_amdgcn_bitop3_b32(tx[c & 1], ty[(c >> 1) & 1], tz[c >> 2], 0x96); // a ^ b ^ c
-      const Entry<F> e = Entry<F>::load(base + byte_off);
+      for (int c = 0; c < 8; c++) {
+        const uint32_t byte_off = __builtin_amdgcn_bitop3_b32(tx[c & 1], ty[(c >> 1) & 1], tz[c >> 2], 0x96); // a ^ b ^ c
+        const Entry<F> e = Entry<F>::load(base + byte_off);
 #pragma unroll
-      for (int k = 0; k < F / 2; k++) vw[c][k] = e.w[k];
+        for (int k = 0; k < F / 2; k++) vw[c][k] = e.w[k];
+      }
     }
   } else {
     uint32_t c1[3];
@@ -409,6 +423,120 @@ __device__ __forceinline__ void encode_level2(const uint16_t* __restrict__ table
   }
 }
 
+// ---- the gather in two explicit phases (CornerCache instances).  The plain path above leaves it to the scheduler to hoist
+// all 44 loads of a sample to the top of one basic block; the cache's per-level branches cut that block into pieces and the
+// scheduler then loads level after level, one memory round trip each.  Here phase 1 issues EVERY load of the sample -- the
+// dense levels' four paired loads into a staging record, the hashed levels' eight loads (only in the lanes whose cell
+// changed) into the cache -- and phase 2 blends; the arithmetic is encode_level2's, operation for operation.
+template <int F>
+struct LevelStage {
+  uint32_t vw[8][F / 2]; // dense levels: the corner entries as loaded
+  half2v wa[3];          // (1 - w, w) per axis, fp16
+};
+
+// (1 - w, w) per axis and the cell of one level
+template <int F>
+__device__ __forceinline__ void level_cell(const LevelDev& L, float px, float py, float pz, uint32_t c0[3], half2v wa[3]) {
+  const float pos[3] = {fmaf(L.scale, px, 0.5f), fmaf(L.scale, py, 0.5f), fmaf(L.scale, pz, 0.5f)};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float w1 = __builtin_amdgcn_fractf(pos[a]);
+    wa[a] = cvt_pk_f16(1.0f - w1, w1);
+    c0[a] = (uint32_t)(int)pos[a];
+  }
+}
+
+template <int F>
+__device__ __forceinline__ void stage_dense_level(const uint16_t* __restrict__ table, const LevelDev& L, float px, float py, float pz,
+                                                  LevelStage<F>& st) {
+  constexpr int ESH = F == 4 ? 3 : 2;
+  uint32_t c0[3];
+  level_cell<F>(L, px, py, pz, c0, st.wa);
+  uint32_t pk = L.pack;
+  asm volatile("" : "+s"(pk));
+  const uint32_t sxl = pk & 31u, off = pk & ~31u;
+  const uint32_t my = (uint32_t)(F * 2) << sxl, mz = (uint32_t)(F * 2) << (2u * sxl);
+  const char* base0 = reinterpret_cast<const char*>(table) + off;
+  const char* base1 = base0 + my;
+  const uint32_t b = (c0[0] << ESH) + __umul24(c0[1], my) + __umul24(c0[2], mz);
+  const uint32_t bz = b + mz;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const EntryPair<F> e = EntryPair<F>::load(((q & 1) ? base1 : base0) + ((q >> 1) ? bz : b));
+#pragma unroll
+    for (int k = 0; k < F / 2; k++) {
+      st.vw[2 * q][k] = e.w[k];
+      st.vw[2 * q + 1][k] = e.w[F / 2 + k];
+    }
+  }
+}
+
+// hashed level, shared hash constants: the lanes whose cell changed since their last sample issue the level's eight loads
+// (the branch narrows EXEC; a wave none of whose lanes moved skips them); nobody waits here
+template <int F>
+__device__ __forceinline__ void stage_hashed_level(const uint16_t* __restrict__ table, const LevelDev& L, const HashConsts& H, float px,
+                                                   float py, float pz, CornerCache<F>& cc, half2v wa[3]) {
+  constexpr int ESH = F == 4 ? 3 : 2;
+  uint32_t c0[3], c1[3];
+  level_cell<F>(L, px, py, pz, c0, wa);
+  uint32_t pk = L.pack;
+  asm volatile("" : "+s"(pk));
+  const uint32_t res_m1 = pk & 4095u;
+  const uint32_t key = c0[0] | (c0[1] << 10) | (c0[2] << 20);
+  if (key != cc.key) {
+    cc.key = key;
+#pragma unroll
+    for (int a = 0; a < 3; a++) c1[a] = min(c0[a] + 1u, res_m1);
+    const char* base = reinterpret_cast<const char*>(table) + (pk & ~4095u);
+    const uint32_t tx[2] = {c0[0] << ESH, c1[0] << ESH};
+    const uint32_t ty[2] = {__umul24(c0[1], H.my_b) & H.m_b, __umul24(c1[1], H.my_b) & H.m_b};
+    const uint32_t tz[2] = {__umul24(c0[2], H.mz_b) & H.m_b, __umul24(c1[2], H.mz_b) & H.m_b};
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const uint32_t byte_off = __builtin_amdgcn_bitop3_b32(tx[c & 1], ty[(c >> 1) & 1], tz[c >> 2], 0x96);
+      const Entry<F> e = Entry<F>::load(base + byte_off);
+#pragma unroll
+      for (int k = 0; k < F / 2; k++) cc.v[c][k] = e.w[k];
+    }
+  }
+}
+
+// the trilinear blend of encode_level2, from eight corner entries and the axis weights
+template <int F>
+__device__ __forceinline__ void blend_level(const uint32_t vw[8][F / 2], const half2v wa[3], half2v out[F / 2]) {
+  half2v wp[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const half2v wy = {wa[1][q & 1], wa[1][q & 1]}, wz = {wa[2][q >> 1], wa[2][q >> 1]};
+    wp[q] = (wa[0] * wy) * wz;
+  }
+#pragma unroll
+  for (int k = 0; k < F / 2; k++) out[k] = half2v{(_Float16)0.0f, (_Float16)0.0f};
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const _Float16 w = wp[c >> 1][c & 1];
+    const half2v ww = {w, w};
+#pragma unroll
+    for (int k = 0; k < F / 2; k++) out[k] = __builtin_elementwise_fma(ww, __builtin_bit_cast(half2v, vw[c][k]), out[k]);
+  }
+}
+
+template <int F, int NDENSE, int... J>
+__device__ __forceinline__ void encode_all_levels_cached(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv,
+                                                         const HashConsts& H, float px, float py, float pz, half2v* out,
+                                                         CornerCache<F>* cc, std::integer_sequence<int, J...>) {
+  constexpr int NH = 32 / F - NDENSE;
+  LevelStage<F> ds[NDENSE];
+  half2v hwa[NH][3];
+  // phase 1: every load of the sample (hashed levels first: theirs are the long ones)
+  ((J >= NDENSE ? stage_hashed_level<F>(table, lv[J], H, px, py, pz, cc[J >= NDENSE ? J - NDENSE : 0], hwa[J >= NDENSE ? J - NDENSE : 0]) : (void)0), ...);
+  ((J < NDENSE ? stage_dense_level<F>(table, lv[J], px, py, pz, ds[J < NDENSE ? J : 0]) : (void)0), ...);
+  __builtin_amdgcn_sched_barrier(0);
+  // phase 2: the blends
+  ((J < NDENSE ? blend_level<F>(ds[J < NDENSE ? J : 0].vw, ds[J < NDENSE ? J : 0].wa, out + J * (F / 2))
+               : blend_level<F>(cc[J >= NDENSE ? J - NDENSE : 0].v, hwa[J >= NDENSE ? J - NDENSE : 0], out + J * (F / 2))), ...);
+}
+
 // NDENSE > 0: the field has EXACTLY NDENSE leading dense levels and its hashed levels share their constants
 // (FieldDev::hash_shared; the host picks the instance).  NDENSE = 0: every level through the generic path.
 template <int F, int NDENSE, int... J>
@@ -419,14 +547,15 @@ __device__ __forceinline__ void encode_all_levels(const uint16_t* __restrict__ t
 
 // all 32 features of one sample in canonical order (feature F*l + f), as four half8 = the k rows [8s, 8s+8) of the first
 // layer; render_queue64 turns them into MFMA B fragments with v_permlane32_swap
-template <int F, int NDENSE>
+template <int F, int NDENSE, bool CACHE = false>
 __device__ __forceinline__ void encode_sample(const uint16_t* __restrict__ table, const LevelDev* __restrict__ lv, const HashConsts& H,
-                                              float px, float py, float pz, half8 f[4]) {
+                                              float px, float py, float pz, half8 f[4], CornerCache<F>* cc = nullptr) {
   px = clamp01(px);
   py = clamp01(py);
   pz = clamp01(pz);
   half2v out[16];
-  encode_all_levels<F, NDENSE>(table, lv, H, px, py, pz, out, std::make_integer_sequence<int, 32 / F>{});
+  if constexpr (CACHE && NDENSE > 0) encode_all_levels_cached<F, NDENSE>(table, lv, H, px, py, pz, out, cc, std::make_integer_sequence<int, 32 / F>{});
+  else encode_all_levels<F, NDENSE>(table, lv, H, px, py, pz, out, std::make_integer_sequence<int, 32 / F>{});
 #pragma unroll
   for (int s = 0; s < 4; s++)
 #pragma unroll

@@ -361,8 +361,10 @@ __device__ __forceinline__ void clock_stamp_end(unsigned long long* stat) {
 // every weight fragment.  A group refills when all its 32 slots are idle (whole-group lockstep).
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
-template <int F, int NDENSE, bool NGP>
-__global__ __launch_bounds__(256) void render_queue64_kernel(RenderParams P) {
+template <int F, int NDENSE, bool NGP, bool CACHE = false>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(CACHE ? 2 : 1))) // the cached instances must keep TWO waves per SIMD (<= 256 registers)
+void render_queue64_kernel(RenderParams P) {
   __shared__ half8 wl[kNumFrags * 64];
   __shared__ uint32_t mv[4][32][6]; // tail merges: {record, next sample, T, r, g, b} of the rays that change slots, per wave
   constexpr uint32_t kPoolCap = 192;
@@ -403,6 +405,11 @@ __global__ __launch_bounds__(256) void render_queue64_kernel(RenderParams P) {
   half8 shA = {0, 0, 0, 0, 0, 0, 0, 0}, shB = {0, 0, 0, 0, 0, 0, 0, 0}; // SH rows [8g, 8g+8) of the rays in slots (r, A) and (r, B)
   bool drained = false;
   unsigned long long n_eval = 0ull, n_rounds = 0ull;
+  // CACHE instances: the lane's last cell and its corner entries on every hashed level (prv_device.hpp: CornerCache)
+  constexpr int kCached = CACHE ? 32 / F - NDENSE : 1;
+  CornerCache<F> cc[kCached];
+#pragma unroll
+  for (int j = 0; j < kCached; j++) cc[j].key = ~0u;
   clock_stamp_begin(P.stat_evaluated);
   uint32_t q_cur = 0, q_end = 0;
   const uint32_t n_seg = (uint32_t)P.n_segments;
@@ -637,7 +644,7 @@ __global__ __launch_bounds__(256) void render_queue64_kernel(RenderParams P) {
         }
       }
       const float t = fmaf((float)i + 0.5f, dt, t0);
-      encode_sample<F, NDENSE>(P.field.table, lvl, hc, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f);
+      encode_sample<F, NDENSE, CACHE>(P.field.table, lvl, hc, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2]), f, cc);
     }
     // f[2s] | f[2s+1] = k rows [16s, 16s+8) | [16s+8, 16s+16) of the lane's own sample -> B operands of the two groups
     swap_halves(f[0], f[1]); // f[0] = group A k-step 0, f[1] = group B k-step 0
@@ -1320,6 +1327,13 @@ int render_instance_dense_levels(const FieldDev& fd) {
 template <bool NGP>
 static void launch_render_mode(const RenderParams& P, int n_blocks, hipStream_t s) {
   const int nd = render_instance_dense_levels(P.field);
+  if (P.cell_cache && nd > 0) { // the caller asked for the per-lane corner cache (prv_api.cpp: render_views says when)
+    if (P.field.n_features == 4 && nd == 5) {
+      hipLaunchKernelGGL((render_queue64_kernel<4, 5, NGP, true>), dim3(n_blocks), dim3(256), 0, s, P);
+      return;
+    }
+    // (the F = 2 fields have six hashed levels: their cache does not fit 256 registers -- 128 spilled -- so they run without)
+  }
   if (P.field.n_features == 4) {
     if (nd == 5) hipLaunchKernelGGL((render_queue64_kernel<4, 5, NGP>), dim3(n_blocks), dim3(256), 0, s, P);
     else if (nd == 3) hipLaunchKernelGGL((render_queue64_kernel<4, 3, NGP>), dim3(n_blocks), dim3(256), 0, s, P);

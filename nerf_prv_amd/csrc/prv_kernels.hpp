@@ -62,6 +62,7 @@ struct RenderParams {
   int last_pass;
   int merge_max; // render_queue64: a group down to <= this many rays hands them to the other group's idle slots (0 = never)
   int pool_on;   // render_queue64: ... or, failing that, to the block's LDS tail pool (any wave's idle slots adopt them)
+  int cell_cache; // render_queue64: the instance whose lanes keep their last cell's corner entries per hashed level (incoherent gathers)
   float bg[4];
 };
 

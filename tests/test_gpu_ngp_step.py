@@ -246,3 +246,40 @@ def test_tile_rejection_never_drops_a_live_ray_random_cameras(ctx, oracle, field
     assert int(st.samples_live) == sum(want)
     assert rec.tobytes() == ctx.score_psnr_images(img, gt).tobytes()
     cs.close()
+
+
+def test_corner_cache_instance_renders_the_same_pixels(oracle, monkeypatch):
+    """render_queue64_kernel<4, 5, NGP, CACHE>: lanes keep the corner entries of their last cell on the three hashed
+    levels and skip the loads while the ray stays in the cell (the default for small images under the engine's rule; forced
+    on here for both rules and a large image too).  The cache maps cells to table entries, nothing else: images and counts
+    are bit-identical to the plain instance, relocation on or off, and equal to the oracle."""
+    kw = dict(api.FIELD_256)
+    pts = util.fibonacci_hemisphere(6)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    runs = {}
+    for cache, merge in (("0", "0"), ("1", "0"), ("1", "24")):
+        monkeypatch.setenv("PRV_CELL_CACHE", cache)
+        monkeypatch.setenv("PRV_MERGE_MAX", merge)
+        monkeypatch.setenv("PRV_POOL", "1" if merge != "0" else "0")
+        c = api.Context(0)
+        try:
+            c.synthetic_model(0, api.L.FieldDesc(**kw), util.SEED_A)
+            out = []
+            for (w, h, spp, spr, min_T) in ((80, 45, 16, 0, 1e-2), (80, 45, 4, 128, 1e-2), (400, 300, 1, 0, 1e-4)):
+                cams = c.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+                img, st = c.render(0, cams, None, api.engine_render_opts(w, h, spr, spp, min_T))
+                out.append((img.cpu().numpy(), int(st.samples_evaluated), int(st.samples_live)))
+                cams.close()
+            runs[(cache, merge)] = out
+        finally:
+            c.close()
+    base = runs[("0", "0")]
+    for key in (("1", "0"), ("1", "24")):
+        for (a, ea, la), (b, eb, lb) in zip(base, runs[key]):
+            assert np.array_equal(a, b) and ea == eb and la == lb, key
+    # and the oracle on one whole 80x45 x 16 spp view under the engine's rule
+    f = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
+    ocams = oracle.cameras_from_transforms(tms, util.FOV_X, 80, 45, scale, offset)
+    wants = [f.render(ocams[2], 80, 45, 0, 16, t, step_mode=oracle.STEP_NGP)[0] for t in util.termination_variants(1e-2)]
+    util.assert_pixels_close_any(runs[("1", "24")][0][0][2], wants)
+    f.close()
