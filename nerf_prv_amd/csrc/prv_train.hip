@@ -1018,6 +1018,7 @@ __device__ __forceinline__ void end_step(const AdamParams& P, uint32_t* sample_c
   if (sample_count) {
     const double n = (double)(done + 1u);
     P.state->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, n)) / (1.0 - pow((double)beta1, n)));
+    sample_count[7] = *sample_count; // dev: the finished step's listed-sample count stays readable (prv_train_api.inc: PRV_TRAIN_TIMING)
     *sample_count = 0u;
   }
 }
@@ -1260,11 +1261,16 @@ hipError_t launch_train_tiles(const TrainTileParams& P0, bool forward, int n_blo
     if (P.bwd_frags) e = f4 ? launch_tile<4, false, 2>(P, n_first, s) : launch_tile<2, false, 2>(P, n_first, s);
     else e = f4 ? launch_tile<4, false, 1>(P, n_first, s) : launch_tile<2, false, 1>(P, n_first, s);
     if (e != hipSuccess) return e;
-    P.tile_begin = kept_tiles;
-    P.tile_limit = ~0u;
-    P.slot_base = n_first; // every slot below n_first + n_tail is written by exactly one block of the two launches
-    e = f4 ? launch_tile<4, false>(P, n_tail, s) : launch_tile<2, false>(P, n_tail, s);
-    n_slots = n_first + n_tail;
+    n_slots = n_first;
+    if (P.sample_cap == 0u || (size_t)kept_tiles * 32u < (size_t)P.sample_cap) {
+      // (a buffer that covers every sample a step can list needs no second launch: at the planner loop's 4096-ray cap it
+      // always does, and the launch of idle blocks cost 6 us of the step and 20 MB of zeroed slots for the reduction to read)
+      P.tile_begin = kept_tiles;
+      P.tile_limit = ~0u;
+      P.slot_base = n_first; // every slot below n_first + n_tail is written by exactly one block of the two launches
+      e = f4 ? launch_tile<4, false>(P, n_tail, s) : launch_tile<2, false>(P, n_tail, s);
+      n_slots = n_first + n_tail;
+    }
   } else {
     e = f4 ? launch_tile<4, false>(P, n_lds74, s) : launch_tile<2, false>(P, n_lds74, s);
     n_slots = n_lds74;

@@ -59,6 +59,7 @@ struct TrainTileParams {
   // [tile][slot 0..15][lane half][sample] x 8 halfs -- the B fragments the forward lanes hold, see act_row()
   uint4* act;
   uint32_t act_cap; // samples covered by `act` (a multiple of 32)
+  uint32_t sample_cap; // the most samples a step can list (n_rays x n_samples): act_cap >= sample_cap = no tile is ever recomputed
   // set by launch_train_tiles: the tiles [tile_begin, min(tile_limit, all)) are this launch's, block b owns slot
   // slot_base + b of mlp_grad_partial (the backward pass is two launches when activations are kept: the tiles the
   // buffer covers, and -- nearly always none -- the tiles beyond it, which recompute their forward pass)

@@ -153,10 +153,17 @@ struct HipScorer {
     const double t0 = now_seconds();
     if (rc == PRV_OK && !trs.empty()) rc = prv_train_steps_multi(trs.data(), (int)trs.size(), steps, nullptr);
     const double t_steps = now_seconds() - t0;
+    uint64_t samples_last = 0;
+    int active_rays = 0;
+    if (timing && !trs.empty()) {
+      (void)prv_train_info(trs[0], nullptr, &samples_last, nullptr);
+      active_rays = prv_train_active_rays(trs[0]);
+    }
     for (prv_trainer* tr : trs) prv_train_destroy(tr);
     if (timing)
       std::cerr << "train_members: views " << prv_camset_count(data_cams) << " gt " << t_gt << " s, fresh " << t_fresh << " s, create "
-                << t_create << " s, steps " << t_steps << " s, total " << now_seconds() - t_start << " s" << std::endl;
+                << t_create << " s, steps " << t_steps << " s, total " << now_seconds() - t_start << " s; last batch of member " << (trs.empty() ? -1 : members[0])
+                << ": " << samples_last << " samples, " << active_rays << " rays" << std::endl;
     if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
     return rc;
   }

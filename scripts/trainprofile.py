@@ -1,0 +1,43 @@
+"""time and batch size of a training run chunk by chunk, in the planner loop's configuration (dev tool): N views of the
+ground-truth field at 1280x720 (the reference camera), a fresh field, n_rays 4096, 2500 steps in chunks of 100;
+--members M trains M fields side by side (prv_train_steps_multi), as a scoring round of the loop does"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+ap = argparse.ArgumentParser()
+ap.add_argument("--views", type=int, default=5)
+ap.add_argument("--rays", type=int, default=4096)
+ap.add_argument("--steps", type=int, default=2500)
+ap.add_argument("--chunk", type=int, default=100)
+ap.add_argument("--members", type=int, default=5)
+args = ap.parse_args()
+import torch
+from nerf_prv_amd import api, planner
+ctx = api.Context(0)
+fd = dict(api.FIELD_256)
+ctx.synthetic_model(6, api.L.FieldDesc(**fd), 1592590338)
+pts = planner.hemisphere_read(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "hemisphere", "144.txt"), 144)
+tms, scale, offset = planner.hemisphere_transforms(pts[:: 144 // args.views][: args.views], 0.3, 0.1, [1e-10] * 3)
+W, H = 1280, 720
+intr = dict(fl_x=915.606689453125, fl_y=913.32666015625, cx=647.1453247070312, cy=372.51531982421875, w=W, h=H)
+cams = ctx.cameras_from_matrices_intr(tms, intr, scale, offset)
+u8, _ = ctx.render_rgba8(6, cams, None, api.engine_render_opts(W, H, 0, 1, 1e-4, background=(0, 0, 0, 0)))
+d = api.L.FieldDesc(**dict(fd, table_amp=1e-4, density_bias=0.0))
+trs = []
+for e in range(args.members):
+    ctx.fresh_model(e, d, 0x1234 + e)
+    trs.append(api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=args.rays, seed=0x7EA10001 + e)))
+torch.cuda.synchronize()
+t_all = time.perf_counter()
+done = 0
+while done < args.steps:
+    n = min(args.chunk, args.steps - done)
+    t0 = time.perf_counter()
+    api.train_many(trs, n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    done += n
+    info = trs[0].info()
+    print(f"steps {done - n:5d}..{done:5d}: {dt / n * 1e3:7.3f} ms per round of {args.members} member-steps; member 0: {info['samples_last']:7d} samples, "
+          f"{info['active_rays']:5d} rays in its last batch", flush=True)
+print(f"{args.steps} steps x {args.members} members in {time.perf_counter() - t_all:.2f} s")
