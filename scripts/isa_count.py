@@ -16,12 +16,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_prv_amd import build as b  # noqa: E402
 
 WANT_JSON = "--json" in sys.argv
-F, ND, NGP = ([a for a in sys.argv if a != "--json"] + ["4", "5", "0"])[1:4]
+F, ND, NGP = ([a for a in sys.argv if a not in ("--json", "--cache")] + ["4", "5", "0"])[1:4]
 asm = "/tmp/prv_kernels.s"
 flags = [f for f in b.HIP_FLAGS if f not in ("-shared", "-fPIC")]
 subprocess.run([b.hipcc()] + flags + ["-S", "--cuda-device-only", "-o", asm, os.path.join(b.CSRC, "prv_kernels.hip")], check=True,
                stderr=subprocess.DEVNULL)
-name = f"_ZN3prv21render_queue64_kernelILi{F}ELi{ND}ELb{NGP}EEEvNS_12RenderParamsE"
+CACHE = "1" if "--cache" in sys.argv else "0"  # the CornerCache instance (small images under the engine's rule)
+name = f"_ZN3prv21render_queue64_kernelILi{F}ELi{ND}ELb{NGP}ELb{CACHE}EEEvNS_12RenderParamsE"
 text = open(asm).read().split("\n")
 start = next(i for i, l in enumerate(text) if l.startswith(name + ":"))
 end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
@@ -47,7 +48,7 @@ def ops(a, z):
 
 
 labels = [i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l)] + [len(lines)]
-print(f"render_queue64_kernel<{F}, {ND}, {NGP}>: blocks with > 12 VALU instructions")
+print(f"render_queue64_kernel<{F}, {ND}, {NGP}, {CACHE}>: blocks with > 12 VALU instructions")
 hot = []
 for a, z in zip(labels, labels[1:]):
     c = collections.Counter(cls(o) for o in ops(a, z))
@@ -86,7 +87,7 @@ if WANT_JSON and len(hot) >= 2:
         hist.update(issue_class(o) for o in ops(a, z) if cls(o) in ("valu", "mfma"))
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_isa_classes.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
-    data[f"64<{F}, {ND}>" + (" ngp" if NGP == "1" else "")] = dict(hist, device_code_sha256=_lib.device_code_digest(),
+    data[f"64<{F}, {ND}>" + (" ngp" if NGP == "1" else "") + (" cache" if CACHE == "1" else "")] = dict(hist, device_code_sha256=_lib.device_code_digest(),
                                                                     source="scripts/isa_count.py: static histogram of the gather block and the MLP + compositing block")
     json.dump(data, open(path, "w"), indent=1)
     print("  issue classes of the hot loop:", dict(hist))

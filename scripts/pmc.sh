@@ -25,7 +25,7 @@ out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-40:]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("prv::", "").split("(")[0]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
 with open(out + "/summary.txt", "w") as w:
     for k in agg:

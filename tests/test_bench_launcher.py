@@ -52,3 +52,37 @@ def test_launcher_passes_a_failing_rank_on():
 def test_mismatched_world_size_is_refused():
     out = run_bench(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "PRV_BENCH_DRY_RUN": "1"})
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stdout + out.stderr)
+
+
+def test_roofline_peak_constants_are_the_committed_microbenchmarks():
+    """bench.py prices the render kernel's instructions at issue costs MEASURED on the chip (scripts/valu_rate.hip ->
+    profiles/r04_valu_issue_rate.txt): the constants in bench.py are the file's figures (grid 1, four waves per SIMD, the
+    slowest wave), class by class, and the floor's instruction count is DESIGN.md's (647 / 913 per 64 samples)"""
+    import importlib.util
+    import re
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    text = open(os.path.join(ROOT, bench.ISSUE_RATE_FILE)).read()
+    grid1 = text.split("## grid 1 block")[1].split("## grid 256")[0]
+
+    def slowest_at_four_waves(name):
+        line = next(l for l in grid1.splitlines() if l.startswith(name + " "))
+        return float(re.findall(r"\[\s*([0-9.]+)\]", line)[3])
+
+    c = bench.ISSUE_CYCLES
+    for op in ("v_fma_f32", "v_mul_f32", "v_add_u32", "v_xor_b32", "v_bitop3_b32", "v_sub_f32"):
+        assert abs(slowest_at_four_waves(op) - c["c2"]) <= 0.08, op
+    for op in ("v_pk_fma_f16", "v_pk_mul_f16", "v_pk_max_f16", "v_cvt_pk_f16_f32", "v_fract_f32", "v_mul_u32_u24", "v_cvt_i32_f32"):
+        assert abs(slowest_at_four_waves(op) - c["c4"]) <= 0.2, op
+    for op in ("v_exp_f32", "v_rcp_f32", "v_permlane32_swap"):
+        assert abs(slowest_at_four_waves(op) - c["c8"]) <= 0.2, op
+    # an MFMA between 24 fillers: (time per MFMA - 24 fillers at the c4 cost) = what the MFMA itself holds the issue port for
+    line = next(l for l in grid1.splitlines() if l.startswith("v_mfma + 24 VALU"))
+    per_mfma = float(re.findall(r"\[\s*([0-9.]+)\]", line)[3])
+    assert 6.0 <= per_mfma - 24 * c["c4"] <= 12.0 and c["mfma"] == 8.0
+    assert bench.isa_floor(8, 5)["valu_per_64_samples"] == 647 and bench.isa_floor(16, 10)["valu_per_64_samples"] == 913
+    f = bench.isa_floor(8, 5)
+    assert abs(f["issue_cycles_per_64_samples"] - (f["c2"] * c["c2"] + f["c4"] * c["c4"] + f["c8"] * c["c8"] + 40 * 8.0)) < 1e-9
+    assert abs(bench.ISSUE_PEAK_GCYC - 1024 * 2.4) < 1e-9
