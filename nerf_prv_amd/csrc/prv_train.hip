@@ -19,7 +19,7 @@
 #include "prv_train.hpp"
 
 #ifndef PRV_TRAIN_ABLATE
-#define PRV_TRAIN_ABLATE 0 // dev only: 1 no table scatter, 2 no dW MFMAs, 16 phase time stamps of block 0 (48: summed over its tiles)
+#define PRV_TRAIN_ABLATE 0 // dev only: 1 no table scatter, 2 no dW MFMAs, 4 item-parallel scatter (no run merging), 16 phase time stamps of block 0 (48: summed over its tiles)
 #endif
 #if PRV_TRAIN_ABLATE & 16
 #if PRV_TRAIN_ABLATE & 32 // phase i's time SUMMED over all tiles of block 0 (and over launches): the average under load
@@ -648,13 +648,38 @@ void train_tile_kernel(TrainTileParams P) {
         }
         __syncthreads();
         if (!(PRV_TRAIN_ABLATE & 1)) {
-          const int k = tid % F;
-          constexpr int kItems = 32 * 8 * 8, kPerPass = 256 / F;
-          for (int it = tid / F; it < kItems; it += kPerPass) {
-            const uint2 e = stage[(it >> 6) * kStageStride + (it & 63)];
-            if (e.x == 0xffffffffu) continue;
-            const int ss = it >> 6, l = pass * 8 + ((it >> 3) & 7);
-            atomicAdd(P.table_grad + (size_t)e.x * F + k, __uint_as_float(e.y) * G[(kGFeat + l * F + k) * kTS + ss]);
+          // The coarse levels meet the memory-side atomic units as a crowd: every tile of the batch adds into the same few
+          // thousand entries of levels 0..3 (4 K ... 150 K entries), and adds to one line serialise there.  A tile's samples
+          // are consecutive along their rays, so neighbours in the tile mostly share their corner entries on those levels:
+          // thread (level, corner, feature) walks the tile's 32 samples, sums while the entry stays the same and issues ONE
+          // add per run (levels 0..3: ~200 adds per tile instead of 1024; the finest levels' runs are one sample long and
+          // cost what the item-parallel form cost: 32 steps per thread either way).  F consecutive lanes still add the F
+          // features of one entry, x-neighbour corners sit on adjacent lane groups.  -12 % per step at the planner loop's batch.
+          if (!(PRV_TRAIN_ABLATE & 4)) {
+            if (tid < 8 * 8 * F) {
+              const int k = tid % F, c = (tid / F) & 7, l8 = tid / (8 * F), l = pass * 8 + l8;
+              uint32_t cur = 0xffffffffu;
+              float acc = 0.0f;
+              for (int ss = 0; ss < 32; ss++) {
+                const uint2 e = stage[ss * kStageStride + l8 * 8 + c];
+                if (e.x != cur) {
+                  if (cur != 0xffffffffu) atomicAdd(P.table_grad + (size_t)cur * F + k, acc);
+                  cur = e.x;
+                  acc = 0.0f;
+                }
+                acc += __uint_as_float(e.y) * G[(kGFeat + l * F + k) * kTS + ss]; // (a dead sample's pair carries cur = ~0: never flushed)
+              }
+              if (cur != 0xffffffffu) atomicAdd(P.table_grad + (size_t)cur * F + k, acc);
+            }
+          } else { // dev (timing builds): the item-parallel form of rounds 1-3, one add per (sample, level, corner)
+            const int k = tid % F;
+            constexpr int kItems = 32 * 8 * 8, kPerPass = 256 / F;
+            for (int it = tid / F; it < kItems; it += kPerPass) {
+              const uint2 e = stage[(it >> 6) * kStageStride + (it & 63)];
+              if (e.x == 0xffffffffu) continue;
+              const int ss = it >> 6, l = pass * 8 + ((it >> 3) & 7);
+              atomicAdd(P.table_grad + (size_t)e.x * F + k, __uint_as_float(e.y) * G[(kGFeat + l * F + k) * kTS + ss]);
+            }
           }
         }
       }
