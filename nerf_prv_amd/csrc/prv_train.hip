@@ -338,6 +338,14 @@ void train_tile_kernel(TrainTileParams P) {
     // exactly those): no table gather, no forward layers -- the corner entries and weights (arithmetic only), the seeds,
     // and 16 KB of activations copied into the [row][sample] array
     if constexpr (SAVED) {
+      // the tile's 16 KB of kept activations: issued FIRST, so that their latency runs beside the sample -> ray -> seed
+      // chain of dependent loads below instead of after it
+      uint4 av[kActSlots / 4];
+      {
+        const uint4* src = P.act + (size_t)tile * kActTileWords;
+#pragma unroll
+        for (int i = 0; i < kActSlots / 4; i++) av[i] = src[(wave + 4 * i) * 64 + lane];
+      }
       float pos[3] = {0.5f, 0.5f, 0.5f};
       if (live) {
         const uint2 sr = P.samples[sid];
@@ -355,11 +363,10 @@ void train_tile_kernel(TrainTileParams P) {
 #pragma unroll
         for (int k = 3; k < 16; k++) G[(kGOrr + k) * kTS + s] = 0.0f;
       }
-      const uint4* src = P.act + (size_t)tile * kActTileWords;
 #pragma unroll
       for (int i = 0; i < kActSlots / 4; i++) {
         const int q = wave + 4 * i; // slot of this wave's 64 words: lane = (half, sample)
-        const uint4 v = src[q * 64 + lane];
+        const uint4 v = av[i];
         const _Float16* e = reinterpret_cast<const _Float16*>(&v);
 #pragma unroll
         for (int j = 0; j < 8; j++) A[act_row<F>(q, h, j) * kTS + r] = e[j];

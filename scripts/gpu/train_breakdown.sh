@@ -10,7 +10,7 @@ tail -4 $O/trainbench.txt
 f=$(find $O/prof -name "*kernel_trace.csv" | head -1)
 python3 scripts/train_trace_summary.py $f | tee $O/trace_summary.txt
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv; rm -rf $O/prof
-for ab in 48 1 2 3; do
+for ab in 48 1 2 4; do
   PRV_TRAIN_ABLATE=$ab python3 -c "from nerf_prv_amd import build as b; b.build_hip(True)" > /dev/null 2>&1
   STAMP_SUMS=1 python3 scripts/trainablate.py --load /tmp/state.prvf --rays 4096 --tag "ablate=$ab" 2>&1 | grep -v amdgpu.ids | tee -a $O/ablate.txt
 done
