@@ -258,7 +258,14 @@ struct HipScorer {
     int rc = train_steps > 0 ? train_members(scene_json) : PRV_OK; // without training: member 0 as loaded
     n_members = keep;
     if (rc != PRV_OK) return rc;
-    // test cameras: the test view set placed like the candidates, full-size dataset header
+    std::string test_json;
+    if ((rc = write_test_json(center, size, &test_json)) != PRV_OK) return rc;
+    return evaluate_on(test_json, 0, psnr, ssim);
+  }
+
+  // the test cameras' json, <gt_path>/<evaluate_views>.json: the test view set placed like the candidates, full-size
+  // dataset header (what get_coverage leaves for the reference's "100" test set, main.cpp:1581-1651)
+  int write_test_json(const Vec3& center, double size, std::string* path) {
     auto sd_test = std::make_shared<Share_Data>(sd->yaml_file_path, sd->name_of_pcd, eval_views, -1, sd->method_of_IG);
     if (!sd_test->ok) {
       std::cerr << sd_test->error << std::endl;
@@ -273,10 +280,48 @@ struct HipScorer {
       v["transform_matrix"] = matrix_json(view_transform_matrix(vs.views[i], Mat4::Identity(), center));
       root["frames"].append(v);
     }
-    const std::string test_json = sd->gt_path + "/" + std::to_string(eval_views) + ".json";
+    *path = sd->gt_path + "/" + std::to_string(eval_views) + ".json";
     sd->access_directory(sd->gt_path);
-    write_text(test_json, prvjson::to_styled_string(root));
-    return evaluate_on(test_json, 0, psnr, ssim);
+    return write_text(*path, prvjson::to_styled_string(root)) ? PRV_OK : PRV_E_IO;
+  }
+
+  // Mode 4's curve points trained SIDE BY SIDE: one fresh field per scene json on model slots 0, 1, ... (at most 5: slots
+  // 6 and 7 hold the ground truth and the reference field), each on its own dataset, all stepped together by
+  // prv_train_steps_multi -- the reference trains them one run.py after another (main.cpp:2469-2479); the fields are the
+  // same fields either way (own slot, own seed, own data), the GPU is just not left idle between a single trainer's kernels.
+  int train_scenes_side_by_side(const std::vector<std::string>& scenes) {
+    struct Job {
+      prv_camset* cams = nullptr;
+      uint8_t* imgs = nullptr;
+      prv_trainer* tr = nullptr;
+    };
+    std::vector<Job> jobs(scenes.size());
+    int rc = PRV_OK;
+    for (size_t k = 0; rc == PRV_OK && k < scenes.size(); k++) {
+      drop_training_data();
+      if ((rc = training_data(scenes[k])) != PRV_OK) break;
+      jobs[k].cams = data_cams; // the job owns them from here
+      jobs[k].imgs = data_imgs;
+      data_cams = nullptr;
+      data_imgs = nullptr;
+      data_scene.clear();
+      rc = prv_model_fresh(ctx, (int)k, &train_desc, train_seed); // every curve point starts from the same initial field, as `evaluate` does
+      prv_train_opts to;
+      prv_train_default_opts(&to);
+      if (train_rays > 0) to.n_rays = train_rays;
+      if (rc == PRV_OK) rc = prv_train_create(ctx, (int)k, jobs[k].cams, jobs[k].imgs, data_w, data_h, &to, &jobs[k].tr);
+    }
+    std::vector<prv_trainer*> trs;
+    for (auto& j : jobs)
+      if (j.tr) trs.push_back(j.tr);
+    if (rc == PRV_OK && !trs.empty()) rc = prv_train_steps_multi(trs.data(), (int)trs.size(), train_steps, nullptr);
+    if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+    for (auto& j : jobs) {
+      if (j.tr) prv_train_destroy(j.tr);
+      if (j.cams) prv_camset_destroy(j.cams);
+      if (j.imgs) prv_free(ctx, j.imgs);
+    }
+    return rc;
   }
 
   // run.py:226-277 for one model slot: every frame of the test json (full-size dataset cameras, lens included) at
@@ -298,16 +343,29 @@ struct HipScorer {
     o.min_transmittance = 1e-4f; // run.py:235
     o.background[3] = 1.f;       // black, opaque (run.py:226)
     const int n = prv_camset_count(cams);
-    float* gt = nullptr;
-    int rc = prv_malloc(ctx, (void**)&gt, (size_t)n * o.width * o.height * 16);
-    prv_render_opts og = o;
-    og.background[3] = 0.f;
-    if (rc == PRV_OK) rc = prv_render(ctx, 6, cams, nullptr, n, &og, gt, nullptr); // the reference images
-    if (rc == PRV_OK) rc = prv_evaluate(ctx, slot, cams, nullptr, n, &o, gt, psnr, ssim);
+    int rc = PRV_OK;
+    // the reference images of the test set are rendered once per test json and size: mode 4 evaluates a dozen fields on them
+    const std::string key = test_json + "@" + std::to_string(o.width) + "x" + std::to_string(o.height);
+    if (!test_gt || test_gt_key != key) {
+      drop_test_images();
+      rc = prv_malloc(ctx, (void**)&test_gt, (size_t)n * o.width * o.height * 16);
+      prv_render_opts og = o;
+      og.background[3] = 0.f;
+      if (rc == PRV_OK) rc = prv_render(ctx, 6, cams, nullptr, n, &og, test_gt, nullptr);
+      if (rc == PRV_OK) test_gt_key = key;
+      else drop_test_images();
+    }
+    if (rc == PRV_OK) rc = prv_evaluate(ctx, slot, cams, nullptr, n, &o, test_gt, psnr, ssim);
     if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
-    if (gt) prv_free(ctx, gt);
     prv_camset_destroy(cams);
     return rc;
+  }
+  float* test_gt = nullptr;
+  std::string test_gt_key;
+  void drop_test_images() {
+    if (test_gt) prv_free(ctx, test_gt);
+    test_gt = nullptr;
+    test_gt_key.clear();
   }
   int eval_views = 100;
 
@@ -533,7 +591,10 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
     return -24;
   }
   const int rc = labeler.nbv_loop(first_view_id, 0);
-  if (engine_state) engine_state->drop_training_data();
+  if (engine_state) {
+    engine_state->drop_training_data();
+    engine_state->drop_test_images();
+  }
   if (scorer.gt_dev) prv_free(ctx, scorer.gt_dev);
   if (labeler.final_psnr >= 0) std::cout << "final PSNR " << labeler.final_psnr << " SSIM " << labeler.final_ssim << std::endl;
   std::cout << "chosen_nbvs:";
@@ -627,47 +688,69 @@ int instant_ngp_curves(prv_ctx* ctx, const std::string& cfg, const std::string& 
   counts.push_back(n_full); // the upper bound of the curve ("100.txt")
   std::vector<double> xs, ys;
   double max_psnr = 0.0;
+  // pass 1: which curve points are missing (existing metrics files are kept, :2473), and their scene jsons
+  std::vector<double> psnrs(counts.size(), 0.0);
+  std::vector<size_t> missing;
+  std::vector<std::string> scenes;
   for (size_t ci = 0; ci < counts.size(); ci++) {
     const int n = counts[ci];
     const std::string metrics = sd0->gt_path + "/" + std::to_string(n) + ".txt";
-    double psnr = 0, ssim = 0;
-    if (prvh_read_metrics(metrics.c_str(), &psnr, &ssim) != 0) { // existing files are kept (:2473)
-      // the n-view coverage set
-      std::vector<std::vector<double>> pts((size_t)n, std::vector<double>(3, 0.0));
-      std::ifstream fin(sd0->viewspace_path + std::to_string(n) + ".txt");
-      if (fin.is_open()) {
-        for (int i = 0; i < n; i++)
-          for (int j = 0; j < 3; j++) fin >> pts[i][j];
-      } else {
-        std::vector<double> flat((size_t)n * 3);
-        prvh_hemisphere_generate(n, flat.data());
-        for (int i = 0; i < n; i++)
-          for (int j = 0; j < 3; j++) pts[i][j] = flat[(size_t)i * 3 + j];
-      }
-      sd0->num_of_views = n;
-      sd0->pt_sphere = pts;
-      sd0->pt_norm = std::sqrt(pts[0][0] * pts[0][0] + pts[0][1] * pts[0][1] + pts[0][2] * pts[0][2]);
-      View_Space vs(sd0);
-      vs.set_view_space(center, size);
-      Value root = transforms_header(sd0->color_intrinsics, sd0->ray_casting_aabb_scale, size, center, 0);
-      for (size_t i = 0; i < vs.views.size(); i++) {
-        Value v;
-        v["file_path"] = Value(std::to_string(n) + "/rgbaClip_" + std::to_string(i) + ".png");
-        v["transform_matrix"] = matrix_json(view_transform_matrix(vs.views[i], Mat4::Identity(), center));
-        root["frames"].append(v);
-      }
-      // the test set's own json is <gt_path>/<evaluate_views>.json: keep the two apart when the sizes coincide
-      const std::string scene = sd0->gt_path + "/" + std::to_string(n) + (n == scorer.eval_views ? "_train.json" : ".json");
-      write_text(scene, prvjson::to_styled_string(root));
-      if ((rc = scorer.evaluate(scene, center, size, &psnr, &ssim)) != PRV_OK) return rc;
-      prvh_write_metrics(metrics.c_str(), psnr, ssim);
-      std::cout << "views " << n << " PSNR " << psnr << " SSIM " << ssim << std::endl;
-    }
-    if (ci + 1 < counts.size()) {
-      xs.push_back((double)n);
-      ys.push_back(psnr);
+    double ssim = 0;
+    if (prvh_read_metrics(metrics.c_str(), &psnrs[ci], &ssim) == 0) continue;
+    // the n-view coverage set
+    std::vector<std::vector<double>> pts((size_t)n, std::vector<double>(3, 0.0));
+    std::ifstream fin(sd0->viewspace_path + std::to_string(n) + ".txt");
+    if (fin.is_open()) {
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) fin >> pts[i][j];
     } else {
-      max_psnr = psnr;
+      std::vector<double> flat((size_t)n * 3);
+      prvh_hemisphere_generate(n, flat.data());
+      for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) pts[i][j] = flat[(size_t)i * 3 + j];
+    }
+    sd0->num_of_views = n;
+    sd0->pt_sphere = pts;
+    sd0->pt_norm = std::sqrt(pts[0][0] * pts[0][0] + pts[0][1] * pts[0][1] + pts[0][2] * pts[0][2]);
+    View_Space vs(sd0);
+    vs.set_view_space(center, size);
+    Value root = transforms_header(sd0->color_intrinsics, sd0->ray_casting_aabb_scale, size, center, 0);
+    for (size_t i = 0; i < vs.views.size(); i++) {
+      Value v;
+      v["file_path"] = Value(std::to_string(n) + "/rgbaClip_" + std::to_string(i) + ".png");
+      v["transform_matrix"] = matrix_json(view_transform_matrix(vs.views[i], Mat4::Identity(), center));
+      root["frames"].append(v);
+    }
+    // the test set's own json is <gt_path>/<evaluate_views>.json: keep the two apart when the sizes coincide
+    const std::string scene = sd0->gt_path + "/" + std::to_string(n) + (n == scorer.eval_views ? "_train.json" : ".json");
+    write_text(scene, prvjson::to_styled_string(root));
+    missing.push_back(ci);
+    scenes.push_back(scene);
+  }
+  // pass 2: the missing points, five fields at a time side by side (train_scenes_side_by_side), each evaluated on the test set
+  std::string test_json;
+  if (!missing.empty() && (rc = scorer.write_test_json(center, size, &test_json)) != PRV_OK) return rc;
+  constexpr size_t kSideBySide = 5;
+  for (size_t g0 = 0; g0 < missing.size(); g0 += kSideBySide) {
+    const size_t g1 = std::min(missing.size(), g0 + kSideBySide);
+    if ((rc = scorer.train_scenes_side_by_side(std::vector<std::string>(scenes.begin() + (long)g0, scenes.begin() + (long)g1))) != PRV_OK) return rc;
+    for (size_t k = g0; k < g1; k++) {
+      const int n = counts[missing[k]];
+      double psnr = 0, ssim = 0;
+      if ((rc = scorer.evaluate_on(test_json, (int)(k - g0), &psnr, &ssim)) != PRV_OK) return rc;
+      prvh_write_metrics((sd0->gt_path + "/" + std::to_string(n) + ".txt").c_str(), psnr, ssim);
+      std::cout << "views " << n << " PSNR " << psnr << " SSIM " << ssim << std::endl;
+      psnrs[missing[k]] = psnr;
+    }
+  }
+  scorer.drop_training_data();
+  scorer.drop_test_images();
+  for (size_t ci = 0; ci < counts.size(); ci++) {
+    if (ci + 1 < counts.size()) {
+      xs.push_back((double)counts[ci]);
+      ys.push_back(psnrs[ci]);
+    } else {
+      max_psnr = psnrs[ci];
     }
   }
   // the label file Origin's fit script leaves next to the curve (NeRF_fit_curve.cpp:119-206)
