@@ -1,11 +1,11 @@
 # exits of prv_planner while another process keeps the GPU busy (round 2 saw ~1 crash in 1000 static teardowns):
-#   usage: scripts/gpu/exit_stress.sh <runs of the ordinary return> <runs of the plain return>
+#   usage: scripts/gpu/exit_stress.sh <runs of the ordinary return> <runs of the plain return> [<runs of the default exit>]
 # normal = prv_runtime_shutdown (hipDeviceReset before main returns) then an ordinary return (round 3's default; the default
 # is now the same shutdown followed by _exit, which cannot die in the runtime's exit handlers); noreset = plain return
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 export PRV_SEGV_TRACE=1
-O=gpurun_out/r03exit
+O=gpurun_out/${EXIT_TAG:-r04exit}
 mkdir -p $O
 CFG=$(python3 scripts/gpu/repro_planner_inputs.py /tmp/repro | tail -1)
 echo cfg $CFG
@@ -24,5 +24,6 @@ loop() { # mode, runs
 }
 [ "${1:-0}" -gt 0 ] && loop normal $1
 [ "${2:-0}" -gt 0 ] && loop noreset $2
+[ "${3:-0}" -gt 0 ] && loop quick $3   # the default: ordered shutdown, flush, _exit
 kill $BG 2>/dev/null; wait $BG 2>/dev/null
 cat $O/summary.txt
