@@ -145,7 +145,7 @@ inline int ensemble_uncertainty_from_pngs(int method, const std::vector<std::str
     h = ih;
   }
   static const int channel_order[3] = {2, 1, 0}; // the reference's rgba[0], rgba[1], rgba[2] of a BGRA pixel
-  double view_uncertainty = 0.0;
+  double score = 0.0;
   for (size_t p = 0; p < (size_t)w * (size_t)h; p++) {
     double var[3];
     for (int c = 0; c < 3; c++) {
@@ -158,16 +158,16 @@ inline int ensemble_uncertainty_from_pngs(int method, const std::vector<std::str
     }
     if (method == EnsembleRGB) {
       for (int c = 0; c < 3; c++)
-        if (var[c] > 1e-10) view_uncertainty += std::log(var[c]);
+        if (var[c] > 1e-10) score += std::log(var[c]);
     } else {
-      double mean_density = 0.0;
-      for (int e = 0; e < E; e++) mean_density += img[(size_t)e][p * 4 + 3] / 255.0;
-      mean_density /= E;
-      view_uncertainty += (var[0] + var[1] + var[2]) / 3.0;
-      view_uncertainty += (1.0 - mean_density) * (1.0 - mean_density);
+      double opacity_mean = 0.0;
+      for (int e = 0; e < E; e++) opacity_mean += img[(size_t)e][p * 4 + 3] / 255.0;
+      opacity_mean /= E;
+      score += (var[0] + var[1] + var[2]) / 3.0;
+      score += (1.0 - opacity_mean) * (1.0 - opacity_mean);
     }
   }
-  *out = view_uncertainty;
+  *out = score;
   return 0;
 }
 
