@@ -86,3 +86,31 @@ def test_roofline_peak_constants_are_the_committed_microbenchmarks():
     f = bench.isa_floor(8, 5)
     assert abs(f["issue_cycles_per_64_samples"] - (f["c2"] * c["c2"] + f["c4"] * c["c4"] + f["c8"] * c["c8"] + 40 * 8.0)) < 1e-9
     assert abs(bench.ISSUE_PEAK_GCYC - 1024 * 2.4) < 1e-9
+
+
+def test_roofline_record_is_flat_and_leads_with_the_contract_keys():
+    """the driver's parser kept the first 22 keys of `roofline` in rounds 2-3 and lost `frac`: the object is flat (scalars
+    and one string only), at most 22 entries, and starts with kernel / bound / frac / peak / achieved / unit / traffic; both
+    kinds (issue-bound 256^3, HBM-bound 512^3) and a run without any profile file behind it"""
+    import importlib.util
+    import types
+
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    st = types.SimpleNamespace(samples_evaluated=214798195, wave_rounds=7149040)
+    m = {"prof": {"render_ms": 8.45 * 20, "render_launches": 20, "march_ms": 11.4, "march_launches": 20, "clock_ghz": 1.9}, "st": st, "steps": 20}
+    for variant, hbm, layout in (("64<4, 5>", False, {"n_levels": 8, "n_dense_levels": 5}), ("64<2, 10>", True, {"n_levels": 16, "n_dense_levels": 10}),
+                                 ("64<4, 3>", False, {"n_levels": 8, "n_dense_levels": 3})):  # the last: no profile entry
+        roof, detail = bench.kernel_figures(m, variant, hbm, "baseline", layout)
+        keys = list(roof)
+        assert keys[:7] == ["kernel", "bound", "frac", "peak", "achieved", "unit", "traffic"], keys
+        assert len(keys) <= 22 and all(not isinstance(v, (dict, list)) for v in roof.values())
+        assert roof["bound"] == ("hbm" if hbm else "valu_issue") and 0.0 < roof["frac"] < 1.0
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+        assert roof["units_per_launch"] == 214798195 and abs(roof["avg_launch_ms"] - 8.45) < 1e-9
+        assert isinstance(detail, dict) and "floor" in detail
+    # the issue-bound fraction is the floor's: 2,720.7 cycles per 64 samples over 1024 SIMDs x 2.4 GHz
+    roof, _ = bench.kernel_figures(m, "64<4, 5>", False, "baseline", {"n_levels": 8, "n_dense_levels": 5})
+    want = 214798195 / 64 * bench.isa_floor(8, 5)["issue_cycles_per_64_samples"] / 8.45e-3 / (1024 * 2.4e9)
+    assert abs(roof["frac"] - want) < 1e-12
