@@ -102,15 +102,18 @@ def test_roofline_record_is_flat_and_leads_with_the_contract_keys():
     m = {"prof": {"render_ms": 8.45 * 20, "render_launches": 20, "march_ms": 11.4, "march_launches": 20, "clock_ghz": 1.9}, "st": st, "steps": 20}
     for variant, hbm, layout in (("64<4, 5>", False, {"n_levels": 8, "n_dense_levels": 5}), ("64<2, 10>", True, {"n_levels": 16, "n_dense_levels": 10}),
                                  ("64<4, 3>", False, {"n_levels": 8, "n_dense_levels": 3})):  # the last: no profile entry
+        ms = 26.3 if hbm else 8.45  # the 512^3 launch is three times as long
+        m["prof"]["render_ms"] = ms * 20
         roof, detail = bench.kernel_figures(m, variant, hbm, "baseline", layout)
         keys = list(roof)
         assert keys[:7] == ["kernel", "bound", "frac", "peak", "achieved", "unit", "traffic"], keys
         assert len(keys) <= 22 and all(not isinstance(v, (dict, list)) for v in roof.values())
         assert roof["bound"] == ("hbm" if hbm else "valu_issue") and 0.0 < roof["frac"] < 1.0
         assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
-        assert roof["units_per_launch"] == 214798195 and abs(roof["avg_launch_ms"] - 8.45) < 1e-9
+        assert roof["units_per_launch"] == 214798195 and abs(roof["avg_launch_ms"] - ms) < 1e-9
         assert isinstance(detail, dict) and "floor" in detail
     # the issue-bound fraction is the floor's: 2,720.7 cycles per 64 samples over 1024 SIMDs x 2.4 GHz
+    m["prof"]["render_ms"] = 8.45 * 20
     roof, _ = bench.kernel_figures(m, "64<4, 5>", False, "baseline", {"n_levels": 8, "n_dense_levels": 5})
     want = 214798195 / 64 * bench.isa_floor(8, 5)["issue_cycles_per_64_samples"] / 8.45e-3 / (1024 * 2.4e9)
     assert abs(roof["frac"] - want) < 1e-12
