@@ -536,7 +536,7 @@ def full_loop(args):
     for mode, key in ((21, "view_planning_s"), (4, "psnr_curve_and_stopping_criterion_s")):
         t0 = time.perf_counter()
         # the planner's default exit (ordered shutdown, flush, _exit): its exit code is the planner's own
-        r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=3600,
+        r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=(1800 if args.full_loop else 300),
                            env=dict(os.environ, PRV_PLANNER_TIMING="1"))  # one line per training call on stderr
         out[key] = time.perf_counter() - t0
         if r.returncode != 0:
@@ -756,7 +756,10 @@ def run_rank(args):
             cpu = cpu_baseline(args, fkw, main.tms, main.scale, main.offset, main.fov_x)
         loop = None
         if world == 1 and not args.no_full_loop and not args.no_extras:
-            loop = full_loop(args)
+            try:
+                loop = full_loop(args)
+            except Exception as e:  # the side measurement must never cost the run its line
+                loop = {"error": f"{type(e).__name__}: {e}"}
         out = {
             # scene in the metric's name: round 3 switched the default scene, and lines of different scenes do not compare
             "metric": f"ray-samples/s (field evaluations composited; candidate views rendered + scored; scene {args.scene}, field {args.field}^3)",
