@@ -253,6 +253,7 @@ double prvh_share_data_number(const prvh_share_data* h, const char* f) try {
   NUM(ray_casting_aabb_scale) NUM(num_of_novel_test_views) NUM(view_space_radius) NUM(octomap_resolution)
   NUM(ground_truth_resolution) NUM(depth_scale) NUM(pt_norm) NUM(render_width) NUM(render_height)
   NUM(samples_per_ray) NUM(screenshot_spp) NUM(candidate_divisor) NUM(min_transmittance) NUM(cost_on) NUM(cost_rate) NUM(show)
+  NUM(score_from_pngs)
 #undef NUM
   return 0;
 } catch (...) { return -1.0; }

@@ -472,3 +472,17 @@ def test_png_score_loops_equal_the_oracle_bit_for_bit(oracle, tmp_path):
         planner.score_view_pngs(3, [files[0], small])  # another size
     with pytest.raises(IOError):
         planner.score_view_pngs(5, files)  # PSNR has no PNG loop in the reference
+
+
+def test_score_path_key_selects_the_references_png_data_flow(config, tmp_path):
+    """yaml `score_path`: fused (default, absent from the reference's file) | png (train_by_instantNGP per member, PNG
+    tree, the loops of main.cpp:2045-2094 / 2105-2158); anything else is refused when the configuration is read"""
+    assert planner.ShareData(config, "a", -1, -1, 3).number("score_from_pngs") == 0
+    for value, want in (("png", 1), ("fused", 0)):
+        cfg = tmp_path / f"{value}.yaml"
+        cfg.write_text(open(config).read() + f"score_path: {value}\n")
+        assert planner.ShareData(cfg, "a", -1, -1, 3).number("score_from_pngs") == want
+    bad = tmp_path / "bad.yaml"
+    bad.write_text(open(config).read() + "score_path: files\n")
+    with pytest.raises(IOError, match="score_path"):
+        planner.ShareData(bad, "a", -1, -1, 3)
