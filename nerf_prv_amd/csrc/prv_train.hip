@@ -19,7 +19,7 @@
 #include "prv_train.hpp"
 
 #ifndef PRV_TRAIN_ABLATE
-#define PRV_TRAIN_ABLATE 0 // dev only: 1 no table scatter, 2 no dW MFMAs, 4 item-parallel scatter (no run merging), 16 phase time stamps of block 0 (48: summed over its tiles)
+#define PRV_TRAIN_ABLATE 0 // dev only: 1 no table scatter, 2 no dW MFMAs, 4 item-parallel scatter (no run merging), 8 no dX chain, 64 no backward tiles at all, 128 dW on the f32 matrix-core form (K = 2), 16 phase time stamps of block 0 (48: summed over its tiles)
 #endif
 #if PRV_TRAIN_ABLATE & 16
 #if PRV_TRAIN_ABLATE & 32 // phase i's time SUMMED over all tiles of block 0 (and over launches): the average under load
@@ -208,6 +208,7 @@ __device__ __forceinline__ f32x16v mfma32(float a, float b, f32x16v c) {
 __device__ __forceinline__ int rho(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
 constexpr int kTS = 33; // sample stride of the [row][sample] LDS arrays (conflict-free in both read directions)
+constexpr int kTSA2 = 40, kTSG2 = 36; // the register-chain instance's strides (halfs of an activation row, floats of a gradient row)
 // layer l: n_in, n_out, canonical offset, padded LDS row stride and LDS offset of the weights
 __device__ constexpr int kLIn[5] = {32, 64, 32, 64, 64}, kLOut[5] = {64, 16, 64, 64, 16};
 __device__ constexpr int kLOff[5] = {0, 2048, 3072, 5120, 9216};
@@ -231,7 +232,10 @@ __device__ __forceinline__ int act_row(int q, int h, int j) {
   if (q == 7) return kAIn2 + 16 + 8 * h + j;
   return (q < 12 ? kAH2 : kAH3) + unit;
 }
-constexpr int kActSlots = 16, kActTileWords = kActSlots * 64; // uint4 per 32-sample tile
+// ... followed by the 32 sample positions of the tile (float4 each: the backward pass computes the corner entries and
+// weights from them without walking sample -> ray first)
+constexpr int kActSlots = 16, kActPosWord = kActSlots * 64, kActTileWords = kActPosWord + 32; // uint4 per 32-sample tile
+static_assert(kActTileBytes == (size_t)kActTileWords * 16, "prv_train.hpp sizes the buffer");
 
 // gradient rows: dOrr 0..15 | dH3 16..79 | dH2 80..143 | dOd 144..175 | dH1 176..239 | dFeat 240..271
 constexpr int kGOrr = 0, kGH3 = 16, kGH2 = 80, kGOd = 144, kGH1 = 176, kGFeat = 240, kGRows = 272;
@@ -276,15 +280,19 @@ __attribute__((amdgpu_waves_per_eu(2))) // two blocks per CU (74 KB of LDS each)
 void train_tile_kernel(TrainTileParams P) {
   constexpr bool SAVED = MODE != 0;
   static_assert(!(FWD && SAVED), "kept activations are a backward-pass input");
+  // sample strides of the [row][sample] arrays.  The register-chain instance reads the operands of its dW tiles as
+  // 16-byte runs of 8 (activations) / 2 x 4 (gradients) consecutive samples of a row: rows 16-byte aligned, and a stride
+  // of 4 (mod 8) dwords spreads eight consecutive rows over all 32 banks
+  constexpr int TSA = MODE == 2 ? kTSA2 : kTS, TSG = MODE == 2 ? kTSG2 : kTS;
   // weights and activations are fp16 VALUES (working weights, rounded activations): stored as fp16, widened
   // at the operand read; 21 + 17 KB (+ 36 KB of f32 gradients backward) -> 2 backward / 4 forward blocks per CU
   extern __shared__ float lds[];
 #if (PRV_TRAIN_ABLATE & 48) == 48
   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
-  float* G = lds;                                                  // kGRows * kTS floats (backward only)
-  _Float16* W = reinterpret_cast<_Float16*>(lds + (FWD ? 0 : kGRows * kTS)); // kWLds halfs: [in][out] weights; MODE 2: the 20 backward A fragments
-  _Float16* A = W + kWLds;                                         // kARows * kTS halfs
+  float* G = lds;                                                  // kGRows * TSG floats (backward only)
+  _Float16* W = reinterpret_cast<_Float16*>(lds + (FWD ? 0 : kGRows * TSG)); // kWLds halfs: [in][out] weights; MODE 2: the 20 backward A fragments
+  _Float16* A = W + kWLds;                                         // kARows * TSA halfs
   static_assert(kBwdFrags * kFragHalfs <= kWLds, "the backward fragments take the weight array's place");
   STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -319,8 +327,27 @@ void train_tile_kernel(TrainTileParams P) {
   f32x16v dw[3];
   for (int q = 0; q < 3; q++) dw[q] = f32x16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+  // what a kept-activation tile reads from memory: this wave's four activation slots, the sample's position and seed
+  struct TileIn {
+    uint4 av[kActSlots / 4];
+    float pos[3];
+    float4 seed;
+  };
+  auto fetch_tile = [&](uint32_t tile, int lane, TileIn& in) {
+    const uint4* src = P.act + (size_t)tile * kActTileWords;
+#pragma unroll
+    for (int i = 0; i < kActSlots / 4; i++) in.av[i] = src[(wave + 4 * i) * 64 + lane];
+    const int s = lane & 31;
+    const uint32_t sid = tile * 32u + (uint32_t)s;
+    const float4 p = __builtin_bit_cast(float4, src[kActPosWord + s]);
+    in.pos[0] = p.x;
+    in.pos[1] = p.y;
+    in.pos[2] = p.z;
+    in.seed = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sid < n_samples) in.seed = P.seeds[sid];
+  };
   const int lane_outer = lane;
-  for (uint32_t tile = P.tile_begin + blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (uint32_t tile = P.tile_begin + blockIdx.x; tile < ((PRV_TRAIN_ABLATE & 64) && !FWD ? 0u : n_tiles); tile += gridDim.x) {
     // The lane id is made opaque once per tile: everything derived from it inside the loop (some 70 LDS addresses of the
     // [row][sample] arrays) is then recomputed per tile instead of being hoisted out of the loop and kept in registers for
     // the whole kernel, which is what pushed the register-chain instance past 256 of them.
@@ -338,30 +365,20 @@ void train_tile_kernel(TrainTileParams P) {
     // exactly those): no table gather, no forward layers -- the corner entries and weights (arithmetic only), the seeds,
     // and 16 KB of activations copied into the [row][sample] array
     if constexpr (SAVED) {
-      // the tile's 16 KB of kept activations: issued FIRST, so that their latency runs beside the sample -> ray -> seed
-      // chain of dependent loads below instead of after it
-      uint4 av[kActSlots / 4];
-      {
-        const uint4* src = P.act + (size_t)tile * kActTileWords;
-#pragma unroll
-        for (int i = 0; i < kActSlots / 4; i++) av[i] = src[(wave + 4 * i) * 64 + lane];
-      }
-      float pos[3] = {0.5f, 0.5f, 0.5f};
-      if (live) {
-        const uint2 sr = P.samples[sid];
-        const TrainRay* ray = P.rays + sr.x;
-        const float t = fmaf((float)sr.y + ray->jitter, ray->dt, ray->t0);
-        for (int a = 0; a < 3; a++) pos[a] = fmaf(t, ray->d[a], ray->o[a]);
-        seed = P.seeds[sid];
-      }
+      // the tile's 16 KB of kept activations, its 32 sample positions and its gradient seeds: independent loads
+      TileIn in;
+      fetch_tile(tile, lane, in);
+      seed = in.seed;
+      const uint4* av = in.av;
+      const float* pos = in.pos;
 #pragma unroll
       for (int q = 0; q < LPT; q++) train_level_corners<F>(lv[g * LPT + q], pos[0], pos[1], pos[2], cidx[q], cw[q]);
       if (g == 1) {
-        G[(kGOrr + 0) * kTS + s] = seed.y;
-        G[(kGOrr + 1) * kTS + s] = seed.z;
-        G[(kGOrr + 2) * kTS + s] = seed.w;
+        G[(kGOrr + 0) * TSG + s] = seed.y;
+        G[(kGOrr + 1) * TSG + s] = seed.z;
+        G[(kGOrr + 2) * TSG + s] = seed.w;
 #pragma unroll
-        for (int k = 3; k < 16; k++) G[(kGOrr + k) * kTS + s] = 0.0f;
+        for (int k = 3; k < 16; k++) G[(kGOrr + k) * TSG + s] = 0.0f;
       }
 #pragma unroll
       for (int i = 0; i < kActSlots / 4; i++) {
@@ -369,7 +386,7 @@ void train_tile_kernel(TrainTileParams P) {
         const uint4 v = av[i];
         const _Float16* e = reinterpret_cast<const _Float16*>(&v);
 #pragma unroll
-        for (int j = 0; j < 8; j++) A[act_row<F>(q, h, j) * kTS + r] = e[j];
+        for (int j = 0; j < 8; j++) A[act_row<F>(q, h, j) * TSA + r] = e[j];
       }
       __syncthreads(); STAMP(2);
     } else {
@@ -459,7 +476,7 @@ void train_tile_kernel(TrainTileParams P) {
         // accumulators (the dropped term is below 2^-16 of the product).  60 MFMAs of K = 16 where the LDS form issues
         // ~350 of K = 2 behind five barriers.  The masked gradients still go to the [row][sample] array: dW and the
         // scatter below read them there.
-        if (wave == 0) {
+        if (wave == 0 && !(PRV_TRAIN_ABLATE & 8)) {
           typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
           const half8* wf = reinterpret_cast<const half8*>(W);
           const f32x16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -505,8 +522,8 @@ void train_tile_kernel(TrainTileParams P) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
               const int row = 32 * mt + rho(i, h);
-              d[mt][i] = A[(kAH3 + row) * kTS + r] > (_Float16)0.0f ? d[mt][i] : 0.0f;
-              G[(kGH3 + row) * kTS + r] = d[mt][i];
+              d[mt][i] = A[(kAH3 + row) * TSA + r] > (_Float16)0.0f ? d[mt][i] : 0.0f;
+              G[(kGH3 + row) * TSG + r] = d[mt][i];
             }
           }
 #pragma unroll
@@ -519,8 +536,8 @@ void train_tile_kernel(TrainTileParams P) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
               const int row = 32 * mt + rho(i, h);
-              c[i] = A[(kAH2 + row) * kTS + r] > (_Float16)0.0f ? c[i] : 0.0f;
-              G[(kGH2 + row) * kTS + r] = c[i];
+              c[i] = A[(kAH2 + row) * TSA + r] > (_Float16)0.0f ? c[i] : 0.0f;
+              G[(kGH2 + row) * TSG + r] = c[i];
             }
             d[mt] = c;
           }
@@ -532,7 +549,7 @@ void train_tile_kernel(TrainTileParams P) {
             for (int st = 0; st < 4; st++) c = mm3(10 + st, bh[st], bl[st], c);
             if (h == 0) c[0] += seed.x; // row 0 = register 0 of lane half 0
 #pragma unroll
-            for (int i = 0; i < 8; i++) G[(kGOd + rho(i, h)) * kTS + r] = c[i]; // registers 0..7 = rows < 16
+            for (int i = 0; i < 8; i++) G[(kGOd + rho(i, h)) * TSG + r] = c[i]; // registers 0..7 = rows < 16
             split8(c, 0, bh[0], bl[0]);
           }
 #pragma unroll
@@ -541,8 +558,8 @@ void train_tile_kernel(TrainTileParams P) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
               const int row = 32 * mt + rho(i, h);
-              d[mt][i] = A[(kAH1 + row) * kTS + r] > (_Float16)0.0f ? d[mt][i] : 0.0f;
-              G[(kGH1 + row) * kTS + r] = d[mt][i];
+              d[mt][i] = A[(kAH1 + row) * TSA + r] > (_Float16)0.0f ? d[mt][i] : 0.0f;
+              G[(kGH1 + row) * TSG + r] = d[mt][i];
             }
           }
 #pragma unroll
@@ -552,7 +569,7 @@ void train_tile_kernel(TrainTileParams P) {
 #pragma unroll
             for (int st = 0; st < 4; st++) c = mm3(16 + st, bh[st], bl[st], c);
 #pragma unroll
-            for (int i = 0; i < 16; i++) G[(kGFeat + rho(i, h)) * kTS + r] = c[i];
+            for (int i = 0; i < 16; i++) G[(kGFeat + rho(i, h)) * TSG + r] = c[i];
           }
         }
         __syncthreads(); STAMP(12);
@@ -610,6 +627,48 @@ void train_tile_kernel(TrainTileParams P) {
       else if (wave == 1) { xa[0] = kAH2 + 32; ga[0] = kGH3; gv[0] = 32; xa[1] = kAH2 + 32; ga[1] = kGH3 + 32; gv[1] = 32; xa[2] = kAH3 + 32; ga[2] = kGOrr; gv[2] = 16; }
       else if (wave == 2) { xa[0] = kAIn2; ga[0] = kGH2; gv[0] = 32; xa[1] = kAIn2; ga[1] = kGH2 + 32; gv[1] = 32; xa[2] = kAH1; ga[2] = kGOd; gv[2] = 16; }
       else { xa[0] = kAFeat; ga[0] = kGH1; gv[0] = 32; xa[1] = kAFeat; ga[1] = kGH1 + 32; gv[1] = 32; xa[2] = kAH1 + 32; ga[2] = kGOd; gv[2] = 16; }
+      if constexpr (MODE == 2 && !(PRV_TRAIN_ABLATE & 128)) {
+        // bf16 matrix cores, 16 samples per instruction (the f32 form below: 2).  Lane (r, h) supplies 8 consecutive samples
+        // of activation row r (one 16-byte LDS read; tiles 0 and 1 of a wave share it) and of gradient row r (two).  Split
+        // operands as in the chain: the fp16 activation = hi + lo exactly, the f32 gradient = hi + lo to 16 bits,
+        // X g ~ X_hi g_hi + X_lo g_hi + X_hi g_lo in the f32 accumulators: 18 instructions per wave and tile for 48.
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        auto split_x = [&](const half8& x, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const float v = (float)x[j];
+            const __bf16 hv = (__bf16)v;
+            hi[j] = hv;
+            lo[j] = (__bf16)(v - (float)hv);
+          }
+        };
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+          const int s0 = 16 * kk + 8 * h;
+          bf16x8 xh[2], xl[2];
+          split_x(*reinterpret_cast<const half8*>(A + (xa[0] + r) * TSA + s0), xh[0], xl[0]);
+          split_x(*reinterpret_cast<const half8*>(A + (xa[2] + r) * TSA + s0), xh[1], xl[1]);
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const float4* gp = reinterpret_cast<const float4*>(G + (ga[q] + r) * TSG + s0);
+            const float4 g0 = gp[0], g1 = gp[1];
+            const float gvv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const bool valid = r < gv[q];
+            bf16x8 gh, gl;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+              const float v = valid ? gvv[j] : 0.0f;
+              const __bf16 hv = (__bf16)v;
+              gh[j] = hv;
+              gl[j] = (__bf16)(v - (float)hv);
+            }
+            const int x = q >> 1;
+            dw[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[x], gh, dw[q], 0, 0, 0);
+            dw[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[x], gh, dw[q], 0, 0, 0);
+            dw[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[x], gl, dw[q], 0, 0, 0);
+          }
+        }
+      } else {
       // the three tiles' MFMAs interleaved (independent accumulators), operands loaded a group ahead
       float a[3][4], b[3][4];
       for (int k0 = h; k0 < 32; k0 += 8) {
@@ -618,13 +677,14 @@ void train_tile_kernel(TrainTileParams P) {
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const int k = k0 + 2 * j;
-            a[q][j] = (float)A[(xa[q] + r) * kTS + k];
-            b[q][j] = r < gv[q] ? G[(ga[q] + r) * kTS + k] : 0.0f;
+            a[q][j] = (float)A[(xa[q] + r) * TSA + k];
+            b[q][j] = r < gv[q] ? G[(ga[q] + r) * TSG + k] : 0.0f;
           }
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
           for (int q = 0; q < 3; q++) dw[q] = mfma32(a[q][j], b[q][j], dw[q]);
+      }
       }
     }
     // ---- scatter the feature gradients into the canonical table gradient.  f32 atomics run at the memory
@@ -638,7 +698,7 @@ void train_tile_kernel(TrainTileParams P) {
       // A sample's 64 (entry, weight) pairs sit 65 pairs apart: the writers (lanes = samples) then hit 32 different banks
       // (with a stride of 64 all of them hit ONE: half of this kernel's LDS cycles were bank conflicts)
       constexpr int kStageStride = 65;
-      static_assert(32 * kStageStride * 8 <= kARows * kTS * 2, "the staging array lives in the activation region");
+      static_assert(32 * kStageStride * 8 <= kARows * TSA * 2, "the staging array lives in the activation region");
       uint2* stage = reinterpret_cast<uint2*>(A);
       constexpr int NL = 32 / F, NPASS = NL / 8;
       const bool contributes = live && (seed.x != 0.0f || seed.y != 0.0f || seed.z != 0.0f || seed.w != 0.0f);
@@ -674,7 +734,7 @@ void train_tile_kernel(TrainTileParams P) {
                   cur = e.x;
                   acc = 0.0f;
                 }
-                acc += __uint_as_float(e.y) * G[(kGFeat + l * F + k) * kTS + ss]; // (a dead sample's pair carries cur = ~0: never flushed)
+                acc += __uint_as_float(e.y) * G[(kGFeat + l * F + k) * TSG + ss]; // (a dead sample's pair carries cur = ~0: never flushed)
               }
               if (cur != 0xffffffffu) atomicAdd(P.table_grad + (size_t)cur * F + k, acc);
             }
@@ -685,7 +745,7 @@ void train_tile_kernel(TrainTileParams P) {
               const uint2 e = stage[(it >> 6) * kStageStride + (it & 63)];
               if (e.x == 0xffffffffu) continue;
               const int ss = it >> 6, l = pass * 8 + ((it >> 3) & 7);
-              atomicAdd(P.table_grad + (size_t)e.x * F + k, __uint_as_float(e.y) * G[(kGFeat + l * F + k) * kTS + ss]);
+              atomicAdd(P.table_grad + (size_t)e.x * F + k, __uint_as_float(e.y) * G[(kGFeat + l * F + k) * TSG + ss]);
             }
           }
         }
@@ -842,6 +902,7 @@ __global__ __launch_bounds__(256) void train_forward_fast_kernel(TrainTileParams
       keep(0, f0);
       keep(1, f1);
       keep(7, shf);
+      if (h == 0) act[kActPosWord] = __builtin_bit_cast(uint4, make_float4(pos[0], pos[1], pos[2], 0.0f)); // act points at this lane's word: + r
     }
     const MlpOut mo = mlp_forward(wl, lane, f0, f1, shf, [&](int stage, const half8* v) {
       if (!act) return;
@@ -1242,7 +1303,10 @@ __global__ __launch_bounds__(256) void density_refresh_fast_kernel(DensityParams
 
 // ------------------------------------------------------------------ launchers
 
-size_t train_tile_lds_bytes(bool fwd, int) { return 2u * (size_t)(kWLds + kARows * kTS) + (fwd ? 0u : 4u * (size_t)(kGRows * kTS)); }
+size_t train_tile_lds_bytes(bool fwd, int mode) {
+  const int tsa = mode == 2 ? kTSA2 : kTS, tsg = mode == 2 ? kTSG2 : kTS;
+  return 2u * (size_t)(kWLds + kARows * tsa) + (fwd ? 0u : 4u * (size_t)(kGRows * tsg));
+}
 
 hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s) {
   hipLaunchKernelGGL(train_rays_kernel, dim3((P.n_rays + 3) / 4), dim3(256), 0, s, P);

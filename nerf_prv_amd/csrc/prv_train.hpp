@@ -69,6 +69,7 @@ struct TrainTileParams {
   // kBwdFrags x 64 lanes x 8 halfs; NULL: the LDS / f32-MFMA chain
   const uint4* bwd_frags;
 };
+constexpr size_t kActTileBytes = (16 * 64 + 32) * 16; // kept activations of a 32-sample tile: 16 slots x 64 lanes x 16 B, then 32 positions
 constexpr int kBwdFrags = 20; // R3: 2 row tiles | R2: 2 x 4 k-steps | R1: 4 k-steps | D2: 2 row tiles | D1: 4 k-steps
 // slots of mlp_grad_partial for a backward pass launched with n_blocks blocks (the stage of the reduction sits behind them)
 inline int train_dw_slots(int n_blocks) { return n_blocks + n_blocks / 2; } // first launch + the tail launch (launch_train_tiles)

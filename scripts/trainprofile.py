@@ -10,6 +10,8 @@ ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=2500)
 ap.add_argument("--chunk", type=int, default=100)
 ap.add_argument("--members", type=int, default=5)
+ap.add_argument("--save-state", help="after the run: store every member's field under this directory")
+ap.add_argument("--load-state", help="start from the fields stored there and keep them (learning rate 0): ablation builds time the same batches")
 args = ap.parse_args()
 import torch
 from nerf_prv_amd import api, planner
@@ -25,8 +27,12 @@ u8, _ = ctx.render_rgba8(6, cams, None, api.engine_render_opts(W, H, 0, 1, 1e-4,
 d = api.L.FieldDesc(**dict(fd, table_amp=1e-4, density_bias=0.0))
 trs = []
 for e in range(args.members):
-    ctx.fresh_model(e, d, 0x1234 + e)
-    trs.append(api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=args.rays, seed=0x7EA10001 + e)))
+    if args.load_state:
+        ctx.load_model_file(e, os.path.join(args.load_state, f"member{e}.prvf"))
+        trs.append(api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=args.rays, seed=0x7EA10001 + e, lr=1e-30, l2_reg=0.0)))
+    else:
+        ctx.fresh_model(e, d, 0x1234 + e)
+        trs.append(api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=args.rays, seed=0x7EA10001 + e)))
 torch.cuda.synchronize()
 t_all = time.perf_counter()
 done = 0
@@ -40,4 +46,14 @@ while done < args.steps:
     info = trs[0].info()
     print(f"steps {done - n:5d}..{done:5d}: {dt / n * 1e3:7.3f} ms per round of {args.members} member-steps; member 0: {info['samples_last']:7d} samples, "
           f"{info['active_rays']:5d} rays in its last batch", flush=True)
+if os.environ.get("STAMP_SUMS"):  # a PRV_TRAIN_ABLATE=48 build: phase time sums of block 0 of member 0's backward launches
+    import ctypes
+    st = np.zeros(64, np.uint64)
+    ctx.lib.prv_train_debug_stamps(trs[0].handle, st.ctypes.data_as(ctypes.c_void_p))
+    v = st[32:64].astype(np.float64) / 2400.0 / args.steps  # s_memtime ticks at the shader clock (~2.4 GHz) -> us per launch
+    print("bwd phase sums per launch, block 0 (us):", " ".join(f"{i}:{x:.1f}" for i, x in enumerate(v) if x > 0), f"total {v.sum():.1f}")
+if args.save_state:
+    os.makedirs(args.save_state, exist_ok=True)
+    for e in range(args.members):
+        ctx.save_model(e, os.path.join(args.save_state, f"member{e}.prvf"))
 print(f"{args.steps} steps x {args.members} members in {time.perf_counter() - t_all:.2f} s")
