@@ -1116,12 +1116,15 @@ __device__ __forceinline__ void end_step(const AdamParams& P, uint32_t* sample_c
   }
 }
 
+// The table's optimiser state is ONE record per group of four scalars: {w[4], m[4], v[4]}, 48 contiguous bytes (the f32
+// master weights and the moments are the trainer's own: no other code reads them in place).  A touched group then reads and
+// writes one or two lines of state where three separate arrays cost three partial lines each way.
 __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n, float* __restrict__ grad,
-                                                         float* __restrict__ w, float* __restrict__ m,
-                                                         float* __restrict__ v, uint16_t* __restrict__ w16) {
+                                                         float* __restrict__ wmv, uint16_t* __restrict__ w16) {
   const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= n) return;
   const float lr_t = P.state->lr_t;
+  float4* rec = reinterpret_cast<float4*>(wmv + i4 * 3);
   if (i4 + 4 <= n) {
     const float4 g4 = *reinterpret_cast<const float4*>(grad + i4);
     if (g4.x == 0.0f && g4.y == 0.0f && g4.z == 0.0f && g4.w == 0.0f) return; // sparse: untouched entries keep their moments
@@ -1129,15 +1132,14 @@ __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n,
     // the touched scalars of a group are one table entry (F = 4) or two (F = 2): whole-group 16-byte loads and
     // stores of weight and moments instead of four scattered 4-byte ones each (untouched lanes are rewritten as read)
     const float g[4] = {g4.x, g4.y, g4.z, g4.w};
-    const float4 w4 = *reinterpret_cast<const float4*>(w + i4), m4 = *reinterpret_cast<const float4*>(m + i4),
-                 v4 = *reinterpret_cast<const float4*>(v + i4);
+    const float4 w4 = rec[0], m4 = rec[1], v4 = rec[2];
     float ww[4] = {w4.x, w4.y, w4.z, w4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
     for (int k = 0; k < 4; k++)
       if (g[k] != 0.0f) adam_update(P, lr_t, g[k], ww[k], mm[k], vv[k]);
-    *reinterpret_cast<float4*>(w + i4) = make_float4(ww[0], ww[1], ww[2], ww[3]);
-    *reinterpret_cast<float4*>(m + i4) = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    *reinterpret_cast<float4*>(v + i4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    rec[0] = make_float4(ww[0], ww[1], ww[2], ww[3]);
+    rec[1] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    rec[2] = make_float4(vv[0], vv[1], vv[2], vv[3]);
     typedef uint16_t ushort4v __attribute__((ext_vector_type(4)));
     ushort4v h4;
 #pragma unroll
@@ -1145,17 +1147,25 @@ __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n,
     *reinterpret_cast<ushort4v*>(w16 + i4) = h4;
     return;
   }
+  float* r = wmv + i4 * 3;
   for (size_t i = i4; i < n; i++) { // the last, partial group
     const float g = grad[i];
     if (g == 0.0f) continue;
     grad[i] = 0.0f;
-    float ww = w[i], mm = m[i], vv = v[i];
+    const int k = (int)(i - i4);
+    float ww = r[k], mm = r[4 + k], vv = r[8 + k];
     adam_update(P, lr_t, g, ww, mm, vv);
-    w[i] = ww;
-    m[i] = mm;
-    v[i] = vv;
+    r[k] = ww;
+    r[4 + k] = mm;
+    r[8 + k] = vv;
     w16[i] = __builtin_bit_cast(uint16_t, to_half(ww));
   }
+}
+
+// the f32 master weights of a fresh trainer: the model's fp16 table widened into the records (moments zeroed by the caller)
+__global__ __launch_bounds__(256) void widen_table_kernel(const uint16_t* __restrict__ in, size_t n, float* __restrict__ wmv) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) wmv[(i >> 2) * 12 + (i & 3)] = (float)__builtin_bit_cast(_Float16, in[i]);
 }
 
 __global__ __launch_bounds__(256) void adam_mlp_kernel(AdamParams P, float l2_reg, float* __restrict__ grad,
@@ -1412,9 +1422,13 @@ hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, in
   return hipGetLastError();
 }
 
-hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* w, float* m, float* v, uint16_t* w16,
-                             hipStream_t s) {
-  hipLaunchKernelGGL(adam_table_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, P, n, grad, w, m, v, w16);
+hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s) {
+  hipLaunchKernelGGL(adam_table_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, P, n, grad, wmv, w16);
+  return hipGetLastError();
+}
+
+hipError_t launch_widen_table(const uint16_t* in, size_t n, float* wmv, hipStream_t s) {
+  hipLaunchKernelGGL(widen_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, wmv);
   return hipGetLastError();
 }
 

@@ -114,8 +114,9 @@ hipError_t launch_train_composite(const TrainCompositeParams& P, hipStream_t s);
 hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2, hipStream_t s);
 hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, const TrainState* state,
                              unsigned long long* out_used, double* part, uint32_t* ticket, hipStream_t s);
-hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* w, float* m, float* v, uint16_t* w16,
-                             hipStream_t s);
+// wmv: one {w[4], m[4], v[4]} record (48 B) per group of four table scalars, ceil(n / 4) records
+hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s);
+hipError_t launch_widen_table(const uint16_t* in, size_t n, float* wmv, hipStream_t s);
 hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float* w, float* m, float* v, uint16_t* w16,
                            float* w16_as_f32, const float* stage, int end_of_step, hipStream_t s);
 hipError_t launch_widen(const uint16_t* in, size_t n, float* out, hipStream_t s);
