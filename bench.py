@@ -743,7 +743,7 @@ def run_rank(args):
                     "rays_per_step_cap": int(tr.opts.n_rays), "active_rays_last_batch": tr.info()["active_rays"],
                     "samples_per_ray": int(tr.opts.n_samples), "used_samples_last_batch": used, "loss_last": float(losses[-1]),
                     "note": "fresh field, 300 warm-up steps untimed; batch adapts to ~2^18 composited samples per step (upstream's "
-                            "batch); f16-MFMA forward (activations kept), backward dX chain on bf16-split MFMAs + f32-MFMA dW, sparse Adam; samples_per_s uses the last batch's count"}
+                            "batch); f16-MFMA forward (activations kept), backward dX chain and dW on bf16-split MFMAs, sparse Adam; samples_per_s uses the last batch's count"}
         tr.close()
         tcams.close()
 

@@ -3,7 +3,8 @@
 #   usage: scripts/gpu/collect_profiles.sh <tag>      -> gpurun_out/<tag>/...
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/${1:-r04prof}
+TAG=${1:-r04prof}
+O=gpurun_out/$TAG
 mkdir -p $O
 for cfg in "256 baseline" "256 dense" "512 baseline"; do
   set -- $cfg
@@ -22,4 +23,4 @@ f=$(find $O/prof -name "*kernel_stats.csv" | head -1); head -5 "$f"; cp "$f" $O/
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof512 -- python3 bench.py --field 512 --no-cpu-baseline --no-extras --no-training > $O/bench_prof512.json 2> $O/bench_prof512.err
 f=$(find $O/prof512 -name "*kernel_stats.csv" | head -1); head -4 "$f"; cp "$f" $O/bench_kernel_stats_field512.csv
 rm -rf $O/prof $O/prof512 $O/pmc_*/p*/
-bash scripts/gpu/profile_reference_round.sh ${1:-r04prof}/ref > $O/ref.log 2>&1; tail -5 $O/ref.log
+bash scripts/gpu/profile_reference_round.sh $TAG/ref > $O/ref.log 2>&1; tail -5 $O/ref.log
