@@ -55,8 +55,9 @@ struct TrainTileParams {
   float* mlp_grad_partial; // n_blocks slots of PRV_MLP_HALFS floats (backward)
   unsigned long long* stamps; // dev only (PRV_TRAIN_ABLATE & 16)
   // activations of the forward pass, kept for the backward pass (train_forward_fast_kernel writes, the backward tile
-  // kernel reads; NULL or a tile beyond act_cap: the backward pass recomputes them).  16 KB per 32-sample tile:
-  // [tile][slot 0..15][lane half][sample] x 8 halfs -- the B fragments the forward lanes hold, see act_row()
+  // kernel reads; NULL or a tile beyond act_cap: the backward pass recomputes them).  kActTileBytes per 32-sample tile:
+  // [tile][slot 0..15][lane half][sample] x 8 halfs -- the B fragments the forward lanes hold, see act_row() -- then the
+  // tile's 32 sample positions (float4 each)
   uint4* act;
   uint32_t act_cap; // samples covered by `act` (a multiple of 32)
   uint32_t sample_cap; // the most samples a step can list (n_rays x n_samples): act_cap >= sample_cap = no tile is ever recomputed
