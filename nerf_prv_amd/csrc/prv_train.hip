@@ -276,7 +276,7 @@ __device__ __forceinline__ f32x16v layer_tile(const _Float16* __restrict__ Wl, i
 
 template <int F, bool FWD, int MODE = 0> // MODE 0: recompute the forward pass | 1: kept activations, LDS chain | 2: kept activations, register chain
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(2))) // two blocks per CU (74 KB of LDS each): at most 256 registers per lane
+__attribute__((amdgpu_waves_per_eu(2))) // two blocks per CU (74 KB of LDS each; 80 KB for the register-chain instance): at most 256 registers per lane
 void train_tile_kernel(TrainTileParams P) {
   constexpr bool SAVED = MODE != 0;
   static_assert(!(FWD && SAVED), "kept activations are a backward-pass input");
@@ -285,7 +285,7 @@ void train_tile_kernel(TrainTileParams P) {
   // of 4 (mod 8) dwords spreads eight consecutive rows over all 32 banks
   constexpr int TSA = MODE == 2 ? kTSA2 : kTS, TSG = MODE == 2 ? kTSG2 : kTS;
   // weights and activations are fp16 VALUES (working weights, rounded activations): stored as fp16, widened
-  // at the operand read; 21 + 17 KB (+ 36 KB of f32 gradients backward) -> 2 backward / 4 forward blocks per CU
+  // at the operand read; 21 + 17 KB (+ 36 KB of f32 gradients backward; 21 + 20 + 39 KB with the register-chain instance's strides) -> 2 backward / 4 forward blocks per CU
   extern __shared__ float lds[];
 #if (PRV_TRAIN_ABLATE & 48) == 48
   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
