@@ -58,6 +58,13 @@ N_SIMD, MAX_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs
 # fifths of this kernel's instructions are c4 (packed-f16 blend, f32 -> f16 conversions, ReLU).
 ISSUE_CYCLES = {"c2": 2.08, "c4": 4.07, "c8": 8.07, "mfma": 8.0}
 ISSUE_RATE_FILE = os.path.join("profiles", "r04_valu_issue_rate.txt")
+# What bounds the trainer: the f32 adds into the table gradient are served by the memory side
+# at one rate per 64-byte request whatever their shape (scripts/atomic_rate.hip), and the backward pass issues ~27 of them
+# per composited sample (TCC_EA0_ATOMIC of the backward tile kernel at the planner loop's batch: 796,687 per 29.4 K samples).
+ATOMIC_REQ_PEAK_G = 20.5
+ATOMIC_RATE_FILE = os.path.join("profiles", "r04_atomic_request_rate.txt")
+ATOMIC_REQ_PER_SAMPLE = 27.1
+ATOMIC_REQ_FILE = os.path.join("profiles", "r04_train_loop_batch_ablations.txt")
 ISSUE_PEAK_GCYC = N_SIMD * MAX_CLOCK_HZ / 1e9  # 2457.6 G SIMD issue-cycles/s at the 2.4 GHz maximum clock
 VALU_PEAK_GINST = ISSUE_PEAK_GCYC / ISSUE_CYCLES["c4"]  # wave-instructions/s if every instruction were c4 (kept for the detail object)
 ROUND_COST_FILE = os.path.join("profiles", "r04_round_cost.json")  # VALU instructions per wave-round, from the PMC pass
@@ -742,6 +749,10 @@ def run_rank(args):
                     "samples_per_s": used * args.train_steps / dt_tr,
                     "rays_per_step_cap": int(tr.opts.n_rays), "active_rays_last_batch": tr.info()["active_rays"],
                     "samples_per_ray": int(tr.opts.n_samples), "used_samples_last_batch": used, "loss_last": float(losses[-1]),
+                    "atomic_bound": {"bound": "memory-side atomic requests (table-gradient adds)", "peak_g_requests_per_s": ATOMIC_REQ_PEAK_G,
+                                     "peak_source": ATOMIC_RATE_FILE, "requests_per_sample_from_profile": ATOMIC_REQ_PER_SAMPLE,
+                                     "requests_source": ATOMIC_REQ_FILE + " (the planner loop's batch; not re-measured at this one)",
+                                     "frac": used * args.train_steps / dt_tr * ATOMIC_REQ_PER_SAMPLE / (ATOMIC_REQ_PEAK_G * 1e9)},
                     "note": "fresh field, 300 warm-up steps untimed; batch adapts to ~2^18 composited samples per step (upstream's "
                             "batch); f16-MFMA forward (activations kept), backward dX chain and dW on bf16-split MFMAs, sparse Adam; samples_per_s uses the last batch's count"}
         tr.close()

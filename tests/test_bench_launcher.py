@@ -88,6 +88,24 @@ def test_roofline_peak_constants_are_the_committed_microbenchmarks():
     assert abs(bench.ISSUE_PEAK_GCYC - 1024 * 2.4) < 1e-9
 
 
+def test_trainer_atomic_bound_constants_are_the_committed_measurements():
+    """the trainer's `atomic_bound` in the bench line: the request rate is scripts/atomic_rate.hip's (every shape and
+    occupancy of profiles/r04_atomic_request_rate.txt within 8 % of it), the requests per sample the backward tile kernel's
+    TCC_EA0_ATOMIC over the composited samples of the frozen-field run the file records"""
+    import importlib.util
+    import re
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rates = [float(l.split()[-2]) for l in open(os.path.join(ROOT, bench.ATOMIC_RATE_FILE)) if re.match(r"^\d+ x \d+ B", l)]
+    assert len(rates) >= 20 and all(abs(r - bench.ATOMIC_REQ_PEAK_G) <= 0.08 * bench.ATOMIC_REQ_PEAK_G for r in rates), rates
+    text = open(os.path.join(ROOT, bench.ATOMIC_REQ_FILE)).read()
+    m = re.search(r"frozen fields: backward launches \d+, atomic requests per launch (\d+) .*\(mean (\d+)\)", text)
+    per_sample = float(m.group(1)) / float(m.group(2))
+    assert abs(per_sample - bench.ATOMIC_REQ_PER_SAMPLE) <= 0.05 * bench.ATOMIC_REQ_PER_SAMPLE, per_sample
+
+
 def test_roofline_record_is_flat_and_leads_with_the_contract_keys():
     """the driver's parser kept the first 22 keys of `roofline` in rounds 2-3 and lost `frac`: the object is flat (scalars
     and one string only), at most 22 entries, and starts with kernel / bound / frac / peak / achieved / unit / traffic; both
