@@ -59,5 +59,19 @@ int main() {
       }
     }
   }
+  // one CU's own ceiling: the 16 x 16 B shape from 8 ... 256 blocks (blocks go round the XCDs first: one per CU up to 256)
+  printf("%-34s %8s %12s %12s\n", "16 x 16 B, 4 waves per block", "blocks", "G req64/s", "M req64/s per block");
+  for (int blocks : {8, 32, 64, 128, 256, 512}) {
+    const uint32_t n_groups = (uint32_t)(bytes / 4 / 4);
+    hipLaunchKernelGGL(add_kernel, dim3(blocks), dim3(256), 0, 0, tab, n_groups, 4, 64, 8);
+    hipEventRecord(a, 0);
+    hipLaunchKernelGGL(add_kernel, dim3(blocks), dim3(256), 0, 0, tab, n_groups, 4, 64, 4 * iters);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    const double req = (double)blocks * 4 * 4 * iters * 16;
+    printf("%-34s %8d %12.2f %12.1f\n", "", blocks, req / ms / 1e6, req / ms / 1e3 / blocks);
+  }
   return 0;
 }
