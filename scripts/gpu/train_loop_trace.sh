@@ -10,7 +10,8 @@ python3 - $O/train_loop_kernel_stats.csv <<'PY' | tee $O/train_loop_per_round.tx
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("kernel time per round of 5 member-steps (1000 rounds), us; kernels overlap across the members' streams")
+import os
+print(f"kernel time per round of {os.environ.get('MEMBERS', '5')} member-steps (1000 rounds), us; kernels overlap across the members' streams")
 for r in rows[:16]:
     name = re.sub(r"\(.*", "", r["Name"]).replace("prv::", "").replace("(anonymous namespace)::", "")[:60]
     m = re.search(r"(train_\w+|adam_\w+|prepack_\w+|density_\w+)(<[^>]*>)?", r["Name"]); name = m.group(0)[:60] if m else name
