@@ -35,6 +35,24 @@ for t, d in ev:
 print(f"{n_members} member streams ({key}), last {rounds} rounds: wall {(t1 - t0) / rounds / 1e3:.1f} us per round, at least one kernel running "
       f"{busy / rounds / 1e3:.1f} us ({100.0 * busy / (t1 - t0):.0f} %), kernels running on average {area / max(busy, 1):.2f} while any runs, "
       f"sum of kernel durations {area / rounds / 1e3:.1f} us per round")
+# per kernel: the share of the wall time at least one launch of it runs, and how many of them run on average while one does
+by = collections.defaultdict(list)
+for r in sel:
+    n = r["Kernel_Name"]
+    n = n[n.find("train_") if "train_" in n else (n.find("adam_") if "adam_" in n else 0):].split("(")[0][:40]
+    by[n].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+for n, iv in sorted(by.items(), key=lambda kv: -sum(b - a for a, b in kv[1]))[:8]:
+    ev2 = sorted([(a, 1) for a, _ in iv] + [(b, -1) for _, b in iv])
+    cover = area2 = depth2 = 0
+    last2 = ev2[0][0]
+    for t, d in ev2:
+        if depth2 > 0:
+            cover += t - last2
+        area2 += depth2 * (t - last2)
+        depth2 += d
+        last2 = t
+    print(f"  {n:40s} runs {100.0 * cover / (t1 - t0):5.1f} % of the wall time, {area2 / max(cover, 1):.2f} launches at once while it does, "
+          f"{area2 / len(iv) / 1e3:.1f} us per launch")
 gaps = collections.defaultdict(list)
 prev = {}
 for r in sel:
