@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PRV_ABI_VERSION 3 /* 2: prv_field_desc.per_level_scale; 3: prv_render_opts.step_mode, prv_stats.samples_live */
+#define PRV_ABI_VERSION 4 /* 2: prv_field_desc.per_level_scale; 3: prv_render_opts.step_mode, prv_stats.samples_live; 4: prv_train_opts.patch_w / patch_h */
 
 /* error codes (0 = ok, < 0 = error; message via prv_last_error) */
 #define PRV_OK 0
@@ -364,6 +364,12 @@ typedef struct prv_train_opts {
                              (upstream keeps 2^18 samples per batch): after every step active = clamp(target *
                              active / used, active/2, 2*active) within [1, n_rays]; first step min(n_rays,
                              target / n_samples).  0: always n_rays */
+  int32_t patch_w, patch_h; /* > 1: a step's rays are drawn as patches of patch_w x patch_h adjacent pixels of one image
+                               (patch_w * patch_h <= 16; ray j = pixel j % P of patch j / P, rows walked in snake order)
+                               that share one jitter, and the step's sample list is ordered depth step by depth step
+                               inside a patch, so that the samples of a backward tile share table entries (fewer
+                               memory-side atomic requests per step); 0 or 1: every ray its own pixel (the published
+                               i.i.d. sampler).  prv_train_default_opts says which this build defaults to */
 } prv_train_opts;
 typedef struct prv_trainer prv_trainer;
 int prv_train_default_opts(prv_train_opts* opts);

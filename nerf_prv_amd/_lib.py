@@ -82,7 +82,8 @@ class TrainOpts(C.Structure):
     _fields_ = [("n_rays", C.c_int32), ("n_samples", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float),
                 ("beta2", C.c_float), ("eps", C.c_float), ("l2_reg", C.c_float), ("min_T", C.c_float),
                 ("seed", C.c_uint64), ("random_bg", C.c_int32), ("occ_every", C.c_int32), ("occ_decay", C.c_float),
-                ("occ_sigma_thresh", C.c_float), ("target_samples", C.c_int32)]
+                ("occ_sigma_thresh", C.c_float), ("target_samples", C.c_int32), ("patch_w", C.c_int32),
+                ("patch_h", C.c_int32)]
 
 
 _vp = C.c_void_p

@@ -1022,6 +1022,9 @@ int prv_model_export(prv_ctx* c, int slot, uint16_t* table, uint16_t* mlp, uint3
   return PRV_OK;
 } catch (...) { return caught(c); }
 
+// the PRVF container's own version (the prv_field_desc of ABI version 3 onwards); not tied to later ABI bumps
+static constexpr uint32_t kModelFileVersion = 3u;
+
 int prv_model_save_file(prv_ctx* c, int slot, const char* path) try {
   if (!c) return PRV_E_INVALID;
   int rc = check_model(c, slot);
@@ -1033,7 +1036,7 @@ int prv_model_save_file(prv_ctx* c, int slot, const char* path) try {
   if ((rc = prv_model_export(c, slot, table.data(), mlp.data(), occ.data())) != PRV_OK) return rc;
   FILE* f = fopen(path, "wb");
   if (!f) return fail(c, PRV_E_IO, "cannot write %s", path);
-  const uint32_t head[2] = {0x46565250u /* "PRVF" */, (uint32_t)PRV_ABI_VERSION};
+  const uint32_t head[2] = {0x46565250u /* "PRVF" */, kModelFileVersion};
   bool ok = fwrite(head, sizeof(head), 1, f) == 1 && fwrite(&m.desc, sizeof(m.desc), 1, f) == 1 &&
             fwrite(table.data(), 2, table.size(), f) == table.size() && fwrite(mlp.data(), 2, mlp.size(), f) == mlp.size() &&
             fwrite(occ.data(), 4, occ.size(), f) == occ.size();
@@ -1049,10 +1052,10 @@ int prv_model_load_file(prv_ctx* c, int slot, const char* path) try {
   uint32_t head[2] = {0, 0};
   prv_field_desc d;
   uint64_t th = 0, mh = 0, ow = 0;
-  if (fread(head, sizeof(head), 1, f) != 1 || head[0] != 0x46565250u || head[1] != (uint32_t)PRV_ABI_VERSION ||
+  if (fread(head, sizeof(head), 1, f) != 1 || head[0] != 0x46565250u || head[1] != kModelFileVersion ||
       fread(&d, sizeof(d), 1, f) != 1 || prv_model_sizes(&d, &th, &mh, &ow) != PRV_OK) {
     fclose(f);
-    return fail(c, PRV_E_IO, "%s is not a PRVF model file of ABI version %d", path, PRV_ABI_VERSION);
+    return fail(c, PRV_E_IO, "%s is not a PRVF model file of format version %u", path, kModelFileVersion);
   }
   { // the descriptor is input, not truth: the file must have the size it implies BEFORE buffers of that size exist
     const long at = ftell(f);

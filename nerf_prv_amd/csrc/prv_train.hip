@@ -18,6 +18,9 @@
 #include <hip/hip_runtime.h>
 #include "prv_train.hpp"
 
+#ifndef PRV_TRAIN_SCATTER_WAYS
+#define PRV_TRAIN_SCATTER_WAYS 4 // (entry, sum) pairs a scattering thread keeps while it walks a tile's samples (dev: 1 = round 4's run merge)
+#endif
 #ifndef PRV_TRAIN_ABLATE
 #define PRV_TRAIN_ABLATE 0 // dev only: 1 no table scatter, 2 no dW MFMAs, 4 item-parallel scatter (no run merging), 8 no dX chain, 64 no backward tiles at all, 128 dW on the f32 matrix-core form (K = 2), 16 phase time stamps of block 0 (48: summed over its tiles)
 #endif
@@ -121,6 +124,108 @@ __global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) {
     r.jitter = jitter;
     r.n_live = n_live;
     r.offset = offset;
+    r.n_used = 0u;
+    r.pad[0] = r.pad[1] = 0u;
+    P.rays[j] = r;
+  }
+}
+
+// Patch mode (prv_train_opts.patch_w x patch_h = PP > 1): one BLOCK = one patch of PP adjacent pixels of one image, one
+// wave per ray as above.  The rays of a patch share image, jitter and (nearly) their depth range, so the samples of ONE
+// depth step of the PP rays lie within a few pixel footprints of each other -- less than a cell of the finest level at
+// the planner loop's 1280x720.  The patch's live samples are listed depth step by depth step (rays of a step in snake
+// order over the patch): the 32 consecutive samples of a backward tile then share their corner entries on every level,
+// the hashed ones included, and the tile's scatter merges them into one add per entry (train_tile_kernel) -- the
+// memory side's atomic-request rate is what bounds the step (profiles/NOTES.md, round 4).  A ray's samples are no longer
+// contiguous in the list: slot_of[ray * S + k] is the list position of its k-th live sample (the compositing kernel's way in).
+__global__ __launch_bounds__(1024) void train_rays_patch_kernel(TrainRaysParams P) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t pw = (uint32_t)P.patch_w, PP = pw * (uint32_t)P.patch_h; // blockDim.x = 64 PP
+  const uint32_t q = blockIdx.x, j = q * PP + (uint32_t)wv;
+  const uint32_t n_active = P.state->n_active;
+  if (q * PP >= n_active) return; // whole patch beyond this step's ray budget (block-uniform)
+  const bool in_budget = j < n_active;
+  const uint64_t st = (uint64_t)P.state->step * 8u;
+  // image, patch origin and jitter are the PATCH's draws (index q), the background is the ray's (index j)
+  const uint32_t ry = (uint32_t)wv / pw, rx = (ry & 1u) ? pw - 1u - (uint32_t)wv % pw : (uint32_t)wv % pw;
+  const uint32_t img = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 0, q) * (uint64_t)P.n_img) >> 24);
+  const uint32_t px = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 1, q) * (uint64_t)(P.W - P.patch_w + 1)) >> 24) + rx;
+  const uint32_t py = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 2, q) * (uint64_t)(P.H - P.patch_h + 1)) >> 24) + ry;
+  const float jitter = (float)rng_u24(P.seed, st + 3, q) * (1.0f / 16777216.0f);
+  TrainRay r;
+  const CamDev cam = P.cams[img];
+  raygen(cam, (int)px, (int)py, 0.5f, 0.5f, r.o, r.d);
+  float t0, t1;
+  r.t0 = 0.f;
+  r.dt = 0.f;
+  unsigned long long m0 = 0ull, m1 = 0ull;
+  if (ray_aabb(r.o, r.d, t0, t1)) {
+    r.t0 = t0;
+    r.dt = (t1 - t0) / (float)P.S;
+    bool on[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int i = h * 64 + lane;
+      const float t = fmaf((float)i + jitter, r.dt, t0);
+      on[h] = i < P.S && occ_bit(P.occ, P.occ_res, fmaf(t, r.d[0], r.o[0]), fmaf(t, r.d[1], r.o[1]), fmaf(t, r.d[2], r.o[2]));
+    }
+    m0 = __ballot(on[0]);
+    m1 = __ballot(on[1]);
+  }
+  if (!in_budget) m0 = m1 = 0ull;
+  __shared__ unsigned long long mask[16][2];
+  __shared__ uint32_t wtot[2], base;
+  if (lane == 0) {
+    mask[wv][0] = m0;
+    mask[wv][1] = m1;
+  }
+  __syncthreads();
+  // thread i < 128 = depth step i of the patch: how many of the PP rays are live there, and where the step's samples start
+  const int i = (int)threadIdx.x;
+  uint32_t cnt = 0u, excl = 0u;
+  if (i < 128) {
+    for (uint32_t rr = 0; rr < PP; rr++) cnt += (uint32_t)((mask[rr][i >> 6] >> (i & 63)) & 1ull);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t u = __shfl_up(incl, d);
+      if (lane >= d) incl += u;
+    }
+    excl = incl - cnt;
+    if (lane == 63) wtot[wv] = incl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wtot[0] + wtot[1];
+    base = tot ? atomicAdd(P.sample_count, tot) : 0u; // one returning atomic per patch
+  }
+  __syncthreads();
+  if (i < 128 && cnt) {
+    uint32_t pos = base + excl + (wv == 1 ? wtot[0] : 0u);
+    const unsigned long long below = (1ull << (i & 63)) - 1ull;
+    for (uint32_t rr = 0; rr < PP; rr++) {
+      const unsigned long long m = mask[rr][i >> 6];
+      if (!((m >> (i & 63)) & 1ull)) continue;
+      const uint32_t jr = q * PP + rr;
+      const uint32_t k = (uint32_t)__popcll(m & below) + (i >= 64 ? (uint32_t)__popcll(mask[rr][0]) : 0u);
+      P.samples[pos] = make_uint2(jr, (uint32_t)i);
+      P.slot_of[(size_t)jr * (size_t)P.S + k] = pos;
+      pos++;
+    }
+  }
+  if (lane == 0 && in_budget) {
+    float bg[3] = {0.f, 0.f, 0.f};
+    if (P.random_bg)
+      for (int k = 0; k < 3; k++) bg[k] = (float)rng_u24(P.seed, st + 4 + k, j) * (1.0f / 16777216.0f);
+    const uint8_t* gp = P.images + (((size_t)img * P.H + py) * P.W + px) * 4;
+    const float ga = (float)gp[3] * (1.0f / 255.0f);
+    for (int k = 0; k < 3; k++) {
+      r.target[k] = fmaf(srgb_to_linear((float)gp[k] * (1.0f / 255.0f)), ga, (1.0f - ga) * bg[k]);
+      r.bg[k] = bg[k];
+    }
+    r.jitter = jitter;
+    r.n_live = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+    r.offset = 0u; // unused in patch mode (slot_of)
     r.n_used = 0u;
     r.pad[0] = r.pad[1] = 0u;
     P.rays[j] = r;
@@ -725,18 +830,42 @@ void train_tile_kernel(TrainTileParams P) {
           if (!(PRV_TRAIN_ABLATE & 4)) {
             if (tid < 8 * 8 * F) {
               const int k = tid % F, c = (tid / F) & 7, l8 = tid / (8 * F), l = pass * 8 + l8;
-              uint32_t cur = 0xffffffffu;
-              float acc = 0.0f;
+              // kWays (entry, sum) pairs, the oldest evicted first.  One pair = the run merge of round 4 (samples along ONE
+              // ray: an entry comes back only on consecutive samples); patch mode lists a patch depth step by depth step,
+              // where a step's rays alternate between the two to four cells the patch straddles (train_rays_patch_kernel)
+              constexpr int kWays = PRV_TRAIN_SCATTER_WAYS;
+              uint32_t key[kWays];
+              float acc[kWays];
+#pragma unroll
+              for (int w = 0; w < kWays; w++) {
+                key[w] = 0xffffffffu;
+                acc[w] = 0.0f;
+              }
               for (int ss = 0; ss < 32; ss++) {
                 const uint2 e = stage[ss * kStageStride + l8 * 8 + c];
-                if (e.x != cur) {
-                  if (cur != 0xffffffffu) atomicAdd(P.table_grad + (size_t)cur * F + k, acc);
-                  cur = e.x;
-                  acc = 0.0f;
+                if (e.x == 0xffffffffu) continue; // a dead sample or one without a gradient
+                const float gv = __uint_as_float(e.y) * G[(kGFeat + l * F + k) * TSG + ss];
+                bool hit = false;
+#pragma unroll
+                for (int w = 0; w < kWays; w++)
+                  if (e.x == key[w]) { // (keys are distinct: at most one way matches)
+                    acc[w] += gv;
+                    hit = true;
+                  }
+                if (!hit) {
+                  if (key[kWays - 1] != 0xffffffffu) atomicAdd(P.table_grad + (size_t)key[kWays - 1] * F + k, acc[kWays - 1]);
+#pragma unroll
+                  for (int w = kWays - 1; w > 0; w--) {
+                    key[w] = key[w - 1];
+                    acc[w] = acc[w - 1];
+                  }
+                  key[0] = e.x;
+                  acc[0] = gv;
                 }
-                acc += __uint_as_float(e.y) * G[(kGFeat + l * F + k) * TSG + ss]; // (a dead sample's pair carries cur = ~0: never flushed)
               }
-              if (cur != 0xffffffffu) atomicAdd(P.table_grad + (size_t)cur * F + k, acc);
+#pragma unroll
+              for (int w = kWays - 1; w >= 0; w--)
+                if (key[w] != 0xffffffffu) atomicAdd(P.table_grad + (size_t)key[w] * F + k, acc[w]);
             }
           } else { // dev (timing builds): the item-parallel form of rounds 1-3, one add per (sample, level, corner)
             const int k = tid % F;
@@ -958,6 +1087,7 @@ __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositePara
   const float dt = ray->dt;
   // per chunk, per lane: the sample's forward values
   float sg[2], al[2], tb[2], rgb[2][3];
+  uint32_t sid[2] = {0u, 0u}; // list position of the lane's sample (patch mode: through slot_of)
   bool usedl[2] = {false, false};
   float T = 1.0f, C[3] = {0.f, 0.f, 0.f};
   uint32_t used = 0;
@@ -966,7 +1096,8 @@ __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositePara
     const uint32_t k = (uint32_t)ch * 64u + (uint32_t)lane;
     const bool have = !stopped && k < n;
     float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (have) lg = P.logits[off + k];
+    sid[ch] = have ? (P.slot_of ? P.slot_of[(size_t)j * (size_t)P.S + k] : off + k) : 0u;
+    if (have) lg = P.logits[sid[ch]];
     sg[ch] = have ? expf(lg.x + P.density_bias) : 0.0f;
     al[ch] = have ? 1.0f - expf(-(sg[ch] * dt)) : 0.0f;
     rgb[ch][0] = 1.0f / (1.0f + expf(-lg.y));
@@ -1021,7 +1152,11 @@ __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositePara
       d_orr[c] = dC[c] * wgt * rgb[ch][c] * (1.0f - rgb[ch][c]);
       tail[c] += __shfl(incl, 0);
     }
-    if (k < n) P.seeds[off + k] = usedl[ch] ? make_float4(d_sigma * sg[ch], d_orr[0], d_orr[1], d_orr[2]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < n) {
+      // (a sample behind the ray's termination was never fetched: its list position is read here)
+      const uint32_t o = usedl[ch] ? sid[ch] : (P.slot_of ? P.slot_of[(size_t)j * (size_t)P.S + k] : off + k);
+      P.seeds[o] = usedl[ch] ? make_float4(d_sigma * sg[ch], d_orr[0], d_orr[1], d_orr[2]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
@@ -1319,7 +1454,9 @@ size_t train_tile_lds_bytes(bool fwd, int mode) {
 }
 
 hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s) {
-  hipLaunchKernelGGL(train_rays_kernel, dim3((P.n_rays + 3) / 4), dim3(256), 0, s, P);
+  const int pp = P.patch_w * P.patch_h;
+  if (pp > 1) hipLaunchKernelGGL(train_rays_patch_kernel, dim3((P.n_rays + pp - 1) / pp), dim3(64 * pp), 0, s, P);
+  else hipLaunchKernelGGL(train_rays_kernel, dim3((P.n_rays + 3) / 4), dim3(256), 0, s, P);
   return hipGetLastError();
 }
 

@@ -36,8 +36,12 @@ struct TrainRaysParams {
   const TrainState* state; // step number = state->step
   uint64_t seed;
   TrainRay* rays;
-  uint2* samples; // (ray, sample index) of every live sample, grouped by ray
+  uint2* samples; // (ray, sample index) of every live sample, grouped by ray (patch mode: by patch, depth step by depth step)
   uint32_t* sample_count;
+  // patch mode (patch_w * patch_h = P > 1, <= 16): ray j = pixel j % P of patch j / P; slot_of[j * S + k] = the list
+  // position of ray j's k-th live sample (a ray's samples are not contiguous in the list any more)
+  int patch_w, patch_h;
+  uint32_t* slot_of;
 };
 
 struct TrainTileParams {
@@ -84,6 +88,8 @@ struct TrainCompositeParams {
   float density_bias, min_T;
   float* ray_loss;
   uint32_t* ray_used;
+  const uint32_t* slot_of; // patch mode: list position of (ray, k-th live sample), row stride S; NULL: offset + k
+  int S;
 };
 
 struct AdamParams {

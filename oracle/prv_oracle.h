@@ -194,6 +194,9 @@ typedef struct {
   int32_t occ_every; /* refresh the density grid every N steps (0: never) */
   float occ_decay, occ_sigma_thresh; /* ema = max(ema*decay, sigma); occupied iff ema > thresh */
   int32_t target_samples; /* > 0: adaptive ray count, see include/prv.h */
+  int32_t patch_w, patch_h; /* > 1: the step's rays are drawn as patches of patch_w x patch_h adjacent pixels of one
+                               image that share one jitter (ray j = pixel j % P of patch j / P, rows in snake order);
+                               0 or 1: every ray its own pixel */
 } orc_train_opts;
 typedef struct orc_trainer orc_trainer;
 uint32_t orc_rng_u24(uint64_t seed, uint64_t stream, uint64_t i);

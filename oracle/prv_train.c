@@ -168,10 +168,16 @@ static float srgb_to_linear(float c) { return c <= 0.04045f ? c / 12.92f : powf(
 static double tr_ray(orc_trainer* t, uint32_t step, uint32_t j, int grad, tr_sample* S) {
   const orc_train_opts* o = &t->o;
   const uint64_t st = (uint64_t)step * 8u;
-  const uint32_t img = (uint32_t)(((uint64_t)orc_rng_u24(o->seed, st + 0, j) * (uint64_t)t->n_img) >> 24);
-  const uint32_t px = (uint32_t)(((uint64_t)orc_rng_u24(o->seed, st + 1, j) * (uint64_t)t->w) >> 24);
-  const uint32_t py = (uint32_t)(((uint64_t)orc_rng_u24(o->seed, st + 2, j) * (uint64_t)t->h) >> 24);
-  const float jitter = (float)orc_rng_u24(o->seed, st + 3, j) * (1.0f / 16777216.0f);
+  /* the batch rule: ray j is pixel j % P of patch j / P (P = patch_w * patch_h adjacent pixels of one image, rows
+   * walked in snake order); image, patch origin and the jitter are drawn per PATCH, the background per ray.
+   * P = 1: every ray its own pixel, as published. */
+  const uint32_t pw = o->patch_w > 1 ? (uint32_t)o->patch_w : 1u, ph = o->patch_h > 1 ? (uint32_t)o->patch_h : 1u;
+  const uint32_t P = pw * ph, q = j / P, r = j % P;
+  const uint32_t ry = r / pw, rx = (ry & 1u) ? pw - 1u - r % pw : r % pw;
+  const uint32_t img = (uint32_t)(((uint64_t)orc_rng_u24(o->seed, st + 0, q) * (uint64_t)t->n_img) >> 24);
+  const uint32_t px = (uint32_t)(((uint64_t)orc_rng_u24(o->seed, st + 1, q) * (uint64_t)(t->w - (int)pw + 1)) >> 24) + rx;
+  const uint32_t py = (uint32_t)(((uint64_t)orc_rng_u24(o->seed, st + 2, q) * (uint64_t)(t->h - (int)ph + 1)) >> 24) + ry;
+  const float jitter = (float)orc_rng_u24(o->seed, st + 3, q) * (1.0f / 16777216.0f);
   float bg[3] = {0, 0, 0};
   if (o->random_bg)
     for (int k = 0; k < 3; k++) bg[k] = (float)orc_rng_u24(o->seed, st + 4 + k, j) * (1.0f / 16777216.0f);
@@ -261,6 +267,7 @@ static void tr_refresh_fp16(orc_trainer* t) {
 orc_trainer* orc_train_create(const orc_field* init, const orc_train_opts* o, const orc_camera* cams, int n_img, int w,
                               int h, const uint8_t* rgba8, int exact) {
   if (!init || !o || o->n_samples < 1 || o->n_samples > TR_MAX_S || o->n_rays < 1 || n_img < 1) return NULL;
+  if (o->patch_w > w || o->patch_h > h || o->patch_w < 0 || o->patch_h < 0) return NULL;
   orc_trainer* t = (orc_trainer*)calloc(1, sizeof(orc_trainer));
   if (!t) return NULL;
   t->o = *o;

@@ -10,8 +10,10 @@ ap.add_argument("--steps", type=int, default=500)
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--samples", type=int, default=128)
 ap.add_argument("--chunk", type=int, default=100)
+ap.add_argument("--patch", default="", help="WxH: rays drawn as patches of adjacent pixels; default: the library's")
 ap.add_argument("--members", type=int, default=0, help="also time an ensemble of this many members stepping side by side")
 args = ap.parse_args()
+pk = dict(patch_w=int(args.patch.split("x")[0]), patch_h=int(args.patch.split("x")[1])) if args.patch else {}
 import torch
 from nerf_prv_amd import api, planner
 ctx = api.Context(0)
@@ -38,7 +40,7 @@ t, m, o = ctx.export_model(0, d)
 ctx.load_model(0, d, t, m, np.full_like(o, 0xFFFFFFFF))
 eopts = api.render_opts(W, H, 128, 1, 1e-4, background=(0, 0, 0, 1))
 p0, s0 = ctx.evaluate(0, cams, test_ids, eopts, gt_lin[test_ids].contiguous())
-tr = api.Trainer(ctx, 0, train_cams, u8[train_ids].contiguous(), api.train_opts(n_rays=args.rays, n_samples=args.samples))
+tr = api.Trainer(ctx, 0, train_cams, u8[train_ids].contiguous(), api.train_opts(n_rays=args.rays, n_samples=args.samples, **pk))
 tr.steps(2)  # warm-up (allocations, LDS attribute)
 torch.cuda.synchronize()
 done, t0, used = 0, time.perf_counter(), 0
@@ -63,7 +65,7 @@ if args.members > 1:
     trs = []
     for e in range(args.members):
         ctx.fresh_model(e, d, 0x1234 + e)
-        trs.append(api.Trainer(ctx, e, train_cams, u8[train_ids].contiguous(), api.train_opts(n_rays=args.rays, n_samples=args.samples, seed=0x7EA10001 + e)))
+        trs.append(api.Trainer(ctx, e, train_cams, u8[train_ids].contiguous(), api.train_opts(n_rays=args.rays, n_samples=args.samples, seed=0x7EA10001 + e, **pk)))
     api.train_many(trs, 300)  # past the all-occupied start
     torch.cuda.synchronize()
     t0 = time.perf_counter()

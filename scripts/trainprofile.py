@@ -10,6 +10,8 @@ ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=2500)
 ap.add_argument("--chunk", type=int, default=100)
 ap.add_argument("--members", type=int, default=5)
+ap.add_argument("--patch", default="", help="WxH: rays drawn as patches of adjacent pixels (prv_train_opts.patch_w / patch_h); default: the library's")
+ap.add_argument("--eval", action="store_true", help="after the run: PSNR / SSIM of every member on 8 held-out views of the 144-view set")
 ap.add_argument("--save-state", help="after the run: store every member's field under this directory")
 ap.add_argument("--load-state", help="start from the fields stored there and keep them (learning rate 0): ablation builds time the same batches")
 args = ap.parse_args()
@@ -25,14 +27,17 @@ intr = dict(fl_x=915.606689453125, fl_y=913.32666015625, cx=647.1453247070312, c
 cams = ctx.cameras_from_matrices_intr(tms, intr, scale, offset)
 u8, _ = ctx.render_rgba8(6, cams, None, api.engine_render_opts(W, H, 0, 1, 1e-4, background=(0, 0, 0, 0)))
 d = api.L.FieldDesc(**dict(fd, table_amp=1e-4, density_bias=0.0))
+pk = {}
+if args.patch:
+    pk = dict(patch_w=int(args.patch.split("x")[0]), patch_h=int(args.patch.split("x")[1]))
 trs = []
 for e in range(args.members):
     if args.load_state:
         ctx.load_model_file(e, os.path.join(args.load_state, f"member{e}.prvf"))
-        trs.append(api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=args.rays, seed=0x7EA10001 + e, lr=1e-30, l2_reg=0.0)))
+        trs.append(api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=args.rays, seed=0x7EA10001 + e, lr=1e-30, l2_reg=0.0, **pk)))
     else:
         ctx.fresh_model(e, d, 0x1234 + e)
-        trs.append(api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=args.rays, seed=0x7EA10001 + e)))
+        trs.append(api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=args.rays, seed=0x7EA10001 + e, **pk)))
 torch.cuda.synchronize()
 t_all = time.perf_counter()
 done = 0
@@ -52,6 +57,17 @@ if os.environ.get("STAMP_SUMS"):  # a PRV_TRAIN_ABLATE=48 build: phase time sums
     ctx.lib.prv_train_debug_stamps(trs[0].handle, st.ctypes.data_as(ctypes.c_void_p))
     v = st[32:64].astype(np.float64) / 2400.0 / args.steps  # s_memtime ticks at the shader clock (~2.4 GHz) -> us per launch
     print("bwd phase sums per launch, block 0 (us):", " ".join(f"{i}:{x:.1f}" for i, x in enumerate(v) if x > 0), f"total {v.sum():.1f}")
+if args.eval:  # held-out views: rows of the 144-view set the training views skip
+    step = 144 // args.views
+    held = [i for i in range(step // 2, 144, step)][:8]
+    htms, _, _ = planner.hemisphere_transforms(np.asarray(pts)[held], 0.3, 0.1, [1e-10] * 3)
+    hcams = ctx.cameras_from_matrices_intr(htms, intr, scale, offset)
+    eo = api.engine_render_opts(W, H, 0, 1, 1e-4, background=(0, 0, 0, 1))
+    gt_lin, _ = ctx.render(6, hcams, None, api.engine_render_opts(W, H, 0, 1, 1e-4, background=(0, 0, 0, 0)))
+    res = [ctx.evaluate(e, hcams, None, eo, gt_lin) for e in range(args.members)]
+    o0 = trs[0].opts
+    print(f"held-out ({len(held)} views, {W}x{H}) after {args.steps} steps, patch {o0.patch_w}x{o0.patch_h}: PSNR " + " ".join(f"{p:.2f}" for p, _ in res) +
+          f" (mean {np.mean([p for p, _ in res]):.2f}); SSIM " + " ".join(f"{q:.4f}" for _, q in res) + f" (mean {np.mean([q for _, q in res]):.4f})")
 if args.save_state:
     os.makedirs(args.save_state, exist_ok=True)
     for e in range(args.members):

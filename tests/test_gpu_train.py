@@ -237,6 +237,48 @@ def test_ragged_batch_sizes(ctx, oracle, scene, n_rays, n_samples):
     np.testing.assert_allclose(got, want, rtol=5e-3, atol=1e-9)
 
 
+@pytest.mark.parametrize("patch,n_rays,n_samples", [((2, 2), 192, 24), ((4, 4), 192, 24), ((4, 2), 190, 24), ((3, 2), 37, 5),
+                                                    ((4, 4), 130, 128), ((16, 1), 50, 24), ((1, 3), 7, 24)])
+def test_patch_batches_match_the_oracle(ctx, oracle, scene, patch, n_rays, n_samples):
+    """patch mode (prv_train_opts.patch_w x patch_h): the step's rays are patches of adjacent pixels that share a
+    jitter and the sample list runs depth step by depth step inside a patch -- the batch (pixels, live samples,
+    termination) and its loss / gradients are the oracle's under the same rule; ray counts that leave the last
+    patch partial, patches as wide as a row segment, one-sample rays"""
+    f, otr, gtr = start(ctx, oracle, scene, n_rays=n_rays, n_samples=n_samples, patch_w=patch[0], patch_h=patch[1])
+    want_loss, want_tg, want_mg = otr.gradients()
+    loss, tg, mg = gtr.gradients()
+    assert gtr.info()["samples_last"] == otr.samples_last > 0
+    assert loss == pytest.approx(want_loss, rel=1e-3)
+    assert rel_l2(mg, want_mg) < 2e-3 and rel_l2(tg, want_tg) < 2e-3
+    assert np.array_equal(tg != 0, want_tg.astype(np.float32) != 0) or rel_l2(tg, want_tg) < 1e-3
+    # not the i.i.d. batch: the same options without patches draw other pixels
+    _, otr1, _ = start(ctx, oracle, scene, n_rays=n_rays, n_samples=n_samples)
+    assert otr1.gradients()[0] != want_loss
+    f, otr, gtr = start(ctx, oracle, scene, n_rays=n_rays, n_samples=n_samples, patch_w=patch[0], patch_h=patch[1], occ_every=2,
+                        occ_sigma_thresh=0.3)
+    got, want = gtr.steps(4), [otr.step() for _ in range(4)]  # across a density-grid refresh: ragged live masks inside a patch
+    np.testing.assert_allclose(got, want, rtol=5e-3, atol=1e-9)
+    wt, wm = otr.master()
+    gt_, gm = gtr.master()
+    assert rel_l2(gm, wm) < 2e-2 and rel_l2(gt_, wt) < 2e-2
+
+
+def test_patch_mode_with_the_sample_budget_and_bad_patches(ctx, oracle, scene):
+    f, otr, gtr = start(ctx, oracle, scene, n_rays=700, n_samples=24, target_samples=2400, patch_w=4, patch_h=2)
+    assert otr.active_rays == gtr.info()["active_rays"] == 100  # 12 whole patches and half of the 13th
+    sched_o, sched_g = [], []
+    for _ in range(6):
+        otr.step()
+        gtr.steps(1)
+        sched_o.append(otr.active_rays)
+        sched_g.append(gtr.info()["active_rays"])
+    np.testing.assert_allclose(sched_g, sched_o, rtol=0.03)
+    kw, ocams, cams, imgs = scene
+    for bad in (dict(patch_w=5, patch_h=4), dict(patch_w=-1, patch_h=2), dict(patch_w=2, patch_h=17), dict(patch_w=1, patch_h=32)):
+        with pytest.raises(api.PrvError):
+            api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(**bad))
+
+
 def test_rays_that_miss_everything(ctx, oracle, scene):
     """an empty density grid: no sample is live, the loss is the background mismatch alone, nothing moves"""
     kw, ocams, cams, imgs = scene

@@ -31,10 +31,11 @@ def all_occupied(oracle, field):
     return oracle.OracleField(field.desc, params=(t, m, np.full_like(o, 0xFFFFFFFF)))
 
 
-def test_backward_matches_finite_differences(oracle, scene):
+@pytest.mark.parametrize("patch", [(0, 0), (4, 2)])
+def test_backward_matches_finite_differences(oracle, scene, patch):
     d, cams, imgs, _ = scene
     init = all_occupied(oracle, oracle.OracleField(d, seed=util.SEED_A))
-    opts = oracle.train_opts(n_rays=96, n_samples=24, occ_every=0)
+    opts = oracle.train_opts(n_rays=96, n_samples=24, occ_every=0, patch_w=patch[0], patch_h=patch[1])
     tr = oracle.OracleTrainer(init, opts, cams, imgs, exact=True)
     loss, tg, mg = tr.gradients()
     assert loss > 1e-3 and tr.samples_last > 500
@@ -106,6 +107,40 @@ def test_rng_and_batch_are_reproducible(oracle, scene):
     assert la == lb and all(np.array_equal(x, y) for x, y in zip(a.params(), b.params()))
     assert oracle.lib().orc_rng_u24(1, 2, 3) == oracle.lib().orc_rng_u24(1, 2, 3) < (1 << 24)
     assert len({oracle.lib().orc_rng_u24(1, 2, i) for i in range(64)}) > 60
+
+
+def test_patch_batch_rule(oracle, scene):
+    """patch_w x patch_h: ray j is pixel j % P of patch j / P; a patch's rays are adjacent pixels of ONE image (rows in
+    snake order) under ONE jitter -- observed through the loss: a dataset whose images are constant colours that differ
+    per image and an empty density grid make a ray's loss a function of its image (and its own background) alone"""
+    d, cams, imgs, (w, h) = scene
+    f = oracle.OracleField(d, seed=util.SEED_A)
+    t, m, o = f.params()
+    empty = oracle.OracleField(f.desc, params=(t, m, np.zeros_like(o)))
+    flat = np.zeros_like(imgs)
+    for i in range(len(flat)):
+        flat[i, ..., :3] = 20 + 25 * i
+        flat[i, ..., 3] = 255
+    lin = lambda c: np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    seed = 0x7EA10001
+
+    def expected(n_rays, pw, ph):
+        P = max(pw, 1) * max(ph, 1)
+        tot = 0.0
+        for j in range(n_rays):
+            img = (oracle.lib().orc_rng_u24(seed, 0, j // P) * len(flat)) >> 24
+            tgt = np.float32(lin(np.float32((20 + 25 * img) / 255.0)))
+            tot += 3 * float(tgt) ** 2  # black prediction (no samples, random_bg off)
+        return tot / (3 * n_rays)
+
+    for pw, ph, n in ((0, 0, 40), (2, 2, 40), (4, 4, 40), (4, 2, 37)):
+        tr = oracle.OracleTrainer(empty, oracle.train_opts(n_rays=n, n_samples=8, occ_every=0, random_bg=0, patch_w=pw, patch_h=ph, seed=seed), cams, flat)
+        assert tr.loss_only() == pytest.approx(expected(n, pw, ph), rel=1e-5)
+    # patches never leave the image: a patch as large as the image has one possible origin
+    tr = oracle.OracleTrainer(empty, oracle.train_opts(n_rays=w * h, n_samples=8, occ_every=0, random_bg=0, patch_w=w, patch_h=h), cams, flat)
+    assert tr.loss_only() > 0
+    with pytest.raises(Exception):
+        oracle.OracleTrainer(empty, oracle.train_opts(n_rays=4, n_samples=8, patch_w=w + 1, patch_h=1), cams, flat)
 
 
 def test_training_fits_the_images(oracle, scene):
