@@ -151,7 +151,7 @@ __global__ __launch_bounds__(1024) void train_rays_patch_kernel(TrainRaysParams 
   const uint32_t img = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 0, q) * (uint64_t)P.n_img) >> 24);
   const uint32_t px = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 1, q) * (uint64_t)(P.W - P.patch_w + 1)) >> 24) + rx;
   const uint32_t py = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 2, q) * (uint64_t)(P.H - P.patch_h + 1)) >> 24) + ry;
-  const float jitter = (float)rng_u24(P.seed, st + 3, q) * (1.0f / 16777216.0f);
+  const float jitter = (float)rng_u24(P.seed, st + 3, P.patch_ray_jitter ? j : q) * (1.0f / 16777216.0f);
   TrainRay r;
   const CamDev cam = P.cams[img];
   raygen(cam, (int)px, (int)py, 0.5f, 0.5f, r.o, r.d);

@@ -41,6 +41,7 @@ struct TrainRaysParams {
   // patch mode (patch_w * patch_h = P > 1, <= 16): ray j = pixel j % P of patch j / P; slot_of[j * S + k] = the list
   // position of ray j's k-th live sample (a ray's samples are not contiguous in the list any more)
   int patch_w, patch_h;
+  int patch_ray_jitter; // dev only (PRV_TRAIN_PATCH_JITTER=ray): every ray of a patch its own jitter (the oracle has no such mode)
   uint32_t* slot_of;
 };
 

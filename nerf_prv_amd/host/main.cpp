@@ -50,6 +50,7 @@ struct HipScorer {
   int gt_w = 0, gt_h = 0;
   // training in the loop
   int train_steps = 0, train_rays = 0 /* 0: the library default */, train_w = 0, train_h = 0;
+  int train_patch_w = 0, train_patch_h = 0; // yaml train_patch_w / train_patch_h: prv_train_opts.patch_w / patch_h (0: the library default, single pixels)
   prv_field_desc train_desc{};
   uint64_t train_seed = 0x1234;
   bool images_from_files = false; // train_images: files -> the json's file_path PNGs (the reference's data flow)
@@ -143,6 +144,8 @@ struct HipScorer {
       prv_train_opts to;
       prv_train_default_opts(&to);
       if (train_rays > 0) to.n_rays = train_rays;
+      if (train_patch_w > 0) to.patch_w = train_patch_w;
+      if (train_patch_h > 0) to.patch_h = train_patch_h;
       to.seed += (uint64_t)e;
       prv_trainer* tr = nullptr;
       t0 = now_seconds();
@@ -309,6 +312,8 @@ struct HipScorer {
       prv_train_opts to;
       prv_train_default_opts(&to);
       if (train_rays > 0) to.n_rays = train_rays;
+      if (train_patch_w > 0) to.patch_w = train_patch_w;
+      if (train_patch_h > 0) to.patch_h = train_patch_h;
       if (rc == PRV_OK) rc = prv_train_create(ctx, (int)k, jobs[k].cams, jobs[k].imgs, data_w, data_h, &to, &jobs[k].tr);
     }
     std::vector<prv_trainer*> trs;
@@ -611,6 +616,8 @@ int configure_training(prv_ctx* ctx, const FileStorage& fs, const prv_field_desc
   }
   scorer.train_steps = train_steps;
   if (fs.has("train_rays")) scorer.train_rays = (int)fs.num("train_rays"); // else prv_train_default_opts' batch
+  if (fs.has("train_patch_w")) scorer.train_patch_w = (int)fs.num("train_patch_w"); // training rays as patches of adjacent pixels (a speed / quality trade)
+  if (fs.has("train_patch_h")) scorer.train_patch_h = (int)fs.num("train_patch_h");
   scorer.train_w = fs.has("train_width") ? (int)fs.num("train_width") : 0;
   scorer.train_h = fs.has("train_height") ? (int)fs.num("train_height") : 0;
   scorer.train_desc = desc;

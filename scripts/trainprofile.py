@@ -11,6 +11,7 @@ ap.add_argument("--steps", type=int, default=2500)
 ap.add_argument("--chunk", type=int, default=100)
 ap.add_argument("--members", type=int, default=5)
 ap.add_argument("--patch", default="", help="WxH: rays drawn as patches of adjacent pixels (prv_train_opts.patch_w / patch_h); default: the library's")
+ap.add_argument("--tail-single", type=int, default=0, help="after the run: this many single steps, member 0's composited-sample count of each printed (pairs with a PMC pass's last launches)")
 ap.add_argument("--eval", action="store_true", help="after the run: PSNR / SSIM of every member on 8 held-out views of the 144-view set")
 ap.add_argument("--save-state", help="after the run: store every member's field under this directory")
 ap.add_argument("--load-state", help="start from the fields stored there and keep them (learning rate 0): ablation builds time the same batches")
@@ -51,6 +52,12 @@ while done < args.steps:
     info = trs[0].info()
     print(f"steps {done - n:5d}..{done:5d}: {dt / n * 1e3:7.3f} ms per round of {args.members} member-steps; member 0: {info['samples_last']:7d} samples, "
           f"{info['active_rays']:5d} rays in its last batch", flush=True)
+if args.tail_single:
+    counts = []
+    for _ in range(args.tail_single):
+        api.train_many(trs, 1)
+        counts.append(trs[0].info()["samples_last"])
+    print("tail single steps, member 0 composited samples:", " ".join(str(c) for c in counts), f"mean {np.mean(counts):.0f}")
 if os.environ.get("STAMP_SUMS"):  # a PRV_TRAIN_ABLATE=48 build: phase time sums of block 0 of member 0's backward launches
     import ctypes
     st = np.zeros(64, np.uint64)
