@@ -117,6 +117,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-training", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the field512 / baseline-scene / first-hit side measurements")
     ap.add_argument("--train-steps", type=int, default=300)
+    ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the configs[3] sub-object (1024 views of the 512^3 field, strong scaling)")
+    ap.add_argument("--train-patch", default="", help="full_loop: WxH, training rays drawn as patches of adjacent pixels (yaml train_patch_w / "
+                                                      "train_patch_h; a speed / quality trade: profiles/r05_train_patch_study.txt)")
     return ap.parse_args(argv)
 
 
@@ -224,6 +227,20 @@ def first_hit_cpu(f, cam, args, cores):
     with ThreadPoolExecutor(max_workers=len(bands)) as pool:
         list(pool.map(lambda b: orc.first_hit_image(f, cam, args.width, args.height, rows=b), bands))
     return args.height * args.width / (time.perf_counter() - t0), len(bands)
+
+
+def mapped_rccl():
+    """distinct librccl files this process has mapped right now (/proc/self/maps)"""
+    seen = []
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                path = line.split(None, 5)[-1].strip() if line.count(" ") >= 5 else ""
+                if os.path.basename(path).startswith("librccl.so") and path not in seen:
+                    seen.append(path)
+    except OSError:
+        pass
+    return seen
 
 
 def load_json(rel):
@@ -533,6 +550,18 @@ def full_loop(args):
     # final evaluation and the curve's test set on the 64-view set (the reference's is its 100-view file, not shipped with
     # this repository); mode 4's curve at n = 3, 6, ..., 30 views + the 64-view upper bound
     cfg += "\nevaluate: 1\nevaluate_views: 64\ncoverage_view_num_max: 30\ncoverage_view_num_add: 3\ncoverage_view_num_full: 64\n"
+    if getattr(args, "train_patch", ""):
+        pw, ph = (int(x) for x in args.train_patch.split("x"))
+        cfg += f"train_patch_w: {pw}\ntrain_patch_h: {ph}\n"
+
+    def cfg_int(key, default):
+        m = re.search(rf"^{key}\s*:\s*(\d+)", cfg, re.M)
+        return int(m.group(1)) if m else default
+
+    # what the planner will run with: method 3 -> five members (Share_Data.hpp:505-510), method 2 -> two; steps per member and round
+    method = cfg_int("method_of_IG", 3)
+    n_members = 5 if method == 3 else 2 if method == 2 else cfg_int("ensemble_num", 1)
+    n_steps = cfg_int("train_steps", cfg_int("n_steps", 2500))
     path = os.path.join(work, "cfg.yaml")
     with open(path, "w") as fh:
         fh.write(cfg)
@@ -558,8 +587,11 @@ def full_loop(args):
                 out["training_calls"] = len(steps_s)
                 out["training_steps_s"] = sum(steps_s)
                 out["training_total_s"] = sum(train_s)
-                out["member_step_us"] = sum(steps_s) / (len(steps_s) * 5 * 2500) * 1e6  # ensemble_num 5 (method 3), n_steps 2500
-                out["round_of_5_member_steps_ms"] = sum(steps_s) / (len(steps_s) * 2500) * 1e3
+                out["members"], out["steps_per_member_and_round"] = n_members, n_steps
+                out["member_step_us"] = sum(steps_s) / (len(steps_s) * n_members * n_steps) * 1e6
+                out["round_of_5_member_steps_ms"] = sum(steps_s) / (len(steps_s) * n_steps) * 1e3 * 5.0 / n_members
+                if getattr(args, "train_patch", ""):
+                    out["train_patch"] = args.train_patch
             chosen = [l for l in r.stdout.splitlines() if l.startswith("chosen_nbvs:")]
             out["views_chosen_last_object"] = [int(x) for x in chosen[-1].split(":")[1].split()] if chosen else None
         else:
@@ -660,6 +692,61 @@ def run_rank(args):
                       "ranks": comm.world if comm is not None else 0, "transport": comm.transport if comm is not None else None,
                       "records_identical_to_torch_gather": same,
                       "error": None if comm is not None else (comm_info or {}).get("error")}
+
+    if collective is not None:
+        # ONE RCCL per process: the library file the C ABI's communicator resolved (prv_comm_library) next to every librccl
+        # this process has mapped (torch.distributed's "nccl" backend brought its own up first)
+        mapped = mapped_rccl()
+        lib = comm.library if comm is not None else None
+        collective["librccl_mapped"] = mapped
+        collective["librccl_prv_comm"] = lib
+        collective["one_rccl_per_process"] = (len(mapped) <= 1 and (lib is None or not lib["path"] or not mapped or
+                                                                    os.path.realpath(lib["path"]) == os.path.realpath(mapped[0])))
+
+    # BASELINE configs[3] literally, in the SAME multi-GPU run, after the (weak) headline: 1024 candidate views of the
+    # synthetic 512^3 field sharded 1024/N per GPU (128 at N = 8), one all-gather of the records per round, at the headline's
+    # image size.  Timed like the headline (barriers, max over ranks), on the same communicator.
+    config3 = None
+    if world > 1 and not args.no_config3 and not (args.mode == "strong" and args.field == "512" and args.views_total == 1024):
+        import threading
+
+        box = {}
+
+        def work3():
+            try:
+                r3 = Round(env, field_kw("512", args.scene), 1024, args, slots=(2, 3), comm=comm)
+                k3 = max(2, min(5, args.steps))
+                m3 = r3.measure(k3, 1)
+                box["out"] = {
+                    "workload": f"BASELINE configs[3]: 1024 hemisphere views sharded {-(-1024 // world)}/GPU over {world} GPUs, {args.width}x{args.height}, "
+                                f"{args.samples} samples/ray, synthetic 512^3 field (L=16 F=2 log2T=21), one all-gather of 16-B records per round",
+                    "scaling": "strong", "steps": k3, "ms_per_step": m3["elapsed"] / k3 * 1e3,
+                    "views_per_s": 1024 * k3 / m3["elapsed"], "value": m3["ev_all"] * k3 / m3["elapsed"], "unit": "ray-samples/s",
+                    "views_per_gpu": len(r3.my_ids), "timed_path": collective["timed_path"] if collective else None,
+                    "comm_ranks": comm.world if comm is not None else 0,
+                    "rccl_ranks": comm.world if comm is not None and comm.transport == "rccl" else 0,
+                    "ranking_sha256": hashlib.sha256(np.asarray(m3["order"], np.int32).tobytes()).hexdigest()[:16],
+                    "records_sha256": hashlib.sha256(m3["records"].tobytes()).hexdigest()[:16]}
+                r3.close()
+            except Exception as e:
+                box["out"] = {"error": f"{type(e).__name__}: {e}"}
+
+        # on a watchdog like the communicator's bring-up: the headline is measured already, and a rank that hangs (or fails
+        # alone) in this side measurement must not cost the run its line -- the line goes out without `config3`, the job
+        # then exits non-zero
+        th = threading.Thread(target=work3, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("PRV_BENCH_CONFIG3_TIMEOUT", "240")))
+        if th.is_alive():
+            config3 = {"error": "no answer within the watchdog's limit"}
+            any_hung = True
+        else:
+            config3 = box.get("out")
+            if use_dist:  # one rank failing alone leaves the others in a barrier above: they hit the watchdog; here all returned
+                bad = torch.tensor([1.0 if (config3 is None or "error" in config3) else 0.0], device=red_device)
+                dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+                if bad.item() > 0 and config3 is not None and "error" not in config3:
+                    config3 = {"error": f"{int(bad.item())} rank(s) failed the configs[3] round"}
 
     extras = {}
     solo_ok = rank == 0 and world == 1 and not args.no_extras  # side measurements only in the N = 1 run
@@ -812,6 +899,9 @@ def run_rank(args):
             lifted["ngp_step_samples_per_s"] = extras["ngp_step"]["value"]
         if training:
             lifted["training_steps_per_s"] = training["steps_per_s"]
+        if config3 and "views_per_s" in config3:
+            lifted["config3_views_per_s"] = config3["views_per_s"]
+            lifted["config3_ms_per_step"] = config3["ms_per_step"]
         if loop and "seconds_per_object" in loop:
             lifted["full_loop_s_per_object"] = loop["seconds_per_object"]
             lifted["full_loop_member_step_us"] = loop.get("member_step_us")
@@ -838,6 +928,8 @@ def run_rank(args):
             "training": training,
         })
         out.update(extras)
+        if config3 is not None:
+            out["config3"] = config3
         if loop is not None:
             out["full_loop"] = loop
         if cpu is None:

@@ -325,6 +325,10 @@ void prv_comm_destroy(prv_comm* comm);
 int prv_comm_rank(const prv_comm* comm);
 int prv_comm_world(const prv_comm* comm);
 const char* prv_comm_transport(const prv_comm* comm); /* "rccl" | "socket" */
+/* which librccl the communicator's calls land in (transport "rccl"; empty strings / 0 for "socket"): the file's path as
+ * the dynamic loader resolved it, ncclGetVersion's code, and how it was found -- "PRV_RCCL_LIB", "already mapped by the
+ * process" (the host program's own copy, e.g. torch.distributed's: ONE RCCL per process) or "soname search" */
+int prv_comm_library(const prv_comm* comm, char* path_out, int path_cap, int* version_out, char* how_out, int how_cap);
 /* recv_dev = world blocks of bytes_per_rank in rank order, identical on every rank; enqueued on the context's stream */
 int prv_comm_all_gather(prv_comm* comm, const void* send_dev, size_t bytes_per_rank, void* recv_dev);
 int prv_comm_barrier(prv_comm* comm);

@@ -132,6 +132,18 @@ int prvh_star_barrier(prvh_star*);
 
 int prvh_nbv_loop(prvh_share_data* sd, const double center[3], double predicted_size, int first_view_id,
                   int test_id, prvh_score_fn score, void* user, prvh_loop_result* out);
+/* 1 when nbv_loop runs this method_of_IG (0, 2, 3, 5); 0 for RandomOneshot = 1 and PVBCoverage = 4 (main.cpp:1981-2037,
+ * 2163-2242: the PRVNet pipeline, outside this build's scope) -- prvh_nbv_loop refuses those with -10 before it
+ * writes anything */
+int prvh_method_in_scope(int method_of_IG);
+
+/* DEPRECATED, kept so that binaries linked against the round 1-3 library still load: both belonged to the out-of-scope
+ * methods (the view budget of method 4; the PCD reader of the asset preparation).  Each returns PRVH_E_UNSUPPORTED and
+ * touches nothing. */
+#define PRVH_E_UNSUPPORTED (-95)
+long long prvh_pcd_read(const char* path, float* xyz_out, uint8_t* rgb_out, long long capacity);
+int prvh_nbv_loop_budget(prvh_share_data* sd, const double center[3], double predicted_size, int first_view_id,
+                         int test_id, prvh_score_fn score, void* user, int view_budget, prvh_loop_result* out);
 
 #ifdef __cplusplus
 }

@@ -155,6 +155,7 @@ SIGNATURES = {
     "prv_comm_rank": (_i, [_vp]),
     "prv_comm_world": (_i, [_vp]),
     "prv_comm_transport": (C.c_char_p, [_vp]),
+    "prv_comm_library": (_i, [_vp, C.c_char_p, _i, _P(_i), C.c_char_p, _i]),
     "prv_comm_all_gather": (_i, [_vp, _vp, C.c_size_t, _vp]),
     "prv_comm_barrier": (_i, [_vp]),
     "prv_shard_views": (_i, [_i, _i, _i, _i, _vp, C.POINTER(_i)]),

@@ -405,6 +405,13 @@ class Comm:
     def transport(self):
         return self.ctx.lib.prv_comm_transport(self.handle).decode()
 
+    @property
+    def library(self):
+        """{"path", "version", "found"}: the librccl file this communicator's calls land in (empty for "socket")"""
+        path, how, ver = C.create_string_buffer(1024), C.create_string_buffer(128), C.c_int(0)
+        self.ctx._chk(self.ctx.lib.prv_comm_library(self.handle, path, len(path), C.byref(ver), how, len(how)))
+        return {"path": path.value.decode(), "version": int(ver.value), "found": how.value.decode()}
+
     def all_gather(self, send):
         """send: device tensor -> device uint8 tensor of world blocks in rank order"""
         t = self.ctx.torch

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <cstdio>
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
@@ -163,7 +164,7 @@ private:
   enum : uint32_t { kSeated = 0, kRetry = 1, kWorldMismatch = 2, kBadRank = 3 };
   struct Hello {
     uint32_t magic;
-    uint32_t seq;   // joiner -> rank 0: unused (0); rank 0 -> joiner: the communicator's sequence number at rank 0
+    uint32_t seq;   // joiner -> rank 0: how many stars this process has opened before this one; rank 0 -> joiner: the communicator's sequence number at rank 0
     uint64_t nonce; // the job: a hash of MASTER_PORT and the job token
     int32_t rank, world;
     uint32_t verdict, pad; // rank 0's answer: kSeated, or why not
@@ -182,6 +183,11 @@ private:
   static uint32_t next_seq() {
     static std::atomic<uint32_t> n{0};
     return n.fetch_add(1);
+  }
+  static bool job_has_token() {
+    const char* a = getenv("PRV_COMM_TOKEN");
+    const char* b = getenv("TORCHELASTIC_RUN_ID");
+    return (a && *a) || (b && *b);
   }
   static double since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -224,6 +230,13 @@ private:
       if (since(t0) > timeout_s) return fail("bind " + addr_text + ": " + std::string(strerror(err)) + " (for the whole timeout)");
       std::this_thread::sleep_for(std::chrono::milliseconds(100)); // a previous job's listener may linger briefly
     }
+    if (want.sin_addr.s_addr == htonl(INADDR_ANY) && !job_has_token()) {
+      // every interface, and the only thing that tells this job's ranks from a stranger is a hash of MASTER_PORT: say so once
+      static std::atomic<bool> warned{false};
+      if (!warned.exchange(true))
+        fprintf(stderr, "prv_star: rank 0 listens on EVERY interface (MASTER_ADDR '%s' is not a local literal) and the job has no token: "
+                        "set PRV_COMM_TOKEN (or run under torchrun, TORCHELASTIC_RUN_ID) so that only this job's ranks are seated\n", addr_text.c_str());
+    }
     if (::listen(listen_fd_, world + 16) != 0) return fail("listen()");
     peers_.assign((size_t)world, -1);
     int arrived = 1;
@@ -250,6 +263,9 @@ private:
         ::close(fd);
         continue;
       }
+      if (h.seq != seq) // seated all the same (rank 0 dictates the number), but a straggler of an attempt this rank gave up on looks like this
+        fprintf(stderr, "prv_star: rank %d joins communicator #%u of rank 0 as its own #%u: the ranks do not count alike (an earlier rendezvous "
+                        "timed out on one side?)\n", h.rank, seq, h.seq);
       tune(fd);
       peers_[(size_t)h.rank] = fd;
       arrived++;
@@ -260,13 +276,14 @@ private:
   }
   bool join(const addrinfo* res, double timeout_s) {
     const uint64_t nonce = job_nonce();
+    const uint32_t mine = next_seq(); // this process's own count of stars (rank 0 compares, prv_star: ... do not count alike)
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
       const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
       if (fd < 0) return fail("socket()");
       if (::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
         set_timeouts(fd, std::max(1.0, std::min(timeout_s - since(t0), 30.0)));
-        const Hello hello{kMagic, 0, nonce, rank, world, 0, 0};
+        const Hello hello{kMagic, mine, nonce, rank, world, 0, 0};
         Hello ack{};
         // seated = rank 0 answered with an acknowledgement; a listener that closes the connection without a word is
         // not this job's (or died), a kRetry answer is this job's listener of an earlier communicator: try again

@@ -1303,6 +1303,12 @@ __global__ __launch_bounds__(256) void widen_table_kernel(const uint16_t* __rest
   if (i < n) wmv[(i >> 2) * 12 + (i & 3)] = (float)__builtin_bit_cast(_Float16, in[i]);
 }
 
+// ... and back: the w part of every record, contiguous (prv_train_master: one linear device-to-host copy afterwards)
+__global__ __launch_bounds__(256) void narrow_table_kernel(const float* __restrict__ wmv, size_t n, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = wmv[(i >> 2) * 12 + (i & 3)];
+}
+
 __global__ __launch_bounds__(256) void adam_mlp_kernel(AdamParams P, float l2_reg, float* __restrict__ grad,
                                                        float* __restrict__ w, float* __restrict__ m,
                                                        float* __restrict__ v, uint16_t* __restrict__ w16,
@@ -1566,6 +1572,11 @@ hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* 
 
 hipError_t launch_widen_table(const uint16_t* in, size_t n, float* wmv, hipStream_t s) {
   hipLaunchKernelGGL(widen_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, wmv);
+  return hipGetLastError();
+}
+
+hipError_t launch_narrow_table(const float* wmv, size_t n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(narrow_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, wmv, n, out);
   return hipGetLastError();
 }
 

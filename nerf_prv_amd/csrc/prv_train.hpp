@@ -125,6 +125,7 @@ hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, in
 // wmv: one {w[4], m[4], v[4]} record (48 B) per group of four table scalars, ceil(n / 4) records
 hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s);
 hipError_t launch_widen_table(const uint16_t* in, size_t n, float* wmv, hipStream_t s);
+hipError_t launch_narrow_table(const float* wmv, size_t n, float* out, hipStream_t s); // the records' w parts, contiguous
 hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float* w, float* m, float* v, uint16_t* w16,
                            float* w16_as_f32, const float* stage, int end_of_step, hipStream_t s);
 hipError_t launch_widen(const uint16_t* in, size_t n, float* out, hipStream_t s);

@@ -292,6 +292,15 @@ int prvh_nbv_loop(prvh_share_data* h, const double center[3], double predicted_s
 } catch (...) { return PRVH_E_INTERNAL; }
 
 
+int prvh_method_in_scope(int method_of_IG) { return NBV_Net_Labeler::method_in_scope(method_of_IG) ? 1 : 0; }
+
+// deprecated entry points of the out-of-scope methods (include/prv_host.h): present, inert
+long long prvh_pcd_read(const char*, float*, uint8_t*, long long) { return PRVH_E_UNSUPPORTED; }
+int prvh_nbv_loop_budget(prvh_share_data*, const double*, double, int, int, prvh_score_fn, void*, int, prvh_loop_result* out) {
+  if (out) out->n_chosen = 0;
+  return PRVH_E_UNSUPPORTED;
+}
+
 static void put_err(char* err, int cap, const std::string& m) {
   if (err && cap > 0) snprintf(err, (size_t)cap, "%s", m.c_str());
 }

@@ -50,6 +50,7 @@ struct HipScorer {
   int gt_w = 0, gt_h = 0;
   // training in the loop
   int train_steps = 0, train_rays = 0 /* 0: the library default */, train_w = 0, train_h = 0;
+  bool dump_records = false; // view_planning sets it (yaml dump_scores: 1, or PRV_PLANNER_DUMP_RECORDS in the environment)
   int train_patch_w = 0, train_patch_h = 0; // yaml train_patch_w / train_patch_h: prv_train_opts.patch_w / patch_h (0: the library default, single pixels)
   prv_field_desc train_desc{};
   uint64_t train_seed = 0x1234;
@@ -204,25 +205,38 @@ struct HipScorer {
       }
       std::string text, err;
       prvjson::Value root;
-      if (!prvjson::read_file(a.screenshot_transforms, text) || !prvjson::Parser(text).parse(root, err)) return -31;
+      if (!prvjson::read_file(a.screenshot_transforms, text) || !prvjson::Parser(text).parse(root, err)) {
+        std::cerr << "prv: cannot read " << a.screenshot_transforms << (err.empty() ? "" : ": " + err) << std::endl;
+        prv_camset_destroy(cams);
+        return -31;
+      }
       const prv_render_opts o = candidate_opts(cams);
       const int n = prv_camset_count(cams);
+      if (!root.has("frames") || (int)root.at("frames").arr.size() != n) { // the names below index the same array the cameras came from
+        std::cerr << "prv: " << a.screenshot_transforms << ": " << n << " cameras but " << (root.has("frames") ? root.at("frames").arr.size() : 0) << " frames" << std::endl;
+        prv_camset_destroy(cams);
+        return -32;
+      }
       const size_t bytes = (size_t)o.width * o.height * 4;
       uint8_t* dev = nullptr;
       std::vector<uint8_t> px(bytes);
       int rc = prv_malloc(ctx, (void**)&dev, (size_t)std::max(1, n) * bytes);
       if (rc == PRV_OK) rc = prv_render_rgba8(ctx, slot, cams, nullptr, n, &o, dev, nullptr);
+      if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
       sd->access_directory(a.screenshot_dir);
       for (int k = 0; rc == PRV_OK && k < n; k++) {
         std::string name = root.at("frames").arr[(size_t)k].at("file_path").s; // os.path.basename(f["file_path"]) (run.py:297)
         name = name.substr(name.find_last_of('/') + 1);
         if (name.find('.') == std::string::npos) name += ".png";
         rc = prv_memcpy_d2h(ctx, px.data(), dev + (size_t)k * bytes, bytes);
-        if (rc == PRV_OK && png_write_rgba8(a.screenshot_dir + name, o.width, o.height, px.data()) != 0) rc = PRV_E_IO;
+        if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+        else if (png_write_rgba8(a.screenshot_dir + name, o.width, o.height, px.data()) != 0) {
+          std::cerr << "prv: cannot write " << a.screenshot_dir + name << std::endl; // (not prv_last_error: the failure is the file's)
+          rc = PRV_E_IO;
+        }
       }
       if (dev) prv_free(ctx, dev);
       prv_camset_destroy(cams);
-      if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
       return rc;
     }
     if (!a.test_transforms.empty()) {
@@ -434,7 +448,7 @@ struct HipScorer {
       return rc;
     }
     for (int k = 0; k < n; k++) scores[k] = rec[k].score;
-    if (getenv("PRV_PLANNER_DUMP_RECORDS")) { // tests: the gathered records of every iteration, byte for byte
+    if (dump_records) { // yaml dump_scores / PRV_PLANNER_DUMP_RECORDS (view_planning): the gathered records of every iteration, byte for byte
       sd->access_directory(sd->save_path + "/records");
       write_text(sd->save_path + "/records/" + std::to_string(iteration) + ".bin",
                  std::string((const char*)rec.data(), rec.size() * sizeof(prv_score_record)));
@@ -474,6 +488,11 @@ prv_field_desc field_from_config(const FileStorage& fs) {
 }
 
 int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name, int method, prv_comm* comm) {
+  if (!NBV_Net_Labeler::method_in_scope(method)) { // before any directory, model or training: methods 1 / 4 are the PRVNet pipeline's
+    std::cerr << "method_of_IG " << method << " is not built: this planner runs methods 0 (RandomIterative), 2 (EnsembleRGB), 3 "
+                 "(EnsembleRGBDensity) and 5 (PSNRCoverage); 1 (RandomOneshot) and 4 (PVBCoverage) need the reference's PRVNet server" << std::endl;
+    return -10;
+  }
   auto sd = std::make_shared<Share_Data>(cfg, name, -1, -1, method); // main.cpp:3876
   if (!sd->ok) {
     std::cerr << sd->error << std::endl;
@@ -486,7 +505,7 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   const prv_field_desc desc = field_from_config(fs);
   const int members = (method == EnsembleRGB || method == EnsembleRGBDensity) ? sd->ensemble_num : 1;
   const int train_steps = configured_train_steps(fs, *sd);
-  if (train_steps == 0 && method != RandomIterative && method != RandomOneshot && method != PVBCoverage)
+  if (train_steps == 0 && method != RandomIterative)
     std::cerr << "WARNING: the members are NOT retrained on the chosen views (train_steps: 0 / pretrained_members: 1): "
                  "the view ranking of this run does not depend on the views it acquires (the reference retrains "
                  "n_steps per member per iteration, main.cpp:1668)" << std::endl;
@@ -525,7 +544,16 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
     if (rc != PRV_OK) return rc;
   }
   if (fs.has("evaluate_views")) scorer.eval_views = (int)fs.num("evaluate_views");
+  // diagnostics of the shell, not of the loop: every iteration's scores (raw doubles) and gathered records on disk
+  const bool dump_scores = (fs.has("dump_scores") && fs.num("dump_scores") > 0) || getenv("PRV_PLANNER_DUMP_RECORDS") != nullptr;
+  scorer.dump_records = dump_scores; // (before the labeler copies the scorer)
   NBV_Net_Labeler labeler(sd, center, size, scorer);
+  if (dump_scores) {
+    labeler.on_scores = [sd](int iteration, const std::vector<int>&, const std::vector<double>& scores) {
+      sd->access_directory(sd->save_path + "/scores");
+      write_text(sd->save_path + "/scores/" + std::to_string(iteration) + ".bin", std::string((const char*)scores.data(), scores.size() * sizeof(double)));
+    };
+  }
   labeler.get_coverage(); // <gt_path>/<N>.json (main.cpp:3882-3978, json part)
   if (fs.has("coverage_images") && fs.num("coverage_images") > 0 && train_steps > 0) {
     const int rc = write_coverage_images(ctx, sd);

@@ -180,6 +180,9 @@ public:
   EvalFn evaluator;   // empty: `evaluate: 1` is ignored
   std::vector<int> chosen_nbvs;
   std::vector<double> last_scores;
+  // called after every scoring iteration with (iteration, unchosen view ids, their scores): logging / test dumps live in
+  // the shell that installs it, not in the loop
+  std::function<void(int, const std::vector<int>&, const std::vector<double>&)> on_scores;
   double total_movement_cost = 0.0;
   double final_psnr = -1.0, final_ssim = -1.0; // the final evaluation's metrics, when it ran
 
@@ -265,11 +268,22 @@ public:
     return ensemble_uncertainty_from_pngs(method, files, out);
   }
 
-  // main.cpp:1718-2277, methods 0-5; chosen views in `chosen_nbvs`
+  // Methods 1 (RandomOneshot, main.cpp:1981-2037) and 4 (PVBCoverage, :2163-2242: PRVNet's view budget) never render and
+  // are outside this build's scope: refused BEFORE the loop writes anything, with a message.
+  static bool method_in_scope(int method) {
+    return method == RandomIterative || method == EnsembleRGB || method == EnsembleRGBDensity || method == PSNRCoverage;
+  }
+
+  // main.cpp:1718-2277 for methods 0, 2, 3 (and 5, this build's single-model score); chosen views in `chosen_nbvs`
   int nbv_loop(int first_view_id = -1, int test_id = 0) {
     if (first_view_id == -1) first_view_id = 0; // :1725-1728
     Share_Data& sd = *share_data;
-    if (sd.method_of_IG != PVBCoverage) { // :1735-1747: the other methods run with the budget method 4 found
+    if (!method_in_scope(sd.method_of_IG)) {
+      std::cerr << "nbv_loop: method_of_IG " << sd.method_of_IG << " is not built (RandomOneshot = 1 and PVBCoverage = 4 belong to the "
+                   "reference's PRVNet pipeline, outside this build's scope); nothing was written" << std::endl;
+      return -10;
+    }
+    { // :1735-1747: the methods run with the view budget a method-4 run of the REFERENCE left behind, when there is one
       std::ifstream fin(sd.pre_path + "Compare/ShapeNet/" + sd.name_of_pcd + "_m4_v1_t" + std::to_string(test_id) + "/view_budget.txt");
       int view_budget = 0;
       if (fin.is_open() && (fin >> view_budget) && view_budget > 0) sd.num_of_max_iteration = view_budget - 1;
@@ -342,12 +356,11 @@ public:
           std::vector<double> scores(candidates.size(), 0.0);
           if (sd.score_from_pngs && sd.method_of_IG != PSNRCoverage) {
             // the reference's data flow, call for call: one engine run per member (:2041-2043, :2101-2103), then the PNGs
-            const double t0 = now_seconds();
+            // (no train_time/<it>.txt here: the reference writes it for ensemble_id == -1 only, :1707-1711)
             for (int ensemble_id = 0; ensemble_id < sd.ensemble_num; ensemble_id++) {
               const int rc = train_by_instantNGP(it, "100", true, ensemble_id);
               if (rc != 0) return rc;
             }
-            write_text(sd.save_path + "/train_time/" + it + ".txt", std::to_string(now_seconds() - t0) + "\n");
             for (size_t k = 0; k < candidates.size(); k++) {
               const int rc = view_uncertainty_from_pngs(sd.method_of_IG, it, candidates[k], &scores[k]);
               if (rc != 0) return rc;
@@ -357,10 +370,7 @@ public:
             if (rc != 0) return rc;
           }
           last_scores = scores;
-          if (getenv("PRV_PLANNER_DUMP_RECORDS")) { // tests: this iteration's scores as raw doubles, either score path
-            sd.access_directory(sd.save_path + "/scores");
-            write_text(sd.save_path + "/scores/" + it + ".bin", std::string((const char*)scores.data(), scores.size() * sizeof(double)));
-          }
+          if (on_scores) on_scores(iteration, candidates, scores); // an observer the shell may install (prv_planner: dump_scores)
           double largest_view_uncertainty = -1e100; // :1971
           int best_view_id = -1;
           for (size_t k = 0; k < candidates.size(); k++) // ascending ids, strict '>' (:2088-2091)
@@ -371,9 +381,7 @@ public:
           next_view_id = best_view_id;
           break;
         }
-        // methods 1 (RandomOneshot) and 4 (PVBCoverage, PRVNet's view budget) never render: SURVEY section 2 keeps them out
-        // of this build's scope; they are refused, not silently mapped to something else
-        default:
+        default: // unreachable: method_in_scope() was checked before anything was written
           return -10;
       }
       if (next_view_id < 0) return -11;

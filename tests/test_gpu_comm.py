@@ -286,6 +286,45 @@ def test_bench_eight_ranks_shard_1024_views_of_the_512_field(tmp_path):
     assert eight["records_sha256"] == ref["records_sha256"]  # 1024 records, byte for byte
     assert eight["ranking_sha256"] == ref["ranking_sha256"] and eight["ranking_head"] == ref["ranking_head"]
     assert eight["samples_evaluated_per_step_per_gpu"] > 0
+    # ... and what the driver's `bench.py --gpus 8` (the WEAK headline) carries beside it: the `config3` sub-object -- the same
+    # 1024 views of the 512^3 field, sharded 128 per rank on the same communicator, timed after the headline
+    weak = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--views-per-gpu", "2", "--width", "40", "--height", "32",
+            "--no-extras", "--no-training", "--no-cpu-baseline", "--no-full-loop", "--gpus", "8"]
+    out = subprocess.run(weak, capture_output=True, text=True, env=dict(env, PRV_BENCH_SHARED_GPU="1"), timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert line["scaling"] == "weak" and line["config"]["views_total"] == 16 and line["comm_ranks"] == 8
+    c3 = line["config3"]
+    assert "error" not in c3, c3
+    assert c3["views_per_gpu"] == 128 and c3["comm_ranks"] == 8 and c3["scaling"] == "strong" and c3["views_per_s"] > 0
+    assert c3["records_sha256"] == ref["records_sha256"] and c3["ranking_sha256"] == ref["ranking_sha256"]
+    assert line["config3_views_per_s"] == c3["views_per_s"]
+    # which librccl: the socket transport loads none of its own, and the process maps at most the one torch links
+    col = line["collective"]
+    assert col["librccl_prv_comm"] == {"path": "", "version": 0, "found": ""} and col["one_rccl_per_process"] is True
+    assert isinstance(col["librccl_mapped"], list) and len(col["librccl_mapped"]) <= 1
+
+
+def test_bench_rccl_communicator_runs_on_the_librccl_the_process_already_has(tmp_path):
+    """`PRV_FORCE_DIST=1 python bench.py`: torch.distributed comes up on "nccl" (torch's bundled librccl) and THEN the C ABI's
+    communicator on transport "rccl": it must resolve to the SAME library file (dlopen RTLD_NOLOAD of what the process has
+    mapped), not to a second copy found by soname -- one RCCL per process.  One rank: the calls are the real
+    ncclCommInitRank / ncclAllGather."""
+    import json
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PRV_RCCL_LIB")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--views-per-gpu", "3", "--width", "96", "--height", "80",
+           "--no-extras", "--no-training", "--no-cpu-baseline", "--no-full-loop"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, PRV_FORCE_DIST="1", MASTER_PORT=str(free_port())), timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    col = line["collective"]
+    assert col["transport"] == "rccl" and line["rccl_ranks"] == 1 and col["records_identical_to_torch_gather"] is True
+    lib = col["librccl_prv_comm"]
+    assert lib["path"] and lib["version"] > 0, lib
+    assert len(col["librccl_mapped"]) == 1 and os.path.realpath(col["librccl_mapped"][0]) == os.path.realpath(lib["path"]), col
+    assert lib["found"] == "already mapped by the process" and col["one_rccl_per_process"] is True
 
 
 def _rccl_shared_device_worker(rank, port, q):

@@ -162,9 +162,10 @@ def test_144_view_set_trained_field_psnr_ranked_next_best_view(ctx, oracle, shap
     got_order, want_order = ctx.rank(rec, ids), oracle.rank(want[:, 0], ids)
     assert got_order[0] == want_order[0] == ctx.argmax(rec, ids) == oracle.argmax(want[:, 0], ids)  # the next-best view
     swapped = np.flatnonzero(got_order != want_order)
-    for p in swapped:  # only views the oracle itself can barely tell apart may trade places
-        assert abs(want[got_order[p], 0] - want[want_order[p], 0]) <= 2e-3 * abs(want[want_order[p], 0])
-    assert len(swapped) <= 8, (len(swapped), "of 144 positions differ")
+    # north_star: integer view rankings bit-exact -- no tolerance; on failure the message lists the oracle's own relative
+    # score gaps of the swapped positions (a near-tie below the score agreement above is the one excusable cause)
+    gaps = [(int(p), int(got_order[p]), int(want_order[p]), float(abs(want[got_order[p], 0] - want[want_order[p], 0]) / abs(want[want_order[p], 0]))) for p in swapped]
+    assert np.array_equal(got_order, want_order), f"{len(swapped)} of 144 positions differ (position, got, want, relative oracle score gap): {gaps}"
     assert want[:, 1].max() - want[:, 1].min() > 1.0  # PSNR does separate the views (dB)
     cams.close()
     ds.close()
@@ -213,9 +214,10 @@ def _ranked_144_views_full_size_field(ctx, oracle):
     got_order, want_order = ctx.rank(rec, ids), oracle.rank(want[:, 0], ids)
     assert got_order[0] == want_order[0] == ctx.argmax(rec, ids)  # the next-best view
     swapped = np.flatnonzero(got_order != want_order)
-    for p in swapped:  # only views the oracle itself can barely tell apart may trade places
-        assert abs(want[got_order[p], 0] - want[want_order[p], 0]) <= 2e-3 * abs(want[want_order[p], 0])
-    assert len(swapped) <= 12, (len(swapped), "of 144 positions differ")
+    # north_star: integer view rankings bit-exact -- no tolerance; on failure the message lists the oracle's own relative
+    # score gaps of the swapped positions (a near-tie below the score agreement above is the one excusable cause)
+    gaps = [(int(p), int(got_order[p]), int(want_order[p]), float(abs(want[got_order[p], 0] - want[want_order[p], 0]) / abs(want[want_order[p], 0]))) for p in swapped]
+    assert np.array_equal(got_order, want_order), f"{len(swapped)} of 144 positions differ (position, got, want, relative oracle score gap): {gaps}"
     assert want[:, 1].max() - want[:, 1].min() > 1.0
     cams.close()
     ds.close()

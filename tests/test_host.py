@@ -247,9 +247,19 @@ def test_view_budget_of_an_earlier_method4_run_caps_the_loop_and_out_of_scope_me
 
     chosen = sd.nbv_loop([1e-10] * 3, 0.1, scorer, first_view_id=1)
     assert len(chosen) == 3 and seen == [0, 1]  # budget 3 -> 2 iterations after the initial view
+    host = planner.host()
+    assert [host.prvh_method_in_scope(m) for m in range(-1, 7)] == [0, 1, 0, 1, 1, 0, 1, 0]
     for method in (1, 4):
+        sdm = planner.ShareData(config, f"m{method}", -1, -1, method)
         with pytest.raises(RuntimeError, match="rc=-10"):
-            planner.ShareData(config, f"m{method}", -1, -1, method).nbv_loop([1e-10] * 3, 0.1, lambda *a: [0], first_view_id=1)
+            sdm.nbv_loop([1e-10] * 3, 0.1, lambda *a: [0], first_view_id=1)
+        # refused BEFORE any side effect: no <save_path>_v1_t0 tree, no movement/-1.txt
+        assert not os.path.exists(sdm.string("save_path") + "_v1_t0")
+    # the entry points of those methods that earlier rounds exported still resolve, and do nothing
+    res = planner.LoopResult()
+    c = np.zeros(3)
+    assert host.prvh_nbv_loop_budget(sd.h, c.ctypes.data, 0.1, 1, 0, planner.SCORE_FN(lambda *a: 0), None, 3, res) == -95 and res.n_chosen == 0
+    assert host.prvh_pcd_read(b"/nonexistent.pcd", None, None, 0) == -95
 
 
 def test_metrics_file_format_and_roundtrip(tmp_path):
