@@ -72,6 +72,8 @@ struct prv_ctx {
   Model models[PRV_MAX_MODELS];
   // grow-only workspaces
   Buffer queue, queue_ext, stage, counters, view_ids, img_f32, partial, records, dbg[6];
+  Buffer counters_multi, occ_multi; // the ensemble's one-launch march: queue heads + counts per member, the interleaved occupancy bytes
+  int march_multi = -1;             // PRV_MARCH_MULTI=0/1 (-1: on where an instance exists, render_ensemble_ngp)
   Buffer img_u8[PRV_MAX_MODELS];
   bool profiling = false;
   std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs of the current profiling window
@@ -483,7 +485,10 @@ CamDev cam_at(const prv_camset* cs, int i, int w, int h) {
 // pass's own rejection test): a ray through pixel p meets a convex box only if p lies in the box's projection, which lies
 // in the bounding rectangle of its eight projected corners -- provided all eight are in front of the camera.  The march
 // pass skips whole 256-pixel tiles outside it before any per-ray work (most of an 800x800 view of the bench scene).
-void set_cull_rect(CamDev& cam, const Model& m, int W, int H) {
+struct OccBox { // the bounding box of a model's occupied cells (Model::occ_lo / occ_hi), or of several models'
+  float occ_lo[3], occ_hi[3];
+};
+void set_cull_rect(CamDev& cam, const OccBox& m, int W, int H) {
   cam.cull[0] = cam.cull[1] = cam.cull[2] = cam.cull[3] = 0; // not set
   if (cam.lens[0] != 0.f || cam.lens[1] != 0.f || cam.lens[2] != 0.f || cam.lens[3] != 0.f) return;
   if (!(m.occ_hi[0] > m.occ_lo[0])) { // empty occupancy grid: every tile is dead
@@ -526,9 +531,43 @@ void set_cull_rect(CamDev& cam, const Model& m, int W, int H) {
   cam.cull[3] = (int)std::max<long>(0, std::min<long>(H, y1));
 }
 
+void set_cull_rect(CamDev& cam, const Model& m, int W, int H) {
+  OccBox b;
+  for (int a = 0; a < 3; a++) {
+    b.occ_lo[a] = m.occ_lo[a];
+    b.occ_hi[a] = m.occ_hi[a];
+  }
+  set_cull_rect(cam, b, W, H);
+}
+
 constexpr size_t kStatOffset = 1024;                        // counters buffer: heads 0..511, counts 512..1023, then the statistics
 constexpr size_t kCountersBytes = kStatOffset + 72 * 8; // {evaluated, wave rounds, clock sums and stamps}, then 8 live-sample shards a cache line apart
 
+
+// which render_queue64 instance and relocation policy a launch gets (results are identical either way)
+void render_policy(prv_ctx* c, const Model& m, size_t npix, bool ngp, RenderParams& rp) {
+  // Tail merge + the block's tail pool raise slot utilisation (0.77 -> 0.93) at the price of incoherent gathers from the
+  // relocated rays.  That pays where the gathers of a fresh cohort are coherent to begin with and the table is cache
+  // resident -- large images of the 256^3 field: launch -8 % -- and costs elsewhere: the 512^3 field is bound by random
+  // HBM requests (+2...5 %), and at the reference's 80x45 candidates neighbouring rays are five finest cells apart
+  // (+3...7 %).  Results are identical either way; the default follows table and image size (PRV_MERGE_MAX / PRV_POOL
+  // override).  Measured: profiles/r02_k_tail_merge.txt, profiles/r02_r_tail_pool.txt
+  const bool coherent = m.table_halfs * 2 <= ((size_t)32 << 20) && npix >= ((size_t)1 << 17);
+  // The per-lane corner cache: under the engine's stepping rule a ray's consecutive samples share their cell on the hashed
+  // levels about half of the time, and where the cohort's gathers are incoherent (small images: every corner of every lane
+  // its own cache line) the launch is bound by the L2's request rate -- 9.5 L2 requests per sample, 135 G/s, the ceiling
+  // scripts/gather_calib.hip finds for this footprint (profiles/r04_reference_round_*) -- so a lane whose cell did not
+  // change skips its eight loads of that level.  Costs ~50 VGPRs (two waves per SIMD, which those images run with
+  // anyway) and a few VALU per level; off for large images, whose launch is issue-bound, and for the F = 2 fields (six
+  // hashed levels do not fit the registers).  Cell keys hold 10 bits per axis.  PRV_CELL_CACHE overrides.
+  const bool cached = (c->cell_cache >= 0 ? c->cell_cache != 0 : (ngp && !coherent)) && m.desc.finest_res <= 1023 &&
+                      m.desc.n_features == 4 && m.dev.hash_shared && m.dev.n_dense_levels == 5;
+  rp.cell_cache = cached ? 1 : 0;
+  // With the cache in place the small-image launch is no longer request-bound and fuller slots pay again: relocation on
+  // (merge threshold 24, pool), 0.68 -> 0.95 slot utilisation, -13 % launch time (profiles/r04_cell_cache_ab.txt)
+  rp.merge_max = c->merge_max >= 0 ? c->merge_max : (coherent ? 16 : cached ? 24 : 0);
+  rp.pool_on = (c->pool_on >= 0 ? c->pool_on != 0 : (coherent || cached)) && rp.merge_max > 0;
+}
 
 // The render of one batch of views into out_f32 (+ optional out_u8).  Views are dealt to
 // the queue in batches so the queue stays within queue_budget bytes.
@@ -696,27 +735,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     rp.inv_spp = 1.0f;
     rp.spp_k = 0;
     rp.last_pass = mp.last_pass;
-    // Tail merge + the block's tail pool raise slot utilisation (0.77 -> 0.93) at the price of incoherent gathers from the
-    // relocated rays.  That pays where the gathers of a fresh cohort are coherent to begin with and the table is cache
-    // resident -- large images of the 256^3 field: launch -8 % -- and costs elsewhere: the 512^3 field is bound by random
-    // HBM requests (+2...5 %), and at the reference's 80x45 candidates neighbouring rays are five finest cells apart
-    // (+3...7 %).  Results are identical either way; the default follows table and image size (PRV_MERGE_MAX / PRV_POOL
-    // override).  Measured: profiles/r02_k_tail_merge.txt, profiles/r02_r_tail_pool.txt
-    const bool coherent = m.table_halfs * 2 <= ((size_t)32 << 20) && npix >= ((size_t)1 << 17);
-    // The per-lane corner cache: under the engine's stepping rule a ray's consecutive samples share their cell on the hashed
-    // levels about half of the time, and where the cohort's gathers are incoherent (small images: every corner of every lane
-    // its own cache line) the launch is bound by the L2's request rate -- 9.5 L2 requests per sample, 135 G/s, the ceiling
-    // scripts/gather_calib.hip finds for this footprint (profiles/r04_reference_round_*) -- so a lane whose cell did not
-    // change skips its eight loads of that level.  Costs ~50 VGPRs (two waves per SIMD, which those images run with
-    // anyway) and a few VALU per level; off for large images, whose launch is issue-bound, and for the F = 2 fields (six
-    // hashed levels do not fit the registers).  Cell keys hold 10 bits per axis.  PRV_CELL_CACHE overrides.
-    const bool cached = (c->cell_cache >= 0 ? c->cell_cache != 0 : (ngp && !coherent)) && m.desc.finest_res <= 1023 &&
-                        m.desc.n_features == 4 && m.dev.hash_shared && m.dev.n_dense_levels == 5;
-    rp.cell_cache = cached ? 1 : 0;
-    // With the cache in place the small-image launch is no longer request-bound and fuller slots pay again: relocation on
-    // (merge threshold 24, pool), 0.68 -> 0.95 slot utilisation, -13 % launch time (profiles/r04_cell_cache_ab.txt)
-    rp.merge_max = c->merge_max >= 0 ? c->merge_max : (coherent ? 16 : cached ? 24 : 0);
-    rp.pool_on = (c->pool_on >= 0 ? c->pool_on != 0 : (coherent || cached)) && rp.merge_max > 0;
+    render_policy(c, m, npix, ngp, rp);
     memcpy(rp.bg, o->background, sizeof(rp.bg));
     if (c->profiling) {
       hipEvent_t a, b;
@@ -730,6 +749,207 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_render.back(), c->stream));
     if (spp > 1) HIPCHK(c, launch_spp_reduce((const float*)c->stage.p, (size_t)nb * npix, spp, o->background, dst_f32, dst_u8, c->stream));
   }
+  return PRV_OK;
+}
+
+// The ensemble's candidates under the engine's stepping rule: ONE march launch for all members (march_multi_kernel: one
+// walk per ray answers every member's occupancy), then one render launch + sub-sample reduce per member from that member's
+// own queue.  Every member's masks, records and images are what render_views gives it on its own; only the order of the
+// records in the queues differs (as between any two launches).  Returns PRV_OK with *done = false when this path does not
+// apply (the caller then renders member by member).
+int render_ensemble_ngp(prv_ctx* c, const int* slots, int E, const prv_camset* cs, const int* view_ids, int n_views,
+                        const prv_render_opts* o, float* scratch_f32, uint8_t* const* out_u8, bool* done) {
+  *done = false;
+  if (o->step_mode != PRV_STEP_NGP || !march_multi_supported(E) || n_views == 0) return PRV_OK;
+  if (c->march_multi == 0) return PRV_OK;
+  // measured (profiles/r05_march_multi.txt): five members 15.6 -> 7.5 ms per round of the reference's size; two members 6.2 ->
+  // 7.0 (the launch walks twice, which two members do not win back): on by default from three members up
+  if (c->march_multi < 0 && E < 3) return PRV_OK;
+  const Model& m0 = c->models[slots[0]];
+  for (int e = 1; e < E; e++) {
+    const Model& m = c->models[slots[e]];
+    if (m.desc.occ_res != m0.desc.occ_res || (m.dev.occ_coarse == nullptr) != (m0.dev.occ_coarse == nullptr)) return PRV_OK;
+    for (int f = 0; f < e; f++)
+      if (slots[f] == slots[e]) return PRV_OK; // (a slot listed twice is legal for the member-by-member path)
+  }
+  const int W = o->width, H = o->height, spp = o->spp;
+  const size_t npix = (size_t)W * H;
+  const size_t slot_bytes = kRecordBytes + kExtBytes;
+  // all views in ONE batch, every member with a queue and a staging image of its own: refuse (-> member by member, batched)
+  // when that does not fit the budgets
+  if ((size_t)n_views * npix * (size_t)spp >= (1ull << 32)) return PRV_OK;
+  if ((size_t)n_views * npix * (size_t)spp * slot_bytes > c->queue_budget) return PRV_OK; // per member, as render_views batches
+  if (spp > 1 && (size_t)n_views * npix * (size_t)spp * 16 > c->stage_budget) return PRV_OK;
+  int rc;
+  if ((rc = ensure(c, c->counters, kCountersBytes)) != PRV_OK) return rc;
+  if ((rc = ensure(c, c->counters_multi, (size_t)E * kStatOffset)) != PRV_OK) return rc;
+  unsigned long long* stat = (unsigned long long*)((char*)c->counters.p + kStatOffset);
+
+  // the members' union box: clip range and cull rectangles (conservative for every member)
+  OccBox box;
+  for (int a = 0; a < 3; a++) {
+    box.occ_lo[a] = 1e30f;
+    box.occ_hi[a] = -1e30f;
+  }
+  bool any = false;
+  for (int e = 0; e < E; e++) {
+    const Model& m = c->models[slots[e]];
+    if (!(m.occ_hi[0] > m.occ_lo[0])) continue; // an empty grid adds nothing
+    any = true;
+    for (int a = 0; a < 3; a++) {
+      box.occ_lo[a] = std::min(box.occ_lo[a], m.occ_lo[a]);
+      box.occ_hi[a] = std::max(box.occ_hi[a], m.occ_hi[a]);
+    }
+  }
+  if (!any)
+    for (int a = 0; a < 3; a++) box.occ_lo[a] = box.occ_hi[a] = 0.f;
+
+  const size_t up_bytes = (size_t)n_views * (sizeof(CamDev) + sizeof(int));
+  if (c->pin_cap < up_bytes) {
+    if (c->pin_ev) HIPCHK(c, hipEventSynchronize(c->pin_ev));
+    if (c->pin) (void)hipHostFree(c->pin);
+    c->pin = nullptr;
+    c->pin_cap = 0;
+    HIPCHK(c, hipHostMalloc(&c->pin, std::max<size_t>(up_bytes, 8192), hipHostMallocDefault));
+    c->pin_cap = std::max<size_t>(up_bytes, 8192);
+  }
+  if (!c->pin_ev) HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev, hipEventDisableTiming));
+  else HIPCHK(c, hipEventSynchronize(c->pin_ev));
+  CamDev* cams = (CamDev*)c->pin;
+  int* ids = (int*)((char*)c->pin + (size_t)n_views * sizeof(CamDev));
+  for (int i = 0; i < n_views; i++) {
+    const int v = view_ids ? view_ids[i] : i;
+    if (v < 0 || v >= (int)cs->cams.size()) return fail(c, PRV_E_INVALID, "view id %d out of range", v);
+    cams[i] = cam_at(cs, v, W, H);
+    set_cull_rect(cams[i], box, W, H);
+    ids[i] = i;
+  }
+  if ((rc = ensure(c, c->view_ids, up_bytes)) != PRV_OK) return rc;
+  CamDev* cams_dev = (CamDev*)c->view_ids.p;
+  int* ids_dev = (int*)((char*)c->view_ids.p + (size_t)n_views * sizeof(CamDev));
+  HIPCHK(c, hipMemcpyAsync(c->view_ids.p, c->pin, up_bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->pin_ev, c->stream));
+
+  // the members' occupancy, interleaved: byte c = bit c of every member's bitfield (fine grid, then the dilated coarse one)
+  const size_t R = (size_t)m0.desc.occ_res, n_fine = R * R * R, Rc = R / 4, n_coarse = Rc * Rc * Rc;
+  const bool have_coarse = m0.dev.occ_coarse != nullptr;
+  if ((rc = ensure(c, c->occ_multi, n_fine + n_coarse + 64)) != PRV_OK) return rc;
+  {
+    OccInterleaveParams ip{};
+    ip.n_members = E;
+    for (int e = 0; e < E; e++) ip.bits[e] = c->models[slots[e]].dev.occ;
+    ip.n_cells = (uint32_t)n_fine;
+    ip.out = (uint8_t*)c->occ_multi.p;
+    HIPCHK(c, launch_occ_interleave(ip, c->stream));
+    if (have_coarse) {
+      for (int e = 0; e < E; e++) ip.bits[e] = c->models[slots[e]].dev.occ_coarse;
+      ip.n_cells = (uint32_t)n_coarse;
+      ip.out = (uint8_t*)c->occ_multi.p + n_fine;
+      HIPCHK(c, launch_occ_interleave(ip, c->stream));
+    }
+  }
+
+  const int n_seg = c->queue_segments;
+  int inner = 0;
+  if (spp > 1 && spp <= 64 && (spp & (spp - 1)) == 0)
+    while ((1 << inner) < spp) inner++;
+  const int pix_log2 = 8 - inner;
+  const int tile_w_log2 = (pix_log2 + 1) / 2, tile_h_log2 = pix_log2 / 2;
+  const uint32_t tiles_x = (uint32_t)((W + (1 << tile_w_log2) - 1) >> tile_w_log2), tiles_y = (uint32_t)((H + (1 << tile_h_log2) - 1) >> tile_h_log2);
+  const size_t blocks = (size_t)tiles_x * tiles_y * (size_t)n_views * (size_t)(inner > 0 ? 1 : spp);
+  const size_t seg_cap = ((blocks + n_seg - 1) / n_seg) * 256;
+  if (seg_cap * (size_t)n_seg >= (1ull << 32)) return PRV_OK;
+  const size_t q_stride = seg_cap * (size_t)n_seg * kRecordBytes, x_stride = seg_cap * (size_t)n_seg * kExtBytes,
+               s_stride = spp > 1 ? (size_t)n_views * npix * (size_t)spp * 16 : 0;
+  if ((rc = ensure(c, c->queue, q_stride * (size_t)E)) != PRV_OK) return rc;
+  if ((rc = ensure(c, c->queue_ext, x_stride * (size_t)E)) != PRV_OK) return rc;
+  if (spp > 1 && (rc = ensure(c, c->stage, s_stride * (size_t)E)) != PRV_OK) return rc;
+  HIPCHK(c, hipMemsetAsync(c->counters.p, 0, kCountersBytes, c->stream)); // a new statistics window (this call renders every member)
+  HIPCHK(c, hipMemsetAsync(c->counters_multi.p, 0, (size_t)E * kStatOffset, c->stream));
+
+  MarchMultiParams mp;
+  memset(&mp, 0, sizeof(mp));
+  mp.occ_bytes = (const uint8_t*)c->occ_multi.p;
+  mp.occ_coarse_bytes = have_coarse ? (const uint8_t*)c->occ_multi.p + n_fine : nullptr;
+  mp.occ_res = (int)R;
+  for (int a = 0; a < 3; a++) {
+    mp.occ_lo[a] = box.occ_lo[a];
+    mp.occ_hi[a] = box.occ_hi[a];
+  }
+  mp.cams = cams_dev;
+  mp.view_ids = ids_dev;
+  mp.W = W;
+  mp.H = H;
+  mp.spp_k = 0;
+  mp.tiles_x = tiles_x;
+  mp.tiles_y = tiles_y;
+  mp.tile_w_log2 = tile_w_log2;
+  mp.tile_h_log2 = tile_h_log2;
+  mp.spp_inner_log2 = inner;
+  mp.stat = stat;
+  mp.n_seg = n_seg;
+  mp.seg_cap = (uint32_t)seg_cap;
+  mp.inv_spp = 1.0f;
+  mp.last_pass = spp == 1;
+  memcpy(mp.bg, o->background, sizeof(mp.bg));
+  mp.n_members = E;
+  for (int e = 0; e < E; e++) {
+    MarchMember& mm = mp.mem[e];
+    mm.queue = (char*)c->queue.p + q_stride * (size_t)e;
+    mm.queue_ext = (uint4*)((char*)c->queue_ext.p + x_stride * (size_t)e);
+    mm.queue_count = (uint32_t*)((char*)c->counters_multi.p + (size_t)e * kStatOffset) + 128;
+    // spp > 1: the member's own staging image; spp == 1: the caller's scratch image is shared (nobody reads it), the bytes are the member's
+    mm.out_f32 = spp > 1 ? (float*)((char*)c->stage.p + s_stride * (size_t)e) : scratch_f32;
+    mm.out_u8 = spp > 1 ? nullptr : (uint32_t*)out_u8[e];
+  }
+  if (c->profiling) {
+    hipEvent_t a, b;
+    HIPCHK(c, take_event(c, &a));
+    HIPCHK(c, take_event(c, &b));
+    c->ev_march.push_back(a);
+    c->ev_march.push_back(b);
+    HIPCHK(c, hipEventRecord(a, c->stream));
+  }
+  HIPCHK(c, launch_march_multi(mp, n_views, spp, c->stream));
+  if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_march.back(), c->stream));
+
+  for (int e = 0; e < E; e++) {
+    const Model& m = c->models[slots[e]];
+    int bpc = c->blocks_per_cu;
+    if (bpc <= 0) bpc = m.table_halfs * 2 > ((size_t)32 << 20) ? 1 : npix < ((size_t)1 << 17) ? 2 : 4;
+    RenderParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.field = m.dev;
+    rp.queue = mp.mem[e].queue;
+    rp.queue_ext = mp.mem[e].queue_ext;
+    rp.step_mode = o->step_mode;
+    rp.queue_count = mp.mem[e].queue_count;
+    rp.queue_head = (uint32_t*)((char*)c->counters_multi.p + (size_t)e * kStatOffset);
+    rp.n_segments = n_seg;
+    rp.seg_cap = mp.seg_cap;
+    rp.stat_evaluated = stat;
+    rp.out_f32 = mp.mem[e].out_f32;
+    rp.out_u8 = mp.mem[e].out_u8;
+    rp.min_T = o->min_transmittance;
+    rp.inv_spp = 1.0f;
+    rp.spp_k = 0;
+    rp.last_pass = mp.last_pass;
+    render_policy(c, m, npix, true, rp);
+    memcpy(rp.bg, o->background, sizeof(rp.bg));
+    if (c->profiling) {
+      hipEvent_t a, b;
+      HIPCHK(c, take_event(c, &a));
+      HIPCHK(c, take_event(c, &b));
+      c->ev_render.push_back(a);
+      c->ev_render.push_back(b);
+      HIPCHK(c, hipEventRecord(a, c->stream));
+    }
+    HIPCHK(c, launch_render(rp, c->n_cu * bpc, c->stream));
+    if (c->profiling) HIPCHK(c, hipEventRecord(c->ev_render.back(), c->stream));
+    if (spp > 1)
+      HIPCHK(c, launch_spp_reduce((const float*)mp.mem[e].out_f32, (size_t)n_views * npix, spp, o->background, scratch_f32, (uint32_t*)out_u8[e], c->stream));
+  }
+  *done = true;
   return PRV_OK;
 }
 
@@ -792,6 +1012,7 @@ int prv_create(prv_ctx** out, int device_id) try {
   if (const char* s = getenv("PRV_MERGE_MAX")) c->merge_max = std::min(31, std::max(0, atoi(s)));
   if (const char* s = getenv("PRV_POOL")) c->pool_on = atoi(s) != 0 ? 1 : 0;
   if (const char* s = getenv("PRV_CELL_CACHE")) c->cell_cache = atoi(s) != 0 ? 1 : 0;
+  if (const char* s = getenv("PRV_MARCH_MULTI")) c->march_multi = atoi(s) != 0 ? 1 : 0;
   if (const char* s = getenv("PRV_QUEUE_MB")) c->queue_budget = (size_t)std::max(1, atoi(s)) << 20;
   g_live_contexts.fetch_add(1);
   if (device_id < 64) g_devices_used.fetch_or(1ull << device_id);
@@ -1549,13 +1770,16 @@ int prv_score_views(prv_ctx* c, int method, const int* model_slots, int n_models
   if ((rc = ensure(c, c->img_f32, std::max<size_t>(16, (size_t)n_views * npix * 16))) != PRV_OK) return rc;
   if (ens) {
     const uint8_t* imgs[PRV_MAX_MODELS];
+    uint8_t* out8[PRV_MAX_MODELS];
     for (int e = 0; e < n_models; e++) {
       if ((rc = ensure(c, c->img_u8[e], std::max<size_t>(16, (size_t)n_views * npix * 4))) != PRV_OK) return rc;
       imgs[e] = (const uint8_t*)c->img_u8[e].p;
-      if ((rc = render_views(c, model_slots[e], cs, view_ids, n_views, o, (float*)c->img_f32.p,
-                             (uint8_t*)c->img_u8[e].p, e == 0)) != PRV_OK)
-        return rc;
+      out8[e] = (uint8_t*)c->img_u8[e].p;
     }
+    bool one_march = false; // the engine's rule, an ensemble size with an instance: ONE march launch for all members
+    if ((rc = render_ensemble_ngp(c, model_slots, n_models, cs, view_ids, n_views, o, (float*)c->img_f32.p, out8, &one_march)) != PRV_OK) return rc;
+    for (int e = 0; e < n_models && !one_march; e++)
+      if ((rc = render_views(c, model_slots[e], cs, view_ids, n_views, o, (float*)c->img_f32.p, out8[e], e == 0)) != PRV_OK) return rc;
     if (n_views && (rc = score_ensemble_dev(c, method, imgs, n_models, n_views, npix, rec)) != PRV_OK) return rc;
   } else {
     // the image is a private temporary of the round: only the tiles inside each view's cull rectangle are rendered and

@@ -19,7 +19,7 @@
 #include <algorithm>
 
 #ifndef PRV_ABLATE
-#define PRV_ABLATE 0 // dev-only timing ablations: 1 no gather, 2 no MLP, 4 no compositing math (wrong pixels!), 8 march without its rejection test
+#define PRV_ABLATE 0 // dev-only timing ablations: 1 no gather, 2 no MLP, 4 no compositing math (wrong pixels!), 8 march without its rejection test, 16 march: ray set-up but no occupancy walk (every ray dead), 32 march: no set-up either (every ray rejected), 64 march: no dead-pixel writes, 128 march: no mask-extension writes, 256 march: no record copy-out
 #endif
 
 namespace prv {
@@ -67,38 +67,220 @@ __device__ __forceinline__ uint32_t march_ngp(const FieldDev& fd, const float o[
   const float fRc = (float)(fd.occ_res >> 2);
   const uint32_t Rc = (uint32_t)(Rc_m1 + 1);
   uint32_t n_live = 0u;
-  for (int k = k_lo; k < k_hi; k++) {
-    uint32_t w = 0u;
-    bool pass = true;
+  // The walk is a chain of memory round trips (a wave has little else to do between them), so what counts is how many
+  // it makes: the coarse tests of EIGHT words are issued together, and the 32 fine tests of a passing word together (until
+  // round 5: a coarse test per word, then four groups of eight -- five round trips per passing word).
+  for (int kb = k_lo; kb < k_hi; kb += 8) {
+    uint32_t pass = 0xffu;
     if (coarse_ok) {
-      const float tm = fmaf((float)(32 * k + 16), dt, t0);
-      const int cx = min(max((int)(fmaf(tm, d[0], o[0]) * fRc), 0), Rc_m1), cy = min(max((int)(fmaf(tm, d[1], o[1]) * fRc), 0), Rc_m1),
-                cz = min(max((int)(fmaf(tm, d[2], o[2]) * fRc), 0), Rc_m1);
-      const uint32_t bit = (uint32_t)cx + Rc * ((uint32_t)cy + Rc * (uint32_t)cz);
-      pass = (fd.occ_coarse[bit >> 5] >> (bit & 31u)) & 1u;
+      pass = 0u;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int k = min(kb + j, k_hi - 1); // (words behind the range repeat its last one: no branch, the bit is dropped below)
+        const float tm = fmaf((float)(32 * k + 16), dt, t0);
+        const int cx = min(max((int)(fmaf(tm, d[0], o[0]) * fRc), 0), Rc_m1), cy = min(max((int)(fmaf(tm, d[1], o[1]) * fRc), 0), Rc_m1),
+                  cz = min(max((int)(fmaf(tm, d[2], o[2]) * fRc), 0), Rc_m1);
+        const uint32_t bit = (uint32_t)cx + Rc * ((uint32_t)cy + Rc * (uint32_t)cz);
+        pass |= ((fd.occ_coarse[bit >> 5] >> (bit & 31u)) & 1u) << j;
+      }
     }
-    if (pass) {
+    for (int j = 0; j < 8 && kb + j < k_hi; j++) {
+      const int k = kb + j;
+      uint32_t w = 0u;
+      if ((pass >> j) & 1u) {
+        bool occ[32];
 #pragma unroll
-      for (int q0 = 0; q0 < 32; q0 += 8) { // eight fine tests issued together (eight loads in flight, one wait)
-        bool occ[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const int i = 32 * k + q0 + q;
+        for (int q = 0; q < 32; q++) {
+          const int i = 32 * k + q;
           const float t = fmaf((float)i + 0.5f, dt, t0);
           occ[q] = occupied(fd, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2])) && t < t1;
         }
 #pragma unroll
-        for (int q = 0; q < 8; q++) w |= (uint32_t)occ[q] << (q0 + q);
+        for (int q = 0; q < 32; q++) w |= (uint32_t)occ[q] << q;
       }
-    }
-    mw[k][threadIdx.x] = w;
-    if (w != 0u) {
-      if (first_nz == 32) first_nz = k;
-      last_nz = k;
-      n_live += (uint32_t)__popc(w);
+      mw[k][threadIdx.x] = w;
+      if (w != 0u) {
+        if (first_nz == 32) first_nz = k;
+        last_nz = k;
+        n_live += (uint32_t)__popc(w);
+      }
     }
   }
   return n_live;
+}
+
+// ---- the three parts of a march block: ray set-up, (the occupancy walk, per kernel), emit
+
+struct MarchRay {
+  float o[3], d[3], t0, t1;
+  uint32_t pix;
+  bool valid, hit; // inside the image; the ray enters the unit cube (and passed the rejection tests)
+};
+
+// pixel / sub-sample of this thread in tile (tx, ty) of view blockIdx.y, the rejection tests against the occupied box
+// [occ_lo, occ_hi], the exact ray, the unit-cube slab test.  PT: MarchParams or MarchMultiParams (same field names).
+template <class PT>
+__device__ __forceinline__ void march_ray_setup(const PT& P, const float occ_lo[3], const float occ_hi[3], uint32_t tx, uint32_t ty, MarchRay& r) {
+  const uint32_t vi = blockIdx.y;
+  // Multi-sample launches: with a power-of-two spp the sub-samples of a pixel sit on ADJACENT lanes
+  // (a wave = 64/spp pixels x spp sub-samples: rays that share nearly every grid cell); otherwise the
+  // sub-sample index is on grid.z.
+  uint32_t ix, iy, kk;
+  if (P.spp_inner_log2 > 0) {
+    kk = threadIdx.x & ((1u << P.spp_inner_log2) - 1u);
+    morton16(threadIdx.x >> P.spp_inner_log2, ix, iy);
+  } else {
+    kk = blockIdx.z;
+    morton16(threadIdx.x, ix, iy);
+  }
+  const int spp_k = P.spp_k + (int)kk;
+  const int px = (int)((tx << P.tile_w_log2) + ix), py = (int)((ty << P.tile_h_log2) + iy);
+  r.valid = px < P.W && py < P.H;
+  r.pix = ((kk * gridDim.y + (uint32_t)vi) * (uint32_t)P.H + (uint32_t)py) * (uint32_t)P.W + (uint32_t)px;
+  r.o[0] = r.o[1] = r.o[2] = 0.f;
+  r.d[0] = r.d[1] = 0.f;
+  r.d[2] = 1.f;
+  r.t0 = r.t1 = 0.f;
+  r.hit = false;
+  bool maybe = r.valid;
+  const CamDev& cam = P.cams[P.view_ids[vi]];
+  float ox, oy;
+  spp_offset(spp_k, ox, oy);
+  // whole-tile rejection (block-uniform, before any per-ray work): the tile's pixels against the rectangle outside which no
+  // ray of this view can meet the occupied box (CamDev::cull, computed on the host in double per render call)
+  if (cam.cull[2] > 0) {
+    const int x0 = (int)(tx << P.tile_w_log2), y0 = (int)(ty << P.tile_h_log2);
+    if (x0 + (1 << P.tile_w_log2) <= cam.cull[0] || x0 >= cam.cull[2] || y0 + (1 << P.tile_h_log2) <= cam.cull[1] || y0 >= cam.cull[3]) maybe = false;
+  }
+  if (maybe && !has_lens(cam)) {
+    // Cheap rejection before the exact (IEEE divides, normalisation: ~300 instructions) ray set-up: nine rays in ten
+    // never come near the object and the pass is VALU bound on that set-up.  A live sample lies in an occupied cell,
+    // hence inside [occ_lo, occ_hi]; a slab test of the UNNORMALISED direction, built with reciprocals, against that
+    // box grown by `grow` can only err towards "hit": the direction is off by < 1e-6 rad, i.e. < 1e-6 * far at the
+    // box, and a ray touching the box crosses the grown one over a chord > 2 * grow.  NaNs (0 * inf) drop a slab.
+    const float far = fmaxf(fmaxf(fabsf(cam.c2w[3] - 0.5f), fabsf(cam.c2w[7] - 0.5f)), fabsf(cam.c2w[11] - 0.5f));
+    const float grow = fmaf(far, 1e-5f, 1e-3f);
+    const float x = (((float)px + ox) - cam.cx) * __builtin_amdgcn_rcpf(cam.fx);
+    const float y = (((float)py + oy) - cam.cy) * __builtin_amdgcn_rcpf(cam.fy);
+    float ta = 0.0f, tb = __builtin_inff();
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float* mrow = cam.c2w + a * 4;
+      const float inv = __builtin_amdgcn_rcpf(fmaf(mrow[0], x, fmaf(mrow[1], y, mrow[2])));
+      const float u = ((occ_lo[a] - grow) - mrow[3]) * inv, w = ((occ_hi[a] + grow) - mrow[3]) * inv;
+      ta = fmaxf(ta, fminf(u, w));
+      tb = fminf(tb, fmaxf(u, w));
+    }
+    maybe = !(tb < ta);
+  }
+#if PRV_ABLATE & 8
+  maybe = r.valid; // dev timing only: no rejection test
+#endif
+  if (maybe) {
+    raygen(cam, px, py, ox, oy, r.o, r.d);
+    r.hit = ray_aabb(r.o, r.d, r.t0, r.t1);
+  }
+}
+
+// the queue a march block appends to, and the image its dead rays are written to (one per ensemble member in the
+// multi-member launch)
+struct MarchSink {
+  void* queue;
+  uint4* queue_ext;  // chunk-major: chunk j (>= 1) of queue slot s at [(j - 1) * ext_stride + s] -- the lanes of a wave hold
+  size_t ext_stride; // consecutive slots, so a chunk's store is one contiguous block (slot-major: 64 lines per instruction)
+  uint32_t* queue_count;
+  float* out_f32;
+  uint32_t* out_u8;
+};
+
+// Wave-level compaction of the live rays into the queue + the record + the statistics + the dead ray's pixel.
+//   m[4]: the record's own 128-step chunk (FIXED_S: the whole mask; NGP: filled here from word(first_nz ...));
+//   word(k): NGP, mask word k of this ray (0 outside what the walk wrote)
+template <bool NGP, bool WORDS_READY = false, class PT, class WordFn>
+__device__ __forceinline__ void march_write(const PT& P, const MarchSink& Q, uint4 (*stage)[64 * kRecordWords], const MarchRay& r, bool live,
+                                            unsigned long long b, uint32_t base, float dt, uint32_t m[4], int first_nz, int last_nz, WordFn word) {
+  // b = the wave's ballot of live rays, base = where its records start in the queue (march_reserve)
+  const int lane = threadIdx.x & 63;
+  if (b != 0ull) {
+    // the wave's live records are consecutive in the queue: they are staged in LDS and leave as one contiguous block,
+    // consecutive lanes writing consecutive 16-byte words (a lane storing its own 96-byte record word by word makes
+    // every store instruction touch 64 different lines, six times over)
+    uint4* st = stage[threadIdx.x >> 6];
+    if (live) {
+      const uint32_t prefix = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+      uint4* rec = st + prefix * kRecordWords;
+      uint32_t chunk_info = 1u << 16; // {first step of chunk 0 (a multiple of 32), number of 128-step mask chunks << 16}
+      if constexpr (NGP) {
+        // the record carries the 128 steps from the first non-empty word on; the chunks behind it (up to 7 more) go to
+        // the record's slot of the extension buffer, which the render kernel reads only when a ray gets that far
+        const int n_chunks = ((last_nz - first_nz) >> 2) + 1;
+        chunk_info = (uint32_t)(32 * first_nz) | ((uint32_t)n_chunks << 16);
+        if constexpr (!WORDS_READY) { // (the multi-member kernel has filled m and written the later chunks itself)
+#pragma unroll
+          for (int q = 0; q < 4; q++) m[q] = word(first_nz + q);
+          uint4* ext = Q.queue_ext + (size_t)(base + prefix);
+          for (int j = 1; j < ((PRV_ABLATE & 128) ? 1 : n_chunks); j++)
+            ext[(size_t)(j - 1) * Q.ext_stride] = make_uint4(word(first_nz + 4 * j), word(first_nz + 4 * j + 1), word(first_nz + 4 * j + 2), word(first_nz + 4 * j + 3));
+        }
+      }
+      rec[0] = make_uint4(__float_as_uint(r.o[0]), __float_as_uint(r.o[1]), __float_as_uint(r.o[2]), __float_as_uint(r.t0));
+      rec[1] = make_uint4(__float_as_uint(r.d[0]), __float_as_uint(r.d[1]), __float_as_uint(r.d[2]), __float_as_uint(dt));
+      rec[2] = make_uint4(m[0], m[1], m[2], m[3]);
+      rec[3] = make_uint4(r.pix, chunk_info, 0u, 0u);
+      // direction encoding once per ray, here, so a slot refill in K_B is loads only
+      reinterpret_cast<half8*>(rec)[4] = sh_fragment(0, r.d[0], r.d[1], r.d[2]);
+      reinterpret_cast<half8*>(rec)[5] = sh_fragment(1, r.d[0], r.d[1], r.d[2]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint4* dst = reinterpret_cast<uint4*>(Q.queue) + (size_t)base * kRecordWords;
+    const uint32_t n_words = (uint32_t)__popcll(b) * kRecordWords;
+    for (uint32_t i = (uint32_t)lane; i < ((PRV_ABLATE & 256) ? 1u : n_words); i += 64u) dst[i] = st[i];
+  }
+  if (!live && r.valid && !(PRV_ABLATE & 64)) {
+    // dead ray: contributes exactly zero to its pixel
+    float4* out = reinterpret_cast<float4*>(Q.out_f32) + r.pix;
+    float4 v = P.spp_k == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *out;
+    if (P.last_pass) {
+      v.x *= P.inv_spp; v.y *= P.inv_spp; v.z *= P.inv_spp; v.w *= P.inv_spp;
+      if (Q.out_u8) Q.out_u8[r.pix] = quantize_rgba8(v.x, v.y, v.z, v.w, P.bg);
+    }
+    if (P.spp_k == 0 || P.last_pass) *out = v;
+  }
+}
+
+// the statistics: the march count (live samples before any early termination), one atomic per wave, on a counter sharded
+// like the queue's (~10^5 atomics on ONE word cost 0.3 ms of a 0.65 ms launch)
+template <class PT>
+__device__ __forceinline__ void march_count(const PT& P, uint32_t n_live) {
+  uint32_t tot = n_live;
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) tot += (uint32_t)__shfl_xor((int)tot, sh);
+  const uint32_t sshard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 7u;
+  if ((threadIdx.x & 63) == 0 && tot) atomicAdd(P.stat + 8u * (1u + sshard), (unsigned long long)tot); // 64 bytes apart: stat[8], stat[16], ...
+}
+
+// Wave-level compaction of the live rays into the queue + the record + the statistics + the dead ray's pixel.
+//   m[4]: the record's own 128-step chunk (FIXED_S: the whole mask; NGP: filled here from word(first_nz ...));
+//   word(k): NGP, mask word k of this ray (0 outside what the walk wrote)
+template <bool NGP, class PT, class WordFn>
+__device__ __forceinline__ void march_emit(const PT& P, const MarchSink& Q, uint4 (*stage)[64 * kRecordWords], const MarchRay& r, bool live,
+                                           uint32_t n_live, float dt, uint32_t m[4], int first_nz, int last_nz, WordFn word) {
+  // wave-level compaction: ballot + prefix popcount, one atomic per wave.  The queue is cut into n_seg regions of
+  // seg_cap records and the counter is sharded with it (a block appends to region `linear block id % n_seg`): one
+  // returning atomic word saturates near 90 per microsecond on this chip and ~10^5 waves append per launch -- with a
+  // single counter that alone was 0.15 ms of the 0.84 ms pass.  The render kernel drains region by region.
+  const unsigned long long b = __ballot(live);
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (b != 0ull) {
+    const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) % (uint32_t)P.n_seg;
+    if (lane == (int)__builtin_ctzll(b)) base = shard * P.seg_cap + atomicAdd(Q.queue_count + 16u * shard, (uint32_t)__popcll(b));
+    base = __shfl(base, (int)__builtin_ctzll(b));
+  }
+  march_write<NGP>(P, Q, stage, r, live, b, base, dt, m, first_nz, last_nz, word);
+  if (b != 0ull) march_count(P, n_live);
 }
 
 template <bool NGP>
@@ -127,66 +309,24 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
     ty = blockIdx.x / P.tiles_x;
     tx = blockIdx.x - ty * P.tiles_x;
   }
-  // Multi-sample launches: with a power-of-two spp the sub-samples of a pixel sit on ADJACENT lanes
-  // (a wave = 64/spp pixels x spp sub-samples: rays that share nearly every grid cell); otherwise the
-  // sub-sample index is on grid.z.
-  uint32_t ix, iy, kk;
-  if (P.spp_inner_log2 > 0) {
-    kk = threadIdx.x & ((1u << P.spp_inner_log2) - 1u);
-    morton16(threadIdx.x >> P.spp_inner_log2, ix, iy);
-  } else {
-    kk = blockIdx.z;
-    morton16(threadIdx.x, ix, iy);
-  }
-  const int spp_k = P.spp_k + (int)kk;
-  const int px = (int)((tx << P.tile_w_log2) + ix), py = (int)((ty << P.tile_h_log2) + iy);
-  const bool valid = px < P.W && py < P.H;
-  const uint32_t pix = ((kk * gridDim.y + (uint32_t)vi) * (uint32_t)P.H + (uint32_t)py) * (uint32_t)P.W + (uint32_t)px;
-
-  float o[3] = {0, 0, 0}, d[3] = {0, 0, 1}, t0 = 0.f, dt = 0.f;
+  MarchRay r;
+  march_ray_setup(P, P.field.occ_lo, P.field.occ_hi, tx, ty, r);
+  const float* o = r.o;
+  const float* d = r.d;
+  const float t0 = r.t0, t1 = r.t1;
+  float dt = 0.f;
   uint32_t m[4] = {0, 0, 0, 0};
   uint32_t n_live = 0u;                              // live samples of this ray (statistics: the march count)
   int k_lo = 0, k_hi = 0, first_nz = 32, last_nz = -1; // NGP: written words of mw, first / last non-empty word
   bool live = false;
-  bool maybe = valid;
-  const CamDev& cam = P.cams[P.view_ids[vi]];
-  float ox, oy;
-  spp_offset(spp_k, ox, oy);
-  // whole-tile rejection (block-uniform, before any per-ray work): the tile's pixels against the rectangle outside which no
-  // ray of this view can meet the occupied box (CamDev::cull, computed on the host in double per render call)
-  if (cam.cull[2] > 0) {
-    const int x0 = (int)(tx << P.tile_w_log2), y0 = (int)(ty << P.tile_h_log2);
-    if (x0 + (1 << P.tile_w_log2) <= cam.cull[0] || x0 >= cam.cull[2] || y0 + (1 << P.tile_h_log2) <= cam.cull[1] || y0 >= cam.cull[3]) maybe = false;
-  }
-  if (maybe && !has_lens(cam)) {
-    // Cheap rejection before the exact (IEEE divides, normalisation: ~300 instructions) ray set-up: nine rays in ten
-    // never come near the object and the pass is VALU bound on that set-up.  A live sample lies in an occupied cell,
-    // hence inside [occ_lo, occ_hi]; a slab test of the UNNORMALISED direction, built with reciprocals, against that
-    // box grown by `grow` can only err towards "hit": the direction is off by < 1e-6 rad, i.e. < 1e-6 * far at the
-    // box, and a ray touching the box crosses the grown one over a chord > 2 * grow.  NaNs (0 * inf) drop a slab.
-    const float far = fmaxf(fmaxf(fabsf(cam.c2w[3] - 0.5f), fabsf(cam.c2w[7] - 0.5f)), fabsf(cam.c2w[11] - 0.5f));
-    const float grow = fmaf(far, 1e-5f, 1e-3f);
-    const float x = (((float)px + ox) - cam.cx) * __builtin_amdgcn_rcpf(cam.fx);
-    const float y = (((float)py + oy) - cam.cy) * __builtin_amdgcn_rcpf(cam.fy);
-    float ta = 0.0f, tb = __builtin_inff();
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      const float* mrow = cam.c2w + a * 4;
-      const float inv = __builtin_amdgcn_rcpf(fmaf(mrow[0], x, fmaf(mrow[1], y, mrow[2])));
-      const float u = ((P.field.occ_lo[a] - grow) - mrow[3]) * inv, w = ((P.field.occ_hi[a] + grow) - mrow[3]) * inv;
-      ta = fmaxf(ta, fminf(u, w));
-      tb = fminf(tb, fmaxf(u, w));
-    }
-    maybe = !(tb < ta);
-  }
-#if PRV_ABLATE & 8
-  maybe = valid; // dev timing only: no rejection test
+#if PRV_ABLATE & 32
+  r.hit = false;
 #endif
-  if (maybe) {
-    raygen(cam, px, py, ox, oy, o, d);
-    float t1;
-    if (!ray_aabb(o, d, t0, t1)) {
-    } else if constexpr (NGP) {
+  if (r.hit) {
+#if PRV_ABLATE & 16
+    live = (t0 + t1 + d[0] + o[1]) == 1.0e30f; // never true, but the compiler cannot know: the set-up stays
+#else
+    if constexpr (NGP) {
       dt = kNgpDt;
       n_live = march_ngp(P.field, o, d, t0, t1, mw, k_lo, k_hi, first_nz, last_nz);
       live = first_nz < 32;
@@ -268,71 +408,210 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
       live = (m[0] | m[1] | m[2] | m[3]) != 0u;
       n_live = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
     }
+#endif
   }
-  // wave-level compaction: ballot + prefix popcount, one atomic per wave.  The queue is cut into n_seg regions of
-  // seg_cap records and the counter is sharded with it (a block appends to region `linear block id % n_seg`): one
-  // returning atomic word saturates near 90 per microsecond on this chip and ~10^5 waves append per launch -- with a
-  // single counter that alone was 0.15 ms of the 0.84 ms pass.  The render kernel drains region by region.
-  const unsigned long long b = __ballot(live);
-  const int lane = threadIdx.x & 63;
-  uint32_t base = 0;
-  if (b != 0ull) {
-    const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) % (uint32_t)P.n_seg;
-    if (lane == (int)__builtin_ctzll(b)) base = shard * P.seg_cap + atomicAdd(P.queue_count + 16u * shard, (uint32_t)__popcll(b));
-    base = __shfl(base, (int)__builtin_ctzll(b));
-    // the wave's live records are consecutive in the queue: they are staged in LDS and leave as one contiguous block,
-    // consecutive lanes writing consecutive 16-byte words (a lane storing its own 96-byte record word by word makes
-    // every store instruction touch 64 different lines, six times over)
-    uint4* st = stage[threadIdx.x >> 6];
-    if (live) {
-      const uint32_t prefix = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-      uint4* rec = st + prefix * kRecordWords;
-      uint32_t chunk_info = 1u << 16; // {first step of chunk 0 (a multiple of 32), number of 128-step mask chunks << 16}
-      if constexpr (NGP) {
-        // the record carries the 128 steps from the first non-empty word on; the chunks behind it (up to 7 more) go to
-        // the record's slot of the extension buffer, which the render kernel reads only when a ray gets that far
-        auto word = [&](int k) { return (k >= k_lo && k < k_hi) ? mw[k][threadIdx.x] : 0u; };
+  const MarchSink Q{P.queue, P.queue_ext, (size_t)P.seg_cap * (size_t)P.n_seg, P.queue_count, P.out_f32, P.out_u8};
+  march_emit<NGP>(P, Q, stage, r, live, n_live, dt, m, first_nz, last_nz,
+                  [&](int k) { return (k >= k_lo && k < k_hi) ? mw[k][threadIdx.x] : 0u; });
+}
+
+// ---- the ensemble's march in ONE launch (PRV_STEP_NGP; the reference trains E members and renders every candidate with
+// each of them, main.cpp:2041-2043, 2101-2103; run.py:296-304 -- E march launches until round 4).  The rays of the E
+// members are the same rays; what differs is the occupancy grid each walks.  One thread = one ray for ALL members: the
+// set-up once, and above all ONE walk -- a step's position, cell and address are computed once (15 of the ~20
+// instructions of a fine test), and one byte of the members' interleaved occupancy (bit e = member e, built per round by
+// occ_interleave_kernel) answers the step for every member.  The clip range is the union box's, a word is walked when ANY
+// member's dilated coarse bit is set: a member's mask bits are its own fine bits wherever they are tested and its grid is
+// empty wherever its own launch would not have looked, so every member's masks, records and march count are what its own
+// launch writes (the queue order differs, as between any two launches).
+// Two walks instead of mask words in LDS (E x 32 words per lane would be 160 KB per block): the first finds every member's
+// first / last non-empty word and its march count, the queue slots are then reserved for all members at once, and the
+// second walk -- only the words some member needs -- puts each word where it belongs: the record's own chunk in registers,
+// the later chunks straight into the member's extension buffer.  The walk is the cheap part of this launch (the records'
+// bytes are what it costs), so walking twice is worth not holding 32 KB of LDS per member.
+template <int E>
+__global__ __launch_bounds__(256) void march_multi_kernel(MarchMultiParams P) {
+  __shared__ uint4 stage[4][64 * kRecordWords];
+  const uint32_t ty = blockIdx.x / P.tiles_x, tx = blockIdx.x - ty * P.tiles_x;
+  MarchRay r;
+  march_ray_setup(P, P.occ_lo, P.occ_hi, tx, ty, r);
+  const float* o = r.o;
+  const float* d = r.d;
+  const float t0 = r.t0, t1 = r.t1, dt = kNgpDt;
+  int first_nz[E], last_nz[E];
+  uint32_t n_live[E];
 #pragma unroll
-        for (int q = 0; q < 4; q++) m[q] = word(first_nz + q);
-        const int n_chunks = ((last_nz - first_nz) >> 2) + 1;
-        chunk_info = (uint32_t)(32 * first_nz) | ((uint32_t)n_chunks << 16);
-        uint4* ext = P.queue_ext + (size_t)(base + prefix) * kExtChunks;
-        for (int j = 1; j < n_chunks; j++)
-          ext[j - 1] = make_uint4(word(first_nz + 4 * j), word(first_nz + 4 * j + 1), word(first_nz + 4 * j + 2), word(first_nz + 4 * j + 3));
+  for (int e = 0; e < E; e++) {
+    first_nz[e] = 32;
+    last_nz[e] = -1;
+    n_live[e] = 0u;
+  }
+  const int R = P.occ_res;
+  const float fR = (float)R;
+  const bool coarse_ok = P.occ_coarse_bytes != nullptr && 16.0f * dt <= 0.99f * 4.0f / (float)R;
+  const int Rc_m1 = (R >> 2) - 1;
+  const float fRc = (float)(R >> 2);
+  const uint32_t Rc = (uint32_t)(Rc_m1 + 1);
+  // the 32 steps of word k for every member: the bytes of the steps' cells (0 behind the ray's exit), transposed.  All 32
+  // loads are issued together: the walk is a chain of memory round trips, one per word this way
+  auto fine_word = [&](int k, uint32_t w[E]) {
+#pragma unroll
+    for (int e = 0; e < E; e++) w[e] = 0u;
+    uint32_t by[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+      const int i = 32 * k + q;
+      const float t = fmaf((float)i + 0.5f, dt, t0);
+      const float px = fmaf(t, d[0], o[0]), py = fmaf(t, d[1], o[1]), pz = fmaf(t, d[2], o[2]);
+      const int cx = min((int)(clamp01(px) * fR), R - 1), cy = min((int)(clamp01(py) * fR), R - 1), cz = min((int)(clamp01(pz) * fR), R - 1);
+      const uint32_t cell = (uint32_t)cx + __umul24((uint32_t)R, (uint32_t)cy + __umul24((uint32_t)R, (uint32_t)cz)); // as occupied()
+      // (the load is unconditional -- the cell is always inside the grid -- and masked afterwards: a conditional load
+      // compiles to a branch and a wait per step)
+      by[q] = (uint32_t)P.occ_bytes[cell] & (0u - (uint32_t)(t < t1));
+    }
+#pragma unroll
+    for (int q = 0; q < 32; q++)
+#pragma unroll
+      for (int e = 0; e < E; e++) w[e] |= ((by[q] >> e) & 1u) << q;
+  };
+  uint32_t passmask = 0u; // bit k: some member's dilated coarse bit is set at the middle of word k (no live sample of any member otherwise)
+  if (r.hit) {
+    // only samples inside the (one-cell-grown) bounding box of the members' occupied cells can be live (march_ngp's clip)
+    float ta = t0, tb = t1;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float inv = 1.0f / d[a];
+      const float u = (P.occ_lo[a] - o[a]) * inv, w = (P.occ_hi[a] - o[a]) * inv;
+      ta = fmaxf(ta, fminf(u, w));
+      tb = fminf(tb, fmaxf(u, w));
+    }
+    int k_lo = 0, k_hi = 0;
+    if (tb > ta) {
+      const float inv_dt = 1024.0f / 1.7320508075688772f;
+      const int g_lo = max(0, (int)((ta - t0) * inv_dt) - 2);
+      const int g_hi = min(kNgpMaxSteps, (int)((tb - t0) * inv_dt) + 3);
+      if (g_lo < g_hi) {
+        k_lo = g_lo >> 5;
+        k_hi = (g_hi + 31) >> 5;
       }
-      rec[0] = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(t0));
-      rec[1] = make_uint4(__float_as_uint(d[0]), __float_as_uint(d[1]), __float_as_uint(d[2]), __float_as_uint(dt));
-      rec[2] = make_uint4(m[0], m[1], m[2], m[3]);
-      rec[3] = make_uint4(pix, chunk_info, 0u, 0u);
-      // direction encoding once per ray, here, so a slot refill in K_B is loads only
-      reinterpret_cast<half8*>(rec)[4] = sh_fragment(0, d[0], d[1], d[2]);
-      reinterpret_cast<half8*>(rec)[5] = sh_fragment(1, d[0], d[1], d[2]);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint4* dst = reinterpret_cast<uint4*>(P.queue) + (size_t)base * kRecordWords;
-    const uint32_t n_words = (uint32_t)__popcll(b) * kRecordWords;
-    for (uint32_t i = (uint32_t)lane; i < n_words; i += 64u) dst[i] = st[i];
-  }
-  if (b != 0ull) { // statistics: the march count (live samples before any early termination), one atomic per wave,
-    // on a counter sharded like the queue's (~10^5 atomics on ONE word cost 0.3 ms of a 0.65 ms launch)
-    uint32_t tot = n_live;
+    for (int kb = k_lo; kb < k_hi; kb += 8) { // the coarse tests of eight words together
+      uint32_t pass = 0xffu;
+      if (coarse_ok) {
+        pass = 0u;
 #pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) tot += (uint32_t)__shfl_xor((int)tot, sh);
-    const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 7u;
-    if (lane == 0) atomicAdd(P.stat + 8u * (1u + shard), (unsigned long long)tot); // 64 bytes apart: stat[8], stat[16], ...
-  }
-  if (!live && valid) {
-    // dead ray: contributes exactly zero to its pixel
-    float4* out = reinterpret_cast<float4*>(P.out_f32) + pix;
-    float4 v = P.spp_k == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : *out;
-    if (P.last_pass) {
-      v.x *= P.inv_spp; v.y *= P.inv_spp; v.z *= P.inv_spp; v.w *= P.inv_spp;
-      if (P.out_u8) P.out_u8[pix] = quantize_rgba8(v.x, v.y, v.z, v.w, P.bg);
+        for (int j = 0; j < 8; j++) {
+          const int k = min(kb + j, k_hi - 1);
+          const float tm = fmaf((float)(32 * k + 16), dt, t0);
+          const int cx = min(max((int)(fmaf(tm, d[0], o[0]) * fRc), 0), Rc_m1), cy = min(max((int)(fmaf(tm, d[1], o[1]) * fRc), 0), Rc_m1),
+                    cz = min(max((int)(fmaf(tm, d[2], o[2]) * fRc), 0), Rc_m1);
+          pass |= (uint32_t)(P.occ_coarse_bytes[(uint32_t)cx + Rc * ((uint32_t)cy + Rc * (uint32_t)cz)] != 0) << j;
+        }
+      }
+      for (int j = 0; j < 8 && kb + j < k_hi; j++) {
+        if (!((pass >> j) & 1u)) continue;
+        const int k = kb + j;
+        passmask |= 1u << k;
+        uint32_t w[E];
+        fine_word(k, w);
+#pragma unroll
+        for (int e = 0; e < E; e++)
+          if (w[e] != 0u) {
+            if (first_nz[e] == 32) first_nz[e] = k;
+            last_nz[e] = k;
+            n_live[e] += (uint32_t)__popc(w[e]);
+          }
+      }
     }
-    if (P.spp_k == 0 || P.last_pass) *out = v;
   }
+  // The E members' queue reservations in ONE wave instruction (lane e adds member e's count to member e's counter): one
+  // returning-atomic latency per wave instead of E in a row; the march count of all members in one add.
+  const int lane = threadIdx.x & 63;
+  const size_t ext_stride = (size_t)P.seg_cap * (size_t)P.n_seg;
+  unsigned long long b[E];
+  uint32_t base[E];
+  {
+    const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) % (uint32_t)P.n_seg;
+    uint32_t* qc = nullptr;
+    uint32_t mine = 0u, tot = 0u;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      b[e] = __ballot(first_nz[e] < 32);
+      if (lane == e) {
+        qc = P.mem[e].queue_count;
+        mine = (uint32_t)__popcll(b[e]);
+      }
+      tot += n_live[e];
+    }
+    uint32_t got = 0u;
+    if (mine) got = shard * P.seg_cap + atomicAdd(qc + 16u * shard, mine);
+#pragma unroll
+    for (int e = 0; e < E; e++) base[e] = __shfl(got, e);
+    march_count(P, tot);
+  }
+  // second walk: word k is word j = k - first_nz[e] of member e's mask -- chunk j / 4: the record's own (0) or one of the
+  // extension buffer's, written as soon as its four words (or the member's last) are there
+  uint32_t m[E][4];
+#pragma unroll
+  for (int e = 0; e < E; e++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) m[e][q] = 0u;
+  {
+    int k2_lo = 32, k2_hi = -1;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      k2_lo = min(k2_lo, first_nz[e]);
+      k2_hi = max(k2_hi, last_nz[e]);
+    }
+    uint32_t acc[E][4];
+#pragma unroll
+    for (int e = 0; e < E; e++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[e][q] = 0u;
+    for (int k = k2_lo; k <= k2_hi; k++) {
+      uint32_t w[E];
+      if ((passmask >> k) & 1u) fine_word(k, w);
+      else {
+#pragma unroll
+        for (int e = 0; e < E; e++) w[e] = 0u;
+      }
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const int j = k - first_nz[e];
+        if (j < 0 || k > last_nz[e]) continue;
+        const int q = j & 3;
+        if (j < 4) {
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (q == u) m[e][u] = w[e];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (q == u) acc[e][u] = w[e];
+          if ((q == 3 || k == last_nz[e]) && !(PRV_ABLATE & 128)) {
+            const uint32_t slot = base[e] + (uint32_t)__popcll(b[e] & ((1ull << lane) - 1ull));
+            P.mem[e].queue_ext[(size_t)((j >> 2) - 1) * ext_stride + slot] = make_uint4(acc[e][0], acc[e][1], acc[e][2], acc[e][3]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc[e][u] = 0u;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const MarchSink Q{P.mem[e].queue, P.mem[e].queue_ext, ext_stride, P.mem[e].queue_count, P.mem[e].out_f32, P.mem[e].out_u8};
+    march_write<true, true>(P, Q, stage, r, first_nz[e] < 32, b[e], base[e], dt, m[e], first_nz[e], last_nz[e], [](int) { return 0u; });
+  }
+}
+
+// byte c of the interleaved grids: bit e = bit c of member e's occupancy bitfield (and of its dilated coarse grid)
+__global__ __launch_bounds__(256) void occ_interleave_kernel(OccInterleaveParams P) {
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= P.n_cells) return;
+  uint32_t v = 0u;
+  for (int e = 0; e < P.n_members; e++) v |= ((P.bits[e][c >> 5] >> (c & 31u)) & 1u) << e;
+  P.out[c] = (uint8_t)v;
 }
 
 // ------------------------------------------------------------------ K_B render from the queue
@@ -436,7 +715,7 @@ void render_queue64_kernel(RenderParams P) {
       base = base0;
       if (next >= base0 + 128u) { // the sample lies in a later chunk
         const uint32_t j = (next - base0) >> 7;
-        mk = P.queue_ext[(size_t)ri * kExtChunks + (j - 1u)];
+        mk = P.queue_ext[(size_t)(j - 1u) * ((size_t)P.seg_cap * (size_t)P.n_segments) + (size_t)ri];
         base = base0 + 128u * j;
       }
     }
@@ -457,7 +736,7 @@ void render_queue64_kernel(RenderParams P) {
     const uint32_t info = queue[(size_t)rec_i * kRecordWords + 3].y;
     const uint32_t base0 = info & 0xffffu, n_chunks = info >> 16;
     for (uint32_t j = ((base - base0) >> 7) + 1u; j < n_chunks; j++) {
-      const uint4 mk = P.queue_ext[(size_t)rec_i * kExtChunks + (j - 1u)];
+      const uint4 mk = P.queue_ext[(size_t)(j - 1u) * ((size_t)P.seg_cap * (size_t)P.n_segments) + (size_t)rec_i];
       if ((mk.x | mk.y | mk.z | mk.w) == 0u) continue; // a gap between two occupied stretches
       cur = mk.x; m1 = mk.y; m2 = mk.z; m3 = mk.w;
       base = base0 + 128u * j;
@@ -1311,6 +1590,23 @@ hipError_t launch_march(const MarchParams& P, int n_views, int n_spp, hipStream_
   if (grid.x == 0) return hipSuccess; // no view of the batch can see the object
   if (P.step_mode == PRV_STEP_NGP) hipLaunchKernelGGL(march_compact_kernel<true>, grid, dim3(256), 0, s, P);
   else hipLaunchKernelGGL(march_compact_kernel<false>, grid, dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_occ_interleave(const OccInterleaveParams& P, hipStream_t s) {
+  hipLaunchKernelGGL(occ_interleave_kernel, dim3((P.n_cells + 255u) / 256u), dim3(256), 0, s, P);
+  return hipGetLastError();
+}
+
+bool march_multi_supported(int n_members) { return n_members == 2 || n_members == 5; }
+
+hipError_t launch_march_multi(const MarchMultiParams& P, int n_views, int n_spp, hipStream_t s) {
+  dim3 grid((unsigned)(P.tiles_x * P.tiles_y), (unsigned)n_views, (unsigned)(P.spp_inner_log2 > 0 ? 1 : n_spp));
+  if (grid.x == 0) return hipSuccess;
+  // the paper's ensembles (Share_Data.hpp:505-510: two members for EnsembleRGB, five for EnsembleRGBDensity)
+  if (P.n_members == 5) hipLaunchKernelGGL((march_multi_kernel<5>), grid, dim3(256), 0, s, P);
+  else if (P.n_members == 2) hipLaunchKernelGGL((march_multi_kernel<2>), grid, dim3(256), 0, s, P);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

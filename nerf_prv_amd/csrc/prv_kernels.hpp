@@ -10,7 +10,8 @@ namespace prv {
 // The mask is one 128-step CHUNK of the ray's live-sample mask.  PRV_STEP_FIXED_S: the only one (chunk info = 1 << 16).
 // PRV_STEP_NGP (up to 1024 steps): the chunk that starts at the ray's first non-empty 32-step word; chunk info = first
 // step of that chunk | number of chunks << 16, and chunks 1..n-1 sit in the record's slot of the extension buffer
-// (kExtChunks x uint4 per queue slot), read by the render kernel only when a ray gets that far.
+// (kExtChunks x uint4 per queue slot, chunk-major: chunk j of slot s at [(j - 1) * n_slots + s], so that the lanes of a
+// march wave -- consecutive slots -- store a chunk as one contiguous block), read by the render kernel only when a ray gets that far.
 constexpr size_t kRecordBytes = 96;
 constexpr int kRecordWords = 6;   // uint4 per record
 constexpr uint32_t kClaim = 64;   // records a wave claims per atomic on the queue head
@@ -32,7 +33,7 @@ struct MarchParams {
   uint32_t live_tiles_max;
   int step_mode; // PRV_STEP_FIXED_S | PRV_STEP_NGP
   void* queue;
-  uint4* queue_ext;      // PRV_STEP_NGP: kExtChunks mask chunks per queue slot
+  uint4* queue_ext;      // PRV_STEP_NGP: kExtChunks mask chunks per queue slot, chunk-major (n_slots = n_seg * seg_cap)
   unsigned long long* stat; // statistics block: [8 (1 + s)] += live samples (the march count), 8 shards a cache line apart
   uint32_t* queue_count; // n_seg counters, 64 bytes apart: records appended to region s of the queue
   int n_seg;             // the queue is n_seg regions of seg_cap records; a block appends to region (linear block id % n_seg)
@@ -43,6 +44,43 @@ struct MarchParams {
   int last_pass;
   float bg[4];
 };
+
+// the ensemble's march in one launch (march_multi_kernel): the common fields carry MarchParams' names
+struct MarchMember {
+  void* queue;
+  uint4* queue_ext;
+  uint32_t* queue_count; // this member's n_seg counters, 64 bytes apart
+  float* out_f32;        // where this member's dead rays are written (its own staging / image)
+  uint32_t* out_u8;
+};
+struct MarchMultiParams {
+  const uint8_t* occ_bytes;        // occ_res^3 bytes, x fastest: bit e = member e's occupancy bit of the cell
+  const uint8_t* occ_coarse_bytes; // (occ_res/4)^3 bytes of the members' dilated coarse grids, or null
+  int occ_res;
+  float occ_lo[3], occ_hi[3]; // the union of the members' occupied boxes
+  const CamDev* cams;         // cull rectangles against the union box
+  const int* view_ids;
+  int W, H, spp_k;
+  uint32_t tiles_x, tiles_y;
+  int tile_w_log2, tile_h_log2, spp_inner_log2;
+  unsigned long long* stat;
+  int n_seg;
+  uint32_t seg_cap;
+  float inv_spp;
+  int last_pass;
+  float bg[4];
+  int n_members;
+  MarchMember mem[PRV_MAX_MODELS];
+};
+struct OccInterleaveParams {
+  const uint32_t* bits[PRV_MAX_MODELS];
+  int n_members;
+  uint32_t n_cells;
+  uint8_t* out;
+};
+bool march_multi_supported(int n_members); // a compiled instance exists (2 and 5: the paper's ensembles)
+hipError_t launch_march_multi(const MarchMultiParams& P, int n_views, int n_spp, hipStream_t s);
+hipError_t launch_occ_interleave(const OccInterleaveParams& P, hipStream_t s);
 
 struct RenderParams {
   FieldDev field;

@@ -283,3 +283,56 @@ def test_corner_cache_instance_renders_the_same_pixels(oracle, monkeypatch):
     wants = [f.render(ocams[2], 80, 45, 0, 16, t, step_mode=oracle.STEP_NGP)[0] for t in util.termination_variants(1e-2)]
     util.assert_pixels_close_any(runs[("1", "24")][0][0][2], wants)
     f.close()
+
+
+def _ensemble_with_own_occupancies(ctx_, oracle, kw, n, seed0):
+    """n members of the same field shape whose occupancy grids DIFFER: the synthetic scene's grid, a solid ball, an
+    all-occupied grid (rays with 600+ consecutive live steps: longer than the march's LDS window), an empty one, a slab"""
+    d_o, d_p = oracle.desc(**kw), api.field_desc(**kw)
+    R = kw["occ_res"]
+    z, y, x = np.meshgrid(np.arange(R), np.arange(R), np.arange(R), indexing="ij")
+    cx = (x + 0.5) / R - 0.5
+    cy = (y + 0.5) / R - 0.5
+    cz = (z + 0.5) / R - 0.5
+    grids = [None, (cx ** 2 + cy ** 2 + cz ** 2) < 0.3 ** 2, np.ones((R, R, R), bool), np.zeros((R, R, R), bool), np.abs(cz + 0.1) < 0.12,
+             (np.abs(cx) < 0.2) & (np.abs(cy) < 0.35), ((x + y + z) % 3 == 0), (cx > 0.1)]
+    for e in range(n):
+        f = oracle.OracleField(d_o, seed=seed0 + e)
+        t, m, o = f.params()
+        if grids[e] is not None:
+            bits = np.packbits(grids[e].reshape(-1).astype(np.uint8), bitorder="little")
+            o = np.frombuffer(bits.tobytes().ljust(o.nbytes, b"\0"), np.uint32).copy()
+        ctx_.load_model(e, d_p, t, m, o)
+    return d_p
+
+
+@pytest.mark.parametrize("n_members,method,spp,size", [(5, 3, 16, (80, 45)), (2, 2, 16, (80, 45)), (5, 3, 1, (44, 36)), (5, 3, 3, (44, 36)), (2, 2, 4, (20, 16))])
+def test_one_march_launch_for_the_ensemble_gives_every_member_its_own_result(oracle, n_members, method, spp, size):
+    """The ensemble's candidates under the engine's rule go through ONE march launch (march_multi_kernel: a ray's steps are
+    walked once, a byte of the members' interleaved occupancy answers a step for all of them) and one render launch per
+    member.  Against the member-by-member path (PRV_MARCH_MULTI=0: one march launch per member) on members whose occupancy
+    grids differ: the same 16-byte records bit for bit (every byte of every member's image enters the score), the same march
+    count (every step's occupancy decision of every member), the same evaluated count."""
+    kw = util.SMALL
+    pts = util.fibonacci_hemisphere(7)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    w, h = size
+    got = {}
+    for multi in ("0", "1"):
+        os.environ["PRV_MARCH_MULTI"] = multi
+        try:
+            c = api.Context(0)
+        finally:
+            del os.environ["PRV_MARCH_MULTI"]
+        _ensemble_with_own_occupancies(c, oracle, kw, n_members, 4242)
+        cs = c.cameras_from_matrices(tms, util.FOV_X, w, h, scale, offset)
+        opts = api.engine_render_opts(w, h, 0, spp, 0.01, background=(0, 0, 0, 1))
+        rec, st = c.score_views(method, list(range(n_members)), cs, None, opts, want_stats=True)
+        rec2, st2 = c.score_views(method, list(range(n_members)), cs, [5, 2, 3], opts, want_stats=True)  # a subset, in another order
+        got[multi] = (rec.tobytes(), int(st.samples_live), int(st.samples_evaluated), rec2.tobytes(), int(st2.samples_live), rec)
+        cs.close()
+        c.close()
+    assert got["0"][1] == got["1"][1] > 0 and got["0"][4] == got["1"][4] > 0
+    assert got["0"][2] == got["1"][2]
+    assert got["0"][0] == got["1"][0] and got["0"][3] == got["1"][3]
+    assert np.all(np.isfinite(got["1"][5]["score"])) and len(set(got["1"][5]["score"].tolist())) > 1
