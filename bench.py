@@ -67,9 +67,9 @@ ATOMIC_REQ_PER_SAMPLE = 27.1
 ATOMIC_REQ_FILE = os.path.join("profiles", "r04_train_loop_batch_ablations.txt")
 ISSUE_PEAK_GCYC = N_SIMD * MAX_CLOCK_HZ / 1e9  # 2457.6 G SIMD issue-cycles/s at the 2.4 GHz maximum clock
 VALU_PEAK_GINST = ISSUE_PEAK_GCYC / ISSUE_CYCLES["c4"]  # wave-instructions/s if every instruction were c4 (kept for the detail object)
-ROUND_COST_FILE = os.path.join("profiles", "r04_round_cost.json")  # VALU instructions per wave-round, from the PMC pass
-TRAFFIC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")    # fabric-side bytes per launch, from the PMC passes
-ISA_CLASSES_FILE = os.path.join("profiles", "r04_isa_classes.json")  # static issue-class histogram of the hot loop (scripts/isa_count.py)
+ROUND_COST_FILE = os.path.join("profiles", "r05_round_cost.json")  # VALU instructions per wave-round, from the PMC pass
+TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")    # fabric-side bytes per launch, from the PMC passes
+ISA_CLASSES_FILE = os.path.join("profiles", "r05_isa_classes.json")  # static issue-class histogram of the hot loop (scripts/isa_count.py)
 
 
 # The algorithmic floor of the render kernel: wave-instructions one 64-sample wave iteration NEEDS for this algorithm

@@ -67,43 +67,35 @@ __device__ __forceinline__ uint32_t march_ngp(const FieldDev& fd, const float o[
   const float fRc = (float)(fd.occ_res >> 2);
   const uint32_t Rc = (uint32_t)(Rc_m1 + 1);
   uint32_t n_live = 0u;
-  // The walk is a chain of memory round trips (a wave has little else to do between them), so what counts is how many
-  // it makes: the coarse tests of EIGHT words are issued together, and the 32 fine tests of a passing word together (until
-  // round 5: a coarse test per word, then four groups of eight -- five round trips per passing word).
-  for (int kb = k_lo; kb < k_hi; kb += 8) {
-    uint32_t pass = 0xffu;
+  for (int k = k_lo; k < k_hi; k++) {
+    uint32_t w = 0u;
+    bool pass = true;
     if (coarse_ok) {
-      pass = 0u;
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int k = min(kb + j, k_hi - 1); // (words behind the range repeat its last one: no branch, the bit is dropped below)
-        const float tm = fmaf((float)(32 * k + 16), dt, t0);
-        const int cx = min(max((int)(fmaf(tm, d[0], o[0]) * fRc), 0), Rc_m1), cy = min(max((int)(fmaf(tm, d[1], o[1]) * fRc), 0), Rc_m1),
-                  cz = min(max((int)(fmaf(tm, d[2], o[2]) * fRc), 0), Rc_m1);
-        const uint32_t bit = (uint32_t)cx + Rc * ((uint32_t)cy + Rc * (uint32_t)cz);
-        pass |= ((fd.occ_coarse[bit >> 5] >> (bit & 31u)) & 1u) << j;
-      }
+      const float tm = fmaf((float)(32 * k + 16), dt, t0);
+      const int cx = min(max((int)(fmaf(tm, d[0], o[0]) * fRc), 0), Rc_m1), cy = min(max((int)(fmaf(tm, d[1], o[1]) * fRc), 0), Rc_m1),
+                cz = min(max((int)(fmaf(tm, d[2], o[2]) * fRc), 0), Rc_m1);
+      const uint32_t bit = (uint32_t)cx + Rc * ((uint32_t)cy + Rc * (uint32_t)cz);
+      pass = (fd.occ_coarse[bit >> 5] >> (bit & 31u)) & 1u;
     }
-    for (int j = 0; j < 8 && kb + j < k_hi; j++) {
-      const int k = kb + j;
-      uint32_t w = 0u;
-      if ((pass >> j) & 1u) {
-        bool occ[32];
+    if (pass) {
 #pragma unroll
-        for (int q = 0; q < 32; q++) {
-          const int i = 32 * k + q;
+      for (int q0 = 0; q0 < 32; q0 += 8) { // eight fine tests issued together (eight loads in flight, one wait)
+        bool occ[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int i = 32 * k + q0 + q;
           const float t = fmaf((float)i + 0.5f, dt, t0);
           occ[q] = occupied(fd, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]), fmaf(t, d[2], o[2])) && t < t1;
         }
 #pragma unroll
-        for (int q = 0; q < 32; q++) w |= (uint32_t)occ[q] << q;
+        for (int q = 0; q < 8; q++) w |= (uint32_t)occ[q] << (q0 + q);
       }
-      mw[k][threadIdx.x] = w;
-      if (w != 0u) {
-        if (first_nz == 32) first_nz = k;
-        last_nz = k;
-        n_live += (uint32_t)__popc(w);
-      }
+    }
+    mw[k][threadIdx.x] = w;
+    if (w != 0u) {
+      if (first_nz == 32) first_nz = k;
+      last_nz = k;
+      n_live += (uint32_t)__popc(w);
     }
   }
   return n_live;
@@ -424,14 +416,15 @@ __global__ __launch_bounds__(256) void march_compact_kernel(MarchParams P) {
 // member's dilated coarse bit is set: a member's mask bits are its own fine bits wherever they are tested and its grid is
 // empty wherever its own launch would not have looked, so every member's masks, records and march count are what its own
 // launch writes (the queue order differs, as between any two launches).
-// Two walks instead of mask words in LDS (E x 32 words per lane would be 160 KB per block): the first finds every member's
-// first / last non-empty word and its march count, the queue slots are then reserved for all members at once, and the
-// second walk -- only the words some member needs -- puts each word where it belongs: the record's own chunk in registers,
-// the later chunks straight into the member's extension buffer.  The walk is the cheap part of this launch (the records'
-// bytes are what it costs), so walking twice is worth not holding 32 KB of LDS per member.
-template <int E>
+// Two passes over the ray's words (all mask words of all members in LDS would be 160 KB per block): the first walks, finds
+// every member's first / last non-empty word and its march count and keeps the first kWin words from each member's first
+// non-empty one in LDS; the queue slots are then reserved for all members at once; the second pass puts each word where it
+// belongs -- the record's own chunk in registers, the later chunks straight into the member's extension buffer -- reading
+// the LDS window and walking again only the words some member needs from behind it (live spans over 32 kWin steps).
+template <int E, int kWin>
 __global__ __launch_bounds__(256) void march_multi_kernel(MarchMultiParams P) {
   __shared__ uint4 stage[4][64 * kRecordWords];
+  __shared__ uint32_t mw[E][kWin][256]; // the first kWin words of every member's mask from its first non-empty one (second walk below)
   const uint32_t ty = blockIdx.x / P.tiles_x, tx = blockIdx.x - ty * P.tiles_x;
   MarchRay r;
   march_ray_setup(P, P.occ_lo, P.occ_hi, tx, ty, r);
@@ -515,12 +508,15 @@ __global__ __launch_bounds__(256) void march_multi_kernel(MarchMultiParams P) {
         uint32_t w[E];
         fine_word(k, w);
 #pragma unroll
-        for (int e = 0; e < E; e++)
+        for (int e = 0; e < E; e++) {
           if (w[e] != 0u) {
             if (first_nz[e] == 32) first_nz[e] = k;
             last_nz[e] = k;
             n_live[e] += (uint32_t)__popc(w[e]);
           }
+          const int j = k - first_nz[e]; // < 0 before the member's first non-empty word
+          if (j >= 0 && j < kWin) mw[e][j][threadIdx.x] = w[e];
+        }
       }
     }
   }
@@ -570,10 +566,22 @@ __global__ __launch_bounds__(256) void march_multi_kernel(MarchMultiParams P) {
       for (int q = 0; q < 4; q++) acc[e][q] = 0u;
     for (int k = k2_lo; k <= k2_hi; k++) {
       uint32_t w[E];
-      if ((passmask >> k) & 1u) fine_word(k, w);
-      else {
+      // a word is walked again only where some member needs it from behind its LDS window (a live span of more than
+      // kWin words: 32 kWin steps); words no member's coarse bit passed were never written and are zero
+      bool behind = false;
+#pragma unroll
+      for (int e = 0; e < E; e++) behind = behind || (k - first_nz[e] >= kWin && k <= last_nz[e]);
+      if (!((passmask >> k) & 1u)) {
 #pragma unroll
         for (int e = 0; e < E; e++) w[e] = 0u;
+      } else if (behind) {
+        fine_word(k, w);
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const int j = k - first_nz[e];
+          w[e] = (j >= 0 && k <= last_nz[e]) ? mw[e][j][threadIdx.x] : 0u;
+        }
       }
 #pragma unroll
       for (int e = 0; e < E; e++) {
@@ -1604,8 +1612,8 @@ hipError_t launch_march_multi(const MarchMultiParams& P, int n_views, int n_spp,
   dim3 grid((unsigned)(P.tiles_x * P.tiles_y), (unsigned)n_views, (unsigned)(P.spp_inner_log2 > 0 ? 1 : n_spp));
   if (grid.x == 0) return hipSuccess;
   // the paper's ensembles (Share_Data.hpp:505-510: two members for EnsembleRGB, five for EnsembleRGBDensity)
-  if (P.n_members == 5) hipLaunchKernelGGL((march_multi_kernel<5>), grid, dim3(256), 0, s, P);
-  else if (P.n_members == 2) hipLaunchKernelGGL((march_multi_kernel<2>), grid, dim3(256), 0, s, P);
+  if (P.n_members == 5) hipLaunchKernelGGL((march_multi_kernel<5, 8>), grid, dim3(256), 0, s, P); // 24 KB of record staging + 40 KB of mask words
+  else if (P.n_members == 2) hipLaunchKernelGGL((march_multi_kernel<2, 12>), grid, dim3(256), 0, s, P);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

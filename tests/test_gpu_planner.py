@@ -271,7 +271,9 @@ def test_reference_signature_png_path_equals_the_fused_round(tmp_path, method):
             names = sorted(os.listdir(save / "render" / str(it) / f"ensemble_{e}"))
             assert names == sorted(f"rgbaClip_{v}.png" for v in range(5) if v not in chosen[: it + 1])
     assert got["png"][3].count("train and eval with executed time") == 3 * E  # main.cpp:1705, once per engine call
-    assert (save / "train_time" / "0.txt").exists()
+    # train_time/<it>.txt is written by train_by_instantNGP for ensemble_id == -1 only (main.cpp:1707-1711): the per-member
+    # calls of the PNG path leave none; the fused round (one call per iteration) times itself there
+    assert not (save / "train_time" / "0.txt").exists() and (got["fused"][2] / "train_time" / "0.txt").exists()
     # the fused records' scores are what the fused path's scores file holds
     rec = np.frombuffer((got["fused"][2] / "records" / "0.bin").read_bytes(), api.RECORD_DTYPE)
     assert rec["score"].tobytes() == got["fused"][0][0].tobytes()
