@@ -861,6 +861,14 @@ int render_ensemble_ngp(prv_ctx* c, const int* slots, int E, const prv_camset* c
   if (seg_cap * (size_t)n_seg >= (1ull << 32)) return PRV_OK;
   const size_t q_stride = seg_cap * (size_t)n_seg * kRecordBytes, x_stride = seg_cap * (size_t)n_seg * kExtBytes,
                s_stride = spp > 1 ? (size_t)n_views * npix * (size_t)spp * 16 : 0;
+  { // E queues, E extension buffers, E staging images at once: only where the device has the room (else member by member,
+    // whose buffers are a fifth of these)
+    const size_t grow = (q_stride * (size_t)E > c->queue.bytes ? q_stride * (size_t)E - c->queue.bytes : 0) +
+                        (x_stride * (size_t)E > c->queue_ext.bytes ? x_stride * (size_t)E - c->queue_ext.bytes : 0) +
+                        (s_stride * (size_t)E > c->stage.bytes ? s_stride * (size_t)E - c->stage.bytes : 0);
+    size_t free_b = 0, total_b = 0;
+    if (grow && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || grow + ((size_t)2 << 30) > free_b)) return PRV_OK;
+  }
   if ((rc = ensure(c, c->queue, q_stride * (size_t)E)) != PRV_OK) return rc;
   if ((rc = ensure(c, c->queue_ext, x_stride * (size_t)E)) != PRV_OK) return rc;
   if (spp > 1 && (rc = ensure(c, c->stage, s_stride * (size_t)E)) != PRV_OK) return rc;

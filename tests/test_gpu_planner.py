@@ -606,6 +606,33 @@ def test_planner_executable_trains_its_ensemble_every_iteration(ctx, tmp_path):
     assert out2.returncode == 0 and "chosen_nbvs:\n" in out2.stdout
 
 
+def test_planner_trains_with_patches_of_adjacent_pixels_when_the_yaml_asks(ctx, tmp_path):
+    """yaml `train_patch_w` / `train_patch_h` -> prv_train_opts.patch_w / patch_h (training rays drawn as patches: the speed /
+    quality trade of profiles/r05_train_patch_study.txt; the default stays single pixels): the loop runs to the end with
+    them, a patch that does not fit is the library's error, and the member trained is not the single-pixel run's"""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    chosen, timing = {}, {}
+    for name, extra in (("single", ""), ("patch", "\ntrain_patch_w: 4\ntrain_patch_h: 2"), ("bad", "\ntrain_patch_w: 5\ntrain_patch_h: 4")):
+        pre = tmp_path / name
+        pre.mkdir()
+        cfg = pre / "cfg.yaml"
+        text = YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=2,
+                           model_source="train_steps: 40\ntrain_rays: 1024\ntrain_width: 64\ntrain_height: 36\nground_truth_seed: 4242" + extra)
+        cfg.write_text(text.replace("ensemble_num: 5", "ensemble_num: 2"))
+        out = subprocess.run([exe, str(cfg)], input="21\nobjA\n-1\n", text=True, capture_output=True, timeout=300,
+                             env=dict(os.environ, PRV_PLANNER_TIMING="1", PRV_PLANNER_DUMP_RECORDS="1"))
+        if name == "bad":
+            assert out.returncode != 0 and "patch_w x patch_h" in out.stdout + out.stderr
+            continue
+        assert out.returncode == 0, out.stdout + out.stderr
+        line = [l for l in out.stdout.splitlines() if l.startswith("chosen_nbvs:")][-1]
+        chosen[name] = [int(x) for x in line.split(":")[1].split()]
+        save = pre / "Compare" / "ShapeNet" / "objA_m2_v1_t0"
+        timing[name] = np.frombuffer((save / "scores" / "0.bin").read_bytes(), np.float64)
+        assert len(chosen[name]) == 4 and len(set(chosen[name])) == 4
+    assert timing["single"].shape == timing["patch"].shape and not np.array_equal(timing["single"], timing["patch"])  # other batches, other members
+
+
 def test_planner_retrains_by_default_with_the_reference_key_n_steps(ctx, tmp_path):
     """the reference retrains every member every iteration with `--n_steps <n_steps>` (main.cpp:1668, 2041-2043): a
     config that only carries the reference's own key trains (the selection then depends on the acquired views);
