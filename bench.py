@@ -1044,10 +1044,20 @@ def dry_run(args, rank, world, np, torch, dist):
         all_d = [torch.zeros_like(digest) for _ in range(world)]
         dist.all_gather(all_d, digest)
         assert all(bool((d == digest).all()) for d in all_d), "ranks disagree on the gathered records"
+    config3 = None
+    if world > 1 and not args.no_config3:  # the shape of the sub-object the real N > 1 run adds: configs[3]'s 1024 views, strong
+        ids3, per3 = planner.shard_views(1024, rank, world, interleaved=True)
+        rec3 = np.zeros(len(ids3), api.RECORD_DTYPE)
+        rec3["score"] = np.sin(ids3.astype(np.float64) * 12.9898) * 43758.5453 % 1.0
+        records3 = planner.gather_records(rec3, per3, 1024, interleaved=True)
+        order3 = api.rank_host(records3, np.arange(1024, dtype=np.int32))
+        config3 = {"scaling": "strong", "views_per_gpu": int(len(ids3)), "comm_ranks": world,
+                   "records_checksum": int(np.frombuffer(records3.tobytes(), np.uint8).astype(np.int64).sum()),
+                   "ranking_head": [int(x) for x in order3[:8]]}
     if rank == 0:
         print(json.dumps({"metric": "dry run (no GPU work, no performance figure)", "value": None, "dry_run": True, "n_gpus": world,
                           "scaling": args.mode, "views_total": n_views, "ranking_head": [int(x) for x in order[:8]],
-                          "records_checksum": int(digest[0])}), flush=True)
+                          "records_checksum": int(digest[0]), "config3": config3}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

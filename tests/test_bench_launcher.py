@@ -35,6 +35,14 @@ def test_plain_invocation_with_two_gpus_launches_its_own_ranks(mode, extra, n_vi
     assert one.returncode == 0, one.stdout + one.stderr
     ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert ref["records_checksum"] == two["records_checksum"] and ref["ranking_head"] == two["ranking_head"]
+    # N > 1 carries BASELINE configs[3] beside the headline: 1024 views sharded 1024 / N per rank, the same records and ranking
+    # as one process scoring all of them
+    c3 = two["config3"]
+    assert c3["views_per_gpu"] == 512 and c3["comm_ranks"] == 2 and c3["scaling"] == "strong" and ref["config3"] is None
+    if mode == "weak":
+        all1024 = run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0", "--mode", "strong", "--views-total", "1024"], {"PRV_BENCH_DRY_RUN": "1"})
+        r3 = json.loads([l for l in all1024.stdout.splitlines() if l.startswith("{")][0])
+        assert r3["records_checksum"] == c3["records_checksum"] and r3["ranking_head"] == c3["ranking_head"]
 
 
 def test_launcher_passes_a_failing_rank_on():
