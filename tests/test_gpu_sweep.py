@@ -308,7 +308,9 @@ def test_placement_and_layout_switches_change_speed_only(ctx, oracle, monkeypatc
 @pytest.mark.parametrize("env", [{"PRV_TRAIN_GRAPH": "0"}, {"PRV_TRAIN_FAST_FWD": "0"},
                                  {"PRV_TRAIN_GRAPH": "0", "PRV_TRAIN_FAST_FWD": "0"}, {"PRV_TRAIN_KEEP_ACT": "0"},
                                  {"PRV_TRAIN_ACT_CAP": "256"}, {"PRV_TRAIN_ACT_CAP": "256", "PRV_TRAIN_GRAPH": "0"},
-                                 {"PRV_TRAIN_REG_CHAIN": "0"}, {"PRV_TRAIN_REG_CHAIN": "0", "PRV_TRAIN_ACT_CAP": "256"}])
+                                 {"PRV_TRAIN_REG_CHAIN": "0"}, {"PRV_TRAIN_REG_CHAIN": "0", "PRV_TRAIN_ACT_CAP": "256"},
+                                 {"patch": "4x2"}, {"patch": "4x2", "PRV_TRAIN_FAST_FWD": "0"}, {"patch": "2x2", "PRV_TRAIN_KEEP_ACT": "0"},
+                                 {"patch": "4x4", "PRV_TRAIN_ACT_CAP": "256", "PRV_TRAIN_GRAPH": "0"}, {"patch": "2x2", "PRV_TRAIN_REG_CHAIN": "0"}])
 def test_trainer_switches_hold_the_same_bars(ctx, oracle, monkeypatch, env):
     """the trainer's switches -- plain launches instead of the captured step graph, f32 tile forward instead of the
     f16-MFMA forward, a backward pass that recomputes the forward activations instead of reading the ones the forward
@@ -329,6 +331,10 @@ def test_trainer_switches_hold_the_same_bars(ctx, oracle, monkeypatch, env):
     f = oracle.OracleField(f.desc, params=(t, m, o))
     ctx.load_model(3, api.field_desc(**kw), t, m, o)
     opts = dict(n_rays=160, n_samples=24, occ_every=4, occ_sigma_thresh=0.3)
+    env = dict(env)
+    if "patch" in env:  # the same switches with the step's rays drawn as patches (the list order and slot_of change under every path)
+        pw, ph = (int(x) for x in env.pop("patch").split("x"))
+        opts.update(patch_w=pw, patch_h=ph)
     otr = oracle.OracleTrainer(f, oracle.train_opts(**opts), ocams, imgs)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
