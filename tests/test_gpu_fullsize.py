@@ -218,8 +218,8 @@ def test_evaluation_block_at_the_reference_size_against_the_oracle_alone(ctx, or
     cs.close()
 
 
-@pytest.mark.parametrize("which", ["256", "512"])
-def test_training_gradients_on_the_full_size_fields(ctx, oracle, which):
+@pytest.mark.parametrize("which,patch", [("256", (0, 0)), ("512", (0, 0)), ("256", (4, 4)), ("512", (2, 2))])
+def test_training_gradients_on_the_full_size_fields(ctx, oracle, which, patch):
     """one training batch on the BASELINE fields (256^3: L=8 F=4 T=2^19; 512^3: L=16 F=2 T=2^21) at 128 samples
     per ray: same ray batch, loss and gradients within 1e-3 of the oracle -- covers the full-size level tables
     (dense up to 79^3 / 215^3 vertices, 2^19 / 2^21-entry hashed levels) in the encoder's backward scatter"""
@@ -238,7 +238,7 @@ def test_training_gradients_on_the_full_size_fields(ctx, oracle, which):
     u8, _ = ctx.render_rgba8(1, cams, None, api.render_opts(96, 72, S, 1, 1e-4, background=(0, 0, 0, 0)))
     imgs = u8.cpu().numpy()
     ocams = oracle.cameras_from_dataset(tms, intr, scale, offset)
-    base = dict(n_rays=192, n_samples=S, occ_every=0)
+    base = dict(n_rays=192, n_samples=S, occ_every=0, patch_w=patch[0], patch_h=patch[1])  # patches: the merging scatter on full-size tables
     otr = oracle.OracleTrainer(f, oracle.train_opts(**base), ocams, imgs)
     gtr = api.Trainer(ctx, 3, cams, u8, api.train_opts(**base))
     want_loss, want_tg, want_mg = otr.gradients()
