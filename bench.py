@@ -714,6 +714,7 @@ def run_rank(args):
 
         def work3():
             try:
+                torch.cuda.set_device(device)  # a new thread starts on device 0: the round's synchronisations must mean THIS rank's GPU
                 r3 = Round(env, field_kw("512", args.scene), 1024, args, slots=(2, 3), comm=comm)
                 k3 = max(2, min(5, args.steps))
                 m3 = r3.measure(k3, 1)
