@@ -1,5 +1,7 @@
 """Full-size (800x800, 128 samples/ray, 256^3 field) checks on the GPU through size-independent
 properties, plus bounded direct comparisons against the oracle (a few rows of one view)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -103,6 +105,31 @@ def test_ensemble_round_at_reference_candidate_size(ctx, oracle, scene):
         else:  # sums of logs: the last bit of an addend may differ between the two log implementations
             np.testing.assert_allclose(rec["score"], want, rtol=1e-13)
         assert (imgs[0][..., 3] == 255).all()  # opaque background: alpha carries nothing
+
+
+def test_reference_round_with_the_march_in_one_launch_scores_what_the_member_renders_score(ctx, oracle, scene):
+    """the reference's round at ITS sizes under the engine's rule -- 80x45, 16 sub-samples, five members of the full-size
+    256^3 field, 144 candidate views -- goes through ONE march launch for the five members (march_multi_kernel).  The
+    records must be the scores of the images each member renders ON ITS OWN (prv_render_rgba8: the one-member march and
+    render), bit for bit (method 3: same bytes in, the reference loop's summation order on both sides), and the round's
+    march count the sum of the members' own"""
+    desc, cams, _ = scene
+    pts = planner.hemisphere_read(os.path.join(os.path.dirname(__file__), "golden", "hemisphere", "144.txt"), 144)
+    tms, scale, offset = planner.hemisphere_transforms(pts, 0.3, 0.1, [1e-10] * 3)
+    small = ctx.cameras_from_matrices(tms, util.FOV_X, 80, 45, scale, offset)
+    for e in range(5):
+        ctx.synthetic_model(2 + e, desc, 4100 + e)
+    opts = api.engine_render_opts(80, 45, 0, 16, 0.01, background=(0, 0, 0, 1))
+    rec, st = ctx.score_views(3, list(range(2, 7)), small, None, opts, want_stats=True)
+    imgs, live = [], 0
+    for e in range(5):
+        im, se = ctx.render_rgba8(2 + e, small, None, opts, want_stats=True)
+        imgs.append(im.cpu().numpy())
+        live += int(se.samples_live)
+    want = np.array([oracle.score_ensemble_rgbdensity([im[v] for im in imgs]) for v in range(144)])
+    assert np.array_equal(rec["score"], want)
+    assert int(st.samples_live) == live > 0 and st.rays == 144 * 80 * 45 * 16 * 5
+    small.close()
 
 
 @pytest.mark.parametrize("rule", ["fixed", "ngp"])
