@@ -136,6 +136,31 @@ def test_patch_batch_rule(oracle, scene):
     for pw, ph, n in ((0, 0, 40), (2, 2, 40), (4, 4, 40), (4, 2, 37)):
         tr = oracle.OracleTrainer(empty, oracle.train_opts(n_rays=n, n_samples=8, occ_every=0, random_bg=0, patch_w=pw, patch_h=ph, seed=seed), cams, flat)
         assert tr.loss_only() == pytest.approx(expected(n, pw, ph), rel=1e-5)
+    # ... and WHICH pixels: images whose colour is the pixel's own coordinates (r = x, g = y, b = image) make a ray's loss term
+    # lin(x)^2 + lin(y)^2 + lin(image)^2; the term of ray n - 1 is 3 n loss(n) - 3 (n - 1) loss(n - 1).  Expected from the rule
+    # restated here: origin drawn per patch in [0, W - pw] x [0, H - ph], ray r of a patch at row r // pw, rows walked in snake order
+    coord = np.zeros_like(imgs)
+    coord[..., 0] = np.arange(w, dtype=np.uint8)[None, None, :]
+    coord[..., 1] = np.arange(h, dtype=np.uint8)[None, :, None]
+    coord[..., 2] = np.arange(len(coord), dtype=np.uint8)[:, None, None]
+    coord[..., 3] = 255
+    u24 = oracle.lib().orc_rng_u24
+    for pw, ph in ((1, 1), (2, 2), (4, 2), (3, 3), (4, 4), (1, 4)):
+        P, n, prev = pw * ph, 2 * pw * ph + 3, 0.0
+        for k in range(1, n + 1):
+            tr = oracle.OracleTrainer(empty, oracle.train_opts(n_rays=k, n_samples=8, occ_every=0, random_bg=0, target_samples=0, patch_w=pw, patch_h=ph,
+                                                               seed=seed), cams, coord)
+            tot = tr.loss_only() * 3 * k
+            j, q, r = k - 1, (k - 1) // P, (k - 1) % P
+            img = (u24(seed, 0, q) * len(coord)) >> 24
+            ry = r // pw
+            rx = pw - 1 - r % pw if ry & 1 else r % pw
+            x = ((u24(seed, 1, q) * (w - pw + 1)) >> 24) + rx
+            y = ((u24(seed, 2, q) * (h - ph + 1)) >> 24) + ry
+            assert 0 <= x < w and 0 <= y < h
+            want = sum(float(lin(np.float32(c / 255.0))) ** 2 for c in (x, y, img))
+            assert tot - prev == pytest.approx(want, rel=2e-4, abs=1e-7), (pw, ph, j, x, y, img)
+            prev = tot
     # patches never leave the image: a patch as large as the image has one possible origin
     tr = oracle.OracleTrainer(empty, oracle.train_opts(n_rays=w * h, n_samples=8, occ_every=0, random_bg=0, patch_w=w, patch_h=h), cams, flat)
     assert tr.loss_only() > 0
