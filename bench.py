@@ -583,6 +583,10 @@ def full_loop(args):
             # round (5 members x 2500 steps side by side)
             steps_s = [float(x) for x in re.findall(r"train_members: .*? steps ([0-9.eE+-]+) s", r.stderr)]
             train_s = [float(x) for x in re.findall(r"train_members: .*? total ([0-9.eE+-]+) s", r.stderr)]
+            for key2, word in (("training_ground_truth_s", "gt"), ("training_fresh_models_s", "fresh"), ("training_create_s", "create")):
+                vals = [float(x) for x in re.findall(rf"train_members: .*? {word} ([0-9.eE+-]+) s", r.stderr)]
+                if vals:
+                    out[key2] = sum(vals)  # where a training call's time outside its optimiser steps goes
             if steps_s:
                 out["training_calls"] = len(steps_s)
                 out["training_steps_s"] = sum(steps_s)
