@@ -995,6 +995,12 @@ def reference_round(env, fkw, layout_of, variant_of):
                      "best_view": int(ctx.argmax(rec, np.arange(n_views))),
                      "roofline": {k: roof[k] for k in ("kernel", "bound", "frac", "peak", "achieved", "unit", "avg_launch_ms", "units_per_launch",
                                                        "slot_utilisation", "samples_per_s_in_kernel", "shader_clock_ghz_measured")}}
+    out["fixed_128"]["note"] = ("not the reference's rule (it renders with the engine's stepping: ngp_step).  Slot utilisation stays ~0.68 here by "
+                                "MEASUREMENT: relocation (tail merge + pool) lifts it to 0.92 and makes this round slower, 46.4 -> 48.8 ms -- 128 uniform "
+                                "samples share no cell, so the corner cache that pays for relocation under the engine's rule has nothing to keep "
+                                "(profiles/r05_march_multi.txt)")
+    out["ngp_step"]["note"] = ("the five members' rays are marched in ONE launch (march_multi_kernel: one occupancy walk per ray answers every member), "
+                               "then one render launch per member")
     cams.close()
     return out
 
