@@ -402,6 +402,44 @@ void train_tile_kernel(TrainTileParams P) {
   STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
+  if constexpr (!FWD) {
+    // The step's loss and used-sample count ride on this launch: its LAST blocks each sum one 1024-ray slice of the per-ray
+    // terms the compositing kernel left (a kernel boundary ago: plain loads) -- thread t the rays t, t + 256, ... of the
+    // slice, then a tree over the 256 partial sums: a fixed order -- and the step's last kernel adds the slices in slice
+    // order (end_step).  Until round 5 a kernel of its own in every member's chain (6 us alone, 13 us beside the other
+    // members' launches); a ticket in the compositing kernel instead costs a device-scope release fence per block: slower.
+    const int n_slices = P.ray_loss ? (P.n_rays + 1023) / 1024 : 0;
+    const int slice = (int)gridDim.x - 1 - (int)blockIdx.x;
+    if (P.tile_begin == 0 && slice < n_slices) {
+      double* sl = reinterpret_cast<double*>(lds);
+      unsigned long long* su = reinterpret_cast<unsigned long long*>(lds) + 256;
+      double a = 0.0;
+      unsigned long long u = 0ull;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int i = slice * 1024 + k * 256 + (int)threadIdx.x;
+        if (i < P.n_rays) {
+          a += (double)P.ray_loss[i];
+          u += P.ray_used[i];
+        }
+      }
+      sl[threadIdx.x] = a;
+      su[threadIdx.x] = u;
+      __syncthreads();
+      for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+          sl[threadIdx.x] += sl[threadIdx.x + w];
+          su[threadIdx.x] += su[threadIdx.x + w];
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        P.loss_part[2 * slice] = sl[0];
+        P.loss_part[2 * slice + 1] = __longlong_as_double((long long)su[0]);
+      }
+      __syncthreads(); // the scratch goes back to the tile loop
+    }
+  }
   const uint32_t n_samples = *P.sample_count;
   const uint32_t n_tiles = min((n_samples + 31u) / 32u, P.tile_limit);
   if (P.tile_begin + blockIdx.x >= n_tiles) { // nothing to do for this block: its slot of the weight-gradient partials is zero
@@ -1160,62 +1198,11 @@ __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositePara
   }
 }
 
-// fixed-order sum of the per-ray losses and used-sample counts (one block)
 // first node of a step: the bias-corrected learning rate of step n = state->step + 1, the sample counter reset
 __global__ void train_begin_kernel(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2) {
   const double n = (double)(state->step + 1u);
   state->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, n)) / (1.0 - pow((double)beta1, n)));
   *sample_count = 0u;
-}
-
-__global__ __launch_bounds__(256) void train_loss_kernel(const float* __restrict__ ray_loss,
-                                                         const uint32_t* __restrict__ ray_used, int n,
-                                                         const TrainState* __restrict__ state,
-                                                         unsigned long long* out_used, double* __restrict__ part,
-                                                         uint32_t* __restrict__ ticket) {
-  // stage 1: every block sums its 1024-ray slice in a fixed order; stage 2: the block that arrives last adds
-  // the slices in slice order -- the result does not depend on which block that is
-  __shared__ double sl[256];
-  __shared__ unsigned long long su[256];
-  __shared__ bool last;
-  double a = 0.0;
-  unsigned long long u = 0ull;
-  const int base = blockIdx.x * 1024;
-  for (int k = 0; k < 4; k++) {
-    const int i = base + k * 256 + threadIdx.x;
-    if (i < n) {
-      a += (double)ray_loss[i];
-      u += ray_used[i];
-    }
-  }
-  sl[threadIdx.x] = a;
-  su[threadIdx.x] = u;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    unsigned long long tu = 0ull;
-    for (int i = 0; i < 256; i++) {
-      t += sl[i];
-      tu += su[i];
-    }
-    part[2 * blockIdx.x] = t;
-    part[2 * blockIdx.x + 1] = __longlong_as_double((long long)tu);
-    __threadfence();
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (last && threadIdx.x == 0) {
-    __threadfence();
-    double t = 0.0;
-    unsigned long long tu = 0ull;
-    for (unsigned i = 0; i < gridDim.x; i++) {
-      t += __hip_atomic_load(part + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      tu += (unsigned long long)__double_as_longlong(__hip_atomic_load(part + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
-    state->losses[state->step - state->step0] = (float)t;
-    *out_used = tu;
-    *ticket = 0u; // ready for the next step
-  }
 }
 
 // ------------------------------------------------------------------ optimiser
@@ -1230,7 +1217,21 @@ __device__ __forceinline__ void adam_update(const AdamParams& P, float lr_t, flo
 // end-of-step bookkeeping, ONE thread of the step's last kernel, which must not read any of these itself: the step
 // counter, the sample budget (integer rule, mirrored by oracle/prv_train.c) and -- when that kernel also opens the
 // next step (sample_count != NULL) -- the next step's bias-corrected learning rate and the sample counter reset
+// the slices of the step's loss / used-sample sums (the backward launch left them) in slice order
+__device__ __forceinline__ void finish_loss(const double* __restrict__ part, int n_rays, TrainState* state, unsigned long long* used) {
+  double t = 0.0;
+  unsigned long long u = 0ull;
+  for (int s = 0; s < (n_rays + 1023) / 1024; s++) {
+    t += part[2 * s];
+    u += (unsigned long long)__double_as_longlong(part[2 * s + 1]);
+  }
+  state->losses[state->step - state->step0] = (float)t;
+  *used = u;
+}
+__global__ void train_loss_finish_kernel(const double* part, int n_rays, TrainState* state, unsigned long long* used) { finish_loss(part, n_rays, state, used); }
+
 __device__ __forceinline__ void end_step(const AdamParams& P, uint32_t* sample_count, float lr, float beta1, float beta2) {
+  if (P.loss_part) finish_loss(P.loss_part, P.n_rays, P.state, P.used);
   const uint32_t done = P.state->step + 1u;
   P.state->step = done;
   if (P.target_samples > 0) {
@@ -1558,10 +1559,8 @@ hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float l
   return hipGetLastError();
 }
 
-hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, const TrainState* state,
-                             unsigned long long* out_used, double* part, uint32_t* ticket, hipStream_t s) {
-  hipLaunchKernelGGL(train_loss_kernel, dim3((n + 1023) / 1024), dim3(256), 0, s, ray_loss, ray_used, n, state, out_used, part,
-                     ticket);
+hipError_t launch_train_loss_finish(const double* loss_part, int n_rays, TrainState* state, unsigned long long* used, hipStream_t s) {
+  hipLaunchKernelGGL(train_loss_finish_kernel, dim3(1), dim3(1), 0, s, loss_part, n_rays, state, used);
   return hipGetLastError();
 }
 

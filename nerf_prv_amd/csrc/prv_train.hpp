@@ -74,6 +74,14 @@ struct TrainTileParams {
   // backward-pass A fragments of the fp16 weights, rebuilt with the forward ones after every optimiser step:
   // kBwdFrags x 64 lanes x 8 halfs; NULL: the LDS / f32-MFMA chain
   const uint4* bwd_frags;
+  // the step's loss rides on the backward launch (no kernel of its own in every member's chain): block gridDim.x - 1 - s of
+  // the launch that starts at tile 0 sums slice s (1024 rays) of the rays' loss terms and used-sample counts in a fixed
+  // order before its own tiles -> loss_part[2 s], [2 s + 1]; the slices are added up by the step's last kernel (end_step)
+  // or by launch_train_loss_finish (ray_loss == NULL: nobody does)
+  const float* ray_loss;
+  const uint32_t* ray_used;
+  int n_rays;
+  double* loss_part;
 };
 constexpr size_t kActTileBytes = (16 * 64 + 32) * 16; // kept activations of a 32-sample tile: 16 slots x 64 lanes x 16 B, then 32 positions
 constexpr int kBwdFrags = 20; // R3: 2 row tiles | R2: 2 x 4 k-steps | R1: 4 k-steps | D2: 2 row tiles | D1: 4 k-steps
@@ -96,9 +104,12 @@ struct TrainCompositeParams {
 struct AdamParams {
   TrainState* state; // lr_t read from it; adam_mlp_kernel advances state->step and adapts state->n_active
   float beta1, beta2, eps;
-  const unsigned long long* used; // samples composited by the step (sample budget rule)
+  unsigned long long* used; // samples composited by the step (sample budget rule); written by end_step from loss_part
   int target_samples, n_rays;
+  const double* loss_part;  // the backward launch's slice sums of the rays' loss / used counts (NULL: `used` and the loss are final already)
 };
+// the slices' sums -> state->losses[step - step0], *used (the parity hook prv_train_gradients: no optimiser kernel follows)
+hipError_t launch_train_loss_finish(const double* loss_part, int n_rays, TrainState* state, unsigned long long* used, hipStream_t s);
 
 struct DensityParams {
   const uint16_t* table;
@@ -120,8 +131,6 @@ hipError_t launch_prepack_frags(const uint16_t* mlp, int n_features, uint16_t* f
 hipError_t launch_train_forward_fast(const TrainTileParams& P, const half8* frags, int n_blocks, hipStream_t s);
 hipError_t launch_train_composite(const TrainCompositeParams& P, hipStream_t s);
 hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2, hipStream_t s);
-hipError_t launch_train_loss(const float* ray_loss, const uint32_t* ray_used, int n, const TrainState* state,
-                             unsigned long long* out_used, double* part, uint32_t* ticket, hipStream_t s);
 // wmv: one {w[4], m[4], v[4]} record (48 B) per group of four table scalars, ceil(n / 4) records
 hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s);
 hipError_t launch_widen_table(const uint16_t* in, size_t n, float* wmv, hipStream_t s);
