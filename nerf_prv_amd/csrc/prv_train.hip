@@ -941,12 +941,12 @@ void train_tile_kernel(TrainTileParams P) {
 // mlp_grad[i] += sum over the blocks' partial slots, in two stages: 16 slot groups summed side by side (grid.y),
 // then the 16 group sums of a weight added in group order -- fixed order throughout, 16x the loads in flight
 constexpr int kDwGroups = 16;
-__global__ __launch_bounds__(256) void train_reduce_dw_kernel(const float* __restrict__ partial, int n_blocks,
-                                                              float* __restrict__ stage) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+constexpr int kDwBlocksX = (PRV_MLP_HALFS + 255) / 256; // the first stage is kDwBlocksX x kDwGroups blocks of 256 threads
+__device__ __forceinline__ void reduce_dw_block(const float* __restrict__ partial, int n_blocks, float* __restrict__ stage, int bx, int by) {
+  const int i = bx * 256 + (int)threadIdx.x;
   if (i >= PRV_MLP_HALFS) return;
   const int per = (n_blocks + kDwGroups - 1) / kDwGroups;
-  const int b0 = blockIdx.y * per, b1 = min(n_blocks, b0 + per);
+  const int b0 = by * per, b1 = min(n_blocks, b0 + per);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   int b = b0;
   for (; b + 3 < b1; b += 4) {
@@ -954,7 +954,11 @@ __global__ __launch_bounds__(256) void train_reduce_dw_kernel(const float* __res
     for (int u = 0; u < 4; u++) acc[u] += partial[(size_t)(b + u) * PRV_MLP_HALFS + i];
   }
   for (; b < b1; b++) acc[0] += partial[(size_t)b * PRV_MLP_HALFS + i];
-  stage[(size_t)blockIdx.y * PRV_MLP_HALFS + i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  stage[(size_t)by * PRV_MLP_HALFS + i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+__global__ __launch_bounds__(256) void train_reduce_dw_kernel(const float* __restrict__ partial, int n_blocks,
+                                                              float* __restrict__ stage) {
+  reduce_dw_block(partial, n_blocks, stage, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 __global__ __launch_bounds__(256) void train_reduce_dw2_kernel(const float* __restrict__ stage, float* __restrict__ mlp_grad) {
@@ -1256,7 +1260,16 @@ __device__ __forceinline__ void end_step(const AdamParams& P, uint32_t* sample_c
 // master weights and the moments are the trainer's own: no other code reads them in place).  A touched group then reads and
 // writes one or two lines of state where three separate arrays cost three partial lines each way.
 __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n, float* __restrict__ grad,
-                                                         float* __restrict__ wmv, uint16_t* __restrict__ w16) {
+                                                         float* __restrict__ wmv, uint16_t* __restrict__ w16,
+                                                         unsigned n_adam_blocks, const float* __restrict__ dw_partial, int dw_slots,
+                                                         float* __restrict__ dw_stage) {
+  // the blocks behind the table's own do the first stage of the MLP's weight-gradient reduction: both read what the backward
+  // launch left and neither needs the other, so the reduction is no node of its own in the step's chain (round 5)
+  if (blockIdx.x >= n_adam_blocks) {
+    const int k = (int)(blockIdx.x - n_adam_blocks);
+    reduce_dw_block(dw_partial, dw_slots, dw_stage, k % kDwBlocksX, k / kDwBlocksX);
+    return;
+  }
   const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= n) return;
   const float lr_t = P.state->lr_t;
@@ -1492,7 +1505,7 @@ hipError_t train_prepare_kernels() {
   return hipSuccess;
 }
 
-hipError_t launch_train_tiles(const TrainTileParams& P0, bool forward, int n_blocks, hipStream_t s, bool finish_reduce) {
+hipError_t launch_train_tiles(const TrainTileParams& P0, bool forward, int n_blocks, hipStream_t s, bool finish_reduce, int* n_slots_out) {
   TrainTileParams P = P0;
   P.tile_begin = 0;
   P.tile_limit = ~0u;
@@ -1528,8 +1541,11 @@ hipError_t launch_train_tiles(const TrainTileParams& P0, bool forward, int n_blo
   if (e != hipSuccess) return e;
   // the stage buffer sits behind the slots (train_dw_slots(n_blocks) slots + kDwGroups group sums)
   float* stage = P.mlp_grad_partial + (size_t)train_dw_slots(n_blocks) * PRV_MLP_HALFS;
-  hipLaunchKernelGGL(train_reduce_dw_kernel, dim3((PRV_MLP_HALFS + 255) / 256, kDwGroups), dim3(256), 0, s, P.mlp_grad_partial,
-                     n_slots, stage);
+  if (n_slots_out) { // the caller's next launch (the table's Adam pass) carries the first stage of the reduction
+    *n_slots_out = n_slots;
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(train_reduce_dw_kernel, dim3(kDwBlocksX, kDwGroups), dim3(256), 0, s, P.mlp_grad_partial, n_slots, stage);
   if (finish_reduce) hipLaunchKernelGGL(train_reduce_dw2_kernel, dim3((PRV_MLP_HALFS + 255) / 256), dim3(256), 0, s, stage, P.mlp_grad);
   return hipGetLastError();
 }
@@ -1564,8 +1580,10 @@ hipError_t launch_train_loss_finish(const double* loss_part, int n_rays, TrainSt
   return hipGetLastError();
 }
 
-hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s) {
-  hipLaunchKernelGGL(adam_table_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, P, n, grad, wmv, w16);
+hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s, const float* dw_partial,
+                             int dw_slots, float* dw_stage) {
+  const unsigned n_adam = (unsigned)((n + 1023) / 1024), extra = dw_partial ? (unsigned)(kDwBlocksX * kDwGroups) : 0u;
+  hipLaunchKernelGGL(adam_table_kernel, dim3(n_adam + extra), dim3(256), 0, s, P, n, grad, wmv, w16, n_adam, dw_partial, dw_slots, dw_stage);
   return hipGetLastError();
 }
 

@@ -125,14 +125,17 @@ size_t train_tile_lds_bytes(bool fwd, int mode);
 hipError_t train_prepare_kernels();
 hipError_t launch_train_rays(const TrainRaysParams& P, hipStream_t s);
 // backward: finish_reduce = false leaves the second stage of the dW reduction to adam_mlp_kernel (stage = slots + n_blocks)
-hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s, bool finish_reduce = true);
+// n_slots_out != NULL: NO reduction launch at all -- the count of written slots is returned and the table's Adam launch does the
+// first stage beside its own work (launch_adam_table's dw_* arguments)
+hipError_t launch_train_tiles(const TrainTileParams& P, bool forward, int n_blocks, hipStream_t s, bool finish_reduce = true, int* n_slots_out = nullptr);
 hipError_t launch_prepack_frags(const uint16_t* mlp, int n_features, uint16_t* frags, const AdamParams* end_of_step,
                                 uint32_t* sample_count, float lr, hipStream_t s);
 hipError_t launch_train_forward_fast(const TrainTileParams& P, const half8* frags, int n_blocks, hipStream_t s);
 hipError_t launch_train_composite(const TrainCompositeParams& P, hipStream_t s);
 hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2, hipStream_t s);
 // wmv: one {w[4], m[4], v[4]} record (48 B) per group of four table scalars, ceil(n / 4) records
-hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s);
+hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s, const float* dw_partial = nullptr,
+                             int dw_slots = 0, float* dw_stage = nullptr);
 hipError_t launch_widen_table(const uint16_t* in, size_t n, float* wmv, hipStream_t s);
 hipError_t launch_narrow_table(const float* wmv, size_t n, float* out, hipStream_t s); // the records' w parts, contiguous
 hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float* w, float* m, float* v, uint16_t* w16,
