@@ -61,14 +61,42 @@ __device__ __forceinline__ bool occ_bit(const uint32_t* __restrict__ occ, int R,
 
 // ------------------------------------------------------------------ rays of one step
 
+// the sample budget: the ray count of the step after one that cast n_active rays and composited `used` samples (integer
+// rule, mirrored by oracle/prv_train.c: orc_train_step)
+__device__ __forceinline__ uint32_t next_active_rays(int target_samples, uint32_t n_active, unsigned long long used_raw, int n_rays) {
+  if (target_samples <= 0) return n_active;
+  const unsigned long long used = used_raw ? used_raw : 1ull, act = n_active;
+  unsigned long long a = (unsigned long long)target_samples * act / used;
+  a = max(a, act / 2ull);
+  a = min(a, act * 2ull);
+  a = max(a, 1ull);
+  a = min(a, (unsigned long long)n_rays);
+  return (uint32_t)a;
+}
+// which step a ray launch prepares, with how many rays, into which counter (TrainRaysParams::next)
+__device__ __forceinline__ void rays_step(const TrainRaysParams& P, uint32_t& step, uint32_t& n_active, uint32_t*& counter) {
+  step = P.state->step;
+  n_active = P.state->n_active;
+  if (P.next) {
+    unsigned long long used = 0ull;
+    for (int s = 0; s < (P.n_rays + 1023) / 1024; s++) used += (unsigned long long)__double_as_longlong(P.loss_part[2 * s + 1]);
+    n_active = next_active_rays(P.target_samples, n_active, used, P.n_rays);
+    step += 1u;
+  }
+  counter = P.sample_count + (step & 1u);
+}
+
 // one WAVE = one ray: the lanes test the occupancy of the S <= 128 sample positions (two per lane), ballots
 // give the live mask, each lane appends its own live samples at (offset + rank)
-__global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) {
+__device__ __forceinline__ void train_rays_block(const TrainRaysParams& P, uint32_t bx) {
   const int lane = threadIdx.x & 63;
-  const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (blockIdx.x * 4u >= P.state->n_active) return; // whole block beyond this step's ray budget (block-uniform)
-  const bool in_budget = j < P.state->n_active;
-  const uint64_t st = (uint64_t)P.state->step * 8u;
+  const uint32_t j = bx * 4u + (threadIdx.x >> 6);
+  uint32_t step, n_active_step;
+  uint32_t* counter;
+  rays_step(P, step, n_active_step, counter);
+  if (bx * 4u >= n_active_step) return; // whole block beyond this step's ray budget (block-uniform)
+  const bool in_budget = j < n_active_step;
+  const uint64_t st = (uint64_t)step * 8u;
   const uint32_t img = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 0, j) * (uint64_t)P.n_img) >> 24);
   const uint32_t px = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 1, j) * (uint64_t)P.W) >> 24);
   const uint32_t py = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 2, j) * (uint64_t)P.H) >> 24);
@@ -103,7 +131,7 @@ __global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) {
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-    base = tot ? atomicAdd(P.sample_count, tot) : 0u;
+    base = tot ? atomicAdd(counter, tot) : 0u;
   }
   __syncthreads();
   uint32_t offset = base;
@@ -129,6 +157,7 @@ __global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) {
     P.rays[j] = r;
   }
 }
+__global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) { train_rays_block(P, blockIdx.x); }
 
 // Patch mode (prv_train_opts.patch_w x patch_h = PP > 1): one BLOCK = one patch of PP adjacent pixels of one image, one
 // wave per ray as above.  The rays of a patch share image, jitter and (nearly) their depth range, so the samples of ONE
@@ -143,6 +172,7 @@ __global__ __launch_bounds__(1024) void train_rays_patch_kernel(TrainRaysParams 
   const uint32_t pw = (uint32_t)P.patch_w, PP = pw * (uint32_t)P.patch_h; // blockDim.x = 64 PP
   const uint32_t q = blockIdx.x, j = q * PP + (uint32_t)wv;
   const uint32_t n_active = P.state->n_active;
+  uint32_t* const counter = P.sample_count + (P.state->step & 1u);
   if (q * PP >= n_active) return; // whole patch beyond this step's ray budget (block-uniform)
   const bool in_budget = j < n_active;
   const uint64_t st = (uint64_t)P.state->step * 8u;
@@ -197,7 +227,7 @@ __global__ __launch_bounds__(1024) void train_rays_patch_kernel(TrainRaysParams 
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t tot = wtot[0] + wtot[1];
-    base = tot ? atomicAdd(P.sample_count, tot) : 0u; // one returning atomic per patch
+    base = tot ? atomicAdd(counter, tot) : 0u; // one returning atomic per patch
   }
   __syncthreads();
   if (i < 128 && cnt) {
@@ -440,7 +470,7 @@ void train_tile_kernel(TrainTileParams P) {
       __syncthreads(); // the scratch goes back to the tile loop
     }
   }
-  const uint32_t n_samples = *P.sample_count;
+  const uint32_t n_samples = P.sample_count[P.state->step & 1u];
   const uint32_t n_tiles = min((n_samples + 31u) / 32u, P.tile_limit);
   if (P.tile_begin + blockIdx.x >= n_tiles) { // nothing to do for this block: its slot of the weight-gradient partials is zero
     if (!FWD)
@@ -1032,7 +1062,7 @@ __global__ __launch_bounds__(256) void train_forward_fast_kernel(TrainTileParams
     reinterpret_cast<uint32_t*>(lv)[threadIdx.x] = reinterpret_cast<const uint32_t*>(P.levels)[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const uint32_t n_samples = *P.sample_count;
+  const uint32_t n_samples = P.sample_count[P.state->step & 1u];
   const uint32_t n_tiles = (n_samples + 31u) / 32u;
   constexpr int LH = 16 / F;
   for (uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * 4u) {
@@ -1206,7 +1236,7 @@ __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositePara
 __global__ void train_begin_kernel(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2) {
   const double n = (double)(state->step + 1u);
   state->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, n)) / (1.0 - pow((double)beta1, n)));
-  *sample_count = 0u;
+  sample_count[state->step & 1u] = 0u;
 }
 
 // ------------------------------------------------------------------ optimiser
@@ -1238,21 +1268,15 @@ __device__ __forceinline__ void end_step(const AdamParams& P, uint32_t* sample_c
   if (P.loss_part) finish_loss(P.loss_part, P.n_rays, P.state, P.used);
   const uint32_t done = P.state->step + 1u;
   P.state->step = done;
-  if (P.target_samples > 0) {
-    const unsigned long long used = *P.used ? *P.used : 1ull;
-    const unsigned long long act = P.state->n_active;
-    unsigned long long a = (unsigned long long)P.target_samples * act / used;
-    a = max(a, act / 2ull);
-    a = min(a, act * 2ull);
-    a = max(a, 1ull);
-    a = min(a, (unsigned long long)P.n_rays);
-    P.state->n_active = (uint32_t)a;
-  }
+  P.state->n_active = next_active_rays(P.target_samples, P.state->n_active, *P.used, P.n_rays);
   if (sample_count) {
     const double n = (double)(done + 1u);
     P.state->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, n)) / (1.0 - pow((double)beta1, n)));
-    sample_count[7] = *sample_count; // dev: the finished step's listed-sample count stays readable (prv_train_api.inc: PRV_TRAIN_TIMING)
-    *sample_count = 0u;
+    // the finished step's counter (the word of ITS parity) is free again: the step after the next one lists into it (the next
+    // step's word was cleared a step ago -- its rays may have been listed already, beside this step's Adam pass)
+    uint32_t* mine = sample_count + ((done - 1u) & 1u);
+    sample_count[7] = *mine; // dev: the finished step's listed-sample count stays readable (prv_train_api.inc: PRV_TRAIN_TIMING)
+    *mine = 0u;
   }
 }
 
@@ -1262,9 +1286,15 @@ __device__ __forceinline__ void end_step(const AdamParams& P, uint32_t* sample_c
 __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n, float* __restrict__ grad,
                                                          float* __restrict__ wmv, uint16_t* __restrict__ w16,
                                                          unsigned n_adam_blocks, const float* __restrict__ dw_partial, int dw_slots,
-                                                         float* __restrict__ dw_stage) {
+                                                         float* __restrict__ dw_stage, unsigned n_dw_blocks, TrainRaysParams R) {
   // the blocks behind the table's own do the first stage of the MLP's weight-gradient reduction: both read what the backward
   // launch left and neither needs the other, so the reduction is no node of its own in the step's chain (round 5)
+  // ... and the blocks behind THOSE list the next step's ray batch (TrainRaysParams::next): it needs the step's used-sample
+  // count and the occupancy grid, neither of which this launch touches, and the step's chain is one kernel shorter
+  if (blockIdx.x >= n_adam_blocks + n_dw_blocks) {
+    train_rays_block(R, blockIdx.x - n_adam_blocks - n_dw_blocks);
+    return;
+  }
   if (blockIdx.x >= n_adam_blocks) {
     const int k = (int)(blockIdx.x - n_adam_blocks);
     reduce_dw_block(dw_partial, dw_slots, dw_stage, k % kDwBlocksX, k / kDwBlocksX);
@@ -1581,9 +1611,16 @@ hipError_t launch_train_loss_finish(const double* loss_part, int n_rays, TrainSt
 }
 
 hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s, const float* dw_partial,
-                             int dw_slots, float* dw_stage) {
-  const unsigned n_adam = (unsigned)((n + 1023) / 1024), extra = dw_partial ? (unsigned)(kDwBlocksX * kDwGroups) : 0u;
-  hipLaunchKernelGGL(adam_table_kernel, dim3(n_adam + extra), dim3(256), 0, s, P, n, grad, wmv, w16, n_adam, dw_partial, dw_slots, dw_stage);
+                             int dw_slots, float* dw_stage, const TrainRaysParams* next_rays) {
+  const unsigned n_adam = (unsigned)((n + 1023) / 1024), n_dw = dw_partial ? (unsigned)(kDwBlocksX * kDwGroups) : 0u;
+  TrainRaysParams R{};
+  unsigned n_rays_blocks = 0u;
+  if (next_rays) {
+    R = *next_rays;
+    n_rays_blocks = (unsigned)((R.n_rays + 3) / 4);
+  }
+  hipLaunchKernelGGL(adam_table_kernel, dim3(n_adam + n_dw + n_rays_blocks), dim3(256), 0, s, P, n, grad, wmv, w16, n_adam, dw_partial, dw_slots,
+                     dw_stage, n_dw, R);
   return hipGetLastError();
 }
 

@@ -37,9 +37,15 @@ struct TrainRaysParams {
   uint64_t seed;
   TrainRay* rays;
   uint2* samples; // (ray, sample index) of every live sample, grouped by ray (patch mode: by patch, depth step by depth step)
-  uint32_t* sample_count;
+  uint32_t* sample_count; // two words: [step & 1]
   // patch mode (patch_w * patch_h = P > 1, <= 16): ray j = pixel j % P of patch j / P; slot_of[j * S + k] = the list
   // position of ray j's k-th live sample (a ray's samples are not contiguous in the list any more)
+  // next = 1: the batch of the step AFTER the one in flight (state->step + 1), launched beside the table's Adam pass of the
+  // step in flight (adam_table_kernel's extra blocks): its ray count is what end_step will set -- the same integer rule
+  // on the same inputs (the backward launch's used-sample slices in loss_part) -- and its samples go to the OTHER counter
+  // (sample_count[step & 1]: a step's live-sample count lives in the word of its parity)
+  int next, target_samples;
+  const double* loss_part;
   int patch_w, patch_h;
   int patch_ray_jitter; // dev only (PRV_TRAIN_PATCH_JITTER=ray): every ray of a patch its own jitter (the oracle has no such mode)
   uint32_t* slot_of;
@@ -52,7 +58,8 @@ struct TrainTileParams {
   int n_levels, n_features;
   const TrainRay* rays;
   const uint2* samples;
-  const uint32_t* sample_count;
+  const uint32_t* sample_count; // two words: the step's count is [state->step & 1]
+  const TrainState* state;
   float4* logits;        // forward: {density logit, r, g, b logits} per sample
   const float4* seeds;   // backward: {dL/d od0 via sigma, dL/d rgb logits}
   float* table_grad;     // canonical, f32
@@ -134,8 +141,10 @@ hipError_t launch_train_forward_fast(const TrainTileParams& P, const half8* frag
 hipError_t launch_train_composite(const TrainCompositeParams& P, hipStream_t s);
 hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float lr, float beta1, float beta2, hipStream_t s);
 // wmv: one {w[4], m[4], v[4]} record (48 B) per group of four table scalars, ceil(n / 4) records
+// next_rays != NULL (single-pixel batches only: the patch kernel has another block size): the NEXT step's ray batch as further
+// extra blocks of the same launch (TrainRaysParams::next = 1)
 hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s, const float* dw_partial = nullptr,
-                             int dw_slots = 0, float* dw_stage = nullptr);
+                             int dw_slots = 0, float* dw_stage = nullptr, const TrainRaysParams* next_rays = nullptr);
 hipError_t launch_widen_table(const uint16_t* in, size_t n, float* wmv, hipStream_t s);
 hipError_t launch_narrow_table(const float* wmv, size_t n, float* out, hipStream_t s); // the records' w parts, contiguous
 hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float* w, float* m, float* v, uint16_t* w16,
