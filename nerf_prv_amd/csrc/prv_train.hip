@@ -1008,16 +1008,12 @@ __device__ __forceinline__ void end_step(const AdamParams& P, uint32_t* sample_c
 // render kernel), rebuilt on the device after every optimiser step: one thread per fragment element
 __device__ __forceinline__ int frag_hidden_k(int s, int h, int j) { return 32 * (s >> 1) + 16 * (s & 1) + 8 * (j >> 2) + 4 * h + (j & 3); }
 
-__global__ __launch_bounds__(256) void prepack_frags_kernel(const uint16_t* __restrict__ mlp, int n_features,
-                                                            uint16_t* __restrict__ frags, AdamParams P,
-                                                            uint32_t* sample_count, float lr) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0 && P.state) end_step(P, sample_count, lr, P.beta1, P.beta2); // the step's last kernel: it opens the next one too
+// which canonical weight element i of the fragment array (forward fragments, then the backward ones) holds; -1: padding
+__device__ __forceinline__ int prepack_source(int n_features, int i) {
   if (i >= kNumFrags * kFragHalfs) {
     // backward fragments: A[row = input unit][K = output unit] of every layer, fp16 as stored; K order = the order in
     // which a lane holds the previous backward layer's accumulator rows (frag_hidden_k), as in the forward fragments
     const int ib = i - kNumFrags * kFragHalfs;
-    if (ib >= kBwdFrags * kFragHalfs) return;
     const int f = ib / kFragHalfs, ln = (ib % kFragHalfs) >> 3, j = ib & 7;
     const int r = ln & 31, h = ln >> 5;
     int layer, mt, st;
@@ -1031,8 +1027,7 @@ __global__ __launch_bounds__(256) void prepack_frags_kernel(const uint16_t* __re
     else if (layer == 1) o = (j & 3) + 8 * (j >> 2) + 4 * h; // the density output as its accumulator rows come
     else o = frag_hidden_k(st, h, j);
     const int k_in = 32 * mt + r;
-    frags[kNumFrags * kFragHalfs + ib] = k_in < kLIn[layer] && o < kLOut[layer] ? mlp[kLOff[layer] + k_in * kLOut[layer] + o] : (uint16_t)0;
-    return;
+    return k_in < kLIn[layer] && o < kLOut[layer] ? kLOff[layer] + k_in * kLOut[layer] + o : -1;
   }
   const int f = i / kFragHalfs, lane = (i % kFragHalfs) >> 3, j = i & 7;
   const int r = lane & 31, h = lane >> 5;
@@ -1047,7 +1042,27 @@ __global__ __launch_bounds__(256) void prepack_frags_kernel(const uint16_t* __re
   else if (layer == 2) k = st == 0 ? frag_hidden_k(0, h, j) : 16 + 8 * h + j;
   else k = frag_hidden_k(st, h, j);
   const int out = 32 * mt + r;
-  frags[i] = out < kLOut[layer] ? mlp[kLOff[layer] + k * kLOut[layer] + out] : (uint16_t)0;
+  return out < kLOut[layer] ? kLOff[layer] + k * kLOut[layer] + out : -1;
+}
+
+// (a launch of its own at trainer creation; inside a step every thread of the MLP's Adam pass writes its own weight's two places)
+__global__ __launch_bounds__(256) void prepack_frags_kernel(const uint16_t* __restrict__ mlp, int n_features,
+                                                            uint16_t* __restrict__ frags, AdamParams P,
+                                                            uint32_t* sample_count, float lr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && P.state) end_step(P, sample_count, lr, P.beta1, P.beta2); // the step's last kernel: it opens the next one too
+  if (i >= (kNumFrags + kBwdFrags) * kFragHalfs) return;
+  const int src = prepack_source(n_features, i);
+  frags[i] = src >= 0 ? mlp[src] : (uint16_t)0;
+}
+
+// the inverse of prepack_source: every canonical weight sits at exactly one place of the forward fragments and one of the
+// backward ones (checked when this was written: both maps are bijections onto the PRV_MLP_HALFS weights, F = 4 and F = 2)
+__global__ __launch_bounds__(256) void frag_positions_kernel(int n_features, int* __restrict__ frag_pos) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (kNumFrags + kBwdFrags) * kFragHalfs) return;
+  const int src = prepack_source(n_features, i);
+  if (src >= 0) frag_pos[(i >= kNumFrags * kFragHalfs ? PRV_MLP_HALFS : 0) + src] = i;
 }
 
 // logits of every live sample with the render kernel's machinery: a lane pair per sample, each lane encodes
@@ -1295,6 +1310,7 @@ __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n,
     train_rays_block(R, blockIdx.x - n_adam_blocks - n_dw_blocks);
     return;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) P.state->lr_cur = P.state->lr_t; // for the step's last kernel (TrainState::lr_cur)
   if (blockIdx.x >= n_adam_blocks) {
     const int k = (int)(blockIdx.x - n_adam_blocks);
     reduce_dw_block(dw_partial, dw_slots, dw_stage, k % kDwBlocksX, k / kDwBlocksX);
@@ -1357,7 +1373,8 @@ __global__ __launch_bounds__(256) void adam_mlp_kernel(AdamParams P, float l2_re
                                                        float* __restrict__ w, float* __restrict__ m,
                                                        float* __restrict__ v, uint16_t* __restrict__ w16,
                                                        float* __restrict__ w16_as_f32, const float* __restrict__ stage,
-                                                       int end_of_step) {
+                                                       int end_of_step, uint16_t* __restrict__ frags, const int* __restrict__ frag_pos,
+                                                       uint32_t* sample_count, float lr) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= PRV_MLP_HALFS) return;
   float gsum = grad[i];
@@ -1368,13 +1385,23 @@ __global__ __launch_bounds__(256) void adam_mlp_kernel(AdamParams P, float l2_re
   const float g = fmaf(l2_reg, w[i], gsum);
   grad[i] = 0.0f;
   float ww = w[i], mm = m[i], vv = v[i];
-  adam_update(P, P.state->lr_t, g, ww, mm, vv);
+  // frags: this is the step's last kernel and thread 0's end_step writes the NEXT step's lr_t while other blocks still run:
+  // the rate of the step in flight is read from the copy the table's Adam launch left (TrainState::lr_cur)
+  adam_update(P, frags ? P.state->lr_cur : P.state->lr_t, g, ww, mm, vv);
   w[i] = ww;
   m[i] = mm;
   v[i] = vv;
   const _Float16 hh = to_half(ww);
   w16[i] = __builtin_bit_cast(uint16_t, hh);
   w16_as_f32[i] = (float)hh;
+  if (frags) {
+    // the MFMA fragments of the next forward / backward pass: this weight's two places (the padding elements never change).
+    // Until round 5 a kernel of its own behind this one (prepack_frags_kernel), one more node in every member's chain.
+    frags[frag_pos[i]] = __builtin_bit_cast(uint16_t, hh);
+    frags[frag_pos[PRV_MLP_HALFS + i]] = __builtin_bit_cast(uint16_t, hh);
+    if (i == 0) end_step(P, sample_count, lr, P.beta1, P.beta2); // closes the step, opens the next
+    return;
+  }
   if (i == 0 && end_of_step) end_step(P, nullptr, 0.f, 0.f, 0.f); // last node of a step unless a later kernel takes that role
 }
 
@@ -1635,9 +1662,15 @@ hipError_t launch_narrow_table(const float* wmv, size_t n, float* out, hipStream
 }
 
 hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float* w, float* m, float* v, uint16_t* w16,
-                           float* w16_as_f32, const float* stage, int end_of_step, hipStream_t s) {
+                           float* w16_as_f32, const float* stage, int end_of_step, hipStream_t s, uint16_t* frags, const int* frag_pos,
+                           uint32_t* sample_count, float lr) {
   hipLaunchKernelGGL(adam_mlp_kernel, dim3((PRV_MLP_HALFS + 255) / 256), dim3(256), 0, s, P, l2_reg, grad, w, m, v, w16,
-                     w16_as_f32, stage, end_of_step);
+                     w16_as_f32, stage, end_of_step, frags, frag_pos, sample_count, lr);
+  return hipGetLastError();
+}
+
+hipError_t launch_frag_positions(int n_features, int* frag_pos, hipStream_t s) {
+  hipLaunchKernelGGL(frag_positions_kernel, dim3(((kNumFrags + kBwdFrags) * kFragHalfs + 255) / 256), dim3(256), 0, s, n_features, frag_pos);
   return hipGetLastError();
 }
 

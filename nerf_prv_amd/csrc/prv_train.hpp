@@ -26,7 +26,11 @@ struct TrainState {
   float lr_t;     // bias-corrected learning rate of the step in flight
   uint32_t n_active; // rays of the step in flight (<= n_rays; adapts to the sample budget)
   float* losses;  // where the call's per-step losses go
+  float lr_cur;   // lr_t again, copied by the table's Adam launch: what the step's LAST kernel (the MLP's Adam pass) reads while its
+                  // end_step already writes the next step's lr_t
+  uint32_t pad;
 };
+static_assert(sizeof(TrainState) == 32, "scal: TrainState sits at [32, 64)");
 
 struct TrainRaysParams {
   const CamDev* cams;    // n_img dataset cameras at (W, H)
@@ -147,8 +151,13 @@ hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* 
                              int dw_slots = 0, float* dw_stage = nullptr, const TrainRaysParams* next_rays = nullptr);
 hipError_t launch_widen_table(const uint16_t* in, size_t n, float* wmv, hipStream_t s);
 hipError_t launch_narrow_table(const float* wmv, size_t n, float* out, hipStream_t s); // the records' w parts, contiguous
+// frags != NULL: the step's last kernel -- every thread also puts its fresh fp16 weight into its place of the forward and of the
+// backward MFMA fragments (frag_pos: launch_frag_positions) and thread 0 closes the step (end_step with sample_count / lr)
 hipError_t launch_adam_mlp(const AdamParams& P, float l2_reg, float* grad, float* w, float* m, float* v, uint16_t* w16,
-                           float* w16_as_f32, const float* stage, int end_of_step, hipStream_t s);
+                           float* w16_as_f32, const float* stage, int end_of_step, hipStream_t s, uint16_t* frags = nullptr,
+                           const int* frag_pos = nullptr, uint32_t* sample_count = nullptr, float lr = 0.f);
+// frag_pos[w] / frag_pos[PRV_MLP_HALFS + w]: where canonical weight w sits in the forward / backward fragments (each map is a bijection)
+hipError_t launch_frag_positions(int n_features, int* frag_pos, hipStream_t s);
 hipError_t launch_widen(const uint16_t* in, size_t n, float* out, hipStream_t s);
 hipError_t launch_density_refresh(const DensityParams& P, int n_features, hipStream_t s);
 hipError_t launch_density_refresh_fast(const DensityParams& P, int n_features, const half8* frags, int n_blocks, hipStream_t s);

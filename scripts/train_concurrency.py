@@ -11,7 +11,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 key = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-prepack = [i for i, r in enumerate(rows) if "prepack_frags_kernel" in r["Kernel_Name"]]
+prepack = [i for i, r in enumerate(rows) if "adam_mlp_kernel" in r["Kernel_Name"]]  # a step's last kernel
 streams = sorted({rows[i][key] for i in prepack[-50:]})
 n_members = len(streams)
 lo = prepack[-(rounds * n_members + 1)]

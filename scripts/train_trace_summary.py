@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """steady-state per-kernel time of the training step from a rocprofv3 kernel trace of scripts/trainbench.py --members N
-(dev tool): the last 100 ensemble steps and the last 100 single-trainer steps.   python scripts/train_trace_summary.py <kernel_trace.csv>"""
+(dev tool): the last 100 steps.   python scripts/train_trace_summary.py <kernel_trace.csv>"""
 import collections
 import csv
 import re
@@ -15,7 +15,7 @@ def short(n):
     return m.group(1) + (m.group(3) or "") if m else n[:40]
 
 
-for tag, pat in (("ensemble (one launch per stage)", "prepack_frags_kernel_m"), ("single trainer", "prepack_frags_kernel(")):
+for tag, pat in (("training steps", "adam_mlp_kernel"),):  # a step's last kernel
     idx = [i for i, r in enumerate(rows) if pat in r["Kernel_Name"]]
     if len(idx) < 101:
         continue
