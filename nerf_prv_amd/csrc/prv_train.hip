@@ -264,6 +264,28 @@ __global__ __launch_bounds__(1024) void train_rays_patch_kernel(TrainRaysParams 
 
 // ------------------------------------------------------------------ one level of the encoder, canonical table
 
+// the eight corner entries of a level: per-axis terms once (two clamped coordinates per axis, the y and z ones multiplied by
+// the hash primes or by the dense strides), then one combine per corner -- the same index, bit for bit, as
+// cc0 ^ cc1 * P1 ^ cc2 * P2 masked / cc0 + res * (cc1 + res * cc2), without two multiplies and a branch per corner.  Hashed or
+// dense is picked with a bit mask ((a & hm) | (b & ~hm): one v_bitop3), not with v_cndmask: that one costs 10-20 issue cycles
+// on this chip (profiles/r04_valu_issue_rate.txt), the three-input bit operation two.
+__device__ __forceinline__ uint32_t pick_bits(uint32_t a, uint32_t b, uint32_t hm) { return (a & hm) | (b & ~hm); }
+__device__ __forceinline__ void level_corner_indices(const LevelCanon& L, const uint32_t c0[3], uint32_t idx[8]) {
+  const uint32_t hm = 0u - L.hashed; // all ones on a hashed level (LevelCanon::hashed is 0 or 1; written so that the compiler does not turn the picks back into selects)
+  const uint32_t my = pick_bits(2654435761u, L.res, hm), mz = pick_bits(805459861u, L.res * L.res, hm), mask = L.size - 1u;
+  uint32_t x[2], ty[2], tz[2], yz[4];
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    x[b] = min(c0[0] + (uint32_t)b, L.res - 1u);
+    ty[b] = min(c0[1] + (uint32_t)b, L.res - 1u) * my;
+    tz[b] = min(c0[2] + (uint32_t)b, L.res - 1u) * mz;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) yz[q] = pick_bits(ty[q & 1] ^ tz[q >> 1], ty[q & 1] + tz[q >> 1], hm);
+#pragma unroll
+  for (int c = 0; c < 8; c++) idx[c] = pick_bits((x[c & 1] ^ yz[c >> 1]) & mask, x[c & 1] + yz[c >> 1], hm);
+}
+
 // features of one level (binary16 blend, bit for bit encode_level / orc_encode) + the corner entries and
 // weights the backward pass scatters into
 template <int F>
@@ -281,27 +303,28 @@ __device__ __forceinline__ void train_encode_level(const uint16_t* __restrict__ 
     wh[a][0] = to_half(1.0f - w);
     wh[a][1] = (_Float16)w;
   }
-  _Float16 acc[F];
+  // the blend: acc_k = fma(w, e_k, acc_k) in fp16, corner after corner -- two features per v_pk_fma_f16 (element by element the
+  // same IEEE fma as the scalar instruction; written out because the build switches the SLP vectoriser off)
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+  half2v acc2[F / 2];
 #pragma unroll
-  for (int k = 0; k < F; k++) acc[k] = (_Float16)0.0f;
+  for (int k = 0; k < F / 2; k++) acc2[k] = half2v{(_Float16)0.0f, (_Float16)0.0f};
+  uint32_t ix[8];
+  level_corner_indices(L, c0, ix);
 #pragma unroll
   for (int c = 0; c < 8; c++) {
-    uint32_t cc[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) cc[a] = min(c0[a] + ((c >> a) & 1u), L.res - 1u);
-    const uint32_t idx = L.hashed ? ((cc[0] ^ (cc[1] * 2654435761u) ^ (cc[2] * 805459861u)) & (L.size - 1u))
-                                  : (cc[0] + L.res * (cc[1] + L.res * cc[2]));
     const _Float16 wxy = wh[0][c & 1] * wh[1][(c >> 1) & 1];
     const _Float16 w = wxy * wh[2][c >> 2];
-    cidx[c] = L.offset + idx;
+    cidx[c] = L.offset + ix[c];
     cw[c] = (float)w;
     typedef _Float16 entry_t __attribute__((ext_vector_type(F)));
-    const entry_t e = *reinterpret_cast<const entry_t*>(table + (size_t)(L.offset + idx) * F); // one 4- or 8-byte load
+    const entry_t e = *reinterpret_cast<const entry_t*>(table + (size_t)cidx[c] * F); // one 4- or 8-byte load
+    const half2v w2 = {w, w};
 #pragma unroll
-    for (int k = 0; k < F; k++) acc[k] = __builtin_fmaf16(w, e[k], acc[k]);
+    for (int k = 0; k < F / 2; k++) acc2[k] = __builtin_elementwise_fma(w2, half2v{e[2 * k], e[2 * k + 1]}, acc2[k]);
   }
 #pragma unroll
-  for (int k = 0; k < F; k++) feat[k] = (float)acc[k];
+  for (int k = 0; k < F; k++) feat[k] = (float)acc2[k >> 1][k & 1];
 }
 
 // the corner entries and weights alone (no table access): what the backward pass needs of a level when the forward
@@ -320,15 +343,12 @@ __device__ __forceinline__ void train_level_corners(const LevelCanon& L, float p
     wh[a][0] = to_half(1.0f - w);
     wh[a][1] = (_Float16)w;
   }
+  uint32_t ix[8];
+  level_corner_indices(L, c0, ix);
 #pragma unroll
   for (int c = 0; c < 8; c++) {
-    uint32_t cc[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) cc[a] = min(c0[a] + ((c >> a) & 1u), L.res - 1u);
-    const uint32_t idx = L.hashed ? ((cc[0] ^ (cc[1] * 2654435761u) ^ (cc[2] * 805459861u)) & (L.size - 1u))
-                                  : (cc[0] + L.res * (cc[1] + L.res * cc[2]));
     const _Float16 wxy = wh[0][c & 1] * wh[1][(c >> 1) & 1];
-    cidx[c] = L.offset + idx;
+    cidx[c] = L.offset + ix[c];
     cw[c] = (float)(wxy * wh[2][c >> 2]);
   }
 }
