@@ -68,6 +68,9 @@ struct prv_ctx {
   int n_cu = 256;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  std::vector<hipStream_t> idle_queues; // streams with a hardware queue of their own, parked by destroyed trainers (prv_train_api.inc)
+  std::vector<Buffer> idle_buffers;     // ... and their device buffers, taken again by size (train_buffer)
+  size_t idle_bytes = 0;
   std::string err;
   Model models[PRV_MAX_MODELS];
   // grow-only workspaces

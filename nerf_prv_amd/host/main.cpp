@@ -762,10 +762,11 @@ int instant_ngp_curves(prv_ctx* ctx, const std::string& cfg, const std::string& 
     missing.push_back(ci);
     scenes.push_back(scene);
   }
-  // pass 2: the missing points, five fields at a time side by side (train_scenes_side_by_side), each evaluated on the test set
+  // pass 2: the missing points, four fields at a time side by side (train_scenes_side_by_side), each evaluated on the test set
+  // (a member-step costs 95 us in a round of four, 101 in a round of five, 98 of three: profiles/r05_member_queues.txt)
   std::string test_json;
   if (!missing.empty() && (rc = scorer.write_test_json(center, size, &test_json)) != PRV_OK) return rc;
-  constexpr size_t kSideBySide = 5;
+  constexpr size_t kSideBySide = 4;
   for (size_t g0 = 0; g0 < missing.size(); g0 += kSideBySide) {
     const size_t g1 = std::min(missing.size(), g0 + kSideBySide);
     if ((rc = scorer.train_scenes_side_by_side(std::vector<std::string>(scenes.begin() + (long)g0, scenes.begin() + (long)g1))) != PRV_OK) return rc;

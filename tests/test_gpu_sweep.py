@@ -309,6 +309,7 @@ def test_placement_and_layout_switches_change_speed_only(ctx, oracle, monkeypatc
                                  {"PRV_TRAIN_GRAPH": "0", "PRV_TRAIN_FAST_FWD": "0"}, {"PRV_TRAIN_KEEP_ACT": "0"},
                                  {"PRV_TRAIN_ACT_CAP": "256"}, {"PRV_TRAIN_ACT_CAP": "256", "PRV_TRAIN_GRAPH": "0"},
                                  {"PRV_TRAIN_REG_CHAIN": "0"}, {"PRV_TRAIN_REG_CHAIN": "0", "PRV_TRAIN_ACT_CAP": "256"},
+                                 {"PRV_TRAIN_OWN_QUEUE": "0"}, {"PRV_TRAIN_OWN_QUEUE": "0", "PRV_TRAIN_GRAPH": "0"},
                                  {"patch": "4x2"}, {"patch": "4x2", "PRV_TRAIN_FAST_FWD": "0"}, {"patch": "2x2", "PRV_TRAIN_KEEP_ACT": "0"},
                                  {"patch": "4x4", "PRV_TRAIN_ACT_CAP": "256", "PRV_TRAIN_GRAPH": "0"}, {"patch": "2x2", "PRV_TRAIN_REG_CHAIN": "0"}])
 def test_trainer_switches_hold_the_same_bars(ctx, oracle, monkeypatch, env):
