@@ -247,7 +247,20 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   {
     const int R = d.occ_res;
     int lo[3] = {R, R, R}, hi[3] = {-1, -1, -1};
-    for (int z = 0; z < R; z++)
+    const bool words = R % 32 == 0; // a row is whole words: 65 K words instead of 2 M bits (the planner loop installs five fields per round)
+    for (int z = 0; words && z < R; z++)
+      for (int y = 0; y < R; y++)
+        for (int w = 0; w < R / 32; w++) {
+          const uint32_t v = occ_host[((size_t)R * ((size_t)y + (size_t)R * (size_t)z)) / 32 + (size_t)w];
+          if (!v) continue;
+          lo[0] = std::min(lo[0], 32 * w + __builtin_ctz(v));
+          hi[0] = std::max(hi[0], 32 * w + 31 - __builtin_clz(v));
+          lo[1] = std::min(lo[1], y);
+          hi[1] = std::max(hi[1], y);
+          lo[2] = std::min(lo[2], z);
+          hi[2] = std::max(hi[2], z);
+        }
+    for (int z = 0; !words && z < R; z++)
       for (int y = 0; y < R; y++)
         for (int x = 0; x < R; x++) {
           const size_t b = (size_t)x + (size_t)R * ((size_t)y + (size_t)R * (size_t)z);
@@ -269,7 +282,17 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   if (d.occ_res % 4 == 0 && d.occ_res >= 8) {
     const int R = d.occ_res, Rc = R / 4;
     std::vector<uint8_t> blk((size_t)Rc * Rc * Rc, 0);
-    for (int z = 0; z < R; z++)
+    const bool words = R % 32 == 0; // as above: a word is eight blocks' worth of one row
+    for (int z = 0; words && z < R; z++)
+      for (int y = 0; y < R; y++)
+        for (int w = 0; w < R / 32; w++) {
+          const uint32_t v = occ_host[((size_t)R * ((size_t)y + (size_t)R * (size_t)z)) / 32 + (size_t)w];
+          if (!v) continue;
+          uint8_t* row = &blk[(size_t)(8 * w) + (size_t)Rc * ((size_t)(y / 4) + (size_t)Rc * (size_t)(z / 4))];
+          for (int k = 0; k < 8; k++)
+            if ((v >> (4 * k)) & 0xfu) row[k] = 1;
+        }
+    for (int z = 0; !words && z < R; z++)
       for (int y = 0; y < R; y++)
         for (int x = 0; x < R; x += 32) { // 32 fine cells of a row = one word (R is a multiple of 4; handle R < 32 too)
           const size_t bit0 = (size_t)x + (size_t)R * ((size_t)y + (size_t)R * (size_t)z);
@@ -1218,11 +1241,16 @@ static int model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64
   const int R = d->occ_res;
   std::vector<uint32_t> occ(((size_t)R * R * R + 31) / 32, 0u);
   const float invR = 1.0f / (float)R;
-  for (int z = 0; z < R; z++)
+  if (all_occupied) { // a fresh field (the planner loop makes five per round): every cell, without the walk over 2 M of them
+    const size_t n_cells = (size_t)R * R * R;
+    std::fill(occ.begin(), occ.end(), 0xffffffffu);
+    if (n_cells & 31) occ.back() = (1u << (n_cells & 31)) - 1u;
+  }
+  for (int z = 0; z < (all_occupied ? 0 : R); z++)
     for (int y = 0; y < R; y++)
       for (int x = 0; x < R; x++) {
         const float cx = ((float)x + 0.5f) * invR, cy = ((float)y + 0.5f) * invR, cz = ((float)z + 0.5f) * invR;
-        bool in = all_occupied;
+        bool in = false;
         for (int b = 0; b < 4 && !in; b++) {
           const float dx = cx - kSynthSpheres[b][0], dy = cy - kSynthSpheres[b][1], dz = cz - kSynthSpheres[b][2];
           const float d2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
