@@ -575,6 +575,9 @@ def full_loop(args):
         r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=(1800 if args.full_loop else 300),
                            env=dict(os.environ, PRV_PLANNER_TIMING="1"))  # one line per training call on stderr
         out[key] = time.perf_counter() - t0
+        if os.environ.get("PRV_BENCH_KEEP_STDERR"):  # dev: the planner's timing lines, one file per mode
+            with open(f"{os.environ['PRV_BENCH_KEEP_STDERR']}.mode{mode}.txt", "w") as fh:
+                fh.write(r.stderr)
         if r.returncode != 0:
             out["error"] = f"mode {mode} exited {r.returncode}: {(r.stdout + r.stderr)[-400:]}"
             return out
@@ -587,6 +590,10 @@ def full_loop(args):
                 vals = [float(x) for x in re.findall(rf"train_members: .*? {word} ([0-9.eE+-]+) s", r.stderr)]
                 if vals:
                     out[key2] = sum(vals)  # where a training call's time outside its optimiser steps goes
+            score_s = [float(x) for x in re.findall(r"score_round: .*? total ([0-9.eE+-]+) s", r.stderr)]
+            if score_s:
+                out["scoring_rounds"] = len(score_s)
+                out["scoring_s"] = sum(score_s)  # render + score of the remaining candidates, every member (camera json included)
             if steps_s:
                 out["training_calls"] = len(steps_s)
                 out["training_steps_s"] = sum(steps_s)

@@ -391,6 +391,8 @@ int prv_train_info(const prv_trainer* t, uint32_t* steps_done, uint64_t* samples
                    uint64_t* table_scalars);
 /* rays the next step will cast (= n_rays unless target_samples is set) */
 int prv_train_active_rays(const prv_trainer* t);
+/* The trainer's stream (it owns a hardware queue) and device buffers stay with the CONTEXT for its next trainer of the same
+ * sizes (at most 16 GiB / 512 buffers, oldest released first); prv_destroy releases them. */
 void prv_train_destroy(prv_trainer* t);
 /* parity hooks: gradients of the NEXT batch without an update (host arrays: table_scalars and
  * PRV_MLP_HALFS floats), the fp32 master weights, one density-grid refresh */

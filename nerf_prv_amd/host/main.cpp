@@ -396,11 +396,14 @@ struct HipScorer {
       const int trc = train_members(scene_json);
       if (trc != PRV_OK) return trc;
     }
+    const bool timing = getenv("PRV_PLANNER_TIMING") != nullptr; // dev: where an iteration's seconds go
+    const double t_round = now_seconds();
     prv_camset* cams = nullptr;
     if (prv_cameras_from_json(ctx, render_json.c_str(), &cams) != PRV_OK) {
       std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
       return -20;
     }
+    const double t_json = now_seconds() - t_round;
     const int n = prv_camset_count(cams);
     prv_render_opts o = candidate_opts(cams);
     std::vector<int> slots(n_members);
@@ -447,6 +450,7 @@ struct HipScorer {
       std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
       return rc;
     }
+    if (timing) std::cerr << "score_round: views " << n << " cameras " << t_json << " s, total " << now_seconds() - t_round << " s" << std::endl;
     for (int k = 0; k < n; k++) scores[k] = rec[k].score;
     if (dump_records) { // yaml dump_scores / PRV_PLANNER_DUMP_RECORDS (view_planning): the gathered records of every iteration, byte for byte
       sd->access_directory(sd->save_path + "/records");
