@@ -773,11 +773,17 @@ int instant_ngp_curves(prv_ctx* ctx, const std::string& cfg, const std::string& 
   constexpr size_t kSideBySide = 4;
   for (size_t g0 = 0; g0 < missing.size(); g0 += kSideBySide) {
     const size_t g1 = std::min(missing.size(), g0 + kSideBySide);
+    const bool timing = getenv("PRV_PLANNER_TIMING") != nullptr; // dev: where the curve's seconds go
+    double t0 = now_seconds();
     if ((rc = scorer.train_scenes_side_by_side(std::vector<std::string>(scenes.begin() + (long)g0, scenes.begin() + (long)g1))) != PRV_OK) return rc;
+    if (timing) std::cerr << "curve_group: " << g1 - g0 << " fields trained in " << now_seconds() - t0 << " s" << std::endl;
     for (size_t k = g0; k < g1; k++) {
       const int n = counts[missing[k]];
       double psnr = 0, ssim = 0;
-      if ((rc = scorer.evaluate_on(test_json, (int)(k - g0), &psnr, &ssim)) != PRV_OK) return rc;
+      t0 = now_seconds();
+      rc = scorer.evaluate_on(test_json, (int)(k - g0), &psnr, &ssim);
+      if (timing) std::cerr << "curve_eval: " << n << " views, evaluated in " << now_seconds() - t0 << " s" << std::endl;
+      if (rc != PRV_OK) return rc;
       prvh_write_metrics((sd0->gt_path + "/" + std::to_string(n) + ".txt").c_str(), psnr, ssim);
       std::cout << "views " << n << " PSNR " << psnr << " SSIM " << ssim << std::endl;
       psnrs[missing[k]] = psnr;
