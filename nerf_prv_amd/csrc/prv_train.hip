@@ -318,7 +318,8 @@ __device__ __forceinline__ void train_encode_level(const uint16_t* __restrict__ 
     cidx[c] = L.offset + ix[c];
     cw[c] = (float)w;
     typedef _Float16 entry_t __attribute__((ext_vector_type(F)));
-    const entry_t e = *reinterpret_cast<const entry_t*>(table + (size_t)cidx[c] * F); // one 4- or 8-byte load
+    // one 4- or 8-byte load at a 32-bit byte offset from the table's (wave-uniform) base: no 64-bit add per corner (a canonical table is < 4 GiB: prv_train_create)
+    const entry_t e = *reinterpret_cast<const entry_t*>(reinterpret_cast<const char*>(table) + (uint32_t)(cidx[c] * (uint32_t)(F * 2)));
     const half2v w2 = {w, w};
 #pragma unroll
     for (int k = 0; k < F / 2; k++) acc2[k] = __builtin_elementwise_fma(w2, half2v{e[2 * k], e[2 * k + 1]}, acc2[k]);
@@ -929,10 +930,21 @@ void train_tile_kernel(TrainTileParams P) {
                 key[w] = 0xffffffffu;
                 acc[w] = 0.0f;
               }
+              // the tile's 32 (entry, weighted gradient) pairs first, all of their LDS reads in flight at once: read inside the
+              // walk below, every step waited for its own two reads (the walk is a serial chain through the pairs' state)
+              uint32_t ek[32];
+              float eg[32];
+#pragma unroll
               for (int ss = 0; ss < 32; ss++) {
                 const uint2 e = stage[ss * kStageStride + l8 * 8 + c];
+                ek[ss] = e.x;
+                eg[ss] = __uint_as_float(e.y) * G[(kGFeat + l * F + k) * TSG + ss];
+              }
+#pragma unroll
+              for (int ss = 0; ss < 32; ss++) {
+                const uint2 e = make_uint2(ek[ss], 0u);
                 if (e.x == 0xffffffffu) continue; // a dead sample or one without a gradient
-                const float gv = __uint_as_float(e.y) * G[(kGFeat + l * F + k) * TSG + ss];
+                const float gv = eg[ss];
                 bool hit = false;
 #pragma unroll
                 for (int w = 0; w < kWays; w++)
