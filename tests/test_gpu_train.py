@@ -325,6 +325,27 @@ def test_sample_budget_adapts_the_ray_count(ctx, oracle, scene):
     assert gtr.info()["active_rays"] == 300 == otr.active_rays
 
 
+def test_a_trainer_on_parked_buffers_matches_the_oracle(ctx, oracle, scene):
+    """a destroyed trainer's stream and device buffers stay with the context and the next trainer of the same sizes takes
+    them (prv_train_api.inc: train_buffer): whatever the first one left in them -- moments, gradients, kept activations,
+    density EMA, counters, a finished step count -- must not reach the second one"""
+    f, otr, gtr = start(ctx, oracle, scene, seed=util.SEED_B, table_amp=2.0, occ_every=2, occ_sigma_thresh=0.3)
+    gtr.steps(5)
+    gtr.close()  # parks
+    f, otr, gtr = start(ctx, oracle, scene, occ_every=4, occ_sigma_thresh=0.3)  # same sizes: the parked buffers and stream
+    want_loss, want_tg, want_mg = otr.gradients()
+    loss, tg, mg = gtr.gradients()
+    assert loss == pytest.approx(want_loss, rel=1e-3) and rel_l2(mg, want_mg) < 1e-3 and rel_l2(tg, want_tg) < 1e-3
+    want = np.array([otr.step() for _ in range(6)])
+    got = gtr.steps(6)
+    np.testing.assert_allclose(got, want, rtol=2e-3)
+    assert gtr.info()["steps"] == 6
+    wt, wm = otr.master()
+    gt_, gm = gtr.master()
+    assert rel_l2(gm, wm) < 2e-2 and rel_l2(gt_, wt) < 2e-2
+    gtr.close()
+
+
 def test_trainer_lifecycle_returns_its_memory(ctx, oracle, scene):
     """an NBV loop creates and destroys a trainer per member and iteration: device memory must come back"""
     kw, ocams, cams, imgs = scene
