@@ -2,7 +2,7 @@
 """How the members' training steps share the GPU (dev tool): from a rocprofv3 kernel trace of scripts/trainprofile.py
 --members N, over the last ROUNDS rounds -- wall time per round, the time at least one kernel runs, the mean number of
 kernels running, and per stream (= member) the time between the end of a kernel and the start of the next one.
-   python scripts/train_concurrency.py <kernel_trace.csv> [rounds]"""
+   python scripts/train_concurrency.py <kernel_trace.csv> [rounds] [members]"""
 import collections
 import csv
 import sys
@@ -12,8 +12,8 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 key = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 prepack = [i for i, r in enumerate(rows) if "adam_mlp_kernel" in r["Kernel_Name"]]  # a step's last kernel
-streams = sorted({rows[i][key] for i in prepack[-50:]})
-n_members = len(streams)
+streams = sorted({rows[i][key] for i in prepack[-50:]})  # hardware queues the members' streams sit on (5 members: 5 with a queue each, 3 when pooled)
+n_members = int(sys.argv[3]) if len(sys.argv) > 3 else len(streams)  # members stepping side by side (one adam_mlp launch per member-step)
 lo = prepack[-(rounds * n_members + 1)]
 sel = rows[lo + 1:]
 t0, t1 = int(sel[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in sel)
@@ -32,7 +32,7 @@ for t, d in ev:
     area += depth * (t - last)
     depth += d
     last = t
-print(f"{n_members} member streams ({key}), last {rounds} rounds: wall {(t1 - t0) / rounds / 1e3:.1f} us per round, at least one kernel running "
+print(f"{n_members} members on {len(streams)} hardware queues ({key}), last {rounds} rounds: wall {(t1 - t0) / rounds / 1e3:.1f} us per round, at least one kernel running "
       f"{busy / rounds / 1e3:.1f} us ({100.0 * busy / (t1 - t0):.0f} %), kernels running on average {area / max(busy, 1):.2f} while any runs, "
       f"sum of kernel durations {area / rounds / 1e3:.1f} us per round")
 # per kernel: the share of the wall time at least one launch of it runs, and how many of them run on average while one does
