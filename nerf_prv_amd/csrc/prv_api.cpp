@@ -69,6 +69,7 @@ struct prv_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::vector<hipStream_t> idle_queues; // streams with a hardware queue of their own, parked by destroyed trainers (prv_train_api.inc)
+  hipStream_t capture_stream = nullptr; // the trainers' step graphs are captured on it (non-blocking; nothing ever runs on it)
   std::vector<Buffer> idle_buffers;     // ... and their device buffers, taken again by size (train_buffer)
   size_t idle_bytes = 0;
   std::string err;

@@ -346,6 +346,42 @@ def test_a_trainer_on_parked_buffers_matches_the_oracle(ctx, oracle, scene):
     gtr.close()
 
 
+def test_default_stream_work_of_another_thread_while_step_graphs_are_captured(ctx, oracle, scene):
+    """a trainer's stream owns a hardware queue (created with a CU mask: a BLOCKING stream) -- its step graphs are captured on
+    a non-blocking stream of the context's instead, so that legacy-default-stream work of another thread (PyTorch's default
+    stream) cannot become an implicit dependency on a capture: neither side may see an error, and the steps still track the
+    oracle (this runtime did not raise the error without the capture stream either: the test pins the behaviour, not a bug)"""
+    import threading
+
+    t = ctx.torch
+    stop, errs = threading.Event(), []
+
+    def worker():
+        try:
+            t.cuda.set_device(ctx.device)
+            x = t.ones(1 << 16, device=ctx.device)
+            while not stop.is_set():
+                x = x * 1.0001 + 0.0  # kernels on the legacy default stream
+                t.cuda.current_stream().query()
+            t.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = threading.Thread(target=worker)
+    th.start()
+    try:
+        for k in range(4):  # every new trainer captures its step graphs anew
+            f, otr, gtr = start(ctx, oracle, scene, occ_every=2, occ_sigma_thresh=0.3, seed=util.SEED_A + k)
+            want = np.array([otr.step() for _ in range(4)])
+            got = gtr.steps(4)
+            np.testing.assert_allclose(got, want, rtol=2e-3)
+            gtr.close()
+    finally:
+        stop.set()
+        th.join()
+    assert not errs, errs
+
+
 def test_trainer_lifecycle_returns_its_memory(ctx, oracle, scene):
     """an NBV loop creates and destroys a trainer per member and iteration: device memory must come back"""
     kw, ocams, cams, imgs = scene
