@@ -53,8 +53,15 @@ def build_hip(force=False):
     deps = srcs + [os.path.join(CSRC, f) for f in ("prv_device.hpp", "prv_kernels.hpp", "prv_json.hpp", "prv_train.hpp",
                                                    "prv_train_api.inc", "prv_comm_api.inc", "prv_star.hpp", "prv_levels.hpp", "prv_ingp.hpp")] + [
         os.path.join(ROOT, "include", "prv.h")]
-    if force or _newer(out, deps):
+    # the flags the library was built with (PRV_ABLATE / PRV_TRAIN_ABLATE / PRV_EXTRA_HIPFLAGS timing builds change them, not the
+    # sources: a comparison of "two builds" that skipped the second compile measures one binary twice)
+    stamp = out + ".flags"
+    flags = " ".join(HIP_FLAGS)
+    same_flags = os.path.exists(stamp) and open(stamp).read() == flags
+    if force or not same_flags or _newer(out, deps):
         _run([hipcc()] + HIP_FLAGS + ["-o", out] + srcs + ["-ldl", "-lz"])  # zlib: .ingp snapshots; librccl itself is dlopen'ed (prv_comm_api.inc)
+        with open(stamp, "w") as fh:
+            fh.write(flags)
     return out
 
 
