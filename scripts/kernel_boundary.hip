@@ -16,16 +16,18 @@ __global__ void write_kernel(uint4* p, size_t n16, uint32_t v) {
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int main() {
+int main(int argc, char** argv) {
   setvbuf(stdout, nullptr, _IOLBF, 0);
+  const bool with_own = argc > 1; // (creating and destroying streams that own a queue takes seconds once a few dozen have existed: off by default)
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
   const int n_cu = prop.multiProcessorCount, kChain = 200;
   printf("%s, %d CUs; chains of %d dependent kernels per stream; us per kernel of a chain\n", prop.gcnArchName, n_cu, kChain);
   const size_t sizes[] = {0, 1 << 20, 16 << 20};
-  for (int own = 0; own < 2; own++)
-    for (int graph = 0; graph < 2; graph++) {
-      printf("\n## %s streams, %s\n%-12s", own ? "own-queue" : "pooled", graph ? "one captured graph of the chain per stream" : "plain launches", "bytes/kernel");
+  for (int own = 0; own < (with_own ? 2 : 1); own++)
+    for (int graph = 0; graph < 4; graph++) {
+      const int per_graph = graph == 1 ? kChain : graph == 2 ? 5 : graph == 3 ? 10 : 0; // kernels per captured graph
+      printf("\n## %s streams, %s\n%-12s", own ? "own-queue" : "pooled", graph == 0 ? "plain launches" : graph == 1 ? "one captured graph of the whole chain per stream" : graph == 2 ? "captured graphs of 5 kernels, launched chain/5 times" : "captured graphs of 10 kernels, launched chain/10 times", "bytes/kernel");
       for (int ns : {1, 2, 3, 5, 8}) printf("  %d stream%s", ns, ns > 1 ? "s" : " ");
       printf("\n");
       for (size_t bytes : sizes) {
@@ -42,8 +44,8 @@ int main() {
           }
           const size_t n16 = bytes / 16;
           const unsigned blocks = bytes ? (unsigned)((bytes + (64 << 10) - 1) / (64 << 10)) : 1u;
-          auto chain = [&](int s, hipStream_t q) {
-            for (int k = 0; k < kChain; k++) hipLaunchKernelGGL(write_kernel, dim3(blocks), dim3(256), 0, q, buf[s], n16, (uint32_t)k);
+          auto chain = [&](int s, hipStream_t q, int n_k = kChain) {
+            for (int k = 0; k < n_k; k++) hipLaunchKernelGGL(write_kernel, dim3(blocks), dim3(256), 0, q, buf[s], n16, (uint32_t)k);
           };
           if (graph) {
             hipStream_t cap;
@@ -51,7 +53,7 @@ int main() {
             for (int s = 0; s < ns; s++) {
               hipGraph_t g;
               hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
-              chain(s, cap);
+              chain(s, cap, per_graph);
               hipStreamEndCapture(cap, &g);
               hipGraphInstantiate(&ge[s], g, nullptr, nullptr, 0);
               hipGraphDestroy(g);
@@ -59,10 +61,11 @@ int main() {
             hipStreamDestroy(cap);
           }
           auto run = [&]() {
-            for (int s = 0; s < ns; s++) {
-              if (graph) hipGraphLaunch(ge[s], st[s]);
-              else chain(s, st[s]);
-            }
+            if (!graph)
+              for (int s = 0; s < ns; s++) chain(s, st[s]);
+            else
+              for (int r = 0; r < kChain / per_graph; r++) // round robin over the streams, as the trainer's enqueue loop
+                for (int s = 0; s < ns; s++) hipGraphLaunch(ge[s], st[s]);
             for (int s = 0; s < ns; s++) hipStreamSynchronize(st[s]);
           };
           run(); // warm-up
