@@ -109,9 +109,12 @@ def parse_args(argv=None):
     ap.add_argument("--full-loop", action="store_true",
                     help="BASELINE configs[4] at size (minutes): prv_planner configs/TrainInLoop.yaml semantics, 5 objects x 20 rounds (mode 21) + "
                          "the PSNR curve and stopping criterion (mode 4), end-to-end wall-clock in the full_loop sub-object.  Without it "
-                         "the default run does ONE object x 20 rounds (under a minute) so that the driver's line carries the figure")
+                         "the default run does ONE object x 20 rounds (a few minutes at upstream's training batch) so that the driver's line carries the figure")
     ap.add_argument("--full-loop-objects", type=int, default=0, help="0 = 1 by default, 5 with --full-loop")
     ap.add_argument("--no-full-loop", action="store_true")
+    ap.add_argument("--full-loop-small", action="store_true",
+                    help="full_loop on configs/TrainInLoop_small.yaml: the 4096-ray training cap of rounds 1-5, about 1/6.6 of upstream's batch "
+                         "(reported as `reduced`; the default trains at the library default = upstream's 2^18-sample batch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-training", action="store_true")
@@ -543,7 +546,12 @@ def full_loop(args):
     if not os.path.exists(exe):
         return {"error": "prv_planner missing: run __graft_entry__.build()"}
     work = tempfile.mkdtemp(prefix="prv_full_loop_")
-    cfg = open(os.path.join(ROOT, "configs", "TrainInLoop.yaml")).read()
+    # configs/TrainInLoop.yaml trains at the library default = upstream's batch (run.py:185-208 leaves the engine's batch alone:
+    # a 2^18-sample target per step under a 2^16-ray cap); --full-loop-small = configs/TrainInLoop_small.yaml, the 4096-ray cap
+    # of rounds 1-5 (about 1/6.6 of that batch), labelled as reduced wherever it is reported
+    small = bool(getattr(args, "full_loop_small", False))
+    cfg_name = "TrainInLoop_small.yaml" if small else "TrainInLoop.yaml"
+    cfg = open(os.path.join(ROOT, "configs", cfg_name)).read()
     cfg = re.sub(r'pre_path: "[^"]*"', f'pre_path: "{work}/"', cfg)
     cfg = re.sub(r'model_path: "[^"]*"', f'model_path: "{work}/models/"', cfg)
     cfg = re.sub(r'viewspace_path: "[^"]*"', f'viewspace_path: "{os.path.join(ROOT, "tests", "golden", "hemisphere")}/"', cfg)
@@ -566,13 +574,21 @@ def full_loop(args):
     with open(path, "w") as fh:
         fh.write(cfg)
     names = [f"object_{k}" for k in range(args.full_loop_objects or (5 if args.full_loop else 1))]
-    out = {"objects": len(names), "rounds_per_object": 20, "config": "configs/TrainInLoop.yaml (144-view set, 5 members x 2500 steps per round, "
-           "candidates 80x45 spp 16, engine stepping rule)", "work_dir": work}
+    from nerf_prv_amd import api as _api  # the library's own defaults (no GPU touched: a struct filled by prv_train_default_opts)
+
+    dflt = _api.train_opts()
+    rays_cap = cfg_int("train_rays", int(dflt.n_rays))
+    out = {"objects": len(names), "rounds_per_object": 20,
+           "config": f"configs/{cfg_name} (144-view set, {n_members} members x {n_steps} steps per round, training batch: {int(dflt.target_samples)}-sample "
+                     f"target per member-step under a {rays_cap}-ray cap" + (" = REDUCED, about 1/6.6 of upstream's batch" if small else " = the library default = upstream's")
+                     + ", candidates 80x45 spp 16, engine stepping rule)",
+           "train_rays_cap": rays_cap, "target_samples": int(dflt.target_samples), "training_batch": "reduced" if small else "library default (upstream's)",
+           "work_dir": work}
     t_all = time.perf_counter()
     for mode, key in ((21, "view_planning_s"), (4, "psnr_curve_and_stopping_criterion_s")):
         t0 = time.perf_counter()
         # the planner's default exit (ordered shutdown, flush, _exit): its exit code is the planner's own
-        r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=(1800 if args.full_loop else 300),
+        r = subprocess.run([exe, path], input=f"{mode}\n" + "\n".join(names) + "\n-1\n", text=True, capture_output=True, timeout=(3600 if args.full_loop else 900),
                            env=dict(os.environ, PRV_PLANNER_TIMING="1"))  # one line per training call on stderr
         out[key] = time.perf_counter() - t0
         if os.environ.get("PRV_BENCH_KEEP_STDERR"):  # dev: the planner's timing lines, one file per mode
@@ -594,6 +610,10 @@ def full_loop(args):
             if score_s:
                 out["scoring_rounds"] = len(score_s)
                 out["scoring_s"] = sum(score_s)  # render + score of the remaining candidates, every member (camera json included)
+            last = [(int(a), int(b)) for a, b in re.findall(r"train_members: .*?: (\d+) samples, (\d+) rays", r.stderr)]
+            if last:  # member 0's last batch of every training call: composited samples and rays cast
+                out["samples_per_member_step"] = sum(a for a, _ in last) / len(last)
+                out["rays_per_member_step"] = sum(b for _, b in last) / len(last)
             if steps_s:
                 out["training_calls"] = len(steps_s)
                 out["training_steps_s"] = sum(steps_s)
@@ -601,6 +621,8 @@ def full_loop(args):
                 out["members"], out["steps_per_member_and_round"] = n_members, n_steps
                 out["member_step_us"] = sum(steps_s) / (len(steps_s) * n_members * n_steps) * 1e6
                 out["round_of_5_member_steps_ms"] = sum(steps_s) / (len(steps_s) * n_steps) * 1e3 * 5.0 / n_members
+                if last:
+                    out["trained_samples_per_s"] = out["samples_per_member_step"] / (out["member_step_us"] * 1e-6)
                 if getattr(args, "train_patch", ""):
                     out["train_patch"] = args.train_patch
             chosen = [l for l in r.stdout.splitlines() if l.startswith("chosen_nbvs:")]
@@ -917,6 +939,9 @@ def run_rank(args):
         if loop and "seconds_per_object" in loop:
             lifted["full_loop_s_per_object"] = loop["seconds_per_object"]
             lifted["full_loop_member_step_us"] = loop.get("member_step_us")
+            lifted["full_loop_training_batch"] = loop.get("training_batch")
+            lifted["full_loop_samples_per_member_step"] = loop.get("samples_per_member_step")
+            lifted["full_loop_trained_samples_per_s"] = loop.get("trained_samples_per_s")
         out.update(lifted)
         out.update({
             "dtype_note": "fp16 table, blend and MLP operands (MFMA f16 -> f32 accumulate); f32 rays, positions, compositing",

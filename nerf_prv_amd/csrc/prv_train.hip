@@ -459,9 +459,9 @@ void train_tile_kernel(TrainTileParams P) {
     // slice, then a tree over the 256 partial sums: a fixed order -- and the step's last kernel adds the slices in slice
     // order (end_step).  Until round 5 a kernel of its own in every member's chain (6 us alone, 13 us beside the other
     // members' launches); a ticket in the compositing kernel instead costs a device-scope release fence per block: slower.
-    const int n_slices = P.ray_loss ? (P.n_rays + 1023) / 1024 : 0;
-    const int slice = (int)gridDim.x - 1 - (int)blockIdx.x;
-    if (P.tile_begin == 0 && slice < n_slices) {
+    // (a block takes every gridDim.x-th slice: n_rays up to 2^22 is 4096 slices, more than any backward grid)
+    const int n_slices = P.ray_loss && P.tile_begin == 0 ? (P.n_rays + 1023) / 1024 : 0;
+    for (int slice = (int)gridDim.x - 1 - (int)blockIdx.x; slice < n_slices; slice += (int)gridDim.x) {
       double* sl = reinterpret_cast<double*>(lds);
       unsigned long long* su = reinterpret_cast<unsigned long long*>(lds) + 256;
       double a = 0.0;

@@ -403,3 +403,19 @@ def test_trainer_lifecycle_returns_its_memory(ctx, oracle, scene):
     t.cuda.synchronize()
     free1, _ = t.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20  # nothing accumulates (a trainer of this size holds ~60 MB)
+
+
+def test_loss_slices_when_the_rays_outnumber_the_backward_grid(ctx, oracle, scene, monkeypatch):
+    """the step's loss and used-sample count are summed per 1024-ray slice by the blocks of the backward launch; with
+    more slices than blocks (here 4 slices on 2 blocks; on the chip: n_rays > 2^18 side by side) every block has to take
+    several -- loss, used samples and the budget's next ray count must still be the oracle's"""
+    monkeypatch.setenv("PRV_TRAIN_BWD_BLOCKS", "2")
+    f, otr, gtr = start(ctx, oracle, scene, n_rays=4096, n_samples=8, target_samples=20000, occ_every=0)
+    want_loss, _, want_mg = otr.gradients()
+    loss, _, mg = gtr.gradients()
+    assert gtr.info()["samples_last"] == otr.samples_last > 8000
+    assert loss == pytest.approx(want_loss, rel=1e-3) and rel_l2(mg, want_mg) < 1e-3
+    want = np.array([otr.step() for _ in range(3)])
+    got = gtr.steps(3)  # end_step and the list-ahead ray pass read every slice
+    np.testing.assert_allclose(got, want, rtol=2e-3)
+    assert gtr.info()["active_rays"] == pytest.approx(otr.active_rays, rel=0.03) and gtr.info()["active_rays"] > 2048
