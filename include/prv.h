@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PRV_ABI_VERSION 4 /* 2: prv_field_desc.per_level_scale; 3: prv_render_opts.step_mode, prv_stats.samples_live; 4: prv_train_opts.patch_w / patch_h */
+#define PRV_ABI_VERSION 5 /* 2: prv_field_desc.per_level_scale; 3: prv_render_opts.step_mode, prv_stats.samples_live; 4: prv_train_opts.patch_w / patch_h; 5: prv_train_opts.step_mode / deterministic */
 
 /* error codes (0 = ok, < 0 = error; message via prv_last_error) */
 #define PRV_OK 0
@@ -356,7 +356,8 @@ int prv_model_exchange(prv_ctx* ctx, prv_comm* comm, int n_members, const prv_fi
  * trained weights and occupancy. */
 typedef struct prv_train_opts {
   int32_t n_rays;    /* rays per step (with target_samples: the cap of the adaptive count; default 2^16) */
-  int32_t n_samples; /* samples per ray between the AABB hits, <= 128 */
+  int32_t n_samples; /* PRV_STEP_FIXED_S: samples per ray between the AABB hits, <= 128.  PRV_STEP_NGP: the most steps a ray takes,
+                        <= PRV_NGP_MAX_STEPS (1024 = the cube's diagonal, what prv_train_default_opts sets for that rule) */
   float lr, beta1, beta2, eps, l2_reg; /* Adam; l2_reg on the MLP weights only */
   float min_T;       /* early termination of a training ray */
   uint64_t seed;
@@ -373,7 +374,17 @@ typedef struct prv_train_opts {
                                that share one jitter, and the step's sample list is ordered depth step by depth step
                                inside a patch, so that the samples of a backward tile share table entries (fewer
                                memory-side atomic requests per step); 0 or 1: every ray its own pixel (the published
-                               i.i.d. sampler).  prv_train_default_opts says which this build defaults to */
+                               i.i.d. sampler).  prv_train_default_opts says which this build defaults to.  PRV_STEP_FIXED_S only */
+  int32_t step_mode; /* how a training ray is sampled (the values of prv_render_opts.step_mode).  PRV_STEP_FIXED_S: n_samples
+                        uniform samples between the AABB hits under one random offset per ray (rounds 1-5).  PRV_STEP_NGP: the
+                        engine's own marcher, what upstream trains with behind run.py:188 `testbed.frame()` --
+                        fixed step dt = sqrt(3)/1024 from the AABB entry, per-ray random start: sample i at t0 + (i + jitter) dt
+                        while that is inside the box and i < n_samples, every step tested against the occupancy grid,
+                        alpha = 1 - exp(-sigma dt) with that dt; the sample budget (target_samples) is unchanged, its first step
+                        casts target_samples / n_samples rays.  A step lists at most 2^24 samples under this rule (64 x the
+                        default budget); a batch beyond that makes prv_train_steps fail with PRV_E_STATE */
+  int32_t deterministic; /* 1 (tests): bit-reproducible training -- the ray batches are listed in ray order and the table gradient
+                            is summed in 64-bit fixed point (order-independent) instead of f32 atomics; slower.  0: the product path */
 } prv_train_opts;
 typedef struct prv_trainer prv_trainer;
 int prv_train_default_opts(prv_train_opts* opts);

@@ -83,7 +83,7 @@ class TrainOpts(C.Structure):
                 ("beta2", C.c_float), ("eps", C.c_float), ("l2_reg", C.c_float), ("min_T", C.c_float),
                 ("seed", C.c_uint64), ("random_bg", C.c_int32), ("occ_every", C.c_int32), ("occ_decay", C.c_float),
                 ("occ_sigma_thresh", C.c_float), ("target_samples", C.c_int32), ("patch_w", C.c_int32),
-                ("patch_h", C.c_int32)]
+                ("patch_h", C.c_int32), ("step_mode", C.c_int32), ("deterministic", C.c_int32)]
 
 
 _vp = C.c_void_p

@@ -485,6 +485,8 @@ def train_opts(**kw):
         if not hasattr(o, k):
             raise TypeError(f"unknown training option {k}")
         setattr(o, k, v)
+    if "step_mode" in kw and "n_samples" not in kw:  # n_samples means another thing under each rule (include/prv.h)
+        o.n_samples = L.NGP_MAX_STEPS if kw["step_mode"] == L.STEP_NGP else 128
     return o
 
 

@@ -2,19 +2,34 @@
 // loop that run.py:185-208 drives for --n_steps 2500 (main.cpp:1668).  The algorithm is the one
 // oracle/prv_train.c states (published instant-ngp optimiser, parity unpinned); this file is its HIP form.
 //
-//   train_rays_kernel      one lane = one training ray: counter RNG -> image / pixel / jitter / background,
-//                          target colour, dataset camera (lens solve), unit-cube slab test, 128-bit occupancy
-//                          mask at the jittered sample positions, live samples appended to the sample list
-//   train_tile_kernel<FWD> one 256-thread block = 32 samples at a time, persistent.  8 threads per sample
-//                          encode (one or two levels each, binary16 blend as in inference); the five layers run
-//                          as f32 MFMAs (v_mfma_f32_32x32x2_f32) with BOTH operands read from plain
-//                          [neuron][sample] / [in][out] LDS arrays, so every layout is trivial:
-//                            FWD : logits out.   BWD : activations recomputed, dX chain, dW accumulated in
-//                          registers over all tiles of the block (3 weight tiles per wave), feature gradients
-//                          scattered into the canonical table gradient with f32 atomics
-//   train_composite_kernel one lane = one ray: compositing, loss, and the per-sample gradient seeds
-//   adam_*_kernel          sparse Adam on the table, dense Adam (+L2) on the MLP, fp16 working copies refreshed
-//   density_refresh_kernel density at every occupancy cell centre -> EMA -> bitfield
+//   train_rays_kernel      one WAVE = one training ray (four per block): counter RNG -> image / pixel / jitter / background, target
+//                          colour, dataset camera (lens solve), unit-cube slab test; the lanes test the occupancy of the ray's steps
+//                          (PRV_STEP_FIXED_S: <= 128 jittered uniform samples, two per lane; PRV_STEP_NGP: the engine's marcher,
+//                          dt = sqrt(3)/1024 from a per-ray random start, <= 1024 steps, sixteen per lane), ballots give the live
+//                          masks, one returning atomic per block reserves the list range, every lane appends its own live samples.
+//                          From the second step of a call on the batch of step n + 1 is listed by extra blocks of step n's table-Adam
+//                          launch.  train_rays_patch_kernel: patches of adjacent pixels, listed depth step by depth step (an option)
+//   train_forward_fast_kernel  a lane pair per sample, 32 samples per wave and round: encode from the canonical table, both MLPs as 24
+//                          v_mfma_f32_32x32x16_f16 on prepacked A fragments (the render kernel's machinery); the B fragments the lanes
+//                          hold between the layers ARE the activations the backward pass needs and are kept (528 B per sample)
+//   train_composite_kernel one WAVE = one ray, 64 samples per chunk: transmittance by a prefix product across the lanes, colour by
+//                          wave sums, loss, then the per-sample gradient seeds chunk by chunk from the back (suffix sums by a
+//                          reverse scan; a chunk's values are recomputed from the logits)
+//   train_tile_kernel<F, false, 2>  the backward pass, one 256-thread block = 32 samples at a time, persistent: kept activations
+//                          -> [row][sample] LDS arrays, the dX chain register-resident on ONE wave (bf16-split operands,
+//                          v_mfma_f32_32x32x16_bf16: a backward layer's accumulator is the next layer's B operand), dW as bf16-split
+//                          MFMAs accumulated in registers over all tiles of the block (three weight tiles per wave), then the MERGING
+//                          TABLE SCATTER: thread (level, corner, feature) walks the tile's 32 samples with four (entry, sum) pairs
+//                          and issues one f32 atomic per entry it evicts (the memory side's atomic-request rate is what bounds the
+//                          step).  The launch's last blocks also sum the step's loss / used-sample slices.  MODE 0 / 1 (recomputed
+//                          forward, LDS chain on v_mfma_f32_32x32x2_f32) are the fallbacks for tiles beyond the activation buffer and
+//                          the dev switches PRV_TRAIN_FAST_FWD / PRV_TRAIN_REG_CHAIN
+//   adam_table_kernel      sparse Adam on the table, one {w[4], m[4], v[4]} record per group of four scalars; extra blocks do the
+//                          first stage of the MLP's dW reduction and list the next step's ray batch
+//   adam_mlp_kernel        dense Adam (+L2) on the MLP, fp16 working copies; every thread writes its weight into the forward and
+//                          backward MFMA fragments; thread 0 closes the step (budget rule) and opens the next
+//   density_refresh_fast_kernel  density at every occupancy cell centre (8 MFMAs per 32 cells) -> EMA -> bitfield
+// Five kernels per step behind the ray batch, one captured HIP graph per step variant (prv_train_api.inc).
 #include <hip/hip_runtime.h>
 #include "prv_train.hpp"
 
@@ -86,8 +101,40 @@ __device__ __forceinline__ void rays_step(const TrainRaysParams& P, uint32_t& st
   counter = P.sample_count + (step & 1u);
 }
 
-// one WAVE = one ray: the lanes test the occupancy of the S <= 128 sample positions (two per lane), ballots
-// give the live mask, each lane appends its own live samples at (offset + rank)
+constexpr float kTrainNgpDt = 1.7320508075688772f / 1024.0f; // = sqrtf(3.0f) / 1024.0f, the oracle's value bit for bit (as prv_kernels.hip)
+constexpr int kOrderWord = 144; // scal word of the deterministic append tickets (two, by step parity): sample_count + kOrderWord
+
+// a block's range of the sample list: ONE returning atomic on the step's counter (thread 0 calls).  deterministic: the blocks
+// append in index order -- block `ticket` waits until the blocks before it have appended (workgroups are dispatched in index
+// order, so the ones it waits for are running or done) -- and the list, its tiles and every sum over them are reproducible.
+// A range that does not fit the list sets the sticky overflow flag: every later kernel then sees an empty batch
+// (batch_samples below) and prv_train_steps reports it.
+__device__ __forceinline__ uint32_t reserve_samples(const TrainRaysParams& P, uint32_t* counter, uint32_t step, uint32_t ticket, uint32_t tot) {
+  uint32_t base;
+  if (P.deterministic) {
+    uint32_t* turn = P.sample_count + kOrderWord + (step & 1u);
+    while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(1);
+    base = *(volatile uint32_t*)counter;
+    *(volatile uint32_t*)counter = base + tot;
+    __hip_atomic_store(turn, ticket + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    base = tot ? atomicAdd(counter, tot) : 0u;
+  }
+  if (tot && (unsigned long long)base + tot > (unsigned long long)P.sample_cap) {
+    P.state->overflow = 1u;
+    base = 0xffffffffu;
+  }
+  return base;
+}
+// the samples of the step in flight as every kernel behind the ray batch sees them
+__device__ __forceinline__ uint32_t batch_samples(const uint32_t* sample_count, const TrainState* state) {
+  return state->overflow ? 0u : sample_count[state->step & 1u];
+}
+
+// one WAVE = one ray: the lanes test the occupancy of the ray's steps (64 per round: two rounds for S <= 128 uniform
+// samples, up to sixteen for the engine's 1024 steps), ballots give the live masks (kept in LDS), each lane appends its
+// own live samples at (offset + rank)
+template <bool NGP>
 __device__ __forceinline__ void train_rays_block(const TrainRaysParams& P, uint32_t bx) {
   const int lane = threadIdx.x & 63;
   const uint32_t j = bx * 4u + (threadIdx.x >> 6);
@@ -107,38 +154,47 @@ __device__ __forceinline__ void train_rays_block(const TrainRaysParams& P, uint3
   float t0, t1;
   r.t0 = 0.f;
   r.dt = 0.f;
-  unsigned long long m0 = 0ull, m1 = 0ull;
-  if (ray_aabb(r.o, r.d, t0, t1)) {
-    r.t0 = t0;
-    r.dt = (t1 - t0) / (float)P.S;
-    bool on[2];
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const int i = q * 64 + lane;
-      const float t = fmaf((float)i + jitter, r.dt, t0);
-      on[q] = i < P.S && occ_bit(P.occ, P.occ_res, fmaf(t, r.d[0], r.o[0]), fmaf(t, r.d[1], r.o[1]), fmaf(t, r.d[2], r.o[2]));
-    }
-    m0 = __ballot(on[0]);
-    m1 = __ballot(on[1]);
-  }
-  if (!in_budget) m0 = m1 = 0ull; // a ray of the last block that lies beyond the budget: takes part in the barriers only
-  const uint32_t n0 = (uint32_t)__popcll(m0), n_live = n0 + (uint32_t)__popcll(m1);
-  // ONE returning atomic per block (its four rays' counts summed through LDS), not one per ray: 2^16 rays appending
-  // to a single counter were a third of this kernel
+  constexpr int kWords = NGP ? kMaxTrainSteps / 64 : 2;
+  __shared__ unsigned long long mk[4][kWords];
   __shared__ uint32_t cnt[4], base;
   const int wv = threadIdx.x >> 6;
+  uint32_t n_live = 0u;
+  int n_words = 0; // wave-uniform: rounds of 64 steps that can hold a live sample
+  if (in_budget && ray_aabb(r.o, r.d, t0, t1)) {
+    r.t0 = t0;
+    r.dt = NGP ? kTrainNgpDt : (t1 - t0) / (float)P.S;
+    if (NGP) { // steps beyond the exit are dead: (t1 - t0) / dt + 2 bounds them (the exact `t < t1` test below decides)
+      const int inside = (int)fminf((t1 - t0) * (1024.0f / 1.7320508075688772f) + 2.0f, (float)P.S);
+      n_words = (min(inside, P.S) + 63) >> 6;
+    } else {
+      n_words = (P.S + 63) >> 6;
+    }
+    for (int q = 0; q < n_words; q++) {
+      const int i = q * 64 + lane;
+      const float t = fmaf((float)i + jitter, r.dt, t0);
+      const bool on = i < P.S && (!NGP || t < t1) && occ_bit(P.occ, P.occ_res, fmaf(t, r.d[0], r.o[0]), fmaf(t, r.d[1], r.o[1]), fmaf(t, r.d[2], r.o[2]));
+      const unsigned long long m = __ballot(on);
+      if (lane == 0) mk[wv][q] = m;
+      n_live += (uint32_t)__popcll(m);
+    }
+  }
+  // ONE returning atomic per block (its four rays' counts summed through LDS), not one per ray: 2^16 rays appending
+  // to a single counter were a third of this kernel
   if (lane == 0) cnt[wv] = n_live;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t tot = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-    base = tot ? atomicAdd(counter, tot) : 0u;
-  }
+  if (threadIdx.x == 0) base = reserve_samples(P, counter, step, bx, cnt[0] + cnt[1] + cnt[2] + cnt[3]);
   __syncthreads();
-  uint32_t offset = base;
+  const bool fits = base != 0xffffffffu;
+  uint32_t offset = fits ? base : 0u;
   for (int w = 0; w < wv; w++) offset += cnt[w];
+  if (!fits) n_live = 0u; // the batch overflowed the list: the step is void (TrainState::overflow)
   const unsigned long long below = (1ull << lane) - 1ull;
-  if ((m0 >> lane) & 1ull) P.samples[offset + (uint32_t)__popcll(m0 & below)] = make_uint2(j, (uint32_t)lane);
-  if ((m1 >> lane) & 1ull) P.samples[offset + n0 + (uint32_t)__popcll(m1 & below)] = make_uint2(j, 64u + (uint32_t)lane);
+  uint32_t pre = 0u;
+  for (int q = 0; q < n_words && fits; q++) {
+    const unsigned long long m = mk[wv][q];
+    if ((m >> lane) & 1ull) P.samples[offset + pre + (uint32_t)__popcll(m & below)] = make_uint2(j, (uint32_t)(q * 64 + lane));
+    pre += (uint32_t)__popcll(m);
+  }
   if (lane == 0 && in_budget) {
     float bg[3] = {0.f, 0.f, 0.f};
     if (P.random_bg)
@@ -157,7 +213,11 @@ __device__ __forceinline__ void train_rays_block(const TrainRaysParams& P, uint3
     P.rays[j] = r;
   }
 }
-__global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) { train_rays_block(P, blockIdx.x); }
+__device__ __forceinline__ void train_rays_block_any(const TrainRaysParams& P, uint32_t bx) {
+  if (P.step_mode == PRV_STEP_NGP) train_rays_block<true>(P, bx);
+  else train_rays_block<false>(P, bx);
+}
+__global__ __launch_bounds__(256) void train_rays_kernel(TrainRaysParams P) { train_rays_block_any(P, blockIdx.x); }
 
 // Patch mode (prv_train_opts.patch_w x patch_h = PP > 1): one BLOCK = one patch of PP adjacent pixels of one image, one
 // wave per ray as above.  The rays of a patch share image, jitter and (nearly) their depth range, so the samples of ONE
@@ -227,10 +287,12 @@ __global__ __launch_bounds__(1024) void train_rays_patch_kernel(TrainRaysParams 
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t tot = wtot[0] + wtot[1];
-    base = tot ? atomicAdd(counter, tot) : 0u; // one returning atomic per patch
+    base = reserve_samples(P, counter, P.state->step, q, tot); // one returning atomic per patch
   }
   __syncthreads();
-  if (i < 128 && cnt) {
+  const bool fits = base != 0xffffffffu;
+  if (!fits) m0 = m1 = 0ull; // the batch overflowed the list: the step is void (TrainState::overflow)
+  if (i < 128 && cnt && fits) {
     uint32_t pos = base + excl + (wv == 1 ? wtot[0] : 0u);
     const unsigned long long below = (1ull << (i & 63)) - 1ull;
     for (uint32_t rr = 0; rr < PP; rr++) {
@@ -430,6 +492,17 @@ __device__ __forceinline__ f32x16v layer_tile(const _Float16* __restrict__ Wl, i
   return acc;
 }
 
+// one add into the table gradient: an f32 atomic at the memory side, or -- deterministic (tests) -- a 64-bit integer atomic
+// on the value in fixed point (2^-kGradQBits; integer adds commute, so the sum does not depend on the order the tiles arrive in)
+__device__ __forceinline__ void table_grad_add(const TrainTileParams& P, size_t idx, float v) {
+  if (P.table_grad_q) {
+    const long long q = __float2ll_rn(v * (float)(1ull << kGradQBits)); // a power-of-two scale: exact until the conversion rounds
+    atomicAdd(reinterpret_cast<unsigned long long*>(P.table_grad_q) + idx, (unsigned long long)q);
+  } else {
+    atomicAdd(P.table_grad + idx, v);
+  }
+}
+
 template <int F, bool FWD, int MODE = 0> // MODE 0: recompute the forward pass | 1: kept activations, LDS chain | 2: kept activations, register chain
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(2))) // two blocks per CU (74 KB of LDS each; 80 KB for the register-chain instance): at most 256 registers per lane
@@ -491,7 +564,7 @@ void train_tile_kernel(TrainTileParams P) {
       __syncthreads(); // the scratch goes back to the tile loop
     }
   }
-  const uint32_t n_samples = P.sample_count[P.state->step & 1u];
+  const uint32_t n_samples = batch_samples(P.sample_count, P.state);
   const uint32_t n_tiles = min((n_samples + 31u) / 32u, P.tile_limit);
   if (P.tile_begin + blockIdx.x >= n_tiles) { // nothing to do for this block: its slot of the weight-gradient partials is zero
     if (!FWD)
@@ -953,7 +1026,7 @@ void train_tile_kernel(TrainTileParams P) {
                     hit = true;
                   }
                 if (!hit) {
-                  if (key[kWays - 1] != 0xffffffffu) atomicAdd(P.table_grad + (size_t)key[kWays - 1] * F + k, acc[kWays - 1]);
+                  if (key[kWays - 1] != 0xffffffffu) table_grad_add(P, (size_t)key[kWays - 1] * F + k, acc[kWays - 1]);
 #pragma unroll
                   for (int w = kWays - 1; w > 0; w--) {
                     key[w] = key[w - 1];
@@ -965,7 +1038,7 @@ void train_tile_kernel(TrainTileParams P) {
               }
 #pragma unroll
               for (int w = kWays - 1; w >= 0; w--)
-                if (key[w] != 0xffffffffu) atomicAdd(P.table_grad + (size_t)key[w] * F + k, acc[w]);
+                if (key[w] != 0xffffffffu) table_grad_add(P, (size_t)key[w] * F + k, acc[w]);
             }
           } else { // dev (timing builds): the item-parallel form of rounds 1-3, one add per (sample, level, corner)
             const int k = tid % F;
@@ -974,7 +1047,7 @@ void train_tile_kernel(TrainTileParams P) {
               const uint2 e = stage[(it >> 6) * kStageStride + (it & 63)];
               if (e.x == 0xffffffffu) continue;
               const int ss = it >> 6, l = pass * 8 + ((it >> 3) & 7);
-              atomicAdd(P.table_grad + (size_t)e.x * F + k, __uint_as_float(e.y) * G[(kGFeat + l * F + k) * TSG + ss]);
+              table_grad_add(P, (size_t)e.x * F + k, __uint_as_float(e.y) * G[(kGFeat + l * F + k) * TSG + ss]);
             }
           }
         }
@@ -1109,7 +1182,7 @@ __global__ __launch_bounds__(256) void train_forward_fast_kernel(TrainTileParams
     reinterpret_cast<uint32_t*>(lv)[threadIdx.x] = reinterpret_cast<const uint32_t*>(P.levels)[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const uint32_t n_samples = P.sample_count[P.state->step & 1u];
+  const uint32_t n_samples = batch_samples(P.sample_count, P.state);
   const uint32_t n_tiles = (n_samples + 31u) / 32u;
   constexpr int LH = 16 / F;
   for (uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6); tile < n_tiles; tile += gridDim.x * 4u) {
@@ -1191,7 +1264,7 @@ __device__ __forceinline__ float scan_add_rev_incl(float v, int lane) {
 }
 
 __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositeParams P) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
   const uint32_t n_active = P.state->n_active;
   if (j >= n_active) {
@@ -1202,45 +1275,55 @@ __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositePara
     return;
   }
   TrainRay* ray = P.rays + j;
-  const uint32_t n = ray->n_live, off = ray->offset;
+  const uint32_t n = P.state->overflow ? 0u : ray->n_live, off = ray->offset; // (a batch that overflowed the list is void)
   const float dt = ray->dt;
-  // per chunk, per lane: the sample's forward values
-  float sg[2], al[2], tb[2], rgb[2][3];
-  uint32_t sid[2] = {0u, 0u}; // list position of the lane's sample (patch mode: through slot_of)
-  bool usedl[2] = {false, false};
+  // chunks of 64 samples, front to back: the transmittance at a chunk's start and the samples it used stay in LDS for the
+  // way back (<= 16 chunks: the engine's 1024 steps; 2 for the 128 uniform samples)
+  constexpr int kChunks = kMaxTrainSteps / 64;
+  __shared__ float t_start[4][kChunks];
+  __shared__ uint32_t c_used[4][kChunks];
+  const int n_chunks = (int)((n + 63u) >> 6);
+  auto list_pos = [&](uint32_t k) { return P.slot_of ? P.slot_of[(size_t)j * (size_t)P.S + k] : off + k; };
+  // a chunk's forward values from the logits (the same arithmetic on the way out and on the way back)
+  struct Chunk {
+    float sg, al, rgb[3], incl;
+  };
+  auto chunk_values = [&](bool have, uint32_t sid, Chunk& c) {
+    float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (have) lg = P.logits[sid];
+    c.sg = have ? expf(lg.x + P.density_bias) : 0.0f;
+    c.al = have ? 1.0f - expf(-(c.sg * dt)) : 0.0f;
+    c.rgb[0] = 1.0f / (1.0f + expf(-lg.y));
+    c.rgb[1] = 1.0f / (1.0f + expf(-lg.z));
+    c.rgb[2] = 1.0f / (1.0f + expf(-lg.w));
+    c.incl = scan_mul_incl(1.0f - c.al, lane);
+  };
   float T = 1.0f, C[3] = {0.f, 0.f, 0.f};
   uint32_t used = 0;
-  bool stopped = false;
-  for (int ch = 0; ch < 2; ch++) {
+  int last_ch = -1; // the last chunk that was composited (the ray terminated there, or it is the ray's last)
+  for (int ch = 0; ch < n_chunks; ch++) {
     const uint32_t k = (uint32_t)ch * 64u + (uint32_t)lane;
-    const bool have = !stopped && k < n;
-    float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
-    sid[ch] = have ? (P.slot_of ? P.slot_of[(size_t)j * (size_t)P.S + k] : off + k) : 0u;
-    if (have) lg = P.logits[sid[ch]];
-    sg[ch] = have ? expf(lg.x + P.density_bias) : 0.0f;
-    al[ch] = have ? 1.0f - expf(-(sg[ch] * dt)) : 0.0f;
-    rgb[ch][0] = 1.0f / (1.0f + expf(-lg.y));
-    rgb[ch][1] = 1.0f / (1.0f + expf(-lg.z));
-    rgb[ch][2] = 1.0f / (1.0f + expf(-lg.w));
-    const float incl = scan_mul_incl(1.0f - al[ch], lane);
-    float excl = __shfl_up(incl, 1);
+    const bool have = k < n;
+    Chunk c;
+    chunk_values(have, have ? list_pos(k) : 0u, c);
+    float excl = __shfl_up(c.incl, 1);
     if (lane == 0) excl = 1.0f;
-    tb[ch] = T * excl;
-    const float T_after = T * incl;
+    const float tb = T * excl;
+    const float T_after = T * c.incl;
     const unsigned long long term = __ballot(have && T_after < P.min_T);
-    const unsigned long long havem = __ballot(have);
-    uint32_t cnt = (uint32_t)__popcll(havem); // samples of this chunk that exist
-    if (term) {
-      cnt = (uint32_t)__builtin_ctzll(term) + 1u; // the terminating sample is the last one used
-      stopped = true;
-    }
-    usedl[ch] = have && (uint32_t)lane < cnt;
-    const float wgt = usedl[ch] ? al[ch] * tb[ch] : 0.0f;
+    uint32_t cnt = (uint32_t)__popcll(__ballot(have)); // samples of this chunk that exist
+    if (term) cnt = (uint32_t)__builtin_ctzll(term) + 1u; // the terminating sample is the last one used
+    const float wgt = have && (uint32_t)lane < cnt ? c.al * tb : 0.0f;
 #pragma unroll
-    for (int c = 0; c < 3; c++) C[c] += wave_sum(wgt * rgb[ch][c]);
+    for (int q = 0; q < 3; q++) C[q] += wave_sum(wgt * c.rgb[q]);
+    if (lane == 0) {
+      t_start[wv][ch] = T;
+      c_used[wv][ch] = cnt;
+    }
     if (cnt > 0) T = __shfl(T_after, (int)cnt - 1);
     used += cnt;
-    if (n <= 64u) break;
+    last_ch = ch;
+    if (term) break;
   }
   float dC[3], loss = 0.0f, tail[3];
   const float inv = 1.0f / (3.0f * (float)n_active);
@@ -1256,26 +1339,37 @@ __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositePara
     P.ray_loss[j] = loss * inv;
     P.ray_used[j] = used;
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // lane 0's LDS notes -> every lane of the wave
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // seeds, last chunk first: suffix_i = sum_{j>i} w_j c_j + T_final bg
-  for (int ch = (n > 64u ? 1 : 0); ch >= 0; ch--) {
+  for (int ch = n_chunks - 1; ch >= 0; ch--) {
     const uint32_t k = (uint32_t)ch * 64u + (uint32_t)lane;
-    const float wgt = usedl[ch] ? al[ch] * tb[ch] : 0.0f;
-    const float T_after = tb[ch] * (1.0f - al[ch]);
+    const bool have = k < n;
+    const uint32_t sid = have ? list_pos(k) : 0u;
+    if (ch > last_ch) { // behind the ray's termination: never evaluated on the way out, no gradient
+      if (have) P.seeds[sid] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    Chunk c;
+    chunk_values(have, sid, c);
+    float excl = __shfl_up(c.incl, 1);
+    if (lane == 0) excl = 1.0f;
+    const float tb = t_start[wv][ch] * excl;
+    const bool usedl = have && (uint32_t)lane < c_used[wv][ch];
+    const float wgt = usedl ? c.al * tb : 0.0f;
+    const float T_after = tb * (1.0f - c.al);
     float d_sigma = 0.0f, d_orr[3];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float wc = wgt * rgb[ch][c];
+    for (int q = 0; q < 3; q++) {
+      const float wc = wgt * c.rgb[q];
       const float incl = scan_add_rev_incl(wc, lane);
-      const float suffix = (incl - wc) + tail[c];
-      d_sigma += dC[c] * dt * (T_after * rgb[ch][c] - suffix);
-      d_orr[c] = dC[c] * wgt * rgb[ch][c] * (1.0f - rgb[ch][c]);
-      tail[c] += __shfl(incl, 0);
+      const float suffix = (incl - wc) + tail[q];
+      d_sigma += dC[q] * dt * (T_after * c.rgb[q] - suffix);
+      d_orr[q] = dC[q] * wgt * c.rgb[q] * (1.0f - c.rgb[q]);
+      tail[q] += __shfl(incl, 0);
     }
-    if (k < n) {
-      // (a sample behind the ray's termination was never fetched: its list position is read here)
-      const uint32_t o = usedl[ch] ? sid[ch] : (P.slot_of ? P.slot_of[(size_t)j * (size_t)P.S + k] : off + k);
-      P.seeds[o] = usedl[ch] ? make_float4(d_sigma * sg[ch], d_orr[0], d_orr[1], d_orr[2]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    if (have) P.seeds[sid] = usedl ? make_float4(d_sigma * c.sg, d_orr[0], d_orr[1], d_orr[2]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -1284,6 +1378,7 @@ __global__ void train_begin_kernel(TrainState* state, uint32_t* sample_count, fl
   const double n = (double)(state->step + 1u);
   state->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)beta2, n)) / (1.0 - pow((double)beta1, n)));
   sample_count[state->step & 1u] = 0u;
+  sample_count[kOrderWord + (state->step & 1u)] = 0u;
 }
 
 // ------------------------------------------------------------------ optimiser
@@ -1324,6 +1419,7 @@ __device__ __forceinline__ void end_step(const AdamParams& P, uint32_t* sample_c
     uint32_t* mine = sample_count + ((done - 1u) & 1u);
     sample_count[7] = *mine; // dev: the finished step's listed-sample count stays readable (prv_train_api.inc: PRV_TRAIN_TIMING)
     *mine = 0u;
+    sample_count[kOrderWord + ((done - 1u) & 1u)] = 0u; // ... and its append ticket (deterministic batches)
   }
 }
 
@@ -1333,13 +1429,14 @@ __device__ __forceinline__ void end_step(const AdamParams& P, uint32_t* sample_c
 __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n, float* __restrict__ grad,
                                                          float* __restrict__ wmv, uint16_t* __restrict__ w16,
                                                          unsigned n_adam_blocks, const float* __restrict__ dw_partial, int dw_slots,
-                                                         float* __restrict__ dw_stage, unsigned n_dw_blocks, TrainRaysParams R) {
+                                                         float* __restrict__ dw_stage, unsigned n_dw_blocks, TrainRaysParams R,
+                                                         long long* __restrict__ grad_q) {
   // the blocks behind the table's own do the first stage of the MLP's weight-gradient reduction: both read what the backward
   // launch left and neither needs the other, so the reduction is no node of its own in the step's chain (round 5)
   // ... and the blocks behind THOSE list the next step's ray batch (TrainRaysParams::next): it needs the step's used-sample
   // count and the occupancy grid, neither of which this launch touches, and the step's chain is one kernel shorter
   if (blockIdx.x >= n_adam_blocks + n_dw_blocks) {
-    train_rays_block(R, blockIdx.x - n_adam_blocks - n_dw_blocks);
+    train_rays_block_any(R, blockIdx.x - n_adam_blocks - n_dw_blocks);
     return;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) P.state->lr_cur = P.state->lr_t; // for the step's last kernel (TrainState::lr_cur)
@@ -1353,9 +1450,21 @@ __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n,
   const float lr_t = P.state->lr_t;
   float4* rec = reinterpret_cast<float4*>(wmv + i4 * 3);
   if (i4 + 4 <= n) {
-    const float4 g4 = *reinterpret_cast<const float4*>(grad + i4);
+    float4 g4;
+    if (grad_q) { // deterministic (tests): the step's gradient was summed in fixed point (table_grad_add)
+      typedef long long ll2 __attribute__((ext_vector_type(2)));
+      ll2* q = reinterpret_cast<ll2*>(grad_q + i4);
+      const ll2 q0 = q[0], q1 = q[1];
+      if ((q0.x | q0.y | q1.x | q1.y) == 0ll) return;
+      q[0] = ll2{0ll, 0ll};
+      q[1] = ll2{0ll, 0ll};
+      constexpr double inv = 1.0 / (double)(1ull << kGradQBits);
+      g4 = make_float4((float)((double)q0.x * inv), (float)((double)q0.y * inv), (float)((double)q1.x * inv), (float)((double)q1.y * inv));
+    } else {
+      g4 = *reinterpret_cast<const float4*>(grad + i4);
+    }
     if (g4.x == 0.0f && g4.y == 0.0f && g4.z == 0.0f && g4.w == 0.0f) return; // sparse: untouched entries keep their moments
-    *reinterpret_cast<float4*>(grad + i4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!grad_q) *reinterpret_cast<float4*>(grad + i4) = make_float4(0.f, 0.f, 0.f, 0.f);
     // the touched scalars of a group are one table entry (F = 4) or two (F = 2): whole-group 16-byte loads and
     // stores of weight and moments instead of four scattered 4-byte ones each (untouched lanes are rewritten as read)
     const float g[4] = {g4.x, g4.y, g4.z, g4.w};
@@ -1376,9 +1485,15 @@ __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n,
   }
   float* r = wmv + i4 * 3;
   for (size_t i = i4; i < n; i++) { // the last, partial group
-    const float g = grad[i];
+    float g;
+    if (grad_q) {
+      g = (float)((double)grad_q[i] * (1.0 / (double)(1ull << kGradQBits)));
+      grad_q[i] = 0ll;
+    } else {
+      g = grad[i];
+    }
     if (g == 0.0f) continue;
-    grad[i] = 0.0f;
+    if (!grad_q) grad[i] = 0.0f;
     const int k = (int)(i - i4);
     float ww = r[k], mm = r[4 + k], vv = r[8 + k];
     adam_update(P, lr_t, g, ww, mm, vv);
@@ -1669,8 +1784,20 @@ hipError_t launch_train_loss_finish(const double* loss_part, int n_rays, TrainSt
   return hipGetLastError();
 }
 
+// the fixed-point table gradient of a deterministic trainer as f32 (prv_train_gradients' copy-out), cleared
+__global__ __launch_bounds__(256) void grad_q_to_f32_kernel(long long* __restrict__ q, size_t n, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = (float)((double)q[i] * (1.0 / (double)(1ull << kGradQBits)));
+  q[i] = 0ll;
+}
+hipError_t launch_grad_q_to_f32(long long* q, size_t n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(grad_q_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q, n, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s, const float* dw_partial,
-                             int dw_slots, float* dw_stage, const TrainRaysParams* next_rays) {
+                             int dw_slots, float* dw_stage, const TrainRaysParams* next_rays, long long* grad_q) {
   const unsigned n_adam = (unsigned)((n + 1023) / 1024), n_dw = dw_partial ? (unsigned)(kDwBlocksX * kDwGroups) : 0u;
   TrainRaysParams R{};
   unsigned n_rays_blocks = 0u;
@@ -1679,7 +1806,7 @@ hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* 
     n_rays_blocks = (unsigned)((R.n_rays + 3) / 4);
   }
   hipLaunchKernelGGL(adam_table_kernel, dim3(n_adam + n_dw + n_rays_blocks), dim3(256), 0, s, P, n, grad, wmv, w16, n_adam, dw_partial, dw_slots,
-                     dw_stage, n_dw, R);
+                     dw_stage, n_dw, R, grad_q);
   return hipGetLastError();
 }
 

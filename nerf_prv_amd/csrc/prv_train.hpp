@@ -5,7 +5,9 @@
 
 namespace prv {
 
-constexpr int kMaxTrainSamples = 128;
+constexpr int kMaxTrainSamples = 128;          // PRV_STEP_FIXED_S
+constexpr int kMaxTrainSteps = PRV_NGP_MAX_STEPS; // PRV_STEP_NGP
+constexpr uint32_t kNgpListCap = 1u << 24;       // samples a step may list under PRV_STEP_NGP (prv.h)
 
 struct LevelCanon { // canonical (ABI) table layout of one level
   float scale;
@@ -28,7 +30,7 @@ struct TrainState {
   float* losses;  // where the call's per-step losses go
   float lr_cur;   // lr_t again, copied by the table's Adam launch: what the step's LAST kernel (the MLP's Adam pass) reads while its
                   // end_step already writes the next step's lr_t
-  uint32_t pad;
+  uint32_t overflow; // sticky: a ray batch did not fit the sample list (PRV_STEP_NGP's 2^24 cap); every later kernel sees an empty batch
 };
 static_assert(sizeof(TrainState) == 32, "scal: TrainState sits at [32, 64)");
 
@@ -37,7 +39,7 @@ struct TrainRaysParams {
   const uint8_t* images; // n_img * H * W * 4 straight-alpha sRGB bytes
   const uint32_t* occ;
   int n_img, W, H, S, n_rays, occ_res, random_bg;
-  const TrainState* state; // step number = state->step
+  TrainState* state; // step number = state->step
   uint64_t seed;
   TrainRay* rays;
   uint2* samples; // (ray, sample index) of every live sample, grouped by ray (patch mode: by patch, depth step by depth step)
@@ -53,6 +55,12 @@ struct TrainRaysParams {
   int patch_w, patch_h;
   int patch_ray_jitter; // dev only (PRV_TRAIN_PATCH_JITTER=ray): every ray of a patch its own jitter (the oracle has no such mode)
   uint32_t* slot_of;
+  int step_mode;        // PRV_STEP_FIXED_S | PRV_STEP_NGP (then S = the most steps of a ray, <= 1024)
+  uint32_t sample_cap;  // capacity of `samples`; a batch that does not fit sets state->overflow
+  // deterministic = 1 (tests): the blocks append in block order -- block b waits for its ticket (scal word kOrderWord +
+  // (step & 1), zeroed with the sample counters; blocks are dispatched in index order), so the sample list, the tiles and
+  // every sum over them are the same run after run
+  int deterministic;
 };
 
 struct TrainTileParams {
@@ -93,7 +101,11 @@ struct TrainTileParams {
   const uint32_t* ray_used;
   int n_rays;
   double* loss_part;
+  // deterministic = 1 (tests): the table gradient is summed in 64-bit fixed point (table_grad_q, one word per scalar,
+  // value * 2^kGradQBits; integer adds commute) and converted by the table's Adam launch; NULL: f32 atomics into table_grad
+  long long* table_grad_q;
 };
+constexpr int kGradQBits = 40;
 constexpr size_t kActTileBytes = (16 * 64 + 32) * 16; // kept activations of a 32-sample tile: 16 slots x 64 lanes x 16 B, then 32 positions
 constexpr int kBwdFrags = 20; // R3: 2 row tiles | R2: 2 x 4 k-steps | R1: 4 k-steps | D2: 2 row tiles | D1: 4 k-steps
 // slots of mlp_grad_partial for a backward pass launched with n_blocks blocks (the stage of the reduction sits behind them)
@@ -148,7 +160,8 @@ hipError_t launch_train_begin(TrainState* state, uint32_t* sample_count, float l
 // next_rays != NULL (single-pixel batches only: the patch kernel has another block size): the NEXT step's ray batch as further
 // extra blocks of the same launch (TrainRaysParams::next = 1)
 hipError_t launch_adam_table(const AdamParams& P, size_t n, float* grad, float* wmv, uint16_t* w16, hipStream_t s, const float* dw_partial = nullptr,
-                             int dw_slots = 0, float* dw_stage = nullptr, const TrainRaysParams* next_rays = nullptr);
+                             int dw_slots = 0, float* dw_stage = nullptr, const TrainRaysParams* next_rays = nullptr, long long* grad_q = nullptr);
+hipError_t launch_grad_q_to_f32(long long* q, size_t n, float* out, hipStream_t s); // deterministic trainers: fixed-point gradient -> f32, cleared
 hipError_t launch_widen_table(const uint16_t* in, size_t n, float* wmv, hipStream_t s);
 hipError_t launch_narrow_table(const float* wmv, size_t n, float* out, hipStream_t s); // the records' w parts, contiguous
 // frags != NULL: the step's last kernel -- every thread also puts its fresh fp16 weight into its place of the forward and of the

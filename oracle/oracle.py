@@ -42,12 +42,12 @@ class TrainOpts(C.Structure):
                 ("beta2", C.c_float), ("eps", C.c_float), ("l2_reg", C.c_float), ("min_T", C.c_float),
                 ("seed", C.c_uint64), ("random_bg", C.c_int32), ("occ_every", C.c_int32), ("occ_decay", C.c_float),
                 ("occ_sigma_thresh", C.c_float), ("target_samples", C.c_int32), ("patch_w", C.c_int32),
-                ("patch_h", C.c_int32)]
+                ("patch_h", C.c_int32), ("step_mode", C.c_int32), ("deterministic", C.c_int32)]
 
 
 TRAIN_DEFAULTS = dict(n_rays=65536, n_samples=128, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, l2_reg=1e-6, min_T=1e-4,
                       seed=0x7EA10001, random_bg=1, occ_every=16, occ_decay=0.95,
-                      occ_sigma_thresh=0.01 * 1024 / 3 ** 0.5, target_samples=1 << 18, patch_w=0, patch_h=0)
+                      occ_sigma_thresh=0.01 * 1024 / 3 ** 0.5, target_samples=1 << 18, patch_w=0, patch_h=0, step_mode=0, deterministic=0)
 
 
 def train_opts(**kw):

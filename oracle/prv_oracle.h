@@ -197,6 +197,12 @@ typedef struct {
   int32_t patch_w, patch_h; /* > 1: the step's rays are drawn as patches of patch_w x patch_h adjacent pixels of one
                                image that share one jitter (ray j = pixel j % P of patch j / P, rows in snake order);
                                0 or 1: every ray its own pixel */
+  int32_t step_mode; /* ORC_STEP_FIXED_S: n_samples jittered uniform samples between the AABB hits.  ORC_STEP_NGP: the
+                        engine's own marcher, as upstream trains (run.py:188 `testbed.frame()`): fixed step
+                        dt = sqrt(3)/1024 from the AABB entry, per-ray random start -- sample i at t0 + (i + jitter) dt
+                        while that is inside the box, i < n_samples <= ORC_NGP_MAX_STEPS --, every step tested against
+                        the occupancy grid, alpha = 1 - exp(-sigma dt) with that dt */
+  int32_t deterministic; /* (the HIP trainer's test switch: order-independent sums; the oracle is sequential anyway) */
 } orc_train_opts;
 typedef struct orc_trainer orc_trainer;
 uint32_t orc_rng_u24(uint64_t seed, uint64_t stream, uint64_t i);

@@ -11,8 +11,10 @@
  * What IS checked: the backward pass against central finite differences of this file's own forward
  * pass in `exact` mode (no fp16 rounding), and the HIP trainer against this file.
  *
- * Deliberate simplifications against upstream, stated: fixed S uniform samples between the AABB hits
- * (the marcher of this build) with one random offset per ray instead of exponential stepping; the sample
+ * Two sampling rules (orc_train_opts.step_mode): ORC_STEP_FIXED_S -- S uniform samples between the AABB hits
+ * with one random offset per ray (rounds 1-5) -- and ORC_STEP_NGP -- the engine's own marcher for aabb_scale = 1,
+ * what upstream trains with (run.py:188): fixed step sqrt(3)/1024, per-ray random start, every step
+ * tested against the occupancy grid (round 6).  Deliberate simplifications against upstream, stated: the sample
  * budget of a step is kept by a simple integer rule on the ray count (upstream smooths its own estimate);
  * fp32 gradients and master weights (upstream:
  * fp16 gradients with loss scaling); the density grid is refreshed over ALL cells at their centres.
@@ -22,7 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define TR_MAX_S 128
+#define TR_MAX_S ORC_NGP_MAX_STEPS /* 128 under ORC_STEP_FIXED_S, 1024 steps under ORC_STEP_NGP */
 
 static uint64_t tr_mix64(uint64_t z) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -193,9 +195,11 @@ static double tr_ray(orc_trainer* t, uint32_t step, uint32_t j, int grad, tr_sam
   if (orc_ray_aabb(ro, rd, &t0, &t1)) {
     float sh[16];
     orc_sh4(rd, sh);
-    dt = (t1 - t0) / (float)o->n_samples;
+    const int ngp = o->step_mode == ORC_STEP_NGP;
+    dt = ngp ? sqrtf(3.0f) / 1024.0f : (t1 - t0) / (float)o->n_samples;
     for (int i = 0; i < o->n_samples; i++) {
       const float tt = fmaf((float)i + jitter, dt, t0);
+      if (ngp && !(tt < t1)) break; /* left the box (as march_ray, prv_oracle.c) */
       const float p[3] = {fmaf(tt, rd[0], ro[0]), fmaf(tt, rd[1], ro[1]), fmaf(tt, rd[2], ro[2])};
       if (!orc_occupied(t->f, p)) continue;
       tr_sample* s = &S[n++];
@@ -266,7 +270,8 @@ static void tr_refresh_fp16(orc_trainer* t) {
 
 orc_trainer* orc_train_create(const orc_field* init, const orc_train_opts* o, const orc_camera* cams, int n_img, int w,
                               int h, const uint8_t* rgba8, int exact) {
-  if (!init || !o || o->n_samples < 1 || o->n_samples > TR_MAX_S || o->n_rays < 1 || n_img < 1) return NULL;
+  if (!init || !o || o->n_samples < 1 || o->n_samples > (o->step_mode == ORC_STEP_NGP ? ORC_NGP_MAX_STEPS : 128) || o->n_rays < 1 || n_img < 1) return NULL;
+  if (o->step_mode != ORC_STEP_FIXED_S && o->step_mode != ORC_STEP_NGP) return NULL;
   if (o->patch_w > w || o->patch_h > h || o->patch_w < 0 || o->patch_h < 0) return NULL;
   orc_trainer* t = (orc_trainer*)calloc(1, sizeof(orc_trainer));
   if (!t) return NULL;

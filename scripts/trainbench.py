@@ -12,8 +12,14 @@ ap.add_argument("--samples", type=int, default=128)
 ap.add_argument("--chunk", type=int, default=100)
 ap.add_argument("--patch", default="", help="WxH: rays drawn as patches of adjacent pixels; default: the library's")
 ap.add_argument("--members", type=int, default=0, help="also time an ensemble of this many members stepping side by side")
+ap.add_argument("--rule", choices=["fixed", "ngp"], default="", help="how a training ray is sampled (prv_train_opts.step_mode); default: the library's")
+ap.add_argument("--det", action="store_true", help="prv_train_opts.deterministic")
 args = ap.parse_args()
 pk = dict(patch_w=int(args.patch.split("x")[0]), patch_h=int(args.patch.split("x")[1])) if args.patch else {}
+if args.rule:
+    pk["step_mode"] = 1 if args.rule == "ngp" else 0
+if args.det:
+    pk["deterministic"] = 1
 import torch
 from nerf_prv_amd import api, planner
 ctx = api.Context(0)
@@ -40,7 +46,7 @@ t, m, o = ctx.export_model(0, d)
 ctx.load_model(0, d, t, m, np.full_like(o, 0xFFFFFFFF))
 eopts = api.render_opts(W, H, 128, 1, 1e-4, background=(0, 0, 0, 1))
 p0, s0 = ctx.evaluate(0, cams, test_ids, eopts, gt_lin[test_ids].contiguous())
-tr = api.Trainer(ctx, 0, train_cams, u8[train_ids].contiguous(), api.train_opts(n_rays=args.rays, n_samples=args.samples, **pk))
+tr = api.Trainer(ctx, 0, train_cams, u8[train_ids].contiguous(), api.train_opts(n_rays=args.rays, n_samples=1024 if args.rule == "ngp" else args.samples, **pk))
 tr.steps(2)  # warm-up (allocations, LDS attribute)
 torch.cuda.synchronize()
 done, t0, used = 0, time.perf_counter(), 0
@@ -59,13 +65,13 @@ t0 = time.perf_counter()
 tr.steps(args.chunk)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(f"pure training: {args.chunk/dt:.1f} steps/s ({dt/args.chunk*1e3:.2f} ms/step, {args.rays} rays x {args.samples} samples)")
+print(f"pure training: {args.chunk/dt:.1f} steps/s ({dt/args.chunk*1e3:.2f} ms/step, {args.rays}-ray cap, rule {args.rule or 'default'}, last batch {tr.info()['samples_last']} samples / {tr.info()['active_rays']} rays = {tr.info()['samples_last']/dt*args.chunk/1e6:.1f} M trained samples/s)")
 
 if args.members > 1:
     trs = []
     for e in range(args.members):
         ctx.fresh_model(e, d, 0x1234 + e)
-        trs.append(api.Trainer(ctx, e, train_cams, u8[train_ids].contiguous(), api.train_opts(n_rays=args.rays, n_samples=args.samples, seed=0x7EA10001 + e, **pk)))
+        trs.append(api.Trainer(ctx, e, train_cams, u8[train_ids].contiguous(), api.train_opts(n_rays=args.rays, n_samples=1024 if args.rule == "ngp" else args.samples, seed=0x7EA10001 + e, **pk)))
     api.train_many(trs, 300)  # past the all-occupied start
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -15,6 +15,8 @@ ap.add_argument("--tail-single", type=int, default=0, help="after the run: this 
 ap.add_argument("--eval", action="store_true", help="after the run: PSNR / SSIM of every member on 8 held-out views of the 144-view set")
 ap.add_argument("--save-state", help="after the run: store every member's field under this directory")
 ap.add_argument("--load-state", help="start from the fields stored there and keep them (learning rate 0): ablation builds time the same batches")
+ap.add_argument("--rule", choices=["fixed", "ngp"], default="", help="how a training ray is sampled (prv_train_opts.step_mode); default: the library's")
+ap.add_argument("--det", action="store_true", help="prv_train_opts.deterministic")
 args = ap.parse_args()
 import torch
 from nerf_prv_amd import api, planner
@@ -31,6 +33,10 @@ d = api.L.FieldDesc(**dict(fd, table_amp=1e-4, density_bias=0.0))
 pk = {}
 if args.patch:
     pk = dict(patch_w=int(args.patch.split("x")[0]), patch_h=int(args.patch.split("x")[1]))
+if args.rule:
+    pk["step_mode"] = 1 if args.rule == "ngp" else 0
+if args.det:
+    pk["deterministic"] = 1
 trs = []
 for e in range(args.members):
     if args.load_state:

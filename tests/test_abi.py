@@ -38,7 +38,7 @@ def test_python_binding_lists_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == declared("prv.h")
     assert sorted(planner.HOST_SIGNATURES) == declared("prv_host.h")
     lib = _lib.load()  # loads on a CPU-only box: no compute entry point is called here
-    assert lib.prv_abi_version() == 4
+    assert lib.prv_abi_version() == 5
     planner.host()
 
 

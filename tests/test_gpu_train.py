@@ -48,8 +48,15 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
-def test_batch_loss_and_gradients(ctx, oracle, scene):
-    f, otr, gtr = start(ctx, oracle, scene)
+# the two sampling rules of a training ray (prv_train_opts.step_mode): 24 jittered uniform samples between the AABB hits, and the
+# engine's own marcher (dt = sqrt(3)/1024, per-ray random start, every step tested, up to 1024 steps: ~600 live per ray in the
+# all-occupied start field) -- what upstream trains with behind run.py:188
+RULES = {"fixed_s": dict(), "ngp": dict(step_mode=api.L.STEP_NGP, n_samples=1024, n_rays=40)}
+
+
+@pytest.mark.parametrize("rule", list(RULES))
+def test_batch_loss_and_gradients(ctx, oracle, scene, rule):
+    f, otr, gtr = start(ctx, oracle, scene, **RULES[rule])
     want_loss, want_tg, want_mg = otr.gradients()
     loss, tg, mg = gtr.gradients()
     assert gtr.info()["samples_last"] == otr.samples_last > 1000  # same rays, same live + used samples
@@ -66,8 +73,9 @@ def test_batch_loss_and_gradients(ctx, oracle, scene):
     assert loss2 == pytest.approx(loss, rel=1e-6) and rel_l2(tg2, tg) < 1e-5 and rel_l2(mg2, mg) < 1e-5
 
 
-def test_optimiser_steps_track_the_oracle(ctx, oracle, scene):
-    f, otr, gtr = start(ctx, oracle, scene, occ_every=4, n_samples=24, occ_sigma_thresh=0.3)
+@pytest.mark.parametrize("rule", list(RULES))
+def test_optimiser_steps_track_the_oracle(ctx, oracle, scene, rule):
+    f, otr, gtr = start(ctx, oracle, scene, **dict(dict(occ_every=4, n_samples=24, occ_sigma_thresh=0.3), **RULES[rule]))
     want = np.array([otr.step() for _ in range(6)])
     got = gtr.steps(6)
     np.testing.assert_allclose(got, want, rtol=2e-3)
@@ -419,3 +427,68 @@ def test_loss_slices_when_the_rays_outnumber_the_backward_grid(ctx, oracle, scen
     got = gtr.steps(3)  # end_step and the list-ahead ray pass read every slice
     np.testing.assert_allclose(got, want, rtol=2e-3)
     assert gtr.info()["active_rays"] == pytest.approx(otr.active_rays, rel=0.03) and gtr.info()["active_rays"] > 2048
+
+
+def test_engine_marcher_batches_with_the_sample_budget_and_a_carved_grid(ctx, oracle, scene):
+    """PRV_STEP_NGP with target_samples: the first step casts target / n_samples rays, the count then follows the budget
+    rule; the density grid is refreshed on the way (rays skip the carved cells); ragged step caps; same schedule, same
+    losses as the oracle"""
+    f, otr, gtr = start(ctx, oracle, scene, step_mode=api.L.STEP_NGP, n_samples=1024, n_rays=300, target_samples=8192, occ_every=2,
+                        occ_sigma_thresh=2.5)
+    assert otr.active_rays == gtr.info()["active_rays"] == 8
+    sched_o, sched_g, lo, lg = [], [], [], []
+    for _ in range(6):
+        lo.append(otr.step())
+        lg.append(gtr.steps(1)[0])
+        sched_o.append(otr.active_rays)
+        sched_g.append(gtr.info()["active_rays"])
+    np.testing.assert_allclose(lg, lo, rtol=5e-3)
+    np.testing.assert_allclose(sched_g, sched_o, rtol=0.05, atol=1)
+    assert sched_o[-1] > 8
+    # a cap below the ray's length: the ray stops after n_samples steps
+    f, otr, gtr = start(ctx, oracle, scene, step_mode=api.L.STEP_NGP, n_samples=70, n_rays=33)
+    want_loss, want_tg, want_mg = otr.gradients()
+    loss, tg, mg = gtr.gradients()
+    assert gtr.info()["samples_last"] == otr.samples_last > 33 * 40
+    assert loss == pytest.approx(want_loss, rel=1e-3) and rel_l2(mg, want_mg) < 1e-3 and rel_l2(tg, want_tg) < 1e-3
+    with pytest.raises(api.PrvError):  # patches are defined for the fixed rule only
+        start(ctx, oracle, scene, step_mode=api.L.STEP_NGP, n_samples=1024, patch_w=2, patch_h=2)
+    with pytest.raises(api.PrvError):
+        api.Trainer(ctx, 3, scene[2], ctx.torch.from_numpy(scene[3]), api.train_opts(step_mode=api.L.STEP_NGP, n_samples=1025))
+
+
+@pytest.mark.parametrize("rule", list(RULES))
+def test_deterministic_training_is_bit_reproducible(ctx, oracle, scene, rule):
+    """prv_train_opts.deterministic (tests): ray batches listed in ray order, the table gradient summed in 64-bit fixed
+    point -- two runs give the same masters bit for bit (the default path's f32 atomics do not), and the gradients are
+    still the oracle's"""
+    opts = dict(dict(occ_every=4, occ_sigma_thresh=0.3, n_rays=200), **RULES[rule])
+    runs = []
+    for _ in range(2):
+        f, otr, gtr = start(ctx, oracle, scene, deterministic=1, **opts)
+        loss, tg, mg = gtr.gradients()
+        losses = gtr.steps(12)
+        runs.append((loss, tg, mg, losses, gtr.master(), ctx.export_model(3, api.field_desc(**scene[0]))))
+        gtr.close()
+    a, b = runs
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert np.array_equal(a[4][0], b[4][0]) and np.array_equal(a[4][1], b[4][1])
+    assert all(np.array_equal(x, y) for x, y in zip(a[5], b[5]))  # fp16 table, MLP and the refreshed occupancy
+    want_loss, want_tg, want_mg = start(ctx, oracle, scene, **opts)[1].gradients()
+    assert a[0] == pytest.approx(want_loss, rel=1e-3) and rel_l2(a[1], want_tg) < 1e-3 and rel_l2(a[2], want_mg) < 1e-3
+    # side by side with the default path: the same training up to the atomics' noise
+    f, otr, gtr = start(ctx, oracle, scene, **opts)
+    np.testing.assert_allclose(gtr.steps(12)[:4], a[3][:4], rtol=1e-3)
+
+
+def test_a_batch_beyond_the_sample_list_fails_loudly(ctx, oracle, scene):
+    """PRV_STEP_NGP: a step may list at most 2^24 samples (64 x the default budget).  40,000 rays through an all-occupied
+    cube are ~24 M: the call fails with a message, nothing is written out of bounds, and the trainer keeps working for a
+    batch that fits"""
+    kw, ocams, cams, imgs = scene
+    f, otr, gtr = start(ctx, oracle, scene, n_rays=8)
+    gtr.close()
+    big = api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(step_mode=api.L.STEP_NGP, n_rays=40000, target_samples=0, occ_every=0))
+    with pytest.raises(api.PrvError, match="sample list"):
+        big.steps(2)
+    big.close()

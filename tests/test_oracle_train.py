@@ -31,11 +31,14 @@ def all_occupied(oracle, field):
     return oracle.OracleField(field.desc, params=(t, m, np.full_like(o, 0xFFFFFFFF)))
 
 
-@pytest.mark.parametrize("patch", [(0, 0), (4, 2)])
-def test_backward_matches_finite_differences(oracle, scene, patch):
+@pytest.mark.parametrize("patch,step_mode", [((0, 0), 0), ((4, 2), 0), ((0, 0), 1)])
+def test_backward_matches_finite_differences(oracle, scene, patch, step_mode):
+    """step_mode 1 = the engine's marcher (dt = sqrt(3)/1024, per-ray random start, here capped at 200 steps per ray)"""
     d, cams, imgs, _ = scene
     init = all_occupied(oracle, oracle.OracleField(d, seed=util.SEED_A))
     opts = oracle.train_opts(n_rays=96, n_samples=24, occ_every=0, patch_w=patch[0], patch_h=patch[1])
+    if step_mode == oracle.STEP_NGP:
+        opts = oracle.train_opts(n_rays=24, n_samples=200, occ_every=0, step_mode=oracle.STEP_NGP)
     tr = oracle.OracleTrainer(init, opts, cams, imgs, exact=True)
     loss, tg, mg = tr.gradients()
     assert loss > 1e-3 and tr.samples_last > 500
