@@ -59,12 +59,13 @@ N_SIMD, MAX_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs
 ISSUE_CYCLES = {"c2": 2.08, "c4": 4.07, "c8": 8.07, "mfma": 8.0}
 ISSUE_RATE_FILE = os.path.join("profiles", "r04_valu_issue_rate.txt")
 # What bounds the trainer: the f32 adds into the table gradient are served by the memory side
-# at one rate per 64-byte request whatever their shape (scripts/atomic_rate.hip), and the backward pass issues ~27 of them
-# per composited sample (TCC_EA0_ATOMIC of the backward tile kernel at the planner loop's batch: 796,687 per 29.4 K samples).
+# at one rate per 64-byte request whatever their shape (scripts/atomic_rate.hip), and the backward pass issues 26.4 of them
+# per composited sample under the fixed sampling rule, 9.8 under the engine's marcher (TCC_EA0_ATOMIC of the backward tile kernel).
 ATOMIC_REQ_PEAK_G = 20.5
 ATOMIC_RATE_FILE = os.path.join("profiles", "r04_atomic_request_rate.txt")
-ATOMIC_REQ_PER_SAMPLE = 27.1
-ATOMIC_REQ_FILE = os.path.join("profiles", "r04_train_loop_batch_ablations.txt")
+# round 6, re-measured at upstream's batch (262 K composited samples per step) under both sampling rules of a training ray:
+ATOMIC_REQ_PER_SAMPLE = {"ngp": 9.76, "fixed": 26.35}
+ATOMIC_REQ_FILE = os.path.join("profiles", "r06_train_rules.txt")
 ISSUE_PEAK_GCYC = N_SIMD * MAX_CLOCK_HZ / 1e9  # 2457.6 G SIMD issue-cycles/s at the 2.4 GHz maximum clock
 VALU_PEAK_GINST = ISSUE_PEAK_GCYC / ISSUE_CYCLES["c4"]  # wave-instructions/s if every instruction were c4 (kept for the detail object)
 ROUND_COST_FILE = os.path.join("profiles", "r05_round_cost.json")  # VALU instructions per wave-round, from the PMC pass
@@ -857,26 +858,38 @@ def run_rank(args):
         u8, _ = ctx.render_rgba8(5, tcams, None, api.render_opts(args.width, args.height, args.samples, 1, 1e-4,
                                                                 background=(0, 0, 0, 0)))
         tdesc = api.L.FieldDesc(**dict(fkw, table_amp=1e-4, density_bias=0.0))
-        ctx.fresh_model(4, tdesc, 0x1234)
-        tr = api.Trainer(ctx, 4, tcams, u8, api.train_opts())
-        tr.steps(300)  # past the all-occupied start
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        losses = tr.steps(args.train_steps)
-        torch.cuda.synchronize()
-        dt_tr = time.perf_counter() - t2
-        used = tr.info()["samples_last"]
-        training = {"steps_per_s": args.train_steps / dt_tr, "ms_per_step": dt_tr / args.train_steps * 1e3,
-                    "samples_per_s": used * args.train_steps / dt_tr,
-                    "rays_per_step_cap": int(tr.opts.n_rays), "active_rays_last_batch": tr.info()["active_rays"],
-                    "samples_per_ray": int(tr.opts.n_samples), "used_samples_last_batch": used, "loss_last": float(losses[-1]),
-                    "atomic_bound": {"bound": "memory-side atomic requests (table-gradient adds)", "peak_g_requests_per_s": ATOMIC_REQ_PEAK_G,
-                                     "peak_source": ATOMIC_RATE_FILE, "requests_per_sample_from_profile": ATOMIC_REQ_PER_SAMPLE,
-                                     "requests_source": ATOMIC_REQ_FILE + " (the planner loop's batch; not re-measured at this one)",
-                                     "frac": used * args.train_steps / dt_tr * ATOMIC_REQ_PER_SAMPLE / (ATOMIC_REQ_PEAK_G * 1e9)},
-                    "note": "fresh field, 300 warm-up steps untimed; batch adapts to ~2^18 composited samples per step (upstream's "
-                            "batch); f16-MFMA forward (activations kept), backward dX chain and dW on bf16-split MFMAs, sparse Adam; samples_per_s uses the last batch's count"}
-        tr.close()
+
+        def train_rate(rule):
+            """a fresh field, 300 warm-up steps untimed (past the all-occupied start), then args.train_steps timed"""
+            ctx.fresh_model(4, tdesc, 0x1234)
+            tr = api.Trainer(ctx, 4, tcams, u8, api.train_opts(step_mode=api.L.STEP_NGP if rule == "ngp" else api.L.STEP_FIXED_S))
+            tr.steps(300)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            losses = tr.steps(args.train_steps)
+            torch.cuda.synchronize()
+            dt_tr = time.perf_counter() - t2
+            used = tr.info()["samples_last"]
+            rate = used * args.train_steps / dt_tr
+            res = {"sampling_rule": "PRV_STEP_NGP: the engine's marcher, dt = sqrt(3)/1024, per-ray random start (upstream's; the default)" if rule == "ngp"
+                                    else "PRV_STEP_FIXED_S: 128 jittered uniform samples between the AABB hits (rounds 1-5)",
+                   "steps_per_s": args.train_steps / dt_tr, "ms_per_step": dt_tr / args.train_steps * 1e3, "samples_per_s": rate,
+                   "rays_per_step_cap": int(tr.opts.n_rays), "target_samples_per_step": int(tr.opts.target_samples),
+                   "active_rays_last_batch": tr.info()["active_rays"], "steps_per_ray_cap": int(tr.opts.n_samples),
+                   "used_samples_last_batch": used, "loss_last": float(losses[-1]),
+                   "atomic_bound": {"bound": "memory-side atomic requests (table-gradient adds)", "peak_g_requests_per_s": ATOMIC_REQ_PEAK_G,
+                                    "peak_source": ATOMIC_RATE_FILE, "requests_per_sample_from_profile": ATOMIC_REQ_PER_SAMPLE[rule],
+                                    "requests_source": ATOMIC_REQ_FILE + " (section 1: TCC_EA0_ATOMIC of the backward launch at this batch, this rule)",
+                                    "frac": rate * ATOMIC_REQ_PER_SAMPLE[rule] / (ATOMIC_REQ_PEAK_G * 1e9)}}
+            tr.close()
+            return res
+
+        training = train_rate("ngp" if api.train_opts().step_mode == api.L.STEP_NGP else "fixed")
+        training["note"] = ("fresh field; batch adapts to ~2^18 composited samples per step (upstream's batch); f16-MFMA forward (activations kept), backward dX chain "
+                            "and dW on bf16-split MFMAs, merging table scatter, sparse Adam; samples_per_s uses the last batch's count.  Under the engine's "
+                            "marcher the backward launch is bound by its own tile work (0.285 ms of a 0.51 ms step; 2.6 M requests = 0.125 ms at the "
+                            "memory side's rate), under the fixed rule by the request rate (profiles/r06_train_rules.txt, section 4)")
+        training["fixed_rule"] = train_rate("fixed")
         tcams.close()
 
     if rank == 0:
@@ -933,6 +946,7 @@ def run_rank(args):
             lifted["ngp_step_samples_per_s"] = extras["ngp_step"]["value"]
         if training:
             lifted["training_steps_per_s"] = training["steps_per_s"]
+            lifted["training_samples_per_s"] = training["samples_per_s"]
         if config3 and "views_per_s" in config3:
             lifted["config3_views_per_s"] = config3["views_per_s"]
             lifted["config3_ms_per_step"] = config3["ms_per_step"]

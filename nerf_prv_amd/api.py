@@ -476,7 +476,9 @@ def rank_host(records, view_ids):
 
 
 def train_opts(**kw):
-    """prv_train_default_opts with overrides"""
+    """prv_train_default_opts with overrides.  n_samples is a parameter of the sampling rule (include/prv.h): given without
+    step_mode it selects PRV_STEP_FIXED_S (n_samples uniform samples per ray); step_mode given without it gets that rule's
+    default (128 samples / 1024 steps)."""
     o = L.TrainOpts()
     rc = L.load().prv_train_default_opts(C.byref(o))
     if rc != 0:
@@ -485,8 +487,10 @@ def train_opts(**kw):
         if not hasattr(o, k):
             raise TypeError(f"unknown training option {k}")
         setattr(o, k, v)
-    if "step_mode" in kw and "n_samples" not in kw:  # n_samples means another thing under each rule (include/prv.h)
+    if "step_mode" in kw and "n_samples" not in kw:
         o.n_samples = L.NGP_MAX_STEPS if kw["step_mode"] == L.STEP_NGP else 128
+    if "n_samples" in kw and "step_mode" not in kw:
+        o.step_mode = L.STEP_FIXED_S
     return o
 
 

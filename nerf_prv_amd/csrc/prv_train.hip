@@ -88,17 +88,26 @@ __device__ __forceinline__ uint32_t next_active_rays(int target_samples, uint32_
   a = min(a, (unsigned long long)n_rays);
   return (uint32_t)a;
 }
-// which step a ray launch prepares, with how many rays, into which counter (TrainRaysParams::next)
-__device__ __forceinline__ void rays_step(const TrainRaysParams& P, uint32_t& step, uint32_t& n_active, uint32_t*& counter) {
+// which step a ray launch prepares, with how many rays, into which counter (TrainRaysParams::next).  false: block bx lies
+// beyond that step's rays whatever the budget rule says (it at most doubles the count) -- decided without touching the
+// used-sample slices: the launch has n_rays / 4 blocks whatever the step needs, and at upstream's batch under the engine's
+// marcher a step casts ~7 K rays of the 2^16 the grid is sized for (the slices' serial walk by every one of the 16 K blocks
+// was the tail of the table's Adam launch).  The slices: one per lane, summed across the wave (integers: any order).
+__device__ __forceinline__ bool rays_step(const TrainRaysParams& P, uint32_t bx, uint32_t& step, uint32_t& n_active, uint32_t*& counter) {
   step = P.state->step;
   n_active = P.state->n_active;
   if (P.next) {
+    if (P.target_samples > 0 && (unsigned long long)bx * 4ull >= 2ull * (unsigned long long)n_active) return false;
+    const int n_slices = (P.n_rays + 1023) / 1024, lane = (int)(threadIdx.x & 63u);
     unsigned long long used = 0ull;
-    for (int s = 0; s < (P.n_rays + 1023) / 1024; s++) used += (unsigned long long)__double_as_longlong(P.loss_part[2 * s + 1]);
+    for (int s = lane; s < n_slices; s += 64) used += (unsigned long long)__double_as_longlong(P.loss_part[2 * s + 1]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) used += __shfl_xor(used, d);
     n_active = next_active_rays(P.target_samples, n_active, used, P.n_rays);
     step += 1u;
   }
   counter = P.sample_count + (step & 1u);
+  return (unsigned long long)bx * 4ull < (unsigned long long)n_active;
 }
 
 constexpr float kTrainNgpDt = 1.7320508075688772f / 1024.0f; // = sqrtf(3.0f) / 1024.0f, the oracle's value bit for bit (as prv_kernels.hip)
@@ -140,8 +149,7 @@ __device__ __forceinline__ void train_rays_block(const TrainRaysParams& P, uint3
   const uint32_t j = bx * 4u + (threadIdx.x >> 6);
   uint32_t step, n_active_step;
   uint32_t* counter;
-  rays_step(P, step, n_active_step, counter);
-  if (bx * 4u >= n_active_step) return; // whole block beyond this step's ray budget (block-uniform)
+  if (!rays_step(P, bx, step, n_active_step, counter)) return; // whole block beyond this step's ray budget (block-uniform)
   const bool in_budget = j < n_active_step;
   const uint64_t st = (uint64_t)step * 8u;
   const uint32_t img = (uint32_t)(((uint64_t)rng_u24(P.seed, st + 0, j) * (uint64_t)P.n_img) >> 24);
@@ -1435,17 +1443,23 @@ __global__ __launch_bounds__(256) void adam_table_kernel(AdamParams P, size_t n,
   // launch left and neither needs the other, so the reduction is no node of its own in the step's chain (round 5)
   // ... and the blocks behind THOSE list the next step's ray batch (TrainRaysParams::next): it needs the step's used-sample
   // count and the occupancy grid, neither of which this launch touches, and the step's chain is one kernel shorter
-  if (blockIdx.x >= n_adam_blocks + n_dw_blocks) {
-    train_rays_block_any(R, blockIdx.x - n_adam_blocks - n_dw_blocks);
+  // Dispatch order (workgroups start in index order): the ray blocks first, then the reduction's, then the table's own -- the
+  // first two are few and latency-bound (a chain of dependent loads each; most ray blocks only find that they lie beyond the
+  // step's budget) and were this launch's tail when they came last; in front, the table's ~9 K bandwidth-bound blocks fill in
+  // behind them.
+  const unsigned n_ray_blocks = gridDim.x - n_adam_blocks - n_dw_blocks;
+  if (blockIdx.x < n_ray_blocks) {
+    train_rays_block_any(R, blockIdx.x);
     return;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) P.state->lr_cur = P.state->lr_t; // for the step's last kernel (TrainState::lr_cur)
-  if (blockIdx.x >= n_adam_blocks) {
-    const int k = (int)(blockIdx.x - n_adam_blocks);
+  if (blockIdx.x < n_ray_blocks + n_dw_blocks) {
+    const int k = (int)(blockIdx.x - n_ray_blocks);
     reduce_dw_block(dw_partial, dw_slots, dw_stage, k % kDwBlocksX, k / kDwBlocksX);
     return;
   }
-  const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const unsigned bx = blockIdx.x - n_ray_blocks - n_dw_blocks;
+  if (bx == 0 && threadIdx.x == 0) P.state->lr_cur = P.state->lr_t; // for the step's last kernel (TrainState::lr_cur)
+  const size_t i4 = ((size_t)bx * 256 + threadIdx.x) * 4;
   if (i4 >= n) return;
   const float lr_t = P.state->lr_t;
   float4* rec = reinterpret_cast<float4*>(wmv + i4 * 3);

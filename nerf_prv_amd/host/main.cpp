@@ -52,6 +52,19 @@ struct HipScorer {
   int train_steps = 0, train_rays = 0 /* 0: the library default */, train_w = 0, train_h = 0;
   bool dump_records = false; // view_planning sets it (yaml dump_scores: 1, or PRV_PLANNER_DUMP_RECORDS in the environment)
   int train_patch_w = 0, train_patch_h = 0; // yaml train_patch_w / train_patch_h: prv_train_opts.patch_w / patch_h (0: the library default, single pixels)
+  int train_step_mode = -1; // yaml train_step_mode: prv_train_opts.step_mode (-1: the library default = the engine's marcher; 0: 128 uniform samples per ray, rounds 1-5)
+  void apply_train_opts(prv_train_opts& to) const {
+    if (train_step_mode == PRV_STEP_FIXED_S) {
+      to.step_mode = PRV_STEP_FIXED_S;
+      to.n_samples = 128;
+    } else if (train_step_mode == PRV_STEP_NGP) {
+      to.step_mode = PRV_STEP_NGP;
+      to.n_samples = PRV_NGP_MAX_STEPS;
+    }
+    if (train_rays > 0) to.n_rays = train_rays;
+    if (train_patch_w > 0) to.patch_w = train_patch_w;
+    if (train_patch_h > 0) to.patch_h = train_patch_h;
+  }
   prv_field_desc train_desc{};
   uint64_t train_seed = 0x1234;
   bool images_from_files = false; // train_images: files -> the json's file_path PNGs (the reference's data flow)
@@ -144,9 +157,7 @@ struct HipScorer {
       t_fresh += now_seconds() - t0;
       prv_train_opts to;
       prv_train_default_opts(&to);
-      if (train_rays > 0) to.n_rays = train_rays;
-      if (train_patch_w > 0) to.patch_w = train_patch_w;
-      if (train_patch_h > 0) to.patch_h = train_patch_h;
+      apply_train_opts(to);
       to.seed += (uint64_t)e;
       prv_trainer* tr = nullptr;
       t0 = now_seconds();
@@ -325,9 +336,7 @@ struct HipScorer {
       rc = prv_model_fresh(ctx, (int)k, &train_desc, train_seed); // every curve point starts from the same initial field, as `evaluate` does
       prv_train_opts to;
       prv_train_default_opts(&to);
-      if (train_rays > 0) to.n_rays = train_rays;
-      if (train_patch_w > 0) to.patch_w = train_patch_w;
-      if (train_patch_h > 0) to.patch_h = train_patch_h;
+      apply_train_opts(to);
       if (rc == PRV_OK) rc = prv_train_create(ctx, (int)k, jobs[k].cams, jobs[k].imgs, data_w, data_h, &to, &jobs[k].tr);
     }
     std::vector<prv_trainer*> trs;
@@ -650,6 +659,7 @@ int configure_training(prv_ctx* ctx, const FileStorage& fs, const prv_field_desc
   if (fs.has("train_rays")) scorer.train_rays = (int)fs.num("train_rays"); // else prv_train_default_opts' batch
   if (fs.has("train_patch_w")) scorer.train_patch_w = (int)fs.num("train_patch_w"); // training rays as patches of adjacent pixels (a speed / quality trade)
   if (fs.has("train_patch_h")) scorer.train_patch_h = (int)fs.num("train_patch_h");
+  if (fs.has("train_step_mode")) scorer.train_step_mode = (int)fs.num("train_step_mode"); // how a training ray is sampled (include/prv.h: prv_train_opts.step_mode)
   scorer.train_w = fs.has("train_width") ? (int)fs.num("train_width") : 0;
   scorer.train_h = fs.has("train_height") ? (int)fs.num("train_height") : 0;
   scorer.train_desc = desc;

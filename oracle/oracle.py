@@ -45,13 +45,20 @@ class TrainOpts(C.Structure):
                 ("patch_h", C.c_int32), ("step_mode", C.c_int32), ("deterministic", C.c_int32)]
 
 
-TRAIN_DEFAULTS = dict(n_rays=65536, n_samples=128, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, l2_reg=1e-6, min_T=1e-4,
+TRAIN_DEFAULTS = dict(n_rays=65536, n_samples=1024, lr=1e-2, beta1=0.9, beta2=0.99, eps=1e-15, l2_reg=1e-6, min_T=1e-4,
                       seed=0x7EA10001, random_bg=1, occ_every=16, occ_decay=0.95,
-                      occ_sigma_thresh=0.01 * 1024 / 3 ** 0.5, target_samples=1 << 18, patch_w=0, patch_h=0, step_mode=0, deterministic=0)
+                      occ_sigma_thresh=0.01 * 1024 / 3 ** 0.5, target_samples=1 << 18, patch_w=0, patch_h=0, step_mode=1, deterministic=0)
 
 
 def train_opts(**kw):
-    return TrainOpts(**dict(TRAIN_DEFAULTS, **kw))
+    """the library's defaults (prv_train_default_opts) with overrides, under nerf_prv_amd.api.train_opts' rule: n_samples without
+    step_mode selects STEP_FIXED_S, step_mode without n_samples gets that rule's default"""
+    o = dict(TRAIN_DEFAULTS, **kw)
+    if "step_mode" in kw and "n_samples" not in kw:
+        o["n_samples"] = NGP_MAX_STEPS if kw["step_mode"] == STEP_NGP else 128
+    if "n_samples" in kw and "step_mode" not in kw:
+        o["step_mode"] = STEP_FIXED_S
+    return TrainOpts(**o)
 
 
 def build():

@@ -14,6 +14,7 @@ ap.add_argument("--patch", default="", help="WxH: rays drawn as patches of adjac
 ap.add_argument("--members", type=int, default=0, help="also time an ensemble of this many members stepping side by side")
 ap.add_argument("--rule", choices=["fixed", "ngp"], default="", help="how a training ray is sampled (prv_train_opts.step_mode); default: the library's")
 ap.add_argument("--det", action="store_true", help="prv_train_opts.deterministic")
+ap.add_argument("--eval-rule", choices=["fixed", "ngp"], default="fixed", help="the stepping rule the held-out views are rendered with (ngp: the engine's, what the planner renders candidates with)")
 args = ap.parse_args()
 pk = dict(patch_w=int(args.patch.split("x")[0]), patch_h=int(args.patch.split("x")[1])) if args.patch else {}
 if args.rule:
@@ -44,7 +45,7 @@ d = api.L.FieldDesc(**init)
 ctx.synthetic_model(0, d, 0x1234)
 t, m, o = ctx.export_model(0, d)
 ctx.load_model(0, d, t, m, np.full_like(o, 0xFFFFFFFF))
-eopts = api.render_opts(W, H, 128, 1, 1e-4, background=(0, 0, 0, 1))
+eopts = api.engine_render_opts(W, H, 0, 1, 1e-4, background=(0, 0, 0, 1)) if args.eval_rule == "ngp" else api.render_opts(W, H, 128, 1, 1e-4, background=(0, 0, 0, 1))
 p0, s0 = ctx.evaluate(0, cams, test_ids, eopts, gt_lin[test_ids].contiguous())
 tr = api.Trainer(ctx, 0, train_cams, u8[train_ids].contiguous(), api.train_opts(n_rays=args.rays, n_samples=1024 if args.rule == "ngp" else args.samples, **pk))
 tr.steps(2)  # warm-up (allocations, LDS attribute)

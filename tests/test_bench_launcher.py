@@ -99,7 +99,7 @@ def test_roofline_peak_constants_are_the_committed_microbenchmarks():
 def test_trainer_atomic_bound_constants_are_the_committed_measurements():
     """the trainer's `atomic_bound` in the bench line: the request rate is scripts/atomic_rate.hip's (every shape and
     occupancy of profiles/r04_atomic_request_rate.txt within 8 % of it), the requests per sample the backward tile kernel's
-    TCC_EA0_ATOMIC over the composited samples of the frozen-field run the file records"""
+    TCC_EA0_ATOMIC over the composited samples of the runs profiles/r06_train_rules.txt records (one per sampling rule)"""
     import importlib.util
     import re
 
@@ -109,9 +109,10 @@ def test_trainer_atomic_bound_constants_are_the_committed_measurements():
     rates = [float(l.split()[-2]) for l in open(os.path.join(ROOT, bench.ATOMIC_RATE_FILE)) if re.match(r"^\d+ x \d+ B( \(16 lanes active\))?\s+\d+\s+[0-9.]+\s", l)]
     assert len(rates) >= 20 and all(abs(r - bench.ATOMIC_REQ_PEAK_G) <= 0.08 * bench.ATOMIC_REQ_PEAK_G for r in rates), rates
     text = open(os.path.join(ROOT, bench.ATOMIC_REQ_FILE)).read()
-    m = re.search(r"frozen fields: backward launches \d+, atomic requests per launch (\d+) .*\(mean (\d+)\)", text)
-    per_sample = float(m.group(1)) / float(m.group(2))
-    assert abs(per_sample - bench.ATOMIC_REQ_PER_SAMPLE) <= 0.05 * bench.ATOMIC_REQ_PER_SAMPLE, per_sample
+    for rule, want in bench.ATOMIC_REQ_PER_SAMPLE.items():  # round 6: re-measured at upstream's batch under both sampling rules
+        m = re.search(rf"^rule {rule}: .*TCC_EA0_ATOMIC per launch (\d+), composited samples per step (\d+), requests per composited sample ([0-9.]+)", text, re.M)
+        per_sample = float(m.group(1)) / float(m.group(2))
+        assert abs(per_sample - want) <= 0.01 * want and abs(float(m.group(3)) - want) <= 0.01 * want, (rule, per_sample)
 
 
 def test_roofline_record_is_flat_and_leads_with_the_contract_keys():

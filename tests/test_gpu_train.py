@@ -482,13 +482,13 @@ def test_deterministic_training_is_bit_reproducible(ctx, oracle, scene, rule):
 
 
 def test_a_batch_beyond_the_sample_list_fails_loudly(ctx, oracle, scene):
-    """PRV_STEP_NGP: a step may list at most 2^24 samples (64 x the default budget).  40,000 rays through an all-occupied
-    cube are ~24 M: the call fails with a message, nothing is written out of bounds, and the trainer keeps working for a
+    """PRV_STEP_NGP: a step may list at most 2^24 samples (64 x the default budget).  200,000 rays of these cameras through an
+    all-occupied cube are well beyond it: the call fails with a message, nothing is written out of bounds, and the trainer keeps working for a
     batch that fits"""
     kw, ocams, cams, imgs = scene
     f, otr, gtr = start(ctx, oracle, scene, n_rays=8)
     gtr.close()
-    big = api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(step_mode=api.L.STEP_NGP, n_rays=40000, target_samples=0, occ_every=0))
+    big = api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(step_mode=api.L.STEP_NGP, n_rays=200000, target_samples=0, occ_every=0))
     with pytest.raises(api.PrvError, match="sample list"):
         big.steps(2)
     big.close()
