@@ -402,7 +402,15 @@ int prv_train_info(const prv_trainer* t, uint32_t* steps_done, uint64_t* samples
                    uint64_t* table_scalars);
 /* rays the next step will cast (= n_rays unless target_samples is set) */
 int prv_train_active_rays(const prv_trainer* t);
-/* The trainer's stream (it owns a hardware queue) and device buffers stay with the CONTEXT for its next trainer of the same
+/* STREAMS: a trainer runs on a stream of its own that owns a hardware queue (hipExtStreamCreateWithCUMask naming every CU; the
+ * pooled streams of hipStreamCreate share four queues, and five members stepping side by side sat on three of them).  That API
+ * takes no flags, so the stream is a BLOCKING one: work an embedder puts on the LEGACY default stream (stream 0; PyTorch's
+ * default stream is that one) serialises with every trainer's stream, which undoes the side-by-side overlap of
+ * prv_train_steps_multi while such work is in flight.  Hosts that use the legacy default stream should move that work to a
+ * stream created with hipStreamNonBlocking (or build with per-thread default streams); PRV_TRAIN_OWN_QUEUE=0 in the
+ * environment gives the trainers pooled non-blocking streams instead (slower side by side: round of five 0.524 -> 0.503 ms
+ * with own queues, profiles/NOTES.md round 5).
+ * The trainer's stream (it owns a hardware queue) and device buffers stay with the CONTEXT for its next trainer of the same
  * sizes (at most 16 GiB / 512 buffers, oldest released first); prv_destroy releases them. */
 void prv_train_destroy(prv_trainer* t);
 /* parity hooks: gradients of the NEXT batch without an update (host arrays: table_scalars and

@@ -139,6 +139,7 @@ int caught(prv_ctx* c) noexcept {
     if (e__ != hipSuccess) return fail((c), PRV_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
   } while (0)
 
+void release(Buffer& b);
 int ensure(prv_ctx* c, Buffer& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return PRV_OK;
   if (b.p) {
@@ -147,7 +148,18 @@ int ensure(prv_ctx* c, Buffer& b, size_t bytes) {
     b.p = nullptr;
     b.bytes = 0;
   }
-  HIPCHK(c, hipMalloc(&b.p, bytes));
+  hipError_t e = hipMalloc(&b.p, bytes);
+  if (e == hipErrorOutOfMemory && !c->idle_buffers.empty()) {
+    // the context's own parked memory (destroyed trainers' buffers, up to 16 GiB: prv_train_api.inc) goes before anybody fails
+    (void)hipGetLastError();
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (Buffer& idle : c->idle_buffers) release(idle);
+    c->idle_buffers.clear();
+    c->idle_bytes = 0;
+    e = hipMalloc(&b.p, bytes);
+  }
+  if (e != hipSuccess) b.p = nullptr;
+  HIPCHK(c, e);
   b.bytes = bytes;
   return PRV_OK;
 }
@@ -894,7 +906,8 @@ int render_ensemble_ngp(prv_ctx* c, const int* slots, int E, const prv_camset* c
                         (x_stride * (size_t)E > c->queue_ext.bytes ? x_stride * (size_t)E - c->queue_ext.bytes : 0) +
                         (s_stride * (size_t)E > c->stage.bytes ? s_stride * (size_t)E - c->stage.bytes : 0);
     size_t free_b = 0, total_b = 0;
-    if (grow && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || grow + ((size_t)2 << 30) > free_b)) return PRV_OK;
+    // (the context's parked trainer buffers count as free: ensure() releases them before an allocation fails)
+    if (grow && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || grow + ((size_t)2 << 30) > free_b + c->idle_bytes)) return PRV_OK;
   }
   if ((rc = ensure(c, c->queue, q_stride * (size_t)E)) != PRV_OK) return rc;
   if ((rc = ensure(c, c->queue_ext, x_stride * (size_t)E)) != PRV_OK) return rc;
