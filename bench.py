@@ -61,7 +61,7 @@ ISSUE_RATE_FILE = os.path.join("profiles", "r04_valu_issue_rate.txt")
 # What bounds the trainer: the f32 adds into the table gradient are served by the memory side
 # at one rate per 64-byte request whatever their shape (scripts/atomic_rate.hip), and the backward pass issues 26.4 of them
 # per composited sample under the fixed sampling rule, 9.8 under the engine's marcher (TCC_EA0_ATOMIC of the backward tile kernel).
-GATHER_CALIB_GBS = 3800.0  # random 64-byte gathers over a 64 MiB footprint (scripts/gather_calib.hip -> profiles/r01_gather_calib.txt)
+GATHER_CALIB_GBS = 3800.0  # random 64-byte gathers over a 64 MiB footprint (scripts/gather_calib.hip -> profiles/archive/r01_gather_calib.txt)
 ATOMIC_REQ_PEAK_G = 20.5
 ATOMIC_RATE_FILE = os.path.join("profiles", "r04_atomic_request_rate.txt")
 # round 6, re-measured at upstream's batch (262 K composited samples per step) under both sampling rules of a training ray:
@@ -427,7 +427,7 @@ def kernel_figures(m, variant, hbm_bound, scene, layout):
                 "unit": "GB/s of random 64-B requests (peak = the gather calibration at this footprint; algorithmic bytes, so frac can pass 1: see fabric_side_frac)"}
         note = ("64 MiB table: lives in the 256 MiB Infinity Cache, so neither this line nor any other in the record is HBM-bandwidth-bound "
                 "(FETCH_SIZE includes Infinity-Cache hits); fabric-side reads ~= algorithmic bytes, random 64-B requests, against the "
-                "3.8 TB/s the gather calibration (profiles/r01_gather_calib.txt) reaches for this access shape; hbm_algorithmic_frac = the "
+                "3.8 TB/s the gather calibration (profiles/archive/r01_gather_calib.txt) reaches for this access shape; hbm_algorithmic_frac = the "
                 "same bytes over the 8 TB/s HBM peak, kept for comparison with earlier rounds' `frac`.  A table that really leaves the caches "
                 "needs > 256 MiB; the hashed gather's byte offsets ride 24-bit arithmetic (csrc/prv_api.cpp: a hashed level <= 16 MiB, "
                 "<= 128 MiB in all), so no such workload exists in this build")

@@ -590,7 +590,7 @@ void render_policy(prv_ctx* c, const Model& m, size_t npix, bool ngp, RenderPara
   // resident -- large images of the 256^3 field: launch -8 % -- and costs elsewhere: the 512^3 field is bound by random
   // HBM requests (+2...5 %), and at the reference's 80x45 candidates neighbouring rays are five finest cells apart
   // (+3...7 %).  Results are identical either way; the default follows table and image size (PRV_MERGE_MAX / PRV_POOL
-  // override).  Measured: profiles/r02_k_tail_merge.txt, profiles/r02_r_tail_pool.txt
+  // override).  Measured: profiles/archive/r02_k_tail_merge.txt, profiles/archive/r02_r_tail_pool.txt
   const bool coherent = m.table_halfs * 2 <= ((size_t)32 << 20) && npix >= ((size_t)1 << 17);
   // The per-lane corner cache: under the engine's stepping rule a ray's consecutive samples share their cell on the hashed
   // levels about half of the time, and where the cohort's gathers are incoherent (small images: every corner of every lane
@@ -682,7 +682,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   if (spp > 1 && (rc = ensure(c, c->stage, batch * npix * (size_t)spp * 16)) != PRV_OK) return rc;
 
   // Persistent render blocks per CU.  More resident waves hide more gather latency but also put more random requests in
-  // flight and draw more power: measured per workload (64-slot kernel, profiles/r02_bm_blocks_per_cu.txt) -- the
+  // flight and draw more power: measured per workload (64-slot kernel, profiles/archive/r02_bm_blocks_per_cu.txt) -- the
   // cache-resident table at large images is flat from 3 up (3 waves per SIMD is what its registers allow), small images
   // (incoherent gathers: the reference's 80x45 candidates, 320x320) are 6 % faster with 2, and the HBM-bound 512^3 table
   // is 10 % faster with ONE wave per SIMD: fewer requests in flight, a better L2 hit rate.

@@ -45,5 +45,5 @@ if "FETCH_SIZE" in rq and "WRITE_SIZE" in rq:
         "samples_evaluated_per_launch": ev,
         "source": f"rocprofv3 --kernel-trace --pmc, separate passes (scripts/pmc.sh sets 4,5,6), scripts/kbench.py one launch; {tag}. "
                   "FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE not doubled: per-lane gathers, one 64-B request per missing load "
-                  "(profiles/r01_gather_calib.txt)"})
+                  "(profiles/archive/r01_gather_calib.txt)"})
 print(json.dumps({k: v for k, v in rq.items()}, indent=1))

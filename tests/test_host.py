@@ -345,7 +345,7 @@ def test_large_view_sets_reach_the_reference_tour_length(n):
     """REFERENCE-PINNED: beyond 20 views the planner is an iterated local search, not a proof -- yet on the
     reference's own view sets it ends at the stored Gurobi tour's length, or below it (the stored tours of
     N = 24, 26, 37, 59, 73 are not optimal).  All 80 sets of 21..100 views: scripts/tourcheck.py,
-    profiles/r01_m_reference_tours.txt; here a sample incl. the sets that were hardest to reach."""
+    profiles/archive/r01_m_reference_tours.txt; here a sample incl. the sets that were hardest to reach."""
     pts, ref, top, seg = _reference_tour(n)
     order, length, exact = planner.global_path(pts, top)
     assert not exact and sorted(order) == list(range(n)) and order[0] == top

@@ -40,7 +40,7 @@ FOV_X = 2.0 * math.atan(0.5 * 1280 / 915.60668945312500)  # DefaultConfiguration
 # that are (nearly) black, so the denominator is floored: |got - want| <= PIX_RTOL * max(|want|, PIX_FLOOR).
 # PIX_FLOOR = 1/255, the value of ONE output byte (run.py:309 writes 8-bit PNGs): below it the bar is an absolute
 # 3.9e-6, 1/255 of the 1e-3-absolute bar round 1 used everywhere.  Measured on the GPU (scripts/relerr_diag.py,
-# gpurun_out/r02a/relerr.txt -> profiles/r02_a_pixel_relative_error.txt): worst relative error 1.2e-4 on the default
+# gpurun_out/r02a/relerr.txt -> profiles/archive/r02_a_pixel_relative_error.txt): worst relative error 1.2e-4 on the default
 # scene, 1.0e-4 on the 512^3 field, 1.4e-5 on the BASELINE.md section 6 scene, floor or no floor.
 PIX_RTOL = 1e-3
 PIX_FLOOR = 1.0 / 255.0
