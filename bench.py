@@ -1050,6 +1050,24 @@ def reference_round(env, fkw, layout_of, variant_of):
     slots = list(range(2, 2 + members))
     out = {"workload": "540 views x 80x45 x 16 spp x 5 members, EnsembleRGBDensity (main.cpp:1796-1806, 2099-2161; run.py:48,304), min_T 0.01"}
     reps = 5
+
+    def per_member(prof, opts):
+        """one render launch per member and round: its mean duration over the timed rounds, beside what that member's field makes
+        a ray do -- samples evaluated before termination (a render of the member alone, untimed) -- and the rate the two give.
+        The members are five different random fields behind ONE occupancy grid: their rays march the same steps and stop at
+        different depths, which is the whole spread of the launch durations"""
+        ms = prof.get("render_launch_ms") or []
+        out_m = []
+        for e in range(members):
+            _, st_e = ctx.render(slots[e], cams, None, opts)
+            mine = ms[e::members] if len(ms) == members * reps else []
+            row = {"member": e, "samples_evaluated": int(st_e.samples_evaluated), "samples_live": int(st_e.samples_live)}
+            if mine:
+                row["launch_ms"] = sum(mine) / len(mine)
+                row["samples_per_s_in_kernel"] = st_e.samples_evaluated / (row["launch_ms"] * 1e-3)
+            out_m.append(row)
+        return out_m
+
     for name, spr in (("fixed_128", 128), ("ngp_step", 0)):
         opts = api.engine_render_opts(80, 45, spr, 16, 0.01, background=(0, 0, 0, 1))
         rec, st = ctx.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, slots, cams, None, opts, want_stats=True)
@@ -1069,6 +1087,7 @@ def reference_round(env, fkw, layout_of, variant_of):
                      "evaluated_samples_per_ray": st.samples_evaluated / max(1, st.rays), "live_samples_per_ray": st.samples_live / max(1, st.rays),
                      "render_ms_per_round": prof["render_ms"] / reps, "march_ms_per_round": prof["march_ms"] / reps,
                      "render_launches_per_round": prof["render_launches"] // reps,
+                     "per_member": per_member(prof, opts),
                      "best_view": int(ctx.argmax(rec, np.arange(n_views))),
                      "roofline": {k: roof[k] for k in ("kernel", "bound", "frac", "peak", "achieved", "unit", "avg_launch_ms", "units_per_launch",
                                                        "slot_utilisation", "samples_per_s_in_kernel", "shader_clock_ghz_measured")}}

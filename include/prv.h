@@ -47,7 +47,8 @@ extern "C" {
                                             density term of main.cpp:2148; w = prv_set_coverage_weight */
 #define PRV_COVERAGE_WEIGHT_DEFAULT 1.0  /* the reference adds its density term with unit weight too (main.cpp:2147-2148) */
 
-#define PRV_MAX_MODELS 8
+#define PRV_MAX_MODELS 8  /* members of one ensemble (one scoring call) */
+#define PRV_MAX_SLOTS 64  /* model slots of a context: several objects' ensembles side by side (prv_planner shard: members) */
 #define PRV_MLP_HALFS 10240 /* 32*64 + 64*16 + 32*64 + 64*64 + 64*16, canonical [in][out] */
 
 typedef struct prv_ctx prv_ctx;
@@ -147,6 +148,10 @@ int prv_set_coverage_weight(prv_ctx* ctx, double weight);
 int prv_profile_begin(prv_ctx* ctx);
 int prv_profile_end(prv_ctx* ctx, double* render_ms, int* render_launches, double* march_ms,
                     int* march_launches);
+/* the render launches of the window prv_profile_end closed last, one duration (ms) each in launch order -- the scoring
+ * round of an E-member ensemble launches E per round, member 0 first (main.cpp:2041-2043: one run.py per member).
+ * Returns their number (>= 0; ms may be NULL or hold fewer than that) or an error code. */
+int prv_profile_render_launches(prv_ctx* ctx, float* ms, int capacity);
 
 /* thin device-memory helpers so a C/C++ host needs no HIP headers */
 int prv_malloc(prv_ctx* ctx, void** dev_ptr, size_t bytes);
@@ -345,6 +350,11 @@ int prv_score_views_sharded(prv_ctx* ctx, prv_comm* comm, int method, const int*
  * main.cpp:2041-2043): member e was trained in slot e of rank e % world; afterwards slot e of EVERY rank holds it bit
  * for bit.  Device to device: one group of broadcasts on the slots' canonical buffers (table | MLP | occupancy). */
 int prv_model_exchange(prv_ctx* ctx, prv_comm* comm, int n_members, const prv_field_desc* desc);
+/* the general form: member e lives in model slot slots[e] and was trained by rank owners[e] (prv_planner's `shard: members`
+ * deals the (object, member) trainings of a round to the ranks round-robin, so an ensemble's members come from different
+ * ranks and different objects' ensembles sit in different slots); prv_model_exchange = slots e, owners e % world */
+int prv_model_exchange_slots(prv_ctx* ctx, prv_comm* comm, int n_members, const int* slots, const int* owners,
+                             const prv_field_desc* desc);
 
 /* ---- training ------------------------------------------------------------- */
 /* replaces: the `while testbed.frame()` loop run.py:185-208 drives for `--train --n_steps 2500`

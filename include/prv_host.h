@@ -137,6 +137,11 @@ int prvh_nbv_loop(prvh_share_data* sd, const double center[3], double predicted_
  * writes anything */
 int prvh_method_in_scope(int method_of_IG);
 
+/* prv_planner `shard: members` (BASELINE configs[4] on more GPUs than objects): which rank trains member `member` of object
+ * `object` in a lockstep round -- the n_objects x n_members trainings are dealt round-robin, pair object * n_members + member
+ * to rank pair % world (main.cpp:2041-2043, 2101-2103 train them one after another).  Returns the rank, or -1 for arguments that make no sense */
+int prvh_member_owner(int object, int member, int n_members, int world);
+
 /* DEPRECATED, kept so that binaries linked against the round 1-3 library still load: both belonged to the out-of-scope
  * methods (the view budget of method 4; the PCD reader of the asset preparation).  Each returns PRVH_E_UNSUPPORTED and
  * touches nothing. */

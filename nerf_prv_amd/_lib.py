@@ -25,6 +25,7 @@ STEP_NGP = 1      # instant-ngp's rule, what run.py:304 renders with: dt = sqrt(
 NGP_MAX_STEPS = 1024
 
 MAX_MODELS = 8
+MAX_SLOTS = 64
 MLP_HALFS = 10240
 
 
@@ -103,6 +104,7 @@ SIGNATURES = {
     "prv_device_count": (_i, []),
     "prv_profile_begin": (_i, [_vp]),
     "prv_profile_end": (_i, [_vp, _P(C.c_double), _P(_i), _P(C.c_double), _P(_i)]),
+    "prv_profile_render_launches": (_i, [_vp, _P(C.c_float), _i]),
     "prv_malloc": (_i, [_vp, _P(_vp), C.c_size_t]),
     "prv_free": (_i, [_vp, _vp]),
     "prv_memcpy_h2d": (_i, [_vp, _vp, _vp, C.c_size_t]),
@@ -161,6 +163,7 @@ SIGNATURES = {
     "prv_shard_views": (_i, [_i, _i, _i, _i, _vp, C.POINTER(_i)]),
     "prv_score_views_sharded": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i, C.POINTER(RenderOpts), _vp, _vp, C.POINTER(Stats)]),
     "prv_model_exchange": (_i, [_vp, _vp, _i, C.POINTER(FieldDesc)]),
+    "prv_model_exchange_slots": (_i, [_vp, _vp, _i, _P(_i), _P(_i), C.POINTER(FieldDesc)]),
     "prv_debug_model_layout": (_i, [_vp, _i, C.POINTER(ModelLayout)]),
     "prv_debug_render_clock": (_i, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "prv_debug_raygen": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

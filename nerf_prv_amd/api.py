@@ -156,7 +156,10 @@ class Context:
         """-> dict(render_ms, render_launches, march_ms, march_launches) from HIP events"""
         rm, mm, rn, mn = C.c_double(), C.c_double(), C.c_int(), C.c_int()
         self._chk(self.lib.prv_profile_end(self.handle, C.byref(rm), C.byref(rn), C.byref(mm), C.byref(mn)))
-        return dict(render_ms=rm.value, render_launches=rn.value, march_ms=mm.value, march_launches=mn.value)
+        each = (C.c_float * max(1, rn.value))()
+        n = self.lib.prv_profile_render_launches(self.handle, each, rn.value)
+        return dict(render_ms=rm.value, render_launches=rn.value, march_ms=mm.value, march_launches=mn.value,
+                    render_launch_ms=[float(each[i]) for i in range(max(0, min(n, rn.value)))])
 
     def close(self):
         if getattr(self, "handle", None):
@@ -491,6 +494,10 @@ def train_opts(**kw):
         o.n_samples = L.NGP_MAX_STEPS if kw["step_mode"] == L.STEP_NGP else 128
     if "n_samples" in kw and "step_mode" not in kw:
         o.step_mode = L.STEP_FIXED_S
+    if "step_mode" not in kw and max(o.patch_w, 1) * max(o.patch_h, 1) > 1:  # pixel patches are an option of the fixed rule
+        o.step_mode = L.STEP_FIXED_S
+        if "n_samples" not in kw:
+            o.n_samples = 128
     return o
 
 

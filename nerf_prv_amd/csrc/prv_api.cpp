@@ -73,7 +73,7 @@ struct prv_ctx {
   std::vector<Buffer> idle_buffers;     // ... and their device buffers, taken again by size (train_buffer)
   size_t idle_bytes = 0;
   std::string err;
-  Model models[PRV_MAX_MODELS];
+  Model models[PRV_MAX_SLOTS];
   // grow-only workspaces
   Buffer queue, queue_ext, stage, counters, view_ids, img_f32, partial, records, dbg[6];
   Buffer counters_multi, occ_multi; // the ensemble's one-launch march: queue heads + counts per member, the interleaved occupancy bytes
@@ -82,6 +82,7 @@ struct prv_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> ev_render, ev_march; // start/stop pairs of the current profiling window
   std::vector<hipEvent_t> ev_free;             // recycled events: a profiling window creates none once the pool is warm
+  std::vector<float> last_render_ms;           // the render launches of the last closed window, one duration each (prv_profile_render_launches)
   void* pin = nullptr;                         // pinned host staging of the per-call camera upload (no pageable copy, no stream sync)
   size_t pin_cap = 0;
   hipEvent_t pin_ev = nullptr; // recorded after the upload: the staging is rewritten only once that copy has run
@@ -445,7 +446,7 @@ int republish_model(prv_ctx* c, int slot) {
 }
 
 int model_present(prv_ctx* c, int slot) {
-  if (slot < 0 || slot >= PRV_MAX_MODELS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
+  if (slot < 0 || slot >= PRV_MAX_SLOTS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
   if (!c->models[slot].loaded) return fail(c, PRV_E_STATE, "model slot %d is empty", slot);
   return PRV_OK;
 }
@@ -1143,12 +1144,14 @@ int prv_synchronize(prv_ctx* c) try {
   return PRV_OK;
 } catch (...) { return caught(c); }
 
-static int drain_events(prv_ctx* c, std::vector<hipEvent_t>& ev, double* ms, int* n) {
+static int drain_events(prv_ctx* c, std::vector<hipEvent_t>& ev, double* ms, int* n, std::vector<float>* each = nullptr) {
   double tot = 0.0;
+  if (each) each->clear();
   for (size_t i = 0; i + 1 < ev.size(); i += 2) {
     float t = 0.f;
     HIPCHK(c, hipEventElapsedTime(&t, ev[i], ev[i + 1]));
     tot += t;
+    if (each) each->push_back(t);
   }
   if (ms) *ms = tot;
   if (n) *n = (int)(ev.size() / 2);
@@ -1172,9 +1175,17 @@ int prv_profile_end(prv_ctx* c, double* render_ms, int* render_n, double* march_
   HIPCHK(c, hipSetDevice(c->device)); // the calling thread may be a new one (its current device would be 0)
   c->profiling = false;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  int rc = drain_events(c, c->ev_render, render_ms, render_n);
+  int rc = drain_events(c, c->ev_render, render_ms, render_n, &c->last_render_ms);
   if (rc != PRV_OK) return rc;
   return drain_events(c, c->ev_march, march_ms, march_n);
+} catch (...) { return caught(c); }
+
+/* the render launches of the window prv_profile_end closed last, one duration each, in launch order (a scoring round of an
+ * E-member ensemble: E per round, member 0 first); returns how many there were (ms may be NULL or shorter) */
+int prv_profile_render_launches(prv_ctx* c, float* ms, int cap) try {
+  if (!c) return PRV_E_INVALID;
+  for (int i = 0; ms && i < cap && i < (int)c->last_render_ms.size(); i++) ms[i] = c->last_render_ms[(size_t)i];
+  return (int)c->last_render_ms.size();
 } catch (...) { return caught(c); }
 
 int prv_malloc(prv_ctx* c, void** p, size_t bytes) try {
@@ -1222,7 +1233,7 @@ int prv_model_sizes(const prv_field_desc* d, uint64_t* table_halfs, uint64_t* ml
 int prv_model_load(prv_ctx* c, int slot, const prv_field_desc* d, const uint16_t* table, const uint16_t* mlp,
                    const uint32_t* occ) try {
   if (!c) return PRV_E_INVALID;
-  if (slot < 0 || slot >= PRV_MAX_MODELS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
+  if (slot < 0 || slot >= PRV_MAX_SLOTS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
   if (!d || !table || !mlp || !occ) return fail(c, PRV_E_INVALID, "NULL argument");
   HIPCHK(c, hipSetDevice(c->device));
   c->models[slot].generation++; // a live trainer of this slot holds stale masters from now on (train_check)
@@ -1238,7 +1249,7 @@ int prv_model_fresh(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed
 } catch (...) { return caught(c); }
 static int model_synthetic(prv_ctx* c, int slot, const prv_field_desc* d, uint64_t seed, bool all_occupied) {
   if (!c) return PRV_E_INVALID;
-  if (slot < 0 || slot >= PRV_MAX_MODELS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
+  if (slot < 0 || slot >= PRV_MAX_SLOTS) return fail(c, PRV_E_INVALID, "model slot %d out of range", slot);
   if (!d) return fail(c, PRV_E_INVALID, "NULL descriptor");
   HIPCHK(c, hipSetDevice(c->device));
   HostLevel lv[kMaxLevels];

@@ -629,6 +629,17 @@ void train_tile_kernel(TrainTileParams P) {
     int lane = lane_outer;
     if constexpr (MODE == 2) asm volatile("" : "+v"(lane)); // (the LDS-chain instances are faster with the hoisted form: they have the registers)
     const int tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
+    if constexpr (!FWD) {
+      // A tile none of whose samples carries a gradient is skipped whole: samples behind their ray's termination are listed
+      // and evaluated (the forward pass cannot know) but seeded with zeros, and they form runs -- the list is ray by ray in
+      // depth order.  Under the engine's marcher a learnt opaque surface has hundreds of live steps behind it: a third of
+      // the list in the planner loop's steady state, nine tenths in its one-view first round (every wave sees the same 32
+      // seeds, so the decision is block-uniform without a barrier).
+      const uint32_t sid0 = tile * 32u + (uint32_t)(lane & 31);
+      float4 sd0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sid0 < n_samples) sd0 = P.seeds[sid0];
+      if (__ballot(sd0.x != 0.0f || sd0.y != 0.0f || sd0.z != 0.0f || sd0.w != 0.0f) == 0ull) continue;
+    }
     // ---- phase E: encode (8 threads per sample), SH inputs, gradient seeds
     const int s = tid & 31, g = tid >> 5;
     const uint32_t sid = tile * 32u + (uint32_t)s;

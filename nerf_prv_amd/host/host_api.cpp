@@ -294,6 +294,11 @@ int prvh_nbv_loop(prvh_share_data* h, const double center[3], double predicted_s
 
 int prvh_method_in_scope(int method_of_IG) { return NBV_Net_Labeler::method_in_scope(method_of_IG) ? 1 : 0; }
 
+int prvh_member_owner(int object, int member, int n_members, int world) {
+  if (object < 0 || member < 0 || n_members < 1 || member >= n_members || world < 1) return -1;
+  return member_pair_owner(object, member, n_members, world);
+}
+
 // deprecated entry points of the out-of-scope methods (include/prv_host.h): present, inert
 long long prvh_pcd_read(const char*, float*, uint8_t*, long long) { return PRVH_E_UNSUPPORTED; }
 int prvh_nbv_loop_budget(prvh_share_data*, const double*, double, int, int, prvh_score_fn, void*, int, prvh_loop_result* out) {

@@ -44,6 +44,15 @@ struct HipScorer {
   // dealt to the ranks and ONE all-gather of the 16-byte records gives every rank every score
   prv_comm* comm = nullptr;
   int rank = 0, world = 1;
+  // where the members live and who trains them.  Default (one object at a time): member e in model slot e, trained by rank
+  // e % world.  `shard: members` walks several objects' loops in lockstep: object o's members sit in slots slot_base + e and
+  // the (object, member) trainings of a round are dealt round-robin, member e to rank (pair_base + e) % world with
+  // pair_base = o * n_members; the shell trains a round's pairs of ALL objects side by side before any object is scored
+  // (members_pretrained: the scoring call then only brings the members together)
+  int slot_base = 0, pair_base = 0;
+  bool members_pretrained = false;
+  int slot_of(int e) const { return slot_base + e; }
+  int owner_of(int e) const { return member_pair_owner(0, pair_base + e, 1 << 30, world); } // (pair_base = object * n_members: planner.hpp's rule)
   std::shared_ptr<Share_Data> sd;
   int n_members = 1;
   float* gt_dev = nullptr; // method 5: reference images of ALL views at the candidate size
@@ -64,6 +73,10 @@ struct HipScorer {
     if (train_rays > 0) to.n_rays = train_rays;
     if (train_patch_w > 0) to.patch_w = train_patch_w;
     if (train_patch_h > 0) to.patch_h = train_patch_h;
+    if (std::max(to.patch_w, 1) * std::max(to.patch_h, 1) > 1 && train_step_mode < 0) { // pixel patches are an option of the fixed rule
+      to.step_mode = PRV_STEP_FIXED_S;
+      to.n_samples = 128;
+    }
   }
   prv_field_desc train_desc{};
   uint64_t train_seed = 0x1234;
@@ -138,8 +151,33 @@ struct HipScorer {
     return PRV_OK;
   }
 
-  // `--train --n_steps N` for the listed members on one scene json: a fresh field per member (seed = train_seed + e),
-  // the members stepping side by side (prv_train_steps_multi); with several ranks a member is trained by rank e % world
+  // trainers of the listed members on one scene json, for the members this rank owns: a fresh field per member
+  // (seed = train_seed + e) in the member's slot; appended to `trs` (the caller steps and destroys them)
+  int create_trainers(const std::string& scene_json, const std::vector<int>& members, std::vector<prv_trainer*>& trs, double* t_fresh = nullptr,
+                      double* t_create = nullptr) {
+    int rc = training_data(scene_json);
+    for (size_t k = 0; rc == PRV_OK && k < members.size(); k++) {
+      const int e = members[k];
+      if (owner_of(e) != rank) continue;
+      double t0 = now_seconds();
+      rc = prv_model_fresh(ctx, slot_of(e), &train_desc, train_seed + (uint64_t)e);
+      if (t_fresh) *t_fresh += now_seconds() - t0;
+      prv_train_opts to;
+      prv_train_default_opts(&to);
+      apply_train_opts(to);
+      to.seed += (uint64_t)e;
+      prv_trainer* tr = nullptr;
+      t0 = now_seconds();
+      if (rc == PRV_OK) rc = prv_train_create(ctx, slot_of(e), data_cams, data_imgs, data_w, data_h, &to, &tr);
+      if (t_create) *t_create += now_seconds() - t0;
+      if (tr) trs.push_back(tr);
+    }
+    if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+    return rc;
+  }
+
+  // `--train --n_steps N` for the listed members on one scene json, the members stepping side by side (prv_train_steps_multi);
+  // with several ranks a member is trained by its owner (owner_of)
   int train_member_list(const std::string& scene_json, const std::vector<int>& members, int steps) {
     const bool timing = getenv("PRV_PLANNER_TIMING") != nullptr; // dev: where an iteration's seconds go
     const double t_start = now_seconds();
@@ -149,22 +187,7 @@ struct HipScorer {
     if (timing) prv_synchronize(ctx);
     const double t_gt = now_seconds() - t_start;
     std::vector<prv_trainer*> trs;
-    for (size_t k = 0; rc == PRV_OK && k < members.size(); k++) {
-      const int e = members[k];
-      if (e % world != rank) continue;
-      double t0 = now_seconds();
-      rc = prv_model_fresh(ctx, e, &train_desc, train_seed + (uint64_t)e);
-      t_fresh += now_seconds() - t0;
-      prv_train_opts to;
-      prv_train_default_opts(&to);
-      apply_train_opts(to);
-      to.seed += (uint64_t)e;
-      prv_trainer* tr = nullptr;
-      t0 = now_seconds();
-      if (rc == PRV_OK) rc = prv_train_create(ctx, e, data_cams, data_imgs, data_w, data_h, &to, &tr);
-      t_create += now_seconds() - t0;
-      if (tr) trs.push_back(tr);
-    }
+    rc = create_trainers(scene_json, members, trs, &t_fresh, &t_create);
     const double t0 = now_seconds();
     if (rc == PRV_OK && !trs.empty()) rc = prv_train_steps_multi(trs.data(), (int)trs.size(), steps, nullptr);
     const double t_steps = now_seconds() - t0;
@@ -183,13 +206,26 @@ struct HipScorer {
     return rc;
   }
 
+  // the members of the ensemble reach every rank (each trained by its owner): one group of broadcasts
+  int exchange_members() {
+    if (!comm) return PRV_OK;
+    std::vector<int> slots(n_members), owners(n_members);
+    for (int e = 0; e < n_members; e++) {
+      slots[e] = slot_of(e);
+      owners[e] = owner_of(e);
+    }
+    const int rc = prv_model_exchange_slots(ctx, comm, n_members, slots.data(), owners.data(), &train_desc);
+    if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+    return rc;
+  }
+
   // the whole ensemble of an iteration in one go (the fused path): train, then exchange between ranks
   int train_members(const std::string& scene_json) {
     std::vector<int> all(n_members);
     for (int e = 0; e < n_members; e++) all[e] = e;
-    int rc = train_member_list(scene_json, all, train_steps);
-    if (rc == PRV_OK && comm) rc = prv_model_exchange(ctx, comm, n_members, &train_desc);
-    if (rc != PRV_OK) std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+    int rc = members_pretrained ? PRV_OK : train_member_list(scene_json, all, train_steps);
+    members_pretrained = false; // (the shell's lockstep round trained them: this call only brings them together)
+    if (rc == PRV_OK) rc = exchange_members();
     drop_training_data(); // the next iteration's json differs
     return rc;
   }
@@ -203,9 +239,9 @@ struct HipScorer {
   //   --test_transforms T --save_metrics M          render every frame of T (spp 1, min_T 1e-4, run.py:231-235), PSNR /
   //                                                SSIM against renders of the ground-truth field, "PSNR\t..\nSSIM\t.." -> M
   int run_py(const RunPyArgs& a) {
-    const int slot = a.ensemble_id >= 0 ? a.ensemble_id : 0;
+    const int member = a.ensemble_id >= 0 ? a.ensemble_id : 0, slot = slot_of(member);
     if (train_steps > 0) {
-      const int rc = train_member_list(a.scene, {slot}, a.n_steps > 0 ? std::min(a.n_steps, train_steps) : train_steps);
+      const int rc = train_member_list(a.scene, {member}, a.n_steps > 0 ? std::min(a.n_steps, train_steps) : train_steps);
       if (rc != PRV_OK) return rc;
     }
     if (!a.screenshot_transforms.empty()) {
@@ -288,7 +324,7 @@ struct HipScorer {
     if (rc != PRV_OK) return rc;
     std::string test_json;
     if ((rc = write_test_json(center, size, &test_json)) != PRV_OK) return rc;
-    return evaluate_on(test_json, 0, psnr, ssim);
+    return evaluate_on(test_json, slot_of(0), psnr, ssim);
   }
 
   // the test cameras' json, <gt_path>/<evaluate_views>.json: the test view set placed like the candidates, full-size
@@ -416,7 +452,7 @@ struct HipScorer {
     const int n = prv_camset_count(cams);
     prv_render_opts o = candidate_opts(cams);
     std::vector<int> slots(n_members);
-    for (int e = 0; e < n_members; e++) slots[e] = e;
+    for (int e = 0; e < n_members; e++) slots[e] = slot_of(e);
     std::vector<prv_score_record> rec(n);
     // this rank's shard of the frames of the render json (all of them with one rank): interleaved, as bench.py deals them
     std::vector<int> mine((size_t)std::max(1, (n + world - 1) / world));
@@ -445,7 +481,7 @@ struct HipScorer {
         for (int e = 0; rc == PRV_OK && e < n_members; e++) {
           const std::string dir = sd->save_path + "/render/" + std::to_string(iteration) + "/ensemble_" + std::to_string(e);
           sd->access_directory(dir);
-          rc = prv_render_rgba8(ctx, e, cams, nullptr, n, &o, dev, nullptr);
+          rc = prv_render_rgba8(ctx, slot_of(e), cams, nullptr, n, &o, dev, nullptr);
           for (int k = 0; rc == PRV_OK && k < n; k++) {
             rc = prv_memcpy_d2h(ctx, px.data(), dev + (size_t)k * px.size(), px.size());
             if (rc == PRV_OK && png_write_rgba8(dir + "/rgbaClip_" + std::to_string(ids[k]) + ".png", o.width, o.height, px.data()) != 0) rc = PRV_E_IO;
@@ -500,13 +536,28 @@ prv_field_desc field_from_config(const FileStorage& fs) {
   return d;
 }
 
-int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name, int method, prv_comm* comm) {
+// One object's planning run: everything view_planning does around NBV_Net_Labeler::nbv_loop, kept in one place so that the
+// shell can hold SEVERAL objects' loops at once (`shard: members`: run_members_lockstep below).  slot_base / pair_base: where
+// the object's members live and who trains them (HipScorer).
+struct PlanningJob {
+  prv_ctx* ctx = nullptr;
+  std::shared_ptr<Share_Data> sd;
+  std::unique_ptr<NBV_Net_Labeler> lab;
+  HipScorer* state = nullptr; // the scorer object inside lab->scorer (engine, evaluator and the loop share it)
+  float* gt_dev = nullptr;
+  int first_view_id = -1;
+  int setup(prv_ctx* ctx_, const std::string& cfg, const std::string& name, int method, prv_comm* comm, int slot_base = 0, int pair_base = 0);
+  int finish(int rc);
+};
+
+int PlanningJob::setup(prv_ctx* ctx_, const std::string& cfg, const std::string& name, int method, prv_comm* comm, int slot_base, int pair_base) {
+  ctx = ctx_;
   if (!NBV_Net_Labeler::method_in_scope(method)) { // before any directory, model or training: methods 1 / 4 are the PRVNet pipeline's
     std::cerr << "method_of_IG " << method << " is not built: this planner runs methods 0 (RandomIterative), 2 (EnsembleRGB), 3 "
                  "(EnsembleRGBDensity) and 5 (PSNRCoverage); 1 (RandomOneshot) and 4 (PVBCoverage) need the reference's PRVNet server" << std::endl;
     return -10;
   }
-  auto sd = std::make_shared<Share_Data>(cfg, name, -1, -1, method); // main.cpp:3876
+  sd = std::make_shared<Share_Data>(cfg, name, -1, -1, method); // main.cpp:3876
   if (!sd->ok) {
     std::cerr << sd->error << std::endl;
     return -1;
@@ -522,6 +573,10 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
     std::cerr << "WARNING: the members are NOT retrained on the chosen views (train_steps: 0 / pretrained_members: 1): "
                  "the view ranking of this run does not depend on the views it acquires (the reference retrains "
                  "n_steps per member per iteration, main.cpp:1668)" << std::endl;
+  if (train_steps == 0 && (slot_base != 0 || pair_base != 0)) {
+    std::cerr << "shard: members deals TRAININGS to the ranks: it needs train_steps > 0" << std::endl;
+    return -25;
+  }
   for (int e = 0; e < members && train_steps == 0; e++) {
     int rc;
     if (fs.has("synthetic_seed")) rc = prv_model_synthetic(ctx, e, &desc, (uint64_t)fs.num("synthetic_seed") + (uint64_t)e);
@@ -551,6 +606,8 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   scorer.rank = rank;
   scorer.world = world;
   scorer.n_members = members;
+  scorer.slot_base = slot_base;
+  scorer.pair_base = pair_base;
   scorer.save_renders = fs.has("save_renders") && fs.num("save_renders") > 0;
   if (train_steps > 0) { // members are trained from scratch every iteration
     const int rc = configure_training(ctx, fs, desc, train_steps, scorer);
@@ -560,7 +617,9 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   // diagnostics of the shell, not of the loop: every iteration's scores (raw doubles) and gathered records on disk
   const bool dump_scores = (fs.has("dump_scores") && fs.num("dump_scores") > 0) || getenv("PRV_PLANNER_DUMP_RECORDS") != nullptr;
   scorer.dump_records = dump_scores; // (before the labeler copies the scorer)
-  NBV_Net_Labeler labeler(sd, center, size, scorer);
+  lab.reset(new NBV_Net_Labeler(sd, center, size, scorer));
+  NBV_Net_Labeler& labeler = *lab;
+  auto sd = this->sd; // (the lambdas below capture the shared pointer by value)
   if (dump_scores) {
     labeler.on_scores = [sd](int iteration, const std::vector<int>&, const std::vector<double>& scores) {
       sd->access_directory(sd->save_path + "/scores");
@@ -611,7 +670,7 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
     labeler.scorer = scorer;
   }
   // first view = the (0,0,r) top view of the set (main.cpp:3985-3995)
-  int first_view_id = -1;
+  first_view_id = -1;
   for (size_t i = 0; i < labeler.view_space->views.size(); i++) {
     const Vec3& p = labeler.view_space->views[i].init_pos;
     if (std::fabs(p.x) < 1e-6 && std::fabs(p.y) < 1e-6 && std::fabs(p.z - sd->view_space_radius) < 1e-6) first_view_id = (int)i;
@@ -631,22 +690,110 @@ int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name,
   // train_by_instantNGP's reference signature -> the in-process engine (one run.py invocation per call); the engine
   // shares the loop's scorer object, so `score_path: png` and the fused path train and render the same members
   HipScorer* engine_state = labeler.scorer.target<HipScorer>();
+  state = engine_state;
+  gt_dev = scorer.gt_dev;
   labeler.engine = [engine_state](const RunPyArgs& a) { return engine_state ? engine_state->run_py(a) : -42; };
   if (sd->score_from_pngs && comm) {
     std::cerr << "score_path: png is the reference's single-process data flow; shard: views needs score_path: fused" << std::endl;
     return -24;
   }
-  const int rc = labeler.nbv_loop(first_view_id, 0);
+  return 0;
+}
+
+int PlanningJob::finish(int rc) {
+  NBV_Net_Labeler& labeler = *lab;
+  HipScorer* engine_state = state;
   if (engine_state) {
     engine_state->drop_training_data();
     engine_state->drop_test_images();
   }
-  if (scorer.gt_dev) prv_free(ctx, scorer.gt_dev);
+  if (gt_dev) prv_free(ctx, gt_dev);
+  gt_dev = nullptr;
   if (labeler.final_psnr >= 0) std::cout << "final PSNR " << labeler.final_psnr << " SSIM " << labeler.final_ssim << std::endl;
   std::cout << "chosen_nbvs:";
   for (int v : labeler.chosen_nbvs) std::cout << ' ' << v;
   std::cout << std::endl;
   return rc;
+}
+
+
+int view_planning(prv_ctx* ctx, const std::string& cfg, const std::string& name, int method, prv_comm* comm) {
+  PlanningJob job;
+  int rc = job.setup(ctx, cfg, name, method, comm);
+  if (rc != 0) return rc;
+  return job.finish(job.lab->nbv_loop(job.first_view_id, 0));
+}
+
+// `shard: members` (BASELINE configs[4] on several GPUs; SURVEY section 8(e), main.cpp:2041-2043): the objects' loops in
+// LOCKSTEP.  Round k of every object is prepared (its json pair written), then the E member-trainings of every object --
+// objects x E (object, member) pairs, dealt to the ranks round-robin: pair p = o * E + e goes to rank p % world -- run side
+// by side on their owners (prv_train_steps_multi over everything this rank owns), then object by object the members are
+// brought together (prv_model_exchange_slots: one group of broadcasts), the candidates scored views-sharded (one all-gather)
+// and the next view chosen.  With `shard: objects` 5 objects keep 5 of 8 GPUs busy; here 25 pairs keep all 8 busy with 3 or 4
+// trainings each (22 % idle against 37.5 %).  Every rank walks every object's loop, so every collective is entered by all
+// ranks in the same order; objects beyond the slots of one context (7 ensembles of up to 8 members) go in further batches.
+int run_members_lockstep(prv_ctx* ctx, const std::string& cfg, const std::vector<std::string>& names, int method, prv_comm* comm) {
+  constexpr int kBatch = (PRV_MAX_SLOTS - 8) / PRV_MAX_MODELS; // slots 0..7 stay the shared ones (ground truth 6, reference 7)
+  int worst = 0;
+  for (size_t b0 = 0; b0 < names.size(); b0 += (size_t)kBatch) {
+    const size_t nb = std::min(names.size() - b0, (size_t)kBatch);
+    std::vector<std::unique_ptr<PlanningJob>> jobs;
+    std::vector<int> live; // 0: in the loop, 1: ended, < 0: failed
+    for (size_t k = 0; k < nb; k++) {
+      std::cout << "object " << names[b0 + k] << " method " << method << " (lockstep batch of " << nb << ")" << std::endl;
+      jobs.emplace_back(new PlanningJob());
+      PlanningJob& j = *jobs.back();
+      int members = 1;
+      {
+        Share_Data probe(cfg, names[b0 + k], -1, -1, method);
+        if (probe.ok && (method == EnsembleRGB || method == EnsembleRGBDensity)) members = probe.ensemble_num;
+      }
+      int rc = j.setup(ctx, cfg, names[b0 + k], method, comm, 8 + (int)k * PRV_MAX_MODELS, (int)(b0 + k) * members);
+      if (rc == 0) rc = j.lab->nbv_begin(j.first_view_id, 0);
+      live.push_back(rc);
+    }
+    for (;;) {
+      bool any = false;
+      for (size_t k = 0; k < nb; k++) // a round's json pairs (and, where a loop ends here, its final evaluation)
+        if (live[k] == 0) {
+          live[k] = jobs[k]->lab->nbv_prepare();
+          any = any || live[k] == 0;
+        }
+      if (!any) break;
+      // every (object, member) pair of the round this rank owns, side by side
+      std::vector<prv_trainer*> trs;
+      int rc = PRV_OK, steps = 0;
+      const double t0 = now_seconds();
+      for (size_t k = 0; k < nb && rc == PRV_OK; k++) {
+        HipScorer* sc = jobs[k]->state;
+        if (live[k] != 0 || !sc || sc->train_steps <= 0 || method == RandomIterative) continue;
+        std::vector<int> all(sc->n_members);
+        for (int e = 0; e < sc->n_members; e++) all[e] = e;
+        rc = sc->create_trainers(jobs[k]->lab->run.scene_json, all, trs);
+        steps = sc->train_steps;
+        sc->members_pretrained = rc == PRV_OK;
+      }
+      const size_t n_mine = trs.size();
+      if (rc == PRV_OK && !trs.empty()) rc = prv_train_steps_multi(trs.data(), (int)trs.size(), steps, nullptr);
+      for (prv_trainer* tr : trs) prv_train_destroy(tr);
+      if (getenv("PRV_PLANNER_TIMING"))
+        std::cerr << "train_pairs: " << n_mine << " (object, member) trainings of this round on rank " << (comm ? prv_comm_rank(comm) : 0) << ", " << steps
+                  << " steps side by side, " << now_seconds() - t0 << " s" << std::endl;
+      if (rc != PRV_OK) {
+        std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
+        for (size_t k = 0; k < nb; k++)
+          if (live[k] == 0) live[k] = rc; // (every rank fails the same way or the next collective reports it)
+        break;
+      }
+      for (size_t k = 0; k < nb; k++)
+        if (live[k] == 0) live[k] = jobs[k]->lab->nbv_decide();
+    }
+    for (size_t k = 0; k < nb; k++) {
+      const int rc = jobs[k]->lab ? jobs[k]->finish(live[k] < 0 ? live[k] : 0) : live[k];
+      if (rc != 0) worst = rc;
+    }
+  }
+  return worst;
 }
 
 int configure_training(prv_ctx* ctx, const FileStorage& fs, const prv_field_desc& desc, int train_steps, HipScorer& scorer) {
@@ -1051,24 +1198,27 @@ static int run(int argc, char** argv) {
   //    no collective;
   //  shard views (`shard: views` in the yaml or PRV_SHARD=views; BASELINE config 4): every rank runs the loop of every
   //    object, the candidates of an iteration are dealt to the ranks, ONE all-gather of the score records per round
-  //    (RCCL over xGMI; PRV_COMM=socket for ranks that share a GPU), trained members exchanged device to device.
+  //    (RCCL over xGMI; PRV_COMM=socket for ranks that share a GPU), trained members exchanged device to device;
+  //  shard members (`shard: members` / PRV_SHARD=members; BASELINE config 5 with more GPUs than objects): the objects'
+  //    loops in lockstep, the (object, member) trainings of a round dealt to the ranks round-robin (run_members_lockstep).
   const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0);
   if (world < 1 || rank < 0 || rank >= world) {
     std::cerr << "RANK " << rank << " / WORLD_SIZE " << world << " make no sense" << std::endl;
     return 2;
   }
-  bool shard_views = false;
+  bool shard_views = false, shard_members = false;
   {
     FileStorage fs0;
     const char* e = getenv("PRV_SHARD");
     std::string how = e && *e ? e : (fs0.open(cfg) && fs0.has("shard") ? fs0.str("shard") : "objects");
-    if (how != "objects" && how != "views") {
-      std::cerr << "shard must be 'objects' or 'views', not '" << how << "'" << std::endl;
+    if (how != "objects" && how != "views" && how != "members") {
+      std::cerr << "shard must be 'objects', 'views' or 'members', not '" << how << "'" << std::endl;
       return 2;
     }
     shard_views = how == "views" && world > 1 && mode == ViewPlanning;
+    shard_members = how == "members" && mode == ViewPlanning; // (with one rank: the lockstep walk alone, every training on this GPU)
   }
-  if (world > 1 && !shard_views) {
+  if (world > 1 && !shard_views && !shard_members) {
     std::vector<std::string> mine;
     for (size_t i = 0; i < names.size(); i++)
       if ((int)(i % (size_t)world) == rank) mine.push_back(names[i]);
@@ -1093,13 +1243,14 @@ static int run(int argc, char** argv) {
     return 5;
   }
   prv_comm* comm = nullptr;
-  if (shard_views) {
+  if (shard_views || (shard_members && world > 1)) {
     if (prv_comm_create(ctx, rank, world, nullptr, nullptr, &comm) != PRV_OK) {
       std::cerr << "prv: " << prv_last_error(ctx) << std::endl;
       prv_destroy(ctx);
       return 6;
     }
-    std::cout << "rank " << rank << " of " << world << ": views sharded, transport " << prv_comm_transport(comm) << std::endl;
+    std::cout << "rank " << rank << " of " << world << ": " << (shard_members ? "member trainings dealt round-robin, views sharded" : "views sharded") << ", transport "
+              << prv_comm_transport(comm) << std::endl;
   }
   if (mode == InstantNGP || mode == GetCoverage) {
     int worst = 0;
@@ -1115,12 +1266,19 @@ static int run(int argc, char** argv) {
   if (fs.has("method_of_IG") && fs.num("method_of_IG") >= 0) methods.push_back((int)fs.num("method_of_IG"));
   else methods = {RandomIterative, EnsembleRGB, EnsembleRGBDensity, PSNRCoverage};
   int worst = 0;
-  for (const auto& n : names)
+  if (shard_members) {
     for (int m : methods) {
-      std::cout << "object " << n << " method " << m << std::endl;
-      const int rc = view_planning(ctx, cfg, n, m, comm);
+      const int rc = run_members_lockstep(ctx, cfg, names, m, comm);
       if (rc != 0) worst = rc;
     }
+  } else {
+    for (const auto& n : names)
+      for (int m : methods) {
+        std::cout << "object " << n << " method " << m << std::endl;
+        const int rc = view_planning(ctx, cfg, n, m, comm);
+        if (rc != 0) worst = rc;
+      }
+  }
   if (comm) prv_comm_destroy(comm);
   prv_destroy(ctx);
   return worst == 0 ? 0 : 1;

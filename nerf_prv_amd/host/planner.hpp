@@ -171,6 +171,13 @@ inline int ensemble_uncertainty_from_pngs(int method, const std::vector<std::str
   return 0;
 }
 
+// `shard: members` (prv_planner): the member trainings of a lockstep round, n_objects x n_members
+// (object, member) pairs, are dealt to the ranks round-robin -- pair p = object * n_members + member is trained by rank
+// p % world (the reference trains them one run.py after another, main.cpp:2041-2043, 2101-2103)
+inline int member_pair_owner(int object, int member, int n_members, int world) {
+  return world > 0 ? (int)(((long long)object * n_members + member) % world) : 0;
+}
+
 class NBV_Net_Labeler {
 public:
   std::shared_ptr<Share_Data> share_data;
@@ -274,8 +281,32 @@ public:
     return method == RandomIterative || method == EnsembleRGB || method == EnsembleRGBDensity || method == PSNRCoverage;
   }
 
-  // main.cpp:1718-2277 for methods 0, 2, 3 (and 5, this build's single-model score); chosen views in `chosen_nbvs`
+  // main.cpp:1718-2277 for methods 0, 2, 3 (and 5, this build's single-model score); chosen views in `chosen_nbvs`.
+  // The loop is three resumable pieces -- nbv_begin (everything before the reference's `while (true)`), nbv_prepare (an
+  // iteration's json / render_json and the termination test, :1885-1966) and nbv_decide (score, pick, movement cost,
+  // :1969-2264) -- so that a shell can walk SEVERAL objects' loops in lockstep (prv_planner `shard: members`: the
+  // (object, member) trainings of a round are dealt to the ranks before any object of the round is scored).
   int nbv_loop(int first_view_id = -1, int test_id = 0) {
+    int rc = nbv_begin(first_view_id, test_id);
+    if (rc != 0) return rc < 0 ? rc : 0; // 1: a finished run was found on disk (idempotent resume)
+    while ((rc = nbv_prepare()) == 0)
+      if ((rc = nbv_decide()) != 0) return rc;
+    return rc < 0 ? rc : 0;
+  }
+
+  // state of a loop in progress (nbv_begin .. the nbv_prepare that returns 1)
+  struct NbvRun {
+    Value root_nbvs, root_render;
+    std::set<int> chosen_nbvs_set;
+    std::mt19937 rng{12345}; // the reference seeds rand() with clock() (Share_Data.hpp:514): unreproducible by design
+    double loop_t0 = 0.0;
+    int iteration = 0;
+    std::vector<int> candidates; // the unchosen views of the iteration in preparation / being decided
+    std::string scene_json, render_json; // its <save>/json/<it>.json and <save>/render_json/<it>.json
+  } run;
+
+  // -> 0: the loop is set up; 1: nothing to do (a finished run on disk); < 0: error
+  int nbv_begin(int first_view_id = -1, int test_id = 0) {
     if (first_view_id == -1) first_view_id = 0; // :1725-1728
     Share_Data& sd = *share_data;
     if (!method_in_scope(sd.method_of_IG)) {
@@ -295,109 +326,126 @@ public:
     { // idempotent resume: finished runs are skipped (:1761-1770)
       std::ifstream check(sd.save_path + "/run_time.txt");
       double run_time = -1;
-      if (check.is_open() && (check >> run_time) && run_time >= 0) return 0;
+      if (check.is_open() && (check >> run_time) && run_time >= 0) return 1;
     }
-    const Value root_nbvs = transforms_header(sd.color_intrinsics, sd.ray_casting_aabb_scale, view_space->predicted_size,
-                                              view_space->object_center_world, 0);
-    const Value root_render = transforms_header(sd.color_intrinsics, sd.ray_casting_aabb_scale, view_space->predicted_size,
-                                                view_space->object_center_world, sd.candidate_divisor);
+    run = NbvRun{};
+    run.root_nbvs = transforms_header(sd.color_intrinsics, sd.ray_casting_aabb_scale, view_space->predicted_size,
+                                      view_space->object_center_world, 0);
+    run.root_render = transforms_header(sd.color_intrinsics, sd.ray_casting_aabb_scale, view_space->predicted_size,
+                                        view_space->object_center_world, sd.candidate_divisor);
     write_text(sd.save_path + "/movement/-1.txt", std::to_string(first_view_id) + "\t0\t0\n"); // :1868-1870
     chosen_nbvs.assign(1, first_view_id);
     total_movement_cost = 0.0; // :1867
-    std::set<int> chosen_nbvs_set{first_view_id};
-    std::mt19937 rng(12345); // the reference seeds rand() with clock() (Share_Data.hpp:514): unreproducible by design
-    const double loop_t0 = now_seconds();
-    int iteration = 0;
-    while (true) {
-      const int n_views = (int)view_space->views.size();
-      const std::string prefix = "../../../../Coverage_images/ShapeNet/" + sd.name_of_pcd + "/" + std::to_string(sd.num_of_views) + "/rgbaClip_";
-      Value now_nbvs_json(root_nbvs), now_render_json(root_render);
-      std::vector<int> candidates;
-      for (int i = 0; i < n_views; i++) { // :1887-1916
-        Value view_image;
-        view_image["file_path"] = Value(prefix + std::to_string(i) + ".png");
-        view_image["transform_matrix"] = matrix_json(
-            view_transform_matrix(view_space->views[i], view_space->now_camera_pose_world, view_space->object_center_world));
-        if (chosen_nbvs_set.count(i)) now_nbvs_json["frames"].append(view_image);
-        else {
-          now_render_json["frames"].append(view_image);
-          candidates.push_back(i);
-        }
+    run.chosen_nbvs_set = {first_view_id};
+    run.loop_t0 = now_seconds();
+    run.iteration = 0;
+    return 0;
+  }
+
+  // the iteration's two json files; -> 0: a view is to be chosen (nbv_decide), 1: the loop has ended (run_time.txt and
+  // the final evaluation are written), < 0: error
+  int nbv_prepare() {
+    Share_Data& sd = *share_data;
+    const int n_views = (int)view_space->views.size();
+    const std::string prefix = "../../../../Coverage_images/ShapeNet/" + sd.name_of_pcd + "/" + std::to_string(sd.num_of_views) + "/rgbaClip_";
+    Value now_nbvs_json(run.root_nbvs), now_render_json(run.root_render);
+    run.candidates.clear();
+    for (int i = 0; i < n_views; i++) { // :1887-1916
+      Value view_image;
+      view_image["file_path"] = Value(prefix + std::to_string(i) + ".png");
+      view_image["transform_matrix"] = matrix_json(
+          view_transform_matrix(view_space->views[i], view_space->now_camera_pose_world, view_space->object_center_world));
+      if (run.chosen_nbvs_set.count(i)) now_nbvs_json["frames"].append(view_image);
+      else {
+        now_render_json["frames"].append(view_image);
+        run.candidates.push_back(i);
       }
-      const std::string it = std::to_string(iteration);
-      write_text(sd.save_path + "/json/" + it + ".json", prvjson::to_styled_string(now_nbvs_json));          // :1918-1920
-      write_text(sd.save_path + "/render_json/" + it + ".json", prvjson::to_styled_string(now_render_json)); // :1922-1924
-      if (iteration == sd.num_of_max_iteration || candidates.empty()) { // :1946-1966
-        const double loops_time = now_seconds() - loop_t0;
-        write_text(sd.save_path + "/run_time.txt", std::to_string(loops_time) + "\n");
-        if (sd.evaluate && evaluator) { // "final evaluating..." (:1954-1965): metrics/<it>.txt in run.py's format
-          double psnr = 0, ssim = 0;
-          const int rc = evaluator(sd.save_path + "/json/" + it + ".json", &psnr, &ssim);
-          if (rc != 0) return rc;
-          char buf[128];
-          snprintf(buf, sizeof(buf), "PSNR\t%.17g\nSSIM\t%.17g", psnr, ssim);
-          write_text(sd.save_path + "/metrics/" + it + ".txt", buf);
-          final_psnr = psnr;
-          final_ssim = ssim;
-        }
+    }
+    const std::string it = std::to_string(run.iteration);
+    run.scene_json = sd.save_path + "/json/" + it + ".json";
+    run.render_json = sd.save_path + "/render_json/" + it + ".json";
+    write_text(run.scene_json, prvjson::to_styled_string(now_nbvs_json));     // :1918-1920
+    write_text(run.render_json, prvjson::to_styled_string(now_render_json)); // :1922-1924
+    if (run.iteration == sd.num_of_max_iteration || run.candidates.empty()) { // :1946-1966
+      const double loops_time = now_seconds() - run.loop_t0;
+      write_text(sd.save_path + "/run_time.txt", std::to_string(loops_time) + "\n");
+      if (sd.evaluate && evaluator) { // "final evaluating..." (:1954-1965): metrics/<it>.txt in run.py's format
+        double psnr = 0, ssim = 0;
+        const int rc = evaluator(run.scene_json, &psnr, &ssim);
+        if (rc != 0) return rc < 0 ? rc : -12;
+        char buf[128];
+        snprintf(buf, sizeof(buf), "PSNR\t%.17g\nSSIM\t%.17g", psnr, ssim);
+        write_text(sd.save_path + "/metrics/" + it + ".txt", buf);
+        final_psnr = psnr;
+        final_ssim = ssim;
+      }
+      return 1;
+    }
+    return 0;
+  }
+
+  // score the prepared iteration's candidates, keep the arg-max, account for the movement (:1969-2264); -> 0 or an error
+  int nbv_decide() {
+    Share_Data& sd = *share_data;
+    const int n_views = (int)view_space->views.size();
+    const std::vector<int>& candidates = run.candidates;
+    const int iteration = run.iteration;
+    const std::string it = std::to_string(iteration);
+    const double infer_t0 = now_seconds();
+    int next_view_id = -1;
+    switch (sd.method_of_IG) {
+      case RandomIterative: { // :1974-1979
+        next_view_id = (int)(run.rng() % (unsigned)n_views);
+        while (run.chosen_nbvs_set.count(next_view_id)) next_view_id = (int)(run.rng() % (unsigned)n_views);
         break;
       }
-      const double infer_t0 = now_seconds();
-      int next_view_id = -1;
-      switch (sd.method_of_IG) {
-        case RandomIterative: { // :1974-1979
-          next_view_id = (int)(rng() % (unsigned)n_views);
-          while (chosen_nbvs_set.count(next_view_id)) next_view_id = (int)(rng() % (unsigned)n_views);
-          break;
-        }
-        case EnsembleRGB:
-        case EnsembleRGBDensity:
-        case PSNRCoverage: { // :2039-2161: score every unchosen view, keep the arg-max
-          std::vector<double> scores(candidates.size(), 0.0);
-          if (sd.score_from_pngs && sd.method_of_IG != PSNRCoverage) {
-            // the reference's data flow, call for call: one engine run per member (:2041-2043, :2101-2103), then the PNGs
-            // (no train_time/<it>.txt here: the reference writes it for ensemble_id == -1 only, :1707-1711)
-            for (int ensemble_id = 0; ensemble_id < sd.ensemble_num; ensemble_id++) {
-              const int rc = train_by_instantNGP(it, "100", true, ensemble_id);
-              if (rc != 0) return rc;
-            }
-            for (size_t k = 0; k < candidates.size(); k++) {
-              const int rc = view_uncertainty_from_pngs(sd.method_of_IG, it, candidates[k], &scores[k]);
-              if (rc != 0) return rc;
-            }
-          } else {
-            const int rc = score_candidates(it, candidates, scores);
+      case EnsembleRGB:
+      case EnsembleRGBDensity:
+      case PSNRCoverage: { // :2039-2161: score every unchosen view, keep the arg-max
+        std::vector<double> scores(candidates.size(), 0.0);
+        if (sd.score_from_pngs && sd.method_of_IG != PSNRCoverage) {
+          // the reference's data flow, call for call: one engine run per member (:2041-2043, :2101-2103), then the PNGs
+          // (no train_time/<it>.txt here: the reference writes it for ensemble_id == -1 only, :1707-1711)
+          for (int ensemble_id = 0; ensemble_id < sd.ensemble_num; ensemble_id++) {
+            const int rc = train_by_instantNGP(it, "100", true, ensemble_id);
             if (rc != 0) return rc;
           }
-          last_scores = scores;
-          if (on_scores) on_scores(iteration, candidates, scores); // an observer the shell may install (prv_planner: dump_scores)
-          double largest_view_uncertainty = -1e100; // :1971
-          int best_view_id = -1;
-          for (size_t k = 0; k < candidates.size(); k++) // ascending ids, strict '>' (:2088-2091)
-            if (scores[k] > largest_view_uncertainty) {
-              largest_view_uncertainty = scores[k];
-              best_view_id = candidates[k];
-            }
-          next_view_id = best_view_id;
-          break;
+          for (size_t k = 0; k < candidates.size(); k++) {
+            const int rc = view_uncertainty_from_pngs(sd.method_of_IG, it, candidates[k], &scores[k]);
+            if (rc != 0) return rc;
+          }
+        } else {
+          const int rc = score_candidates(it, candidates, scores);
+          if (rc != 0) return rc;
         }
-        default: // unreachable: method_in_scope() was checked before anything was written
-          return -10;
+        last_scores = scores;
+        if (on_scores) on_scores(iteration, candidates, scores); // an observer the shell may install (prv_planner: dump_scores)
+        double largest_view_uncertainty = -1e100; // :1971
+        int best_view_id = -1;
+        for (size_t k = 0; k < candidates.size(); k++) // ascending ids, strict '>' (:2088-2091)
+          if (scores[k] > largest_view_uncertainty) {
+            largest_view_uncertainty = scores[k];
+            best_view_id = candidates[k];
+          }
+        next_view_id = best_view_id;
+        break;
       }
-      if (next_view_id < 0) return -11;
-      chosen_nbvs.push_back(next_view_id); // :2246-2247
-      chosen_nbvs_set.insert(next_view_id);
-      write_text(sd.save_path + "/infer_time/" + it + ".txt",
-                 std::to_string(now_seconds() - infer_t0) + "\n"); // :2250-2253
-      // movement cost: view id \t local path \t running total (:2256-2264)
-      const auto local_path = get_local_path(view_space->views[chosen_nbvs[iteration]].init_pos,
-                                             view_space->views[next_view_id].init_pos,
-                                             view_space->object_center_world + Vec3(1e-10, 1e-10, 1e-10), view_space->predicted_size);
-      total_movement_cost += local_path.second;
-      write_text(sd.save_path + "/movement/" + it + ".txt",
-                 std::to_string(next_view_id) + "\t" + std::to_string(local_path.second) + "\t" + std::to_string(total_movement_cost) + "\n");
-      iteration++;
+      default: // unreachable: method_in_scope() was checked before anything was written
+        return -10;
     }
+    if (next_view_id < 0) return -11;
+    chosen_nbvs.push_back(next_view_id); // :2246-2247
+    run.chosen_nbvs_set.insert(next_view_id);
+    write_text(sd.save_path + "/infer_time/" + it + ".txt",
+               std::to_string(now_seconds() - infer_t0) + "\n"); // :2250-2253
+    // movement cost: view id \t local path \t running total (:2256-2264)
+    const auto local_path = get_local_path(view_space->views[chosen_nbvs[iteration]].init_pos,
+                                           view_space->views[next_view_id].init_pos,
+                                           view_space->object_center_world + Vec3(1e-10, 1e-10, 1e-10), view_space->predicted_size);
+    total_movement_cost += local_path.second;
+    write_text(sd.save_path + "/movement/" + it + ".txt",
+               std::to_string(next_view_id) + "\t" + std::to_string(local_path.second) + "\t" + std::to_string(total_movement_cost) + "\n");
+    run.iteration++;
     return 0;
   }
 };

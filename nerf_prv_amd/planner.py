@@ -66,6 +66,7 @@ HOST_SIGNATURES = {
     "prvh_star_barrier": (_i, [_vp]),
     "prvh_nbv_loop": (_i, [_vp, _vp, _d, _i, _i, SCORE_FN, _vp, C.POINTER(LoopResult)]),
     "prvh_method_in_scope": (_i, [_i]),
+    "prvh_member_owner": (_i, [_i, _i, _i, _i]),
     "prvh_pcd_read": (C.c_longlong, [C.c_char_p, _vp, _vp, C.c_longlong]),  # deprecated stub
     "prvh_nbv_loop_budget": (_i, [_vp, _vp, _d, _i, _i, SCORE_FN, _vp, _i, C.POINTER(LoopResult)]),  # deprecated stub
 }

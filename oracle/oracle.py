@@ -58,6 +58,10 @@ def train_opts(**kw):
         o["n_samples"] = NGP_MAX_STEPS if kw["step_mode"] == STEP_NGP else 128
     if "n_samples" in kw and "step_mode" not in kw:
         o["step_mode"] = STEP_FIXED_S
+    if "step_mode" not in kw and max(o["patch_w"], 1) * max(o["patch_h"], 1) > 1:
+        o["step_mode"] = STEP_FIXED_S
+        if "n_samples" not in kw:
+            o["n_samples"] = 128
     return TrainOpts(**o)
 
 

@@ -496,3 +496,30 @@ def test_score_path_key_selects_the_references_png_data_flow(config, tmp_path):
     bad.write_text(open(config).read() + "score_path: files\n")
     with pytest.raises(IOError, match="score_path"):
         planner.ShareData(bad, "a", -1, -1, 3)
+
+
+def test_member_trainings_are_dealt_round_robin_over_the_ranks():
+    """prv_planner `shard: members` (BASELINE configs[4] on 8 GPUs: 5 objects x 5 members = 25 trainings per lockstep round):
+    pair object * E + member goes to rank pair % world -- every pair has exactly one owner, the ranks' loads differ by at
+    most one, an ensemble's members sit on different ranks while world >= E, and the plan's idle share is what DESIGN.md
+    section 8 states (8 GPUs: loads 4,3,3,3,3,3,3,3 -> 25 of 32 slots busy; `shard: objects` keeps 5 of 8 GPUs busy)"""
+    from nerf_prv_amd import planner
+
+    h = planner.host()
+    E, objects = 5, 5
+    for world in (1, 2, 3, 8, 16):
+        load = [0] * world
+        for o in range(objects):
+            owners = [h.prvh_member_owner(o, e, E, world) for e in range(E)]
+            assert all(0 <= r < world for r in owners)
+            if world >= E:
+                assert len(set(owners)) == E  # no rank trains two members of one object
+            for r in owners:
+                load[r] += 1
+        assert sum(load) == objects * E and max(load) - min(load) <= 1
+        if world == 8:
+            assert sorted(load, reverse=True) == [4, 3, 3, 3, 3, 3, 3, 3]
+            assert 1.0 - sum(load) / (world * max(load)) == pytest.approx(7 / 32)  # 22 % of the GPU-rounds idle (objects: 3 of 8 = 37.5 %)
+        if world == 2:
+            assert sorted(load) == [12, 13]
+    assert h.prvh_member_owner(0, 5, 5, 8) == -1 and h.prvh_member_owner(0, 0, 5, 0) == -1 and h.prvh_member_owner(-1, 0, 5, 2) == -1
