@@ -218,6 +218,51 @@ def test_planner_views_sharded_trains_its_members_on_their_owners(ctx, tmp_path)
     assert all(se.count("train_members:") == 3 for _, se in res)  # both ranks went through the training step each iteration
 
 
+def test_planner_members_sharded_deals_the_trainings_and_walks_the_objects_in_lockstep(ctx, tmp_path):
+    """prv_planner `shard: members` (BASELINE configs[4] with more GPUs than objects): two objects, method 2 (two members
+    each), two ranks on the one GPU over the socket transport.  The four (object, member) trainings of a lockstep round are
+    dealt round-robin -- pair object * 2 + member to rank pair % 2: each rank trains ONE member of EACH object, side by side --,
+    then object by object the members are exchanged and the candidates scored views-sharded: both ranks end every round of
+    both objects with byte-identical records and the same chosen views.  The same yaml on ONE rank walks the same lockstep
+    rounds with all four trainings on that rank."""
+    exe = os.path.join(ROOT, "nerf_prv_amd", "prv_planner")
+    names = ["objA", "objB"]
+
+    def run(world, pre):
+        pre.mkdir()
+        cfg = pre / "cfg.yaml"
+        cfg.write_text(YAML.format(pre=pre, vs=os.path.join(GOLD, "hemisphere"), method=2,
+                                   model_source="n_steps: 40\ntrain_rays: 1024\ntrain_width: 64\ntrain_height: 36\nground_truth_seed: 4242\nshard: \"members\""))
+        base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        base.update(PRV_PLANNER_DUMP_RECORDS="1", PRV_PLANNER_TIMING="1")
+        port = free_port()
+        procs = []
+        for r in range(world):
+            env = dict(base, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), PRV_COMM="socket", MASTER_ADDR="127.0.0.1", PRV_COMM_PORT=str(port)) if world > 1 else base
+            procs.append(subprocess.Popen([exe, str(cfg)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+        res = feed_all_then_wait(procs, "21\n" + "\n".join(names) + "\n-1\n")
+        for p, (so, se) in zip(procs, res):
+            assert p.returncode == 0, so + se
+        return res
+
+    two = run(2, tmp_path / "two")
+    for r, (so, se) in enumerate(two):
+        assert "member trainings dealt round-robin" in so and so.count("lockstep batch of 2") == 2
+        # three lockstep rounds, in each: 2 trainings on this rank (one member of each object), side by side
+        assert se.count("train_pairs: 2 (object, member) trainings of this round on rank %d" % r) == 3, se
+        assert "train_members:" not in se  # nobody trained inside a scoring call
+    chosen = [[[int(x) for x in l.split(":")[1].split()] for l in so.splitlines() if l.startswith("chosen_nbvs:")] for so, _ in two]
+    assert chosen[0] == chosen[1] and len(chosen[0]) == 2 and all(len(set(c)) == 4 for c in chosen[0])
+    for name in names:
+        for it in range(3):
+            a = (tmp_path / "two" / "Compare" / "ShapeNet" / f"{name}_m2_v1_t0" / "records" / f"{it}.bin").read_bytes()
+            b = (tmp_path / "two" / "rank1" / "Compare" / "ShapeNet" / f"{name}_m2_v1_t0" / "records" / f"{it}.bin").read_bytes()
+            assert a == b and len(a) == 16 * (4 - it) and np.isfinite(np.frombuffer(a, api.RECORD_DTYPE)["score"]).all()
+    one = run(1, tmp_path / "one")
+    so, se = one[0]
+    assert se.count("train_pairs: 4 (object, member) trainings of this round on rank 0") == 3 and so.count("chosen_nbvs:") == 2
+
+
 def test_communicator_outliving_its_context_is_inert():
     """destroying the context first (interpreter shutdown order) must not leave the communicator pointing at freed memory"""
     c2 = api.Context(0)
