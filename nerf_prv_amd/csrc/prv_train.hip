@@ -622,24 +622,29 @@ void train_tile_kernel(TrainTileParams P) {
     if (sid < n_samples) in.seed = P.seeds[sid];
   };
   const int lane_outer = lane;
-  for (uint32_t tile = P.tile_begin + blockIdx.x; tile < ((PRV_TRAIN_ABLATE & 64) && !FWD ? 0u : n_tiles); tile += gridDim.x) {
+  // Backward: only LIVE tiles are walked -- tile_live[t] != 0: the compositing kernel saw a used sample there.  Samples behind
+  // their ray's termination are listed and evaluated (the forward pass cannot know) but carry no gradient, and they form runs
+  // (the list is ray by ray in depth order): under the engine's marcher a learnt opaque surface has hundreds of live steps
+  // behind it -- a third of the list in the planner loop's steady state, nine tenths in its one-view first round.  A block
+  // clears the bytes of the tiles it has read (it is their only reader), so the next step starts from zeros.
+  auto next_live = [&](uint32_t t) {
+    if constexpr (!FWD)
+      while (t < n_tiles && P.tile_live && P.tile_live[t] == 0) t += gridDim.x;
+    return t;
+  };
+  TileIn pre; // MODE 2: the NEXT live tile's kept activations, fetched while this one is worked on
+  uint32_t tile = next_live(P.tile_begin + blockIdx.x);
+  if ((PRV_TRAIN_ABLATE & 64) && !FWD) tile = n_tiles;
+  if constexpr (MODE == 2)
+    if (tile < n_tiles) fetch_tile(tile, lane_outer, pre);
+  for (; tile < n_tiles;) {
     // The lane id is made opaque once per tile: everything derived from it inside the loop (some 70 LDS addresses of the
     // [row][sample] arrays) is then recomputed per tile instead of being hoisted out of the loop and kept in registers for
     // the whole kernel, which is what pushed the register-chain instance past 256 of them.
     int lane = lane_outer;
     if constexpr (MODE == 2) asm volatile("" : "+v"(lane)); // (the LDS-chain instances are faster with the hoisted form: they have the registers)
     const int tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
-    if constexpr (!FWD) {
-      // A tile none of whose samples carries a gradient is skipped whole: samples behind their ray's termination are listed
-      // and evaluated (the forward pass cannot know) but seeded with zeros, and they form runs -- the list is ray by ray in
-      // depth order.  Under the engine's marcher a learnt opaque surface has hundreds of live steps behind it: a third of
-      // the list in the planner loop's steady state, nine tenths in its one-view first round (every wave sees the same 32
-      // seeds, so the decision is block-uniform without a barrier).
-      const uint32_t sid0 = tile * 32u + (uint32_t)(lane & 31);
-      float4 sd0 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (sid0 < n_samples) sd0 = P.seeds[sid0];
-      if (__ballot(sd0.x != 0.0f || sd0.y != 0.0f || sd0.z != 0.0f || sd0.w != 0.0f) == 0ull) continue;
-    }
+    const uint32_t tile_next = next_live(tile + gridDim.x);
     // ---- phase E: encode (8 threads per sample), SH inputs, gradient seeds
     const int s = tid & 31, g = tid >> 5;
     const uint32_t sid = tile * 32u + (uint32_t)s;
@@ -653,7 +658,17 @@ void train_tile_kernel(TrainTileParams P) {
     if constexpr (SAVED) {
       // the tile's 16 KB of kept activations, its 32 sample positions and its gradient seeds: independent loads
       TileIn in;
-      fetch_tile(tile, lane, in);
+      if constexpr (MODE == 2) {
+        in = pre;
+        // (opaque here: otherwise the unpacking of these registers is scheduled right behind the loads of the PREVIOUS
+        // iteration -- pure arithmetic on their results -- and the wave waits for the prefetch the moment it is issued)
+#pragma unroll
+        for (int i = 0; i < kActSlots / 4; i++) asm volatile("" : "+v"(in.av[i].x), "+v"(in.av[i].y), "+v"(in.av[i].z), "+v"(in.av[i].w));
+        asm volatile("" : "+v"(in.pos[0]), "+v"(in.pos[1]), "+v"(in.pos[2]));
+        asm volatile("" : "+v"(in.seed.x), "+v"(in.seed.y), "+v"(in.seed.z), "+v"(in.seed.w));
+      } else {
+        fetch_tile(tile, lane, in);
+      }
       seed = in.seed;
       const uint4* av = in.av;
       const float* pos = in.pos;
@@ -670,11 +685,15 @@ void train_tile_kernel(TrainTileParams P) {
       for (int i = 0; i < kActSlots / 4; i++) {
         const int q = wave + 4 * i; // slot of this wave's 64 words: lane = (half, sample)
         const uint4 v = av[i];
-        const _Float16* e = reinterpret_cast<const _Float16*>(&v);
+        const uint32_t vw[4] = {v.x, v.y, v.z, v.w}; // (halves by shifts, not by a pointer cast: the cast makes the compiler carry the
+        // prefetched registers from iteration to iteration as sixteen-bit pieces, cut up the moment the load returns)
 #pragma unroll
-        for (int j = 0; j < 8; j++) A[act_row<F>(q, h, j) * TSA + r] = e[j];
+        for (int j = 0; j < 8; j++) A[act_row<F>(q, h, j) * TSA + r] = __builtin_bit_cast(_Float16, (uint16_t)(vw[j >> 1] >> (16 * (j & 1))));
       }
       __syncthreads(); STAMP(2);
+      // the next live tile's activations, positions and seeds: in flight while this tile's chain, dW and scatter run
+      if constexpr (MODE == 2)
+        if (tile_next < n_tiles) fetch_tile(tile_next, lane, pre);
     } else {
     {
       float pos[3] = {0.5f, 0.5f, 0.5f}, dir[3] = {0.f, 0.f, 1.f};
@@ -749,6 +768,7 @@ void train_tile_kernel(TrainTileParams P) {
         if (h == 0 && o < n_samples) P.logits[o] = make_float4(od0, a[0], a[1], a[2]);
       }
       __syncthreads(); STAMP(7);
+      tile = tile_next; // (forward tiles: every tile is walked)
       continue;
     }
     } // !saved
@@ -1073,6 +1093,8 @@ void train_tile_kernel(TrainTileParams P) {
       }
     }
     __syncthreads(); STAMP(15);
+    if (P.tile_live && threadIdx.x == 0) P.tile_live[tile] = 0; // read by this block alone, at the top of the iteration
+    tile = tile_next;
   }
   if (!FWD) { // this block's weight-gradient tiles -> its own slot of the partials (plain stores; a second
     // kernel sums the slots in block order: no same-address atomics, and a reproducible sum)
@@ -1389,6 +1411,7 @@ __global__ __launch_bounds__(256) void train_composite_kernel(TrainCompositePara
       tail[q] += __shfl(incl, 0);
     }
     if (have) P.seeds[sid] = usedl ? make_float4(d_sigma * c.sg, d_orr[0], d_orr[1], d_orr[2]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (usedl && P.tile_live) P.tile_live[sid >> 5] = 1; // the backward pass walks the tiles that hold a used sample (and clears the byte)
   }
 }
 

@@ -104,6 +104,9 @@ struct TrainTileParams {
   // deterministic = 1 (tests): the table gradient is summed in 64-bit fixed point (table_grad_q, one word per scalar,
   // value * 2^kGradQBits; integer adds commute) and converted by the table's Adam launch; NULL: f32 atomics into table_grad
   long long* table_grad_q;
+  // one byte per 32-sample tile, set by the compositing kernel where a tile holds a used sample, cleared by the backward block
+  // that walks the tile: the backward pass skips the tiles behind the rays' terminations (NULL: every tile is walked)
+  uint8_t* tile_live;
 };
 constexpr int kGradQBits = 40;
 constexpr size_t kActTileBytes = (16 * 64 + 32) * 16; // kept activations of a 32-sample tile: 16 slots x 64 lanes x 16 B, then 32 positions
@@ -122,6 +125,7 @@ struct TrainCompositeParams {
   uint32_t* ray_used;
   const uint32_t* slot_of; // patch mode: list position of (ray, k-th live sample), row stride S; NULL: offset + k
   int S;
+  uint8_t* tile_live; // TrainTileParams::tile_live
 };
 
 struct AdamParams {
