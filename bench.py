@@ -69,9 +69,9 @@ ATOMIC_REQ_PER_SAMPLE = {"ngp": 9.76, "fixed": 26.35}
 ATOMIC_REQ_FILE = os.path.join("profiles", "r06_train_rules.txt")
 ISSUE_PEAK_GCYC = N_SIMD * MAX_CLOCK_HZ / 1e9  # 2457.6 G SIMD issue-cycles/s at the 2.4 GHz maximum clock
 VALU_PEAK_GINST = ISSUE_PEAK_GCYC / ISSUE_CYCLES["c4"]  # wave-instructions/s if every instruction were c4 (kept for the detail object)
-ROUND_COST_FILE = os.path.join("profiles", "r05_round_cost.json")  # VALU instructions per wave-round, from the PMC pass
-TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")    # fabric-side bytes per launch, from the PMC passes
-ISA_CLASSES_FILE = os.path.join("profiles", "r05_isa_classes.json")  # static issue-class histogram of the hot loop (scripts/isa_count.py)
+ROUND_COST_FILE = os.path.join("profiles", "r06_round_cost.json")  # VALU instructions per wave-round, from the PMC pass
+TRAFFIC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")    # fabric-side bytes per launch, from the PMC passes
+ISA_CLASSES_FILE = os.path.join("profiles", "r06_isa_classes.json")  # static issue-class histogram of the hot loop (scripts/isa_count.py)
 
 
 # The algorithmic floor of the render kernel: wave-instructions one 64-sample wave iteration NEEDS for this algorithm
@@ -119,6 +119,7 @@ def parse_args(argv=None):
                          "(reported as `reduced`; the default trains at the library default = upstream's 2^18-sample batch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference-round-fixed", action="store_true", help="reference_round: also the round with 128 uniform samples per ray (not the reference's rule)")
     ap.add_argument("--no-training", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the field512 / baseline-scene / first-hit side measurements")
     ap.add_argument("--train-steps", type=int, default=300)
@@ -861,7 +862,7 @@ def run_rank(args):
         r.close()
         # (3) the reference's OWN scoring round: 540 candidates at 80x45, spp 16, 5 members, EnsembleRGBDensity
         #     (main.cpp:1796-1806, run.py:48,304, Share_Data.hpp:505-510), in both stepping rules
-        extras["reference_round"] = reference_round(env, field_kw(args.field, "dense"), layout_of, variant_of)
+        extras["reference_round"] = reference_round(env, field_kw(args.field, "dense"), layout_of, variant_of, args)
         # (4) the headline's views under the engine's own stepping rule
         extras["ngp_step"] = ngp_step_round(solo, fkw, args, layout_of, variant_of)
 
@@ -972,7 +973,9 @@ def run_rank(args):
         rr = extras.get("reference_round")
         if rr:
             lifted.update({"reference_round_ms": rr["ngp_step"]["ms_per_round"], "reference_round_views_per_s": rr["ngp_step"]["views_per_s"],
-                           "reference_round_fixed_128_ms": rr["fixed_128"]["ms_per_round"]})
+                           })
+            if "fixed_128" in rr:
+                lifted["reference_round_fixed_128_ms"] = rr["fixed_128"]["ms_per_round"]
         if extras.get("ngp_step"):
             lifted["ngp_step_samples_per_s"] = extras["ngp_step"]["value"]
         if training:
@@ -1034,7 +1037,7 @@ def run_rank(args):
     return 0
 
 
-def reference_round(env, fkw, layout_of, variant_of):
+def reference_round(env, fkw, layout_of, variant_of, args):
     """the reference's own scoring round on this GPU: 540 candidate views at 80x45, 16 sub-samples per pixel, a 5-member
     ensemble, EnsembleRGBDensity -- once with 128 uniform samples per ray, once with the engine's stepping rule; each with
     its own roofline of the render launches (one per member), measured in the run like the headline's"""
@@ -1068,7 +1071,9 @@ def reference_round(env, fkw, layout_of, variant_of):
             out_m.append(row)
         return out_m
 
-    for name, spr in (("fixed_128", 128), ("ngp_step", 0)):
+    # (the round with 128 uniform samples per ray is NOT the reference's rule -- it renders with the engine's stepping -- and left
+    # the default line in round 6: --reference-round-fixed brings it back)
+    for name, spr in ((("fixed_128", 128),) if args.reference_round_fixed else ()) + (("ngp_step", 0),):
         opts = api.engine_render_opts(80, 45, spr, 16, 0.01, background=(0, 0, 0, 1))
         rec, st = ctx.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, slots, cams, None, opts, want_stats=True)
         torch.cuda.synchronize()
@@ -1091,12 +1096,15 @@ def reference_round(env, fkw, layout_of, variant_of):
                      "best_view": int(ctx.argmax(rec, np.arange(n_views))),
                      "roofline": {k: roof[k] for k in ("kernel", "bound", "frac", "peak", "achieved", "unit", "avg_launch_ms", "units_per_launch",
                                                        "slot_utilisation", "samples_per_s_in_kernel", "shader_clock_ghz_measured")}}
-    out["fixed_128"]["note"] = ("not the reference's rule (it renders with the engine's stepping: ngp_step).  Slot utilisation stays ~0.68 here by "
+    if "fixed_128" in out:
+        out["fixed_128"]["note"] = ("not the reference's rule (it renders with the engine's stepping: ngp_step).  Slot utilisation stays ~0.68 here by "
                                 "MEASUREMENT: relocation (tail merge + pool) lifts it to 0.92 and makes this round slower, 46.4 -> 48.8 ms -- 128 uniform "
                                 "samples share no cell, so the corner cache that pays for relocation under the engine's rule has nothing to keep "
                                 "(profiles/r05_march_multi.txt)")
     out["ngp_step"]["note"] = ("the five members' rays are marched in ONE launch (march_multi_kernel: one occupancy walk per ray answers every member), "
-                               "then one render launch per member")
+                               "then one render launch per member; per_member: each launch's mean duration beside the samples that member's field makes "
+                               "the rays evaluate -- the members are random fields behind one occupancy grid, their rays stop at different depths: the "
+                               "launches' spread is the spread of evaluated samples (DESIGN.md section 10, row 2: why the five launches were not fused)")
     cams.close()
     return out
 

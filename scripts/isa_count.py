@@ -4,7 +4,7 @@ prints, per basic block with more than a few VALU instructions, the VALU / MFMA 
 histogram of the two hot blocks (gather, MLP + compositing).
   python scripts/isa_count.py [F] [NDENSE] [ngp: 0|1] [--json]
 --json: also record the issue-class histogram of the two hot blocks (c2 / c4 / c8 / mfma: the classes
-scripts/valu_rate.hip measured, profiles/r04_valu_issue_rate.txt) in profiles/r05_isa_classes.json, keyed by the kernel
+scripts/valu_rate.hip measured, profiles/r04_valu_issue_rate.txt) in profiles/r06_isa_classes.json, keyed by the kernel
 instance and stamped with the digest of the device code -- what bench.py prices the ISSUED instructions with."""
 import collections
 import os
@@ -85,7 +85,7 @@ if WANT_JSON and len(hot) >= 2:
     hist = collections.Counter()
     for a, z in hot[:2]:  # the gather block and the MLP + compositing block: once per 64-slot iteration
         hist.update(issue_class(o) for o in ops(a, z) if cls(o) in ("valu", "mfma"))
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_isa_classes.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_isa_classes.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
     data[f"64<{F}, {ND}>" + (" ngp" if NGP == "1" else "") + (" cache" if CACHE == "1" else "")] = dict(hist, device_code_sha256=_lib.device_code_digest(),
                                                                     source="scripts/isa_count.py: static histogram of the gather block and the MLP + compositing block")

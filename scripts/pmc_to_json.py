@@ -1,6 +1,6 @@
 """PMC summaries (scripts/pmc.sh) + the kbench line of the same workload -> the two JSON files bench.py reads:
-profiles/r05_round_cost.json (VALU / MFMA instructions per 32-sample wave-round of render_queue64) and
-profiles/r05_pmc_traffic.json (fabric-side bytes per launch), keyed "<variant> <scene>" and stamped with the sha256 of
+profiles/r06_round_cost.json (VALU / MFMA instructions per 32-sample wave-round of render_queue64) and
+profiles/r06_pmc_traffic.json (fabric-side bytes per launch), keyed "<variant> <scene>" and stamped with the sha256 of
 the libprv_hip.so they were measured on (bench.py compares it with the library it loads).  usage:
   python scripts/pmc_to_json.py <key e.g. "64<4, 5> baseline"> <pmc summary.txt> <kbench log> <tag>"""
 import hashlib, json, os, re, sys
@@ -32,14 +32,14 @@ def update(path, entry):
     json.dump(data, open(full, "w"), indent=1)
 
 if "SQ_INSTS_VALU" in rq:
-    update("profiles/r05_round_cost.json", {
+    update("profiles/r06_round_cost.json", {
         "valu_insts_per_round": rq["SQ_INSTS_VALU"] / rounds,
         "mfma_insts_per_round": rq.get("SQ_INSTS_MFMA", 0) / rounds if "SQ_INSTS_MFMA" in rq else None,
         "valu_active_quadcycles_per_inst": rq["SQ_ACTIVE_INST_VALU"] / rq["SQ_INSTS_VALU"] if "SQ_ACTIVE_INST_VALU" in rq else None,
         "sq_insts_valu_per_launch": rq["SQ_INSTS_VALU"], "wave_rounds_per_launch": rounds, "samples_evaluated_per_launch": ev,
         "source": f"rocprofv3 --kernel-trace --pmc (scripts/pmc.sh), one render_queue launch of scripts/kbench.py; {tag}"})
 if "FETCH_SIZE" in rq and "WRITE_SIZE" in rq:
-    update("profiles/r05_pmc_traffic.json", {
+    update("profiles/r06_pmc_traffic.json", {
         "fetch_kib_per_launch": rq["FETCH_SIZE"], "write_kib_per_launch": rq["WRITE_SIZE"],
         "tcc_hit_per_launch": rq.get("TCC_HIT_sum"), "tcc_miss_per_launch": rq.get("TCC_MISS_sum"),
         "samples_evaluated_per_launch": ev,
