@@ -424,8 +424,12 @@ def kernel_figures(m, variant, hbm_bound, scene, layout):
         # (achieved = the algorithmic bytes, as the contract defines it; the fraction is taken on what reaches the fabric -- the
         # committed PMC pass's FETCH_SIZE + WRITE_SIZE, ~0.88 of the algorithmic bytes: rays of a cohort share lines in L1 / L2)
         fabric_gbs = traffic_bytes / kernel_s / 1e9 if traffic_bytes else alg_gbs
-        head = {"bound": "fabric_request_rate", "frac": alg_gbs / GATHER_CALIB_GBS, "peak": GATHER_CALIB_GBS, "achieved": alg_gbs,
-                "unit": "GB/s of random 64-B requests (peak = the gather calibration at this footprint; algorithmic bytes, so frac can pass 1: see fabric_side_frac)"}
+        # the peak in ALGORITHMIC bytes: the calibration's 3.8 TB/s of 64-B lines, times the algorithmic bytes this kernel gets out
+        # of a fabric-side byte (1 / 0.88 from the committed PMC pass; 1 without one) -- so that frac = achieved / peak = the share
+        # of the fabric's request rate the launch uses (= fabric_side_frac)
+        peak_alg = GATHER_CALIB_GBS * (alg_gbs / fabric_gbs if fabric_gbs else 1.0)
+        head = {"bound": "fabric_request_rate", "frac": alg_gbs / peak_alg, "peak": peak_alg, "achieved": alg_gbs,
+                "unit": "GB/s of algorithmic gather bytes (peak = the 3.8 TB/s random-64-B-request calibration at this footprint x algorithmic bytes per fabric-side byte)"}
         note = ("64 MiB table: lives in the 256 MiB Infinity Cache, so neither this line nor any other in the record is HBM-bandwidth-bound "
                 "(FETCH_SIZE includes Infinity-Cache hits); fabric-side reads ~= algorithmic bytes, random 64-B requests, against the "
                 "3.8 TB/s the gather calibration (profiles/archive/r01_gather_calib.txt) reaches for this access shape; hbm_algorithmic_frac = the "

@@ -161,21 +161,23 @@ def test_training_images_at_another_size_than_the_dataset(ctx, oracle, scene):
     assert loss == pytest.approx(want_loss, rel=1e-3) and rel_l2(mg, want_mg) < 1e-3 and rel_l2(tg, want_tg) < 1e-3
 
 
-def test_ensemble_members_step_side_by_side(ctx, oracle, scene):
+@pytest.mark.parametrize("rule", ["fixed_s", "ngp"])
+def test_ensemble_members_step_side_by_side(ctx, oracle, scene, rule):
     """prv_train_steps_multi: members on their own streams give what each gives alone (up to atomics order)"""
     kw, ocams, cams, imgs = scene
+    extra = dict(n_samples=24) if rule == "fixed_s" else dict(step_mode=api.L.STEP_NGP, n_samples=1024, target_samples=20000)
     d = api.field_desc(**dict(kw, table_amp=1e-4))
     u8 = ctx.torch.from_numpy(imgs)
     alone = []
     for e in range(3):
         ctx.fresh_model(e, d, 500 + e)
-        tr = api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=256, n_samples=24, seed=900 + e, occ_every=8, occ_sigma_thresh=0.1))
+        tr = api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=256, seed=900 + e, occ_every=8, occ_sigma_thresh=0.1, **extra))
         alone.append(tr.steps(24))
         tr.close()
     trs = []
     for e in range(3):
         ctx.fresh_model(e, d, 500 + e)
-        trs.append(api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=256, n_samples=24, seed=900 + e, occ_every=8, occ_sigma_thresh=0.1)))
+        trs.append(api.Trainer(ctx, e, cams, u8, api.train_opts(n_rays=256, seed=900 + e, occ_every=8, occ_sigma_thresh=0.1, **extra)))
     together = api.train_many(trs, 24)
     assert together.shape == (3, 24) and all(t.info()["steps"] == 24 for t in trs)
     np.testing.assert_allclose(together, np.stack(alone), rtol=2e-2)
@@ -296,16 +298,18 @@ def test_rays_that_miss_everything(ctx, oracle, scene):
     o = np.zeros_like(o)
     f = oracle.OracleField(f.desc, params=(t, m, o))
     ctx.load_model(3, api.field_desc(**kw), t, m, o)
-    base = dict(n_rays=200, n_samples=24, occ_every=0, l2_reg=0.0)
-    otr = oracle.OracleTrainer(f, oracle.train_opts(**base), ocams, imgs)
-    gtr = api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(**base))
-    loss, tg, mg = gtr.gradients()
-    assert gtr.info()["samples_last"] == otr.samples_last == 0
-    assert loss == pytest.approx(otr.gradients()[0], rel=1e-5) and loss > 0 and not tg.any() and not mg.any()
-    before = gtr.master()
-    gtr.steps(2)
-    after = gtr.master()
-    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    for base in (dict(n_rays=200, n_samples=24, occ_every=0, l2_reg=0.0),
+                 dict(n_rays=200, step_mode=api.L.STEP_NGP, n_samples=1024, occ_every=0, l2_reg=0.0)):  # both sampling rules
+        otr = oracle.OracleTrainer(f, oracle.train_opts(**base), ocams, imgs)
+        gtr = api.Trainer(ctx, 3, cams, ctx.torch.from_numpy(imgs), api.train_opts(**base))
+        loss, tg, mg = gtr.gradients()
+        assert gtr.info()["samples_last"] == otr.samples_last == 0
+        assert loss == pytest.approx(otr.gradients()[0], rel=1e-5) and loss > 0 and not tg.any() and not mg.any()
+        before = gtr.master()
+        gtr.steps(2)
+        after = gtr.master()
+        assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+        gtr.close()
 
 
 def test_sample_budget_adapts_the_ray_count(ctx, oracle, scene):
