@@ -42,6 +42,7 @@ MFMA_PER_ROUND = 24      # v_mfma_f32_32x32x16_f16 per 32-slot round (prv_device
                          # kernel counts a wave iteration as two rounds)
 # peaks, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0        # 8 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming kernel reaches (MI355X_MICROARCH.md)
 L2_PEAK_GBS = 34500.0        # aggregate L2, ~34.5 TB/s
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16
 N_SIMD, MAX_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs
@@ -123,6 +124,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-training", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the field512 / baseline-scene / first-hit side measurements")
     ap.add_argument("--train-steps", type=int, default=300)
+    ap.add_argument("--no-field-hbm", action="store_true", help="skip the field_hbm side workload (a 448 MiB table: the one HBM-bound line of the record)")
     ap.add_argument("--no-config3", action="store_true", help="N > 1: skip the configs[3] sub-object (1024 views of the 512^3 field, strong scaling)")
     ap.add_argument("--train-patch", default="", help="full_loop: WxH, training rays drawn as patches of adjacent pixels (yaml train_patch_w / "
                                                       "train_patch_h; a speed / quality trade: profiles/r05_train_patch_study.txt)")
@@ -841,6 +843,69 @@ def run_rank(args):
             extras["field512_frac"] = roof512["frac"]
             extras["field512_avg_launch_ms"] = roof512["avg_launch_ms"]
             r.close()
+        # (1b) a table that really leaves the caches (round 6; the 512^3 field's 64 MiB sit in the 256 MiB Infinity Cache): seven
+        #      hashed levels of 64 MiB = 448 MiB of random 4-byte gathers.  Render only (no reference images: a second such field is
+        #      another gigabyte), 16 views; the roofline that binds THIS one is HBM: every 4-byte entry of a hashed level drags a
+        #      64-byte line out of DRAM, so beside the algorithmic fraction the line carries the line-traffic estimate
+        if args.field == "256" and not args.no_field_hbm:
+            hkw = dict(api.FIELD_HBM)
+            if args.scene == "baseline":
+                hkw.update(table_amp=0.1, density_bias=0.0)
+            ctx.synthetic_model(2, api.L.FieldDesc(**hkw), SEED_A)
+            n_hv = min(16, args.views_per_gpu)
+            hcams = ctx.cameras_from_matrices(np.asarray(main.tms)[:n_hv], main.fov_x, args.width, args.height, main.scale, main.offset)
+            hopts = api.render_opts(args.width, args.height, args.samples, 1, 1e-4)
+            himg = torch.empty((n_hv, args.height, args.width, 4), dtype=torch.float32, device=device)
+            _, hst = ctx.render(2, hcams, None, hopts, out=himg)
+            torch.cuda.synchronize()
+            ctx.profile_begin()
+            t_h = time.perf_counter()
+            h_reps = 3
+            for _ in range(h_reps):
+                ctx.render(2, hcams, None, hopts, out=himg, want_stats=False)
+            torch.cuda.synchronize()
+            dt_h = (time.perf_counter() - t_h) / h_reps
+            hprof = ctx.profile_end()
+            lay = ctx.model_layout(2)
+            k_s = hprof["render_ms"] * 1e-3 / max(1, hprof["render_launches"])
+            alg_gbs = hst.samples_evaluated * BYTES_PER_SAMPLE / k_s / 1e9
+            # lines per sample that cannot be cached: 8 corners of every hashed level, each its own 64-byte line (the table is
+            # 448 MiB of uniformly hashed entries); the dense levels' lines are shared by neighbouring samples and mostly hit
+            line_gbs = hst.samples_evaluated * lay["n_hashed_levels"] * 8 * 64 / k_s / 1e9
+            # ... and what the counters say (FETCH_SIZE + WRITE_SIZE of the committed PMC pass of this workload, per sample):
+            # neighbouring rays do share lines, even on the coarser hashed levels -- 18 lines per sample, not 56
+            tr = (load_json(TRAFFIC_FILE) or {}).get("hbm " + args.scene)
+            traffic_bytes = fabric_gbs_h = None
+            if tr:
+                traffic_bytes = (tr["fetch_kib_per_launch"] + tr["write_kib_per_launch"]) * 1024.0 / tr["samples_evaluated_per_launch"] * hst.samples_evaluated
+                fabric_gbs_h = traffic_bytes / k_s / 1e9
+            extras["field_hbm"] = {
+                "workload": f"{n_hv} views {args.width}x{args.height} x {args.samples} samples, synthetic field L=16 F=2 log2T=24 finest 2048: "
+                            f"{lay['n_hashed_levels']} hashed levels of 64 MiB (448 MiB of random gathers; canonical table "
+                            f"{lay['table_bytes_canonical'] / 2**20:.0f} MiB), {lay['n_dense_levels']} dense; generic gather with 32-bit offsets; render only",
+                "value": hst.samples_evaluated / dt_h, "unit": "ray-samples/s", "steps": h_reps, "ms_per_step": dt_h * 1e3,
+                "samples_evaluated_per_step": int(hst.samples_evaluated),
+                "roofline": {"kernel": "render_queue64_kernel<2, 0>", "bound": "hbm", "frac": alg_gbs / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
+                             "achieved": alg_gbs, "unit": "GB/s", "traffic": traffic_bytes, "avg_launch_ms": k_s * 1e3,
+                             "memory_side_GBps": fabric_gbs_h, "memory_side_frac_of_peak": fabric_gbs_h / HBM_PEAK_GBS if fabric_gbs_h else None,
+                             "memory_side_frac_of_achievable": fabric_gbs_h / HBM_ACHIEVABLE_GBS if fabric_gbs_h else None,
+                             "memory_side_frac_of_random_request_calibration": fabric_gbs_h / 3600.0 if fabric_gbs_h else None,
+                             "units_per_launch": float(hst.samples_evaluated), "bytes_per_unit": BYTES_PER_SAMPLE,
+                             "line_traffic_estimate_GBps": line_gbs, "line_traffic_frac_of_peak": line_gbs / HBM_PEAK_GBS,
+                             "line_traffic_frac_of_achievable": line_gbs / HBM_ACHIEVABLE_GBS,
+                             "note": "the one workload of the record whose table (448 MiB of hashed levels) exceeds the 256 MiB Infinity Cache: HBM-bound.  "
+                                     "frac = algorithmic gather bytes (512 B per sample) over the 8 TB/s peak; what the memory side moves is a 64-byte "
+                                     "line per 4-byte entry: memory_side_* = FETCH_SIZE + WRITE_SIZE of the committed PMC pass (1,176 B = 18 lines per "
+                                     "sample: neighbouring rays share lines even on the hashed levels; L2 hit 9 %) over the 8 TB/s peak, the guide's 6.3 "
+                                     "TB/s achievable, and the 3.3-3.6 TB/s the random-64-B-request calibration reaches at 1-4 GiB footprints "
+                                     "(profiles/archive/r01_gather_calib.txt) -- that last one, not the sequential peak, is this access shape's ceiling; "
+                                     "line_traffic_* = the no-sharing estimate (7 levels x 8 corners x 64 B per sample)"}}
+            extras["field_hbm_value"] = extras["field_hbm"]["value"]
+            extras["field_hbm_frac"] = alg_gbs / HBM_PEAK_GBS
+            extras["field_hbm_memory_side_frac"] = fabric_gbs_h / HBM_PEAK_GBS if fabric_gbs_h else None
+            hcams.close()
+            del himg
+            ctx.synthetic_model(2, api.L.FieldDesc(**field_kw(args.field, args.scene)), SEED_A)  # (the slot gives the gigabyte back)
         # (2) the other scene: dense (table U(-4,4), density bias 3: an opaque object, rays terminate early) when the
         #     headline is BASELINE.md section 6's nearly transparent one, and the other way round
         other = "dense" if args.scene == "baseline" else "baseline"
@@ -971,7 +1036,7 @@ def run_rank(args):
         }
         # scalars a parser that drops nested objects still keeps
         lifted = {"roofline_frac": roof["frac"], "roofline_bound": roof["bound"]}
-        for key in ("field512_value", "field512_frac", "field512_avg_launch_ms"):
+        for key in ("field512_value", "field512_frac", "field512_avg_launch_ms", "field_hbm_value", "field_hbm_frac", "field_hbm_memory_side_frac"):
             if key in extras:
                 lifted[key] = extras.pop(key)
         rr = extras.get("reference_round")

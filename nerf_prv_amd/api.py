@@ -25,6 +25,11 @@ FIELD_256 = dict(n_levels=8, n_features=4, log2_hashmap=19, base_res=16, finest_
                  density_bias=3.0, table_amp=4.0)
 FIELD_512 = dict(n_levels=16, n_features=2, log2_hashmap=21, base_res=16, finest_res=512, occ_res=128,
                  density_bias=3.0, table_amp=4.0)
+# a table that really leaves the caches (round 6): log2T = 24 at F = 2 -- seven hashed levels of 64 MiB each (448 MiB of random
+# 4-byte gathers against a 256 MiB Infinity Cache) behind nine dense ones; levels beyond 16 MiB take the generic gather's 32-bit
+# offsets (prv_api.cpp: FieldDev::wide_offsets)
+FIELD_HBM = dict(n_levels=16, n_features=2, log2_hashmap=24, base_res=16, finest_res=2048, occ_res=128,
+                 density_bias=3.0, table_amp=4.0)
 
 
 class PrvError(RuntimeError):

@@ -395,6 +395,7 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
   f.hash_mz_b = (805459861u * ebytes) & 0xffffffu;
   f.hash_m_b = (uint32_t)(((1ull << d.log2_hashmap) - 1ull) * ebytes);
   f.hash_shared = 1;
+  f.wide_offsets = 0;
   for (int l = 0; l < d.n_levels; l++)
     if (lv[l].hashed && (lv[l].res > lv[l].size || l < f.n_dense_levels)) f.hash_shared = 0;
   if (getenv("PRV_NO_PAIR")) f.hash_shared = 0;
@@ -403,11 +404,19 @@ int install_model(prv_ctx* c, int slot, const prv_field_desc& d, const uint16_t*
     L.scale = lv[l].scale;
     L.res_m1 = lv[l].res - 1;
     if (lv[l].res > 4096) return fail(c, PRV_E_INVALID, "level %d has %u vertices per axis (limit 4096)", l, lv[l].res);
-    if (lv[l].hashed) { // the kernel multiplies with v_mul_u32_u24: keep the low 24 bits
-      L.my_b = (2654435761u * ebytes) & 0xffffffu;
-      L.mz_b = (805459861u * ebytes) & 0xffffffu;
+    if (lv[l].hashed) {
+      // the kernels multiply with v_mul_u32_u24 (the low 24 bits of the constants are all a level of <= 16 MiB needs).  A hashed
+      // level LARGER than 16 MiB (round 6: tables that really leave the 256 MiB Infinity Cache, e.g. log2_hashmap 24 at F = 2)
+      // keeps the full 32-bit constants and runs the generic instance, whose gather then multiplies in 32 bits (wide_offsets)
+      if ((uint64_t)(lv[l].size - 1u) * ebytes >= (1ull << 32)) return fail(c, PRV_E_INVALID, "hashed level of 4 GiB or more");
       L.m_b = (lv[l].size - 1u) * ebytes;
-      if (L.m_b >= (1u << 24)) return fail(c, PRV_E_INVALID, "hashed level larger than 16 MiB (log2_hashmap too big for F=%d)", d.n_features);
+      const bool wide = L.m_b >= (1u << 24);
+      L.my_b = wide ? 2654435761u * ebytes : (2654435761u * ebytes) & 0xffffffu;
+      L.mz_b = wide ? 805459861u * ebytes : (805459861u * ebytes) & 0xffffffu;
+      if (wide) {
+        f.wide_offsets = 1;
+        f.hash_shared = 0;
+      }
     } else {
       L.my_b = ebytes << sx[l];
       L.mz_b = ebytes << (2 * sx[l]);

@@ -62,6 +62,7 @@ struct FieldDev {
   // the x term (x << esh) lies inside the mask by itself).
   uint32_t hash_my_b, hash_mz_b, hash_m_b;
   int hash_shared;
+  int wide_offsets; // some hashed level is larger than 16 MiB: its constants are full 32-bit, the (generic) gather multiplies in 32 bits
   float density_bias;
   float occ_lo[3], occ_hi[3]; // bounding box of the occupied cells, grown by one cell (march pass clips to it)
 };
@@ -316,6 +317,7 @@ __device__ __forceinline__ half2v cvt_pk_f16(float lo, float hi) { // {RNE(lo), 
 
 struct HashConsts { // the field's shared hash constants, wave-uniform (FieldDev::hash_*)
   uint32_t my_b, mz_b, m_b;
+  uint32_t wide; // FieldDev::wide_offsets (the generic gather's 32-bit multiplies)
 };
 enum { kLevelDense = 0, kLevelHashedShared = 1, kLevelGeneric = 2 };
 
@@ -395,9 +397,11 @@ __device__ __forceinline__ void encode_level2(const uint16_t* __restrict__ table
     uint32_t c1[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) c1[a] = min(c0[a] + 1u, L.res_m1);
+    // (levels beyond 16 MiB -- FieldDev::wide_offsets, wave-uniform -- need more than the 24 low bits of the products)
+    auto mul = [&](uint32_t a, uint32_t b) { return H.wide ? a * b : __umul24(a, b); };
     const uint32_t tx[2] = {(c0[0] << ESH) & L.m_b, (c1[0] << ESH) & L.m_b};
-    const uint32_t ty[2] = {__umul24(c0[1], L.my_b) & L.m_b, __umul24(c1[1], L.my_b) & L.m_b};
-    const uint32_t tz[2] = {(__umul24(c0[2], L.mz_b) & L.m_b) | L.off_b, (__umul24(c1[2], L.mz_b) & L.m_b) | L.off_b};
+    const uint32_t ty[2] = {mul(c0[1], L.my_b) & L.m_b, mul(c1[1], L.my_b) & L.m_b};
+    const uint32_t tz[2] = {(mul(c0[2], L.mz_b) & L.m_b) | L.off_b, (mul(c1[2], L.mz_b) & L.m_b) | L.off_b};
 #pragma unroll
     for (int c = 0; c < 8; c++) {
       const uint32_t byte_off = tx[c & 1] ^ ty[(c >> 1) & 1] ^ tz[c >> 2];

@@ -677,7 +677,7 @@ void render_queue64_kernel(RenderParams P) {
   // every lane gathers every level, so the level constants are wave-uniform: they are read straight from the kernel
   // arguments (scalar loads, SGPR operands) instead of LDS -> VGPRs
   const LevelDev* __restrict__ lvl = P.field.levels;
-  const HashConsts hc = {P.field.hash_my_b, P.field.hash_mz_b, P.field.hash_m_b};
+  const HashConsts hc = {P.field.hash_my_b, P.field.hash_mz_b, P.field.hash_m_b, (uint32_t)P.field.wide_offsets};
 
   const int lane = threadIdx.x & 63, r = lane & 31, g = lane >> 5; // g: the lane's group (A = 0, B = 1) AND its k-row half
 
@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(256) void debug_field64_kernel(FieldDev fd, const f
   dir_of(idxA, dA);
   dir_of(idxB, dB);
   half8 f[4];
-  const HashConsts hc = {fd.hash_my_b, fd.hash_mz_b, fd.hash_m_b};
+  const HashConsts hc = {fd.hash_my_b, fd.hash_mz_b, fd.hash_m_b, (uint32_t)fd.wide_offsets};
   encode_sample<F, NDENSE>(fd.table, lvl, hc, p[0], p[1], p[2], f);
   if (ok && feat) {
     typedef uint16_t ushort8 __attribute__((ext_vector_type(8)));

@@ -22,7 +22,7 @@ W, H = (args.width or args.size), (args.height or args.size)
 import torch
 from nerf_prv_amd import api, planner
 ctx = api.Context(0)
-fd = dict(api.FIELD_256 if args.field == "256" else api.FIELD_512)
+fd = dict(api.FIELD_256 if args.field == "256" else api.FIELD_HBM if args.field == "hbm" else api.FIELD_512)
 if args.scene == "baseline": fd.update(table_amp=0.1, density_bias=0.0)
 if args.bias is not None: fd["density_bias"] = args.bias
 ctx.synthetic_model(0, api.L.FieldDesc(**fd), 0x5EED0001)

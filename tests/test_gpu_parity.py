@@ -427,7 +427,7 @@ def test_precept_per_voxel_ray_cast_with_realsense_model(ctx, oracle, fields):
 def test_error_behaviour(ctx, fields, cams):
     cs, ocams, w, h = cams
     with pytest.raises(api.PrvError) as e:
-        ctx.render(8, cs, None, api.render_opts(w, h))  # slot out of range
+        ctx.render(api.L.MAX_SLOTS, cs, None, api.render_opts(w, h))  # slot out of range (PRV_MAX_SLOTS)
     assert e.value.code == api.L.PRV_E_INVALID
     fresh = api.Context(0)
     cs2 = fresh.cameras_from_matrices(np.eye(4)[None], util.FOV_X, w, h, 1.0, [0.5, 0.5, 0.5])

@@ -181,3 +181,26 @@ def test_ngp_step_whole_views_of_the_headline_scene(ctx, oracle, round_cams, sce
         n_eval += ne
     assert n_eval > 0
     f.close()
+
+
+def test_whole_views_of_a_table_beyond_the_caches(ctx, oracle, round_cams, round_march_count):
+    """round 6: a field whose hashed levels are 64 MiB each (log2T = 24, F = 2, finest 2048: seven hashed levels = 448 MiB of
+    random gathers, beyond the 256 MiB Infinity Cache -- bench.py's `field_hbm`).  Levels larger than 16 MiB take the generic
+    gather with 32-bit offsets (FieldDev::wide_offsets); the limit of rounds 1-5 refused them.  Four views of the 64-view
+    round in one call: the march count is the analytic grid's, four WHOLE 800x800 views against the oracle pixel by pixel."""
+    cams, ocams = round_cams
+    kw = dict(api.FIELD_HBM, table_amp=0.1, density_bias=0.0)
+    ctx.synthetic_model(6, api.L.FieldDesc(**kw), util.SEED_A)
+    lay = ctx.model_layout(6)
+    assert lay["n_hashed_levels"] == 7 and lay["n_dense_levels"] == 9
+    f = oracle.OracleField(oracle.desc(**kw), seed=util.SEED_A)
+    views = [0, 21, 42, 63]
+    opts = api.render_opts(W, H, S, 1, 1e-4)
+    img, st = ctx.render(6, cams, views, opts)
+    assert int(st.samples_live) == sum(round_march_count[v] for v in views) == int(st.samples_evaluated)
+    for k, v in enumerate(views):
+        want, ne = f.render(ocams[v], W, H, S, 1, 1e-4, threads=THREADS)
+        util.assert_pixels_close(img[k].cpu().numpy(), want)
+        assert ne == round_march_count[v] and want[..., 3].max() > 0.05
+    f.close()
+    ctx.synthetic_model(6, api.L.FieldDesc(**SCENES["baseline256"]), util.SEED_A)  # (give the gigabyte back)
