@@ -853,7 +853,10 @@ def run_rank(args):
                 hkw.update(table_amp=0.1, density_bias=0.0)
             ctx.synthetic_model(2, api.L.FieldDesc(**hkw), SEED_A)
             n_hv = min(16, args.views_per_gpu)
-            hcams = ctx.cameras_from_matrices(np.asarray(main.tms)[:n_hv], main.fov_x, args.width, args.height, main.scale, main.offset)
+            # (a 16-view hemisphere of its own, generated as scripts/kbench.py --field hbm --views 16 generates it: the PMC pass behind
+            # `traffic` is of exactly these views)
+            htms, hscale, hoffset = planner.hemisphere_transforms(planner.hemisphere_generate(n_hv), 0.3, 0.1, [1e-10] * 3)
+            hcams = ctx.cameras_from_matrices(htms, main.fov_x, args.width, args.height, hscale, hoffset)
             hopts = api.render_opts(args.width, args.height, args.samples, 1, 1e-4)
             himg = torch.empty((n_hv, args.height, args.width, 4), dtype=torch.float32, device=device)
             _, hst = ctx.render(2, hcams, None, hopts, out=himg)
@@ -876,9 +879,11 @@ def run_rank(args):
             # neighbouring rays do share lines, even on the coarser hashed levels -- 18 lines per sample, not 56
             tr = (load_json(TRAFFIC_FILE) or {}).get("hbm " + args.scene)
             traffic_bytes = fabric_gbs_h = None
+            same_launch = False
             if tr:
                 traffic_bytes = (tr["fetch_kib_per_launch"] + tr["write_kib_per_launch"]) * 1024.0 / tr["samples_evaluated_per_launch"] * hst.samples_evaluated
                 fabric_gbs_h = traffic_bytes / k_s / 1e9
+                same_launch = n_hv == 16 and int(tr["samples_evaluated_per_launch"]) == int(hst.samples_evaluated)  # the PMC pass saw this very launch
             extras["field_hbm"] = {
                 "workload": f"{n_hv} views {args.width}x{args.height} x {args.samples} samples, synthetic field L=16 F=2 log2T=24 finest 2048: "
                             f"{lay['n_hashed_levels']} hashed levels of 64 MiB (448 MiB of random gathers; canonical table "
@@ -887,7 +892,7 @@ def run_rank(args):
                 "samples_evaluated_per_step": int(hst.samples_evaluated),
                 "roofline": {"kernel": "render_queue64_kernel<2, 0>", "bound": "hbm", "frac": alg_gbs / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
                              "achieved": alg_gbs, "unit": "GB/s", "traffic": traffic_bytes, "avg_launch_ms": k_s * 1e3,
-                             "memory_side_GBps": fabric_gbs_h, "memory_side_frac_of_peak": fabric_gbs_h / HBM_PEAK_GBS if fabric_gbs_h else None,
+                             "memory_side_GBps": fabric_gbs_h, "traffic_is_of_this_launch": bool(tr) and same_launch, "memory_side_frac_of_peak": fabric_gbs_h / HBM_PEAK_GBS if fabric_gbs_h else None,
                              "memory_side_frac_of_achievable": fabric_gbs_h / HBM_ACHIEVABLE_GBS if fabric_gbs_h else None,
                              "memory_side_frac_of_random_request_calibration": fabric_gbs_h / 3600.0 if fabric_gbs_h else None,
                              "units_per_launch": float(hst.samples_evaluated), "bytes_per_unit": BYTES_PER_SAMPLE,
