@@ -91,6 +91,7 @@ struct prv_ctx {
   std::vector<struct prv_trainer*> trainers; // live trainers of this context (detached by prv_destroy)
   std::vector<struct prv_comm*> comms;       // live communicators of this context (detached by prv_destroy)
   int queue_segments = 8; // ray-queue segments = XCDs (PRV_QUEUE_SEGMENTS: 1 = single shared head)
+  int spatial_regions = 1; // a wave's records go to the region of its first live ray's octant (PRV_SPATIAL_REGIONS=0: block id % regions, rounds 1-5)
   int pool_on = -1;       // render_queue64 block-level tail pool (PRV_POOL=0/1; -1 = by table and image size, see render_views)
   int merge_max = -1;     // render_queue64 tail merge threshold (PRV_MERGE_MAX; 0 = off; -1 = by table size, see render_views)
   size_t stage_budget = (size_t)4 << 30; // staging bytes for multi-sample renders (spp x batch x image)
@@ -589,7 +590,8 @@ void set_cull_rect(CamDev& cam, const Model& m, int W, int H) {
   set_cull_rect(cam, b, W, H);
 }
 
-constexpr size_t kStatOffset = 1024;                        // counters buffer: heads 0..511, counts 512..1023, then the statistics
+constexpr int kSubRegions = 8, kMaxSegments = 8 * kSubRegions; // queue regions (<= 8: one per XCD) x their sub-regions
+constexpr size_t kStatOffset = (size_t)kMaxSegments * 128;  // counters buffer: heads (64 B apart), then counts (64 B apart), then the statistics
 constexpr size_t kCountersBytes = kStatOffset + 72 * 8; // {evaluated, wave rounds, clock sums and stamps}, then 8 live-sample shards a cache line apart
 
 
@@ -630,7 +632,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   // counters: 8 region heads (one 64-byte line each) | 8 region counts (same) | stats {evaluated, wave rounds} | dev histogram
   if ((rc = ensure(c, c->counters, kCountersBytes)) != PRV_OK) return rc;
   uint32_t* q_head = (uint32_t*)c->counters.p;
-  uint32_t* q_count = (uint32_t*)c->counters.p + 128;
+  uint32_t* q_count = (uint32_t*)c->counters.p + kMaxSegments * 16;
   unsigned long long* stat = (unsigned long long*)((char*)c->counters.p + kStatOffset);
   if (n_views == 0) {
     if (zero_stats) HIPCHK(c, hipMemsetAsync(stat, 0, kCountersBytes - kStatOffset, c->stream));
@@ -677,7 +679,11 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
   if (batch == 0) return fail(c, PRV_E_INVALID, "image x spp too large");
   // the queue is n_seg regions: a march block appends to region (linear block id % n_seg), so a region holds at most
   // ceil(blocks / n_seg) * 256 records -- the same total as one flat queue plus less than one block per region
-  const int n_seg = c->queue_segments;
+  // spatial regions: every octant's region is cut into kSubRegions sub-regions with a counter each (a march block appends to
+  // sub-region `linear block id % kSubRegions` of its octant's region): the waves running at any one time are neighbours in
+  // the image, i.e. in ONE octant, and one returning-atomic word serves ~90 of them per microsecond
+  const int n_sub = c->spatial_regions ? kSubRegions : 1;
+  const int n_seg = c->queue_segments * n_sub;
   auto march_blocks = [&](int nb) {
     const int inner = (spp > 1 && spp <= 64 && (spp & (spp - 1)) == 0) ? spp : 1;
     int pl = 8;
@@ -685,7 +691,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     const size_t tw = (size_t)1 << ((pl + 1) / 2), th = (size_t)1 << (pl / 2);
     return ((W + tw - 1) / tw) * ((H + th - 1) / th) * (size_t)nb * (size_t)(inner > 1 ? 1 : spp);
   };
-  const size_t seg_cap_max = ((march_blocks((int)batch) + n_seg - 1) / n_seg) * 256;
+  const size_t seg_cap_max = ((march_blocks((int)batch) + n_seg - 1) / n_seg) * 256 + 64; // (+ 64: a wave moves to the next region when its own is full, region_reserve)
   if (seg_cap_max * (size_t)n_seg >= (1ull << 32)) return fail(c, PRV_E_INVALID, "image x spp too large");
   if ((rc = ensure(c, c->queue, seg_cap_max * (size_t)n_seg * kRecordBytes)) != PRV_OK) return rc;
   if (ngp && (rc = ensure(c, c->queue_ext, seg_cap_max * (size_t)n_seg * kExtBytes)) != PRV_OK) return rc;
@@ -730,7 +736,9 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     mp.stat = stat;
     mp.queue_count = q_count;
     mp.n_seg = n_seg;
-    mp.seg_cap = (uint32_t)(((march_blocks(nb) + n_seg - 1) / n_seg) * 256);
+    mp.n_sub = n_sub;
+    mp.seg_cap = (uint32_t)(((march_blocks(nb) + n_seg - 1) / n_seg) * 256 + 64);
+    mp.spatial_regions = c->spatial_regions;
     mp.out_f32 = spp > 1 ? (float*)c->stage.p : dst_f32;
     mp.out_u8 = spp > 1 ? nullptr : dst_u8;
     mp.inv_spp = 1.0f;
@@ -776,6 +784,7 @@ int render_views(prv_ctx* c, int slot, const prv_camset* cs, const int* view_ids
     rp.queue_count = q_count;
     rp.queue_head = q_head;
     rp.n_segments = n_seg;
+    rp.n_sub = n_sub;
     rp.seg_cap = mp.seg_cap;
     rp.stat_evaluated = stat;
     rp.out_f32 = mp.out_f32;
@@ -898,7 +907,11 @@ int render_ensemble_ngp(prv_ctx* c, const int* slots, int E, const prv_camset* c
     }
   }
 
-  const int n_seg = c->queue_segments;
+  // spatial regions: every octant's region is cut into kSubRegions sub-regions with a counter each (a march block appends to
+  // sub-region `linear block id % kSubRegions` of its octant's region): the waves running at any one time are neighbours in
+  // the image, i.e. in ONE octant, and one returning-atomic word serves ~90 of them per microsecond
+  const int n_sub = c->spatial_regions ? kSubRegions : 1;
+  const int n_seg = c->queue_segments * n_sub;
   int inner = 0;
   if (spp > 1 && spp <= 64 && (spp & (spp - 1)) == 0)
     while ((1 << inner) < spp) inner++;
@@ -906,7 +919,7 @@ int render_ensemble_ngp(prv_ctx* c, const int* slots, int E, const prv_camset* c
   const int tile_w_log2 = (pix_log2 + 1) / 2, tile_h_log2 = pix_log2 / 2;
   const uint32_t tiles_x = (uint32_t)((W + (1 << tile_w_log2) - 1) >> tile_w_log2), tiles_y = (uint32_t)((H + (1 << tile_h_log2) - 1) >> tile_h_log2);
   const size_t blocks = (size_t)tiles_x * tiles_y * (size_t)n_views * (size_t)(inner > 0 ? 1 : spp);
-  const size_t seg_cap = ((blocks + n_seg - 1) / n_seg) * 256;
+  const size_t seg_cap = ((blocks + n_seg - 1) / n_seg) * 256 + 64;
   if (seg_cap * (size_t)n_seg >= (1ull << 32)) return PRV_OK;
   const size_t q_stride = seg_cap * (size_t)n_seg * kRecordBytes, x_stride = seg_cap * (size_t)n_seg * kExtBytes,
                s_stride = spp > 1 ? (size_t)n_views * npix * (size_t)spp * 16 : 0;
@@ -946,7 +959,9 @@ int render_ensemble_ngp(prv_ctx* c, const int* slots, int E, const prv_camset* c
   mp.spp_inner_log2 = inner;
   mp.stat = stat;
   mp.n_seg = n_seg;
+  mp.n_sub = n_sub;
   mp.seg_cap = (uint32_t)seg_cap;
+  mp.spatial_regions = c->spatial_regions;
   mp.inv_spp = 1.0f;
   mp.last_pass = spp == 1;
   memcpy(mp.bg, o->background, sizeof(mp.bg));
@@ -955,7 +970,7 @@ int render_ensemble_ngp(prv_ctx* c, const int* slots, int E, const prv_camset* c
     MarchMember& mm = mp.mem[e];
     mm.queue = (char*)c->queue.p + q_stride * (size_t)e;
     mm.queue_ext = (uint4*)((char*)c->queue_ext.p + x_stride * (size_t)e);
-    mm.queue_count = (uint32_t*)((char*)c->counters_multi.p + (size_t)e * kStatOffset) + 128;
+    mm.queue_count = (uint32_t*)((char*)c->counters_multi.p + (size_t)e * kStatOffset) + kMaxSegments * 16;
     // spp > 1: the member's own staging image; spp == 1: the caller's scratch image is shared (nobody reads it), the bytes are the member's
     mm.out_f32 = spp > 1 ? (float*)((char*)c->stage.p + s_stride * (size_t)e) : scratch_f32;
     mm.out_u8 = spp > 1 ? nullptr : (uint32_t*)out_u8[e];
@@ -984,6 +999,7 @@ int render_ensemble_ngp(prv_ctx* c, const int* slots, int E, const prv_camset* c
     rp.queue_count = mp.mem[e].queue_count;
     rp.queue_head = (uint32_t*)((char*)c->counters_multi.p + (size_t)e * kStatOffset);
     rp.n_segments = n_seg;
+    rp.n_sub = n_sub;
     rp.seg_cap = mp.seg_cap;
     rp.stat_evaluated = stat;
     rp.out_f32 = mp.mem[e].out_f32;
@@ -1067,6 +1083,7 @@ int prv_create(prv_ctx** out, int device_id) try {
   c->stream = c->own_stream;
   if (const char* s = getenv("PRV_BLOCKS_PER_CU")) c->blocks_per_cu = std::max(1, atoi(s));
   if (const char* s = getenv("PRV_QUEUE_SEGMENTS")) c->queue_segments = std::min(8, std::max(1, atoi(s)));
+  if (const char* s = getenv("PRV_SPATIAL_REGIONS")) c->spatial_regions = std::max(0, std::min(2, atoi(s)));
   if (const char* s = getenv("PRV_MERGE_MAX")) c->merge_max = std::min(31, std::max(0, atoi(s)));
   if (const char* s = getenv("PRV_POOL")) c->pool_on = atoi(s) != 0 ? 1 : 0;
   if (const char* s = getenv("PRV_CELL_CACHE")) c->cell_cache = atoi(s) != 0 ? 1 : 0;

@@ -242,6 +242,35 @@ __device__ __forceinline__ void march_write(const PT& P, const MarchSink& Q, uin
   }
 }
 
+// Which of the queue's regions a wave's live rays go to (round 6).  A region is drained by ONE XCD (render_queue64: seg = XCC id)
+// and every XCD has an L2 of its own: until round 5 the region was the block's index modulo the region count, every region a thin
+// slice of EVERY part of the scene, so every L2 held a share of the whole table.  Now it is the OCTANT, about the occupied box's
+// centre, of the MIDDLE OF THE LIVE SPAN of the wave's first live ray (a wave is a patch of adjacent pixels / sub-samples: its rays
+// cross the object together; the first live sample as the key measured 2-6 % slower): an XCD renders the rays that cross one part
+// of the field, and its L2 holds that part.  Pixels do not
+// depend on which slot renders a ray (tests/test_gpu_sweep.py).  A region holds 1 / n_seg of the batch's rays (+ 64 slots); a wave
+// whose region is full moves on to the next one -- with that slack some region always has room for a wave's <= 64 records.
+__device__ __forceinline__ uint32_t ray_octant(const float o[3], const float d[3], float t, const float lo[3], const float hi[3]) {
+  uint32_t oct = 0u;
+#pragma unroll
+  for (int a = 0; a < 3; a++) oct |= (uint32_t)(fmaf(t, d[a], o[a]) > 0.5f * (lo[a] + hi[a])) << a;
+  return oct;
+}
+// called by ONE lane: n records in region `pref` or the first region after it with room; returns the first record's queue slot
+__device__ __forceinline__ uint32_t region_reserve(uint32_t* queue_count, uint32_t n_seg, uint32_t seg_cap, uint32_t pref, uint32_t n) {
+  for (uint32_t k = 0; k < n_seg; k++) {
+    const uint32_t shard = (pref + k) % n_seg;
+    uint32_t* c = queue_count + 16u * shard;
+    uint32_t old = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (old + n <= seg_cap) {
+      const uint32_t seen = atomicCAS(c, old, old + n);
+      if (seen == old) return shard * seg_cap + old;
+      old = seen;
+    }
+  }
+  return 0u; // unreachable: the regions together hold every ray of the batch plus 64 slots each (prv_api.cpp: seg_cap)
+}
+
 // the statistics: the march count (live samples before any early termination), one atomic per wave, on a counter sharded
 // like the queue's (~10^5 atomics on ONE word cost 0.3 ms of a 0.65 ms launch)
 template <class PT>
@@ -267,8 +296,23 @@ __device__ __forceinline__ void march_emit(const PT& P, const MarchSink& Q, uint
   const int lane = threadIdx.x & 63;
   uint32_t base = 0;
   if (b != 0ull) {
-    const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) % (uint32_t)P.n_seg;
-    if (lane == (int)__builtin_ctzll(b)) base = shard * P.seg_cap + atomicAdd(Q.queue_count + 16u * shard, (uint32_t)__popcll(b));
+    if (lane == (int)__builtin_ctzll(b)) { // the wave's first live ray: the middle of its live span names the region (ray_octant)
+      uint32_t i0 = 0u;
+      if constexpr (NGP) {
+        i0 = 32u * (uint32_t)first_nz + (uint32_t)__builtin_ctz(word(first_nz));
+        if (P.spatial_regions != 2) i0 = (i0 + 32u * (uint32_t)last_nz + 31u - (uint32_t)__builtin_clz(word(last_nz))) >> 1; // the middle of the live span (2, dev: its first sample)
+      } else {
+        i0 = m[0] ? (uint32_t)__builtin_ctz(m[0]) : m[1] ? 32u + (uint32_t)__builtin_ctz(m[1]) : m[2] ? 64u + (uint32_t)__builtin_ctz(m[2]) : 96u + (uint32_t)__builtin_ctz(m[3]);
+        if (P.spatial_regions != 2) {
+          const uint32_t i1 = m[3] ? 127u - (uint32_t)__builtin_clz(m[3]) : m[2] ? 95u - (uint32_t)__builtin_clz(m[2]) : m[1] ? 63u - (uint32_t)__builtin_clz(m[1]) : 31u - (uint32_t)__builtin_clz(m[0]);
+          i0 = (i0 + i1) >> 1;
+        }
+      }
+      const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const uint32_t pref = P.spatial_regions ? ray_octant(r.o, r.d, fmaf((float)i0 + 0.5f, dt, r.t0), P.field.occ_lo, P.field.occ_hi) * (uint32_t)P.n_sub + lin % (uint32_t)P.n_sub
+                                              : lin;
+      base = region_reserve(Q.queue_count, (uint32_t)P.n_seg, P.seg_cap, pref % (uint32_t)P.n_seg, (uint32_t)__popcll(b));
+    }
     base = __shfl(base, (int)__builtin_ctzll(b));
   }
   march_write<NGP>(P, Q, stage, r, live, b, base, dt, m, first_nz, last_nz, word);
@@ -527,7 +571,21 @@ __global__ __launch_bounds__(256) void march_multi_kernel(MarchMultiParams P) {
   unsigned long long b[E];
   uint32_t base[E];
   {
-    const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) % (uint32_t)P.n_seg;
+    // the region (ray_octant): the middle of the live span -- of all members together, in whole words -- of the wave's first ray
+    // that is live for any member
+    int first_any = 32, last_any = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      first_any = min(first_any, first_nz[e]);
+      last_any = max(last_any, last_nz[e]);
+    }
+    const unsigned long long b_any = __ballot(first_any < 32);
+    uint32_t pref = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (P.spatial_regions && b_any != 0ull) {
+      const uint32_t oct = ray_octant(o, d, fmaf((float)(16 * (min(first_any, 31) + last_any)) + 16.0f, dt, t0), P.occ_lo, P.occ_hi);
+      pref = (uint32_t)__shfl((int)oct, (int)__builtin_ctzll(b_any)) * (uint32_t)P.n_sub + pref % (uint32_t)P.n_sub;
+    }
+    const uint32_t shard = pref % (uint32_t)P.n_seg;
     uint32_t* qc = nullptr;
     uint32_t mine = 0u, tot = 0u;
 #pragma unroll
@@ -540,7 +598,7 @@ __global__ __launch_bounds__(256) void march_multi_kernel(MarchMultiParams P) {
       tot += n_live[e];
     }
     uint32_t got = 0u;
-    if (mine) got = shard * P.seg_cap + atomicAdd(qc + 16u * shard, mine);
+    if (mine) got = region_reserve(qc, (uint32_t)P.n_seg, P.seg_cap, shard, mine);
 #pragma unroll
     for (int e = 0; e < E; e++) base[e] = __shfl(got, e);
     march_count(P, tot);
@@ -700,7 +758,9 @@ void render_queue64_kernel(RenderParams P) {
   clock_stamp_begin(P.stat_evaluated);
   uint32_t q_cur = 0, q_end = 0;
   const uint32_t n_seg = (uint32_t)P.n_segments;
-  uint32_t seg = n_seg > 1u ? ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % n_seg : 0u;
+  // (an XCD starts at the first sub-region of its own octant region and walks on from there)
+  const uint32_t n_sub = (uint32_t)max(P.n_sub, 1);
+  uint32_t seg = n_seg > 1u ? (((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % (n_seg / n_sub)) * n_sub + (blockIdx.x * 4u + (threadIdx.x >> 6)) % n_sub : 0u;
   uint32_t seg_tried = 0;
   const uint4* __restrict__ queue = reinterpret_cast<const uint4*>(P.queue);
 

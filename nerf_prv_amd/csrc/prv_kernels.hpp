@@ -36,8 +36,10 @@ struct MarchParams {
   uint4* queue_ext;      // PRV_STEP_NGP: kExtChunks mask chunks per queue slot, chunk-major (n_slots = n_seg * seg_cap)
   unsigned long long* stat; // statistics block: [8 (1 + s)] += live samples (the march count), 8 shards a cache line apart
   uint32_t* queue_count; // n_seg counters, 64 bytes apart: records appended to region s of the queue
-  int n_seg;             // the queue is n_seg regions of seg_cap records; a block appends to region (linear block id % n_seg)
-  uint32_t seg_cap;
+  int n_seg;             // the queue is n_seg regions of seg_cap records; a wave appends to the region of its first live ray's octant
+  uint32_t seg_cap;      // (spatial_regions; 0: linear block id % n_seg, rounds 1-5), or to the next region that has room
+  int spatial_regions;
+  int n_sub;             // spatial_regions: the n_seg regions are n_seg / n_sub octant regions of n_sub sub-regions each (a counter per sub-region)
   float* out_f32; // n_views*H*W*4
   uint32_t* out_u8; // optional, n_views*H*W
   float inv_spp;
@@ -66,6 +68,7 @@ struct MarchMultiParams {
   unsigned long long* stat;
   int n_seg;
   uint32_t seg_cap;
+  int spatial_regions, n_sub; // MarchParams::spatial_regions, n_sub
   float inv_spp;
   int last_pass;
   float bg[4];
@@ -90,6 +93,7 @@ struct RenderParams {
   const uint32_t* queue_count; // n_segments counters, 64 bytes apart: records in region s
   uint32_t* queue_head; // n_segments heads, 64 bytes apart (region-relative record counts)
   int n_segments;
+  int n_sub; // an XCD starts at sub-region 0 of ITS octant region: segment (XCC id % (n_segments / n_sub)) * n_sub
   uint32_t seg_cap;     // records per region: region s = [s * seg_cap, s * seg_cap + queue_count[16 s])
   unsigned long long* stat_evaluated;
   float* out_f32;

@@ -268,13 +268,15 @@ def test_view_batches_do_not_change_anything(ctx, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"PRV_QUEUE_SEGMENTS": "1"}, {"PRV_QUEUE_SEGMENTS": "3"}, {"PRV_NO_PAIR": "1"},
+                                 {"PRV_SPATIAL_REGIONS": "0"}, {"PRV_SPATIAL_REGIONS": "2"}, {"PRV_SPATIAL_REGIONS": "0", "PRV_QUEUE_SEGMENTS": "2"},
                                  {"PRV_BLOCKS_PER_CU": "1"}, {"PRV_BLOCKS_PER_CU": "6"},
                                  {"PRV_MERGE_MAX": "0"}, {"PRV_MERGE_MAX": "6", "PRV_POOL": "0"}, {"PRV_MERGE_MAX": "31", "PRV_BLOCKS_PER_CU": "2"},
                                  {"PRV_MERGE_MAX": "12", "PRV_POOL": "1"}, {"PRV_MERGE_MAX": "31", "PRV_POOL": "1", "PRV_BLOCKS_PER_CU": "1"}])
 @pytest.mark.parametrize("which", ["F4", "F2"])
 @pytest.mark.parametrize("step_mode", ["fixed", "ngp"])
 def test_placement_and_layout_switches_change_speed_only(ctx, oracle, monkeypatch, env, which, step_mode):
-    """the tuning switches of the render path (queue segments per XCD, the generic gather for every level, resident
+    """the tuning switches of the render path (queue segments per XCD, which region a wave's rays go to -- the octant of the
+    middle of their live span, round 6's default, or the block index --, the generic gather for every level, resident
     blocks per CU, tail merge and tail pool: rays change lanes mid-flight) decide where and in which order rays are
     rendered -- never the arithmetic: images and counts are bit-identical to the defaults, in both stepping modes"""
     kw = util.SMALL if which == "F4" else util.SMALL_F2
@@ -352,3 +354,34 @@ def test_trainer_switches_hold_the_same_bars(ctx, oracle, monkeypatch, env):
     assert gtr.info()["active_rays"] == otr.active_rays
     gtr.close()
     cams.close()
+
+
+def test_queue_regions_by_octant_leave_the_ensemble_round_unchanged(ctx, oracle, monkeypatch):
+    """round 6: a wave's records go to the queue region of the OCTANT its first live ray crosses (an XCD drains a region: its L2
+    then holds one part of the table), in sub-regions with a counter each, moving on to the next when one is full.  The
+    reference-shaped scoring round -- five members marched in one launch, 16 sub-samples per pixel, the engine's stepping --
+    must give the same records and the same member images as the block-index regions of rounds 1-5, byte for byte."""
+    d_p = api.field_desc(**util.SMALL)
+    pts = util.fibonacci_hemisphere(12)
+    tms, scale, offset = util.hemisphere_transforms(oracle, pts)
+    opts = api.engine_render_opts(80, 45, 0, 16, 0.01, background=(0, 0, 0, 1))
+
+    def round_of(c):
+        for e in range(5):
+            c.synthetic_model(e, d_p, util.SEED_A + e)
+        cs = c.cameras_from_matrices(tms, util.FOV_X, 80, 45, scale, offset)
+        rec, st = c.score_views(api.L.SCORE_ENSEMBLE_RGB_DENSITY, [0, 1, 2, 3, 4], cs, None, opts, want_stats=True)
+        u8 = [c.render_rgba8(e, cs, None, opts)[0].cpu().numpy() for e in (0, 4)]
+        cs.close()
+        return rec.tobytes(), u8, int(st.samples_evaluated), int(st.samples_live)
+
+    want = round_of(ctx)
+    for v in ("0", "2"):
+        monkeypatch.setenv("PRV_SPATIAL_REGIONS", v)
+        other = api.Context(0)
+        monkeypatch.delenv("PRV_SPATIAL_REGIONS")
+        try:
+            got = round_of(other)
+        finally:
+            other.close()
+        assert got[0] == want[0] and got[2:] == want[2:] and all(np.array_equal(a, b) for a, b in zip(got[1], want[1])), v
