@@ -256,17 +256,19 @@ __device__ __forceinline__ uint32_t ray_octant(const float o[3], const float d[3
   for (int a = 0; a < 3; a++) oct |= (uint32_t)(fmaf(t, d[a], o[a]) > 0.5f * (lo[a] + hi[a])) << a;
   return oct;
 }
-// called by ONE lane: n records in region `pref` or the first region after it with room; returns the first record's queue slot
+// called by ONE lane: n records in region `pref` or the first region after it with room; returns the first record's queue slot.
+// ONE returning add in the common case (a compare-and-swap loop here made the march pass five times as long: the waves running
+// at any one time are neighbours, i.e. all on the same few counters).  The one reservation that straddles a region's end keeps
+// its slots empty and says so in the word behind the counter (tail cut: the render kernel drains count - cut records); every
+// later add on that counter lands beyond the end and moves on as well.
 __device__ __forceinline__ uint32_t region_reserve(uint32_t* queue_count, uint32_t n_seg, uint32_t seg_cap, uint32_t pref, uint32_t n) {
   for (uint32_t k = 0; k < n_seg; k++) {
     const uint32_t shard = (pref + k) % n_seg;
     uint32_t* c = queue_count + 16u * shard;
-    uint32_t old = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (old + n <= seg_cap) {
-      const uint32_t seen = atomicCAS(c, old, old + n);
-      if (seen == old) return shard * seg_cap + old;
-      old = seen;
-    }
+    if (k != 0u && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seg_cap) continue; // (a full region: no add at all)
+    const uint32_t old = atomicAdd(c, n);
+    if (old + n <= seg_cap) return shard * seg_cap + old;
+    if (old < seg_cap) c[1] = seg_cap - old; // this reservation straddles the end: [old, seg_cap) stays unwritten
   }
   return 0u; // unreachable: the regions together hold every ray of the batch plus 64 slots each (prv_api.cpp: seg_cap)
 }
@@ -937,7 +939,8 @@ void render_queue64_kernel(RenderParams P) {
           uint32_t claim = 0;
           if (lane == 0) claim = atomicAdd(P.queue_head + 16u * seg, kClaim);
           claim = __builtin_amdgcn_readfirstlane(claim);
-          const uint32_t s_lo = seg * P.seg_cap, s_cnt = P.queue_count[16u * seg]; // region `seg` of the queue
+          // region `seg` of the queue: the records added to it, less the slots a reservation left empty at its end (region_reserve)
+          const uint32_t s_lo = seg * P.seg_cap, s_cnt = min(P.queue_count[16u * seg], P.seg_cap) - P.queue_count[16u * seg + 1u];
           if (claim < s_cnt) {
             q_cur = s_lo + claim;
             q_end = min(q_cur + kClaim, s_lo + s_cnt);
