@@ -14,6 +14,8 @@ ap.add_argument("--patch", default="", help="WxH: rays drawn as patches of adjac
 ap.add_argument("--members", type=int, default=0, help="also time an ensemble of this many members stepping side by side")
 ap.add_argument("--rule", choices=["fixed", "ngp"], default="", help="how a training ray is sampled (prv_train_opts.step_mode); default: the library's")
 ap.add_argument("--det", action="store_true", help="prv_train_opts.deterministic")
+ap.add_argument("--thresh", type=float, default=0.0, help="prv_train_opts.occ_sigma_thresh (0: the library's)")
+ap.add_argument("--occ-every", type=int, default=0, help="prv_train_opts.occ_every (0: the library's)")
 ap.add_argument("--eval-rule", choices=["fixed", "ngp"], default="fixed", help="the stepping rule the held-out views are rendered with (ngp: the engine's, what the planner renders candidates with)")
 args = ap.parse_args()
 pk = dict(patch_w=int(args.patch.split("x")[0]), patch_h=int(args.patch.split("x")[1])) if args.patch else {}
@@ -21,6 +23,10 @@ if args.rule:
     pk["step_mode"] = 1 if args.rule == "ngp" else 0
 if args.det:
     pk["deterministic"] = 1
+if args.thresh > 0:
+    pk["occ_sigma_thresh"] = args.thresh
+if args.occ_every > 0:
+    pk["occ_every"] = args.occ_every
 import torch
 from nerf_prv_amd import api, planner
 ctx = api.Context(0)

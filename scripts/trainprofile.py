@@ -17,6 +17,8 @@ ap.add_argument("--save-state", help="after the run: store every member's field 
 ap.add_argument("--load-state", help="start from the fields stored there and keep them (learning rate 0): ablation builds time the same batches")
 ap.add_argument("--rule", choices=["fixed", "ngp"], default="", help="how a training ray is sampled (prv_train_opts.step_mode); default: the library's")
 ap.add_argument("--det", action="store_true", help="prv_train_opts.deterministic")
+ap.add_argument("--thresh", type=float, default=0.0, help="prv_train_opts.occ_sigma_thresh (0: the library's)")
+ap.add_argument("--occ-every", type=int, default=0, help="prv_train_opts.occ_every (0: the library's)")
 args = ap.parse_args()
 import torch
 from nerf_prv_amd import api, planner
@@ -37,6 +39,10 @@ if args.rule:
     pk["step_mode"] = 1 if args.rule == "ngp" else 0
 if args.det:
     pk["deterministic"] = 1
+if args.thresh > 0:
+    pk["occ_sigma_thresh"] = args.thresh
+if args.occ_every > 0:
+    pk["occ_every"] = args.occ_every
 trs = []
 for e in range(args.members):
     if args.load_state:
