@@ -32,9 +32,13 @@
 // Five kernels per step behind the ray batch, one captured HIP graph per step variant (prv_train_api.inc).
 #include <hip/hip_runtime.h>
 #include "prv_train.hpp"
+#include <type_traits>
 
 #ifndef PRV_TRAIN_SCATTER_WAYS
-#define PRV_TRAIN_SCATTER_WAYS 4 // (entry, sum) pairs a scattering thread keeps while it walks a tile's samples (dev: 1 = round 4's run merge)
+#define PRV_TRAIN_SCATTER_WAYS 4 // (entry, sum) pairs a scattering thread keeps while it walks a PATCH batch's tile (TrainTileParams::scatter_ways > 1; one pair otherwise)
+#endif
+#ifndef PRV_TRAIN_CHAIN_WAVES
+#define PRV_TRAIN_CHAIN_WAVES 2 // dev (A/B): 1 = the backward dX chain on one wave (rounds 4-5)
 #endif
 #ifndef PRV_TRAIN_ABLATE
 #define PRV_TRAIN_ABLATE 0 // dev only: 1 no table scatter, 2 no dW MFMAs, 4 item-parallel scatter (no run merging), 8 no dX chain, 64 no backward tiles at all, 128 dW on the f32 matrix-core form (K = 2), 16 phase time stamps of block 0 (48: summed over its tiles)
@@ -627,13 +631,39 @@ void train_tile_kernel(TrainTileParams P) {
   // (the list is ray by ray in depth order): under the engine's marcher a learnt opaque surface has hundreds of live steps
   // behind it -- a third of the list in the planner loop's steady state, nine tenths in its one-view first round.  A block
   // clears the bytes of the tiles it has read (it is their only reader), so the next step starts from zeros.
-  auto next_live = [&](uint32_t t) {
-    if constexpr (!FWD)
-      while (t < n_tiles && P.tile_live && P.tile_live[t] == 0) t += gridDim.x;
-    return t;
+  // The block's candidates are the tiles first + c * gridDim.x; their bytes are read 64 candidates at a time (lane j the byte of
+  // candidate win_c0 + j, one ballot): a byte per step of the walk was a dependent global load -- a microsecond -- in front of
+  // every tile.  (A window's bits are consumed forwards only, so the clearing of the bytes behind the walk does not matter.)
+  const uint32_t first = P.tile_begin + blockIdx.x;
+  uint32_t win_c0 = 0u;
+  unsigned long long win = 0ull;
+  auto window = [&](uint32_t c0) {
+    const uint32_t t = first + (c0 + (uint32_t)lane) * gridDim.x;
+    return __ballot(t < n_tiles && (!P.tile_live || P.tile_live[t] != 0));
+  };
+  if constexpr (!FWD) win = window(0u);
+  uint32_t cand = 0u; // candidate index of `tile`
+  auto next_live = [&](uint32_t c) { // the first live candidate >= c (its tile may lie beyond n_tiles: the walk's end)
+    if constexpr (!FWD) {
+      for (;;) {
+        if (first + c * gridDim.x >= n_tiles) break;
+        if (c >= win_c0 + 64u) {
+          win_c0 = c;
+          win = window(c);
+        }
+        const unsigned long long m = win >> (c - win_c0);
+        if (m != 0ull) {
+          c += (uint32_t)__builtin_ctzll(m);
+          break;
+        }
+        c = win_c0 + 64u;
+      }
+    }
+    return c;
   };
   TileIn pre; // MODE 2: the NEXT live tile's kept activations, fetched while this one is worked on
-  uint32_t tile = next_live(P.tile_begin + blockIdx.x);
+  cand = next_live(0u);
+  uint32_t tile = first + cand * gridDim.x;
   if ((PRV_TRAIN_ABLATE & 64) && !FWD) tile = n_tiles;
   if constexpr (MODE == 2)
     if (tile < n_tiles) fetch_tile(tile, lane_outer, pre);
@@ -644,7 +674,8 @@ void train_tile_kernel(TrainTileParams P) {
     int lane = lane_outer;
     if constexpr (MODE == 2) asm volatile("" : "+v"(lane)); // (the LDS-chain instances are faster with the hoisted form: they have the registers)
     const int tid = wave * 64 + lane, r = lane & 31, h = lane >> 5;
-    const uint32_t tile_next = next_live(tile + gridDim.x);
+    const uint32_t cand_next = next_live(cand + 1u);
+    const uint32_t tile_next = first + cand_next * gridDim.x;
     // ---- phase E: encode (8 threads per sample), SH inputs, gradient seeds
     const int s = tid & 31, g = tid >> 5;
     const uint32_t sid = tile * 32u + (uint32_t)s;
@@ -769,6 +800,7 @@ void train_tile_kernel(TrainTileParams P) {
       }
       __syncthreads(); STAMP(7);
       tile = tile_next; // (forward tiles: every tile is walked)
+      cand = cand_next;
       continue;
     }
     } // !saved
@@ -782,6 +814,143 @@ void train_tile_kernel(TrainTileParams P) {
         // accumulators (the dropped term is below 2^-16 of the product).  60 MFMAs of K = 16 where the LDS form issues
         // ~350 of K = 2 behind five barriers.  The masked gradients still go to the [row][sample] array: dW and the
         // scatter below read them there.
+#if PRV_TRAIN_CHAIN_WAVES == 2
+        // ... on TWO waves since round 6: wave w owns row tile w of the 64-row layers (its masks, its rows of G), which is k-steps
+        // 2w, 2w + 1 of the layer behind it -- a K split.  A wave multiplies its own half of K into BOTH row tiles (R2) or into the
+        // one 32-row tile (R1, D1) and hands the other wave the partial sums of the rows that wave owns, through the rows of G
+        // the final values go to anyway (the lane that reads a value is the lane position that wrote it: one C layout), behind
+        // a barrier: three more barriers per tile, half the splits, masks and matrix instructions per wave.  Waves 2 and 3 only
+        // keep the barriers company.  (Sums: (k-steps 0, 1) + (k-steps 2, 3) where one wave's accumulator took them in turn.)
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+        const half8* wf = reinterpret_cast<const half8*>(W);
+        const f32x16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const bool chain = wave < 2 && !(PRV_TRAIN_ABLATE & 8);
+        auto mm3 = [&](int f, const bf16x8& bh, const bf16x8& bl, f32x16v c) {
+          const half8 w = wf[f * 64 + lane]; // one LDS read; the split into bf16 high + low parts is exact (11 bits into 8 + 8)
+          bf16x8 ah, al;
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const float wv = (float)w[j];
+            const __bf16 hv = (__bf16)wv;
+            ah[j] = hv;
+            al[j] = (__bf16)(wv - (float)hv);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+          return c;
+        };
+        // registers [base, base + 8) of an accumulator -> the high and low bf16 parts of one B operand
+        auto split8 = [&](const f32x16v& acc, int base, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const float v = acc[base + j];
+            const __bf16 hv = (__bf16)v;
+            hi[j] = hv;
+            lo[j] = (__bf16)(v - (float)hv);
+          }
+        };
+        const int ws = __builtin_amdgcn_readfirstlane(wave); // (a scalar the compiler can branch on)
+        const int own = 32 * wave, other = 32 * (1 - wave); // first row of this wave's / the other wave's tile of a 64-row layer
+        bf16x8 bh[2], bl[2];
+        f32x16v d = zero, part = zero; // this wave's rows of the layer in hand | its half-K sum of its own rows, until the other half arrives
+        if (chain) {
+          { // colour logits' seeds: lane half 0 holds outputs 0..7, of which r, g, b carry a gradient
+            f32x16v sd = zero;
+            if (h == 0) {
+              sd[0] = seed.y;
+              sd[1] = seed.z;
+              sd[2] = seed.w;
+            }
+            split8(sd, 0, bh[0], bl[0]);
+          }
+          d = mm3(wave, bh[0], bl[0], zero); // dH3 = W_r3 dOrr, this wave's rows
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            const int row = own + rho(i, h);
+            d[i] = A[(kAH3 + row) * TSA + r] > (_Float16)0.0f ? d[i] : 0.0f;
+            G[(kGH3 + row) * TSG + r] = d[i];
+          }
+          split8(d, 0, bh[0], bl[0]);
+          split8(d, 8, bh[1], bl[1]);
+          // dH2 = W_r2 dH3: k-steps 2 wave, 2 wave + 1 into both row tiles
+          part = zero; // fragment 2 + 4 mt + st: its own row tile mt = wave, the other wave's mt = 1 - wave
+          f32x16v give = zero;
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            part = mm3(2 + 6 * wave + j, bh[j], bl[j], part);
+            give = mm3(6 - 2 * wave + j, bh[j], bl[j], give);
+          }
+#pragma unroll
+          for (int i = 0; i < 16; i++) G[(kGH2 + other + rho(i, h)) * TSG + r] = give[i];
+        }
+        __syncthreads();
+        if (chain) {
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            const int row = own + rho(i, h);
+            const float got = G[(kGH2 + row) * TSG + r];
+            const float v = part[i] + got; // (k-steps 0, 1) + (k-steps 2, 3): the same sum on either wave
+            d[i] = A[(kAH2 + row) * TSA + r] > (_Float16)0.0f ? v : 0.0f;
+            G[(kGH2 + row) * TSG + r] = d[i];
+          }
+          split8(d, 0, bh[0], bl[0]);
+          split8(d, 8, bh[1], bl[1]);
+          // dOd = (W_r1 dH2)[0..15] (+ the density seed on row 0); the SH rows carry no parameters.  Both waves finish the
+          // sum (each needs it as its B operand): wave 1's half goes through rows 0..15 of the dOd block, wave 0's through
+          // the block's unused rows 16..31; wave 0 then writes the final rows
+          part = zero;
+#pragma unroll
+          for (int j = 0; j < 2; j++) part = mm3(10 + 2 * wave + j, bh[j], bl[j], part);
+#pragma unroll
+          for (int i = 0; i < 8; i++) G[(kGOd + 16 * (1 - wave) + rho(i, h)) * TSG + r] = part[i]; // registers 0..7 = rows < 16
+        }
+        __syncthreads();
+        if (chain) {
+          f32x16v c = zero;
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const float got = G[(kGOd + 16 * wave + rho(i, h)) * TSG + r];
+            c[i] = part[i] + got;
+          }
+          if (h == 0) c[0] += seed.x; // row 0 = register 0 of lane half 0
+          if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) G[(kGOd + rho(i, h)) * TSG + r] = c[i];
+          }
+          split8(c, 0, bh[0], bl[0]);
+          d = mm3(14 + wave, bh[0], bl[0], zero); // dH1 = W_d2 dOd, this wave's rows
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            const int row = own + rho(i, h);
+            d[i] = A[(kAH1 + row) * TSA + r] > (_Float16)0.0f ? d[i] : 0.0f;
+            G[(kGH1 + row) * TSG + r] = d[i];
+          }
+          split8(d, 0, bh[0], bl[0]);
+          split8(d, 8, bh[1], bl[1]);
+          // dFeat = W_d1 dH1: one 32-row tile; wave w finishes accumulator registers [8 w, 8 w + 8) and hands over the others
+          part = zero;
+#pragma unroll
+          for (int j = 0; j < 2; j++) part = mm3(16 + 2 * wave + j, bh[j], bl[j], part);
+          if (ws == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) G[(kGFeat + rho(8 + i, h)) * TSG + r] = part[8 + i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) G[(kGFeat + rho(i, h)) * TSG + r] = part[i];
+          }
+        }
+        __syncthreads();
+        if (chain) {
+          if (ws == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) G[(kGFeat + rho(i, h)) * TSG + r] += part[i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) G[(kGFeat + rho(8 + i, h)) * TSG + r] += part[8 + i];
+          }
+        }
+#else
         if (wave == 0 && !(PRV_TRAIN_ABLATE & 8)) {
           typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
           const half8* wf = reinterpret_cast<const half8*>(W);
@@ -878,6 +1047,7 @@ void train_tile_kernel(TrainTileParams P) {
             for (int i = 0; i < 16; i++) G[(kGFeat + rho(i, h)) * TSG + r] = c[i];
           }
         }
+#endif
         __syncthreads(); STAMP(12);
       }
     } else {
@@ -1034,7 +1204,9 @@ void train_tile_kernel(TrainTileParams P) {
               // kWays (entry, sum) pairs, the oldest evicted first.  One pair = the run merge of round 4 (samples along ONE
               // ray: an entry comes back only on consecutive samples); patch mode lists a patch depth step by depth step,
               // where a step's rays alternate between the two to four cells the patch straddles (train_rays_patch_kernel)
-              constexpr int kWays = PRV_TRAIN_SCATTER_WAYS;
+              // One pair is what i.i.d. rays need, and the walk with four costs 5 % of the step (r06ae): four only for patch batches
+              auto walk = [&](auto ways) {
+              constexpr int kWays = decltype(ways)::value;
               uint32_t key[kWays];
               float acc[kWays];
 #pragma unroll
@@ -1078,6 +1250,45 @@ void train_tile_kernel(TrainTileParams P) {
 #pragma unroll
               for (int w = kWays - 1; w >= 0; w--)
                 if (key[w] != 0xffffffffu) table_grad_add(P, (size_t)key[w] * F + k, acc[w]);
+              };
+              // The one-pair walk, flat: a run ends where the entry changes (a sample without a gradient counts as an entry of its
+              // own: its sum is never added), ONE predicated region per step -- the add of the finished run -- and a select; which
+              // form of add (f32 / fixed point) is decided once per walk, not per add.  The nested form above took ~25 instructions
+              // and four branches per step for this case.
+              auto walk1 = [&](auto det) {
+                constexpr bool kDet = decltype(det)::value;
+                uint32_t ek[32];
+                float eg[32];
+#pragma unroll
+                for (int ss = 0; ss < 32; ss++) {
+                  const uint2 e = stage[ss * kStageStride + l8 * 8 + c];
+                  ek[ss] = e.x;
+                  eg[ss] = __uint_as_float(e.y) * G[(kGFeat + l * F + k) * TSG + ss];
+                }
+                auto add = [&](uint32_t entry, float v) {
+                  const size_t idx = (size_t)entry * F + k;
+                  if constexpr (kDet) {
+                    const long long q = __float2ll_rn(v * (float)(1ull << kGradQBits));
+                    atomicAdd(reinterpret_cast<unsigned long long*>(P.table_grad_q) + idx, (unsigned long long)q);
+                  } else {
+                    atomicAdd(P.table_grad + idx, v);
+                  }
+                };
+                uint32_t key = 0xffffffffu;
+                float acc = 0.0f;
+#pragma unroll
+                for (int ss = 0; ss < 32; ss++) {
+                  const uint32_t e = ek[ss];
+                  const bool brk = e != key;
+                  if (brk && key != 0xffffffffu) add(key, acc);
+                  acc = brk ? eg[ss] : acc + eg[ss];
+                  key = e;
+                }
+                if (key != 0xffffffffu) add(key, acc);
+              };
+              if (P.scatter_ways > 1) walk(std::integral_constant<int, PRV_TRAIN_SCATTER_WAYS>{});
+              else if (P.table_grad_q) walk1(std::true_type{});
+              else walk1(std::false_type{});
             }
           } else { // dev (timing builds): the item-parallel form of rounds 1-3, one add per (sample, level, corner)
             const int k = tid % F;
@@ -1095,6 +1306,7 @@ void train_tile_kernel(TrainTileParams P) {
     __syncthreads(); STAMP(15);
     if (P.tile_live && threadIdx.x == 0) P.tile_live[tile] = 0; // read by this block alone, at the top of the iteration
     tile = tile_next;
+    cand = cand_next;
   }
   if (!FWD) { // this block's weight-gradient tiles -> its own slot of the partials (plain stores; a second
     // kernel sums the slots in block order: no same-address atomics, and a reproducible sum)

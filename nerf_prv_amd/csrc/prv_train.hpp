@@ -107,6 +107,9 @@ struct TrainTileParams {
   // one byte per 32-sample tile, set by the compositing kernel where a tile holds a used sample, cleared by the backward block
   // that walks the tile: the backward pass skips the tiles behind the rays' terminations (NULL: every tile is walked)
   uint8_t* tile_live;
+  // (entry, sum) pairs a scattering thread keeps while it walks a tile: 1 -- samples along one ray come back to an entry only on
+  // consecutive steps -- or, > 1, the kernel's four for patch batches (a depth step's rays alternate between the cells the patch straddles)
+  int scatter_ways;
 };
 constexpr int kGradQBits = 40;
 constexpr size_t kActTileBytes = (16 * 64 + 32) * 16; // kept activations of a 32-sample tile: 16 slots x 64 lanes x 16 B, then 32 positions
