@@ -37,9 +37,6 @@
 #ifndef PRV_TRAIN_SCATTER_WAYS
 #define PRV_TRAIN_SCATTER_WAYS 4 // (entry, sum) pairs a scattering thread keeps while it walks a PATCH batch's tile (TrainTileParams::scatter_ways > 1; one pair otherwise)
 #endif
-#ifndef PRV_TRAIN_CHAIN_WAVES
-#define PRV_TRAIN_CHAIN_WAVES 2 // dev (A/B): 1 = the backward dX chain on one wave (rounds 4-5)
-#endif
 #ifndef PRV_TRAIN_ABLATE
 #define PRV_TRAIN_ABLATE 0 // dev only: 1 no table scatter, 2 no dW MFMAs, 4 item-parallel scatter (no run merging), 8 no dX chain, 64 no backward tiles at all, 128 dW on the f32 matrix-core form (K = 2), 16 phase time stamps of block 0 (48: summed over its tiles)
 #endif
@@ -434,6 +431,27 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16v mfma32(float a, float b, f32x16v c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// v = hi + lo, both bf16 (16 significant bits).  Written on pairs: one v_cvt_pk_bf16_f32 per two values each way, the high parts
+// widened again by a shift / a mask of the packed word, the differences as one v_pk_add_f32 -- 20 instructions per eight values.
+// The scalar form ((__bf16)v per element) cost 32: this build switches the SLP vectoriser off, and every conversion became an
+// instruction of its own.  Same roundings, same bits.
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_bf16(const float (&v)[8], bf16x8v& hi, bf16x8v& lo) {
+  typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const f32x2v x = {v[j], v[j + 1]};
+    const bf16x2v h = __builtin_convertvector(x, bf16x2v);
+    const uint32_t p = __builtin_bit_cast(uint32_t, h);
+    const f32x2v hf = {__uint_as_float(p << 16), __uint_as_float(p & 0xffff0000u)};
+    const bf16x2v l = __builtin_convertvector(x - hf, bf16x2v);
+    hi[j] = h[0];
+    hi[j + 1] = h[1];
+    lo[j] = l[0];
+    lo[j + 1] = l[1];
+  }
+}
 // accumulator register i of lane half h holds row rho(i, h) of the 32x32 tile
 __device__ __forceinline__ int rho(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
@@ -450,17 +468,23 @@ constexpr int kAFeat = 0, kAH1 = 32, kAIn2 = 96, kAH2 = 128, kAH3 = 192, kARows 
 // Saved activations (TrainTileParams::act): slot q of lane half h of a forward lane holds 8 halfs; element j is row
 // act_row(q, h, j) of the [row][sample] activation array.  Slots: 0,1 the lane's features (levels h, 2+h, 4+h, ...:
 // the lane pair splits the levels) | 2..5 h1 | 6 density output | 7 SH | 8..11 h2 | 12..15 h3
+// Every slot is {first row, rows per lane half, how j walks the rows}: row = base + per_half * h + act_step(walk, j)
+struct ActSlot {
+  int base, per_half, walk; // walk 0: 8 (j >> 2) + (j & 3), the accumulator order of a 32x32 tile | 1: j | 2: 4 (j >> 1) + (j & 1) (F = 2 features)
+};
+template <int F>
+__device__ __forceinline__ ActSlot act_slot(int q) {
+  if (q < 2) return ActSlot{kAFeat + 16 * q, F, F == 4 ? 0 : F == 8 ? 1 : 2};
+  if (q < 6) return ActSlot{kAH1 + 16 * (q - 2), 4, 0};
+  if (q == 6) return ActSlot{kAIn2, 4, 0};
+  if (q == 7) return ActSlot{kAIn2 + 16, 8, 1};
+  return ActSlot{(q < 12 ? kAH2 : kAH3) + 16 * (q & 3), 4, 0};
+}
+__device__ __forceinline__ constexpr int act_step(int walk, int j) { return walk == 0 ? 8 * (j >> 2) + (j & 3) : walk == 1 ? j : 4 * (j >> 1) + (j & 1); }
 template <int F>
 __device__ __forceinline__ int act_row(int q, int h, int j) {
-  const int unit = 32 * ((q & 3) >> 1) + 16 * (q & 1) + 8 * (j >> 2) + (j & 3) + 4 * h; // of a 64-unit layer, fragment q & 3
-  if (q < 2) {
-    const int e = q * 8 + j;
-    return kAFeat + (2 * (e / F) + h) * F + e % F;
-  }
-  if (q < 6) return kAH1 + 32 * (((q - 2) & 3) >> 1) + 16 * ((q - 2) & 1) + 8 * (j >> 2) + (j & 3) + 4 * h;
-  if (q == 6) return kAIn2 + (j & 3) + 8 * (j >> 2) + 4 * h;
-  if (q == 7) return kAIn2 + 16 + 8 * h + j;
-  return (q < 12 ? kAH2 : kAH3) + unit;
+  const ActSlot sl = act_slot<F>(q);
+  return sl.base + sl.per_half * h + act_step(sl.walk, j);
 }
 // ... followed by the 32 sample positions of the tile (float4 each: the backward pass computes the corner entries and
 // weights from them without walking sample -> ray first)
@@ -536,7 +560,8 @@ void train_tile_kernel(TrainTileParams P) {
   _Float16* A = W + kWLds;                                         // kARows * TSA halfs
   static_assert(kBwdFrags * kFragHalfs <= kWLds, "the backward fragments take the weight array's place");
   STAMP(0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave index as a scalar: what depends on it -- act_row()'s slot classes, the chain's and dW's roles -- branches on SCC, not on exec masks)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   if constexpr (!FWD) {
     // The step's loss and used-sample count ride on this launch: its LAST blocks each sum one 1024-ray slice of the per-ray
@@ -586,6 +611,8 @@ void train_tile_kernel(TrainTileParams P) {
   // level constants: kernel arguments indexed by a per-lane level would be re-fetched from the kernarg
   // segment through the vector memory path before every corner (measured: 37 us per tile) -> LDS copy
   __shared__ LevelCanon lv[16];
+  // (no byte of static LDS to spare here: the block's LDS is 80 KB less 960 bytes, two blocks fill a CU's 160 KB, and one more 4-byte
+  // __shared__ word halved the occupancy -- 0.34 -> 0.50 ms per step, r06aj)
   if (tid < 16 * (int)(sizeof(LevelCanon) / 4))
     reinterpret_cast<uint32_t*>(lv)[tid] = reinterpret_cast<const uint32_t*>(P.levels)[tid];
   if constexpr (MODE == 2) { // fp16 fragments as prepack_frags_kernel left them: 20 KB, 16 bytes per thread and step
@@ -718,8 +745,19 @@ void train_tile_kernel(TrainTileParams P) {
         const uint4 v = av[i];
         const uint32_t vw[4] = {v.x, v.y, v.z, v.w}; // (halves by shifts, not by a pointer cast: the cast makes the compiler carry the
         // prefetched registers from iteration to iteration as sixteen-bit pieces, cut up the moment the load returns)
+        // the slot's rows: one base address per slot, the element's row a constant offset -- the way j walks the rows is the same
+        // for every slot but the SH one (and the feature slots of F != 4): ONE scalar branch per slot where it can differ.  (With
+        // act_row() per element the row was picked by a ladder of scalar branches per 16-bit store: 700 scalar instructions per tile.)
+        const ActSlot sl = act_slot<F>(q);
+        _Float16* dst = A + (sl.base + sl.per_half * h) * TSA + r;
+        auto put = [&](auto walk) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) A[act_row<F>(q, h, j) * TSA + r] = __builtin_bit_cast(_Float16, (uint16_t)(vw[j >> 1] >> (16 * (j & 1))));
+          for (int j = 0; j < 8; j++) dst[act_step(decltype(walk)::value, j) * TSA] = __builtin_bit_cast(_Float16, (uint16_t)(vw[j >> 1] >> (16 * (j & 1))));
+        };
+        if (i >= 2 || (i == 0 && F == 4)) put(std::integral_constant<int, 0>{}); // hidden layers (and F = 4 features): the accumulator order
+        else if (sl.walk == 0) put(std::integral_constant<int, 0>{});
+        else if (sl.walk == 1) put(std::integral_constant<int, 1>{});
+        else put(std::integral_constant<int, 2>{});
       }
       __syncthreads(); STAMP(2);
       // the next live tile's activations, positions and seeds: in flight while this tile's chain, dW and scatter run
@@ -814,7 +852,6 @@ void train_tile_kernel(TrainTileParams P) {
         // accumulators (the dropped term is below 2^-16 of the product).  60 MFMAs of K = 16 where the LDS form issues
         // ~350 of K = 2 behind five barriers.  The masked gradients still go to the [row][sample] array: dW and the
         // scatter below read them there.
-#if PRV_TRAIN_CHAIN_WAVES == 2
         // ... on TWO waves since round 6: wave w owns row tile w of the 64-row layers (its masks, its rows of G), which is k-steps
         // 2w, 2w + 1 of the layer behind it -- a K split.  A wave multiplies its own half of K into BOTH row tiles (R2) or into the
         // one 32-row tile (R1, D1) and hands the other wave the partial sums of the rows that wave owns, through the rows of G
@@ -824,17 +861,15 @@ void train_tile_kernel(TrainTileParams P) {
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
         const half8* wf = reinterpret_cast<const half8*>(W);
         const f32x16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const bool chain = wave < 2 && !(PRV_TRAIN_ABLATE & 8);
+        const int cwv = wave; // 0 / 1: the chain's two waves.  (Waves 2, 3 instead in the block that shares the CU -- HW_ID.wave_id parity -- measured: nothing, r06al)
+        const bool chain = (cwv == 0 || cwv == 1) && !(PRV_TRAIN_ABLATE & 8);
         auto mm3 = [&](int f, const bf16x8& bh, const bf16x8& bl, f32x16v c) {
           const half8 w = wf[f * 64 + lane]; // one LDS read; the split into bf16 high + low parts is exact (11 bits into 8 + 8)
           bf16x8 ah, al;
+          float wv[8];
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const float wv = (float)w[j];
-            const __bf16 hv = (__bf16)wv;
-            ah[j] = hv;
-            al[j] = (__bf16)(wv - (float)hv);
-          }
+          for (int j = 0; j < 8; j++) wv[j] = (float)w[j];
+          split_bf16(wv, ah, al);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
@@ -842,16 +877,13 @@ void train_tile_kernel(TrainTileParams P) {
         };
         // registers [base, base + 8) of an accumulator -> the high and low bf16 parts of one B operand
         auto split8 = [&](const f32x16v& acc, int base, bf16x8& hi, bf16x8& lo) {
+          float v[8];
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const float v = acc[base + j];
-            const __bf16 hv = (__bf16)v;
-            hi[j] = hv;
-            lo[j] = (__bf16)(v - (float)hv);
-          }
+          for (int j = 0; j < 8; j++) v[j] = acc[base + j];
+          split_bf16(v, hi, lo);
         };
-        const int ws = __builtin_amdgcn_readfirstlane(wave); // (a scalar the compiler can branch on)
-        const int own = 32 * wave, other = 32 * (1 - wave); // first row of this wave's / the other wave's tile of a 64-row layer
+        const int ws = cwv;
+        const int own = 32 * cwv, other = 32 * (1 - cwv); // first row of this wave's / the other wave's tile of a 64-row layer
         bf16x8 bh[2], bl[2];
         f32x16v d = zero, part = zero; // this wave's rows of the layer in hand | its half-K sum of its own rows, until the other half arrives
         if (chain) {
@@ -864,7 +896,7 @@ void train_tile_kernel(TrainTileParams P) {
             }
             split8(sd, 0, bh[0], bl[0]);
           }
-          d = mm3(wave, bh[0], bl[0], zero); // dH3 = W_r3 dOrr, this wave's rows
+          d = mm3(cwv, bh[0], bl[0], zero); // dH3 = W_r3 dOrr, this wave's rows
 #pragma unroll
           for (int i = 0; i < 16; i++) {
             const int row = own + rho(i, h);
@@ -878,8 +910,8 @@ void train_tile_kernel(TrainTileParams P) {
           f32x16v give = zero;
 #pragma unroll
           for (int j = 0; j < 2; j++) {
-            part = mm3(2 + 6 * wave + j, bh[j], bl[j], part);
-            give = mm3(6 - 2 * wave + j, bh[j], bl[j], give);
+            part = mm3(2 + 6 * cwv + j, bh[j], bl[j], part);
+            give = mm3(6 - 2 * cwv + j, bh[j], bl[j], give);
           }
 #pragma unroll
           for (int i = 0; i < 16; i++) G[(kGH2 + other + rho(i, h)) * TSG + r] = give[i];
@@ -901,25 +933,25 @@ void train_tile_kernel(TrainTileParams P) {
           // the block's unused rows 16..31; wave 0 then writes the final rows
           part = zero;
 #pragma unroll
-          for (int j = 0; j < 2; j++) part = mm3(10 + 2 * wave + j, bh[j], bl[j], part);
+          for (int j = 0; j < 2; j++) part = mm3(10 + 2 * cwv + j, bh[j], bl[j], part);
 #pragma unroll
-          for (int i = 0; i < 8; i++) G[(kGOd + 16 * (1 - wave) + rho(i, h)) * TSG + r] = part[i]; // registers 0..7 = rows < 16
+          for (int i = 0; i < 8; i++) G[(kGOd + 16 * (1 - cwv) + rho(i, h)) * TSG + r] = part[i]; // registers 0..7 = rows < 16
         }
         __syncthreads();
         if (chain) {
           f32x16v c = zero;
 #pragma unroll
           for (int i = 0; i < 8; i++) {
-            const float got = G[(kGOd + 16 * wave + rho(i, h)) * TSG + r];
+            const float got = G[(kGOd + 16 * cwv + rho(i, h)) * TSG + r];
             c[i] = part[i] + got;
           }
           if (h == 0) c[0] += seed.x; // row 0 = register 0 of lane half 0
-          if (wave == 0) {
+          if (cwv == 0) {
 #pragma unroll
             for (int i = 0; i < 8; i++) G[(kGOd + rho(i, h)) * TSG + r] = c[i];
           }
           split8(c, 0, bh[0], bl[0]);
-          d = mm3(14 + wave, bh[0], bl[0], zero); // dH1 = W_d2 dOd, this wave's rows
+          d = mm3(14 + cwv, bh[0], bl[0], zero); // dH1 = W_d2 dOd, this wave's rows
 #pragma unroll
           for (int i = 0; i < 16; i++) {
             const int row = own + rho(i, h);
@@ -931,7 +963,7 @@ void train_tile_kernel(TrainTileParams P) {
           // dFeat = W_d1 dH1: one 32-row tile; wave w finishes accumulator registers [8 w, 8 w + 8) and hands over the others
           part = zero;
 #pragma unroll
-          for (int j = 0; j < 2; j++) part = mm3(16 + 2 * wave + j, bh[j], bl[j], part);
+          for (int j = 0; j < 2; j++) part = mm3(16 + 2 * cwv + j, bh[j], bl[j], part);
           if (ws == 0) {
 #pragma unroll
             for (int i = 0; i < 8; i++) G[(kGFeat + rho(8 + i, h)) * TSG + r] = part[8 + i];
@@ -950,104 +982,6 @@ void train_tile_kernel(TrainTileParams P) {
             for (int i = 0; i < 8; i++) G[(kGFeat + rho(8 + i, h)) * TSG + r] += part[8 + i];
           }
         }
-#else
-        if (wave == 0 && !(PRV_TRAIN_ABLATE & 8)) {
-          typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-          const half8* wf = reinterpret_cast<const half8*>(W);
-          const f32x16v zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-          auto mm3 = [&](int f, const bf16x8& bh, const bf16x8& bl, f32x16v c) {
-            const half8 w = wf[f * 64 + lane]; // one LDS read; the split into bf16 high + low parts is exact (11 bits into 8 + 8)
-            bf16x8 ah, al;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-              const float wv = (float)w[j];
-              const __bf16 hv = (__bf16)wv;
-              ah[j] = hv;
-              al[j] = (__bf16)(wv - (float)hv);
-            }
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-            return c;
-          };
-          // registers [base, base + 8) of an accumulator -> the high and low bf16 parts of one B operand
-          auto split8 = [&](const f32x16v& acc, int base, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-              const float v = acc[base + j];
-              const __bf16 hv = (__bf16)v;
-              hi[j] = hv;
-              lo[j] = (__bf16)(v - (float)hv);
-            }
-          };
-          bf16x8 bh[4], bl[4];
-          { // colour logits' seeds: lane half 0 holds outputs 0..7, of which r, g, b carry a gradient
-            f32x16v sd = zero;
-            if (h == 0) {
-              sd[0] = seed.y;
-              sd[1] = seed.z;
-              sd[2] = seed.w;
-            }
-            split8(sd, 0, bh[0], bl[0]);
-          }
-          f32x16v d[2];
-#pragma unroll
-          for (int mt = 0; mt < 2; mt++) { // dH3 = W_r3 dOrr
-            d[mt] = mm3(mt, bh[0], bl[0], zero);
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-              const int row = 32 * mt + rho(i, h);
-              d[mt][i] = A[(kAH3 + row) * TSA + r] > (_Float16)0.0f ? d[mt][i] : 0.0f;
-              G[(kGH3 + row) * TSG + r] = d[mt][i];
-            }
-          }
-#pragma unroll
-          for (int st = 0; st < 4; st++) split8(d[st >> 1], 8 * (st & 1), bh[st], bl[st]);
-#pragma unroll
-          for (int mt = 0; mt < 2; mt++) { // dH2 = W_r2 dH3
-            f32x16v c = zero;
-#pragma unroll
-            for (int st = 0; st < 4; st++) c = mm3(2 + 4 * mt + st, bh[st], bl[st], c);
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-              const int row = 32 * mt + rho(i, h);
-              c[i] = A[(kAH2 + row) * TSA + r] > (_Float16)0.0f ? c[i] : 0.0f;
-              G[(kGH2 + row) * TSG + r] = c[i];
-            }
-            d[mt] = c;
-          }
-#pragma unroll
-          for (int st = 0; st < 4; st++) split8(d[st >> 1], 8 * (st & 1), bh[st], bl[st]);
-          { // dOd = (W_r1 dH2)[0..15] (+ the density seed on row 0); the SH rows carry no parameters
-            f32x16v c = zero;
-#pragma unroll
-            for (int st = 0; st < 4; st++) c = mm3(10 + st, bh[st], bl[st], c);
-            if (h == 0) c[0] += seed.x; // row 0 = register 0 of lane half 0
-#pragma unroll
-            for (int i = 0; i < 8; i++) G[(kGOd + rho(i, h)) * TSG + r] = c[i]; // registers 0..7 = rows < 16
-            split8(c, 0, bh[0], bl[0]);
-          }
-#pragma unroll
-          for (int mt = 0; mt < 2; mt++) { // dH1 = W_d2 dOd
-            d[mt] = mm3(14 + mt, bh[0], bl[0], zero);
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-              const int row = 32 * mt + rho(i, h);
-              d[mt][i] = A[(kAH1 + row) * TSA + r] > (_Float16)0.0f ? d[mt][i] : 0.0f;
-              G[(kGH1 + row) * TSG + r] = d[mt][i];
-            }
-          }
-#pragma unroll
-          for (int st = 0; st < 4; st++) split8(d[st >> 1], 8 * (st & 1), bh[st], bl[st]);
-          { // dFeat = W_d1 dH1
-            f32x16v c = zero;
-#pragma unroll
-            for (int st = 0; st < 4; st++) c = mm3(16 + st, bh[st], bl[st], c);
-#pragma unroll
-            for (int i = 0; i < 16; i++) G[(kGFeat + rho(i, h)) * TSG + r] = c[i];
-          }
-        }
-#endif
         __syncthreads(); STAMP(12);
       }
     } else {
@@ -1110,13 +1044,10 @@ void train_tile_kernel(TrainTileParams P) {
         // X g ~ X_hi g_hi + X_lo g_hi + X_hi g_lo in the f32 accumulators: 18 instructions per wave and tile for 48.
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
         auto split_x = [&](const half8& x, bf16x8& hi, bf16x8& lo) {
+          float v[8];
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const float v = (float)x[j];
-            const __bf16 hv = (__bf16)v;
-            hi[j] = hv;
-            lo[j] = (__bf16)(v - (float)hv);
-          }
+          for (int j = 0; j < 8; j++) v[j] = (float)x[j];
+          split_bf16(v, hi, lo);
         };
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
@@ -1131,13 +1062,10 @@ void train_tile_kernel(TrainTileParams P) {
             const float gvv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             const bool valid = r < gv[q];
             bf16x8 gh, gl;
+            float gz[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-              const float v = valid ? gvv[j] : 0.0f;
-              const __bf16 hv = (__bf16)v;
-              gh[j] = hv;
-              gl[j] = (__bf16)(v - (float)hv);
-            }
+            for (int j = 0; j < 8; j++) gz[j] = valid ? gvv[j] : 0.0f;
+            split_bf16(gz, gh, gl);
             const int x = q >> 1;
             dw[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[x], gh, dw[q], 0, 0, 0);
             dw[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[x], gh, dw[q], 0, 0, 0);
