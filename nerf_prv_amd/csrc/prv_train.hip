@@ -16,12 +16,15 @@
 //                          wave sums, loss, then the per-sample gradient seeds chunk by chunk from the back (suffix sums by a
 //                          reverse scan; a chunk's values are recomputed from the logits)
 //   train_tile_kernel<F, false, 2>  the backward pass, one 256-thread block = 32 samples at a time, persistent: kept activations
-//                          -> [row][sample] LDS arrays, the dX chain register-resident on ONE wave (bf16-split operands,
-//                          v_mfma_f32_32x32x16_bf16: a backward layer's accumulator is the next layer's B operand), dW as bf16-split
-//                          MFMAs accumulated in registers over all tiles of the block (three weight tiles per wave), then the MERGING
-//                          TABLE SCATTER: thread (level, corner, feature) walks the tile's 32 samples with four (entry, sum) pairs
-//                          and issues one f32 atomic per entry it evicts (the memory side's atomic-request rate is what bounds the
-//                          step).  The launch's last blocks also sum the step's loss / used-sample slices.  MODE 0 / 1 (recomputed
+//                          -> [row][sample] LDS arrays (live tiles only: a byte per tile, read 64 candidates at a time), the dX
+//                          chain register-resident on TWO waves (bf16-split operands, v_mfma_f32_32x32x16_bf16: a backward layer's
+//                          accumulator is the next layer's B operand; wave w owns row tile w = k-steps 2w, 2w + 1 of the layer
+//                          behind, partial sums cross through the rows of G they end in), dW as bf16-split MFMAs accumulated in
+//                          registers over all tiles of the block (three weight tiles per wave), then the MERGING TABLE SCATTER:
+//                          thread (level, corner, feature) walks the tile's 32 samples with one (entry, sum) pair (four for patch
+//                          batches) and issues one f32 atomic per run (under PRV_STEP_FIXED_S the memory side's atomic-request rate
+//                          bounds the step; under the engine's marcher the tile work does).  The launch's last blocks also sum the
+//                          step's loss / used-sample slices.  No byte of static LDS to spare: two blocks fill a CU.  MODE 0 / 1 (recomputed
 //                          forward, LDS chain on v_mfma_f32_32x32x2_f32) are the fallbacks for tiles beyond the activation buffer and
 //                          the dev switches PRV_TRAIN_FAST_FWD / PRV_TRAIN_REG_CHAIN
 //   adam_table_kernel      sparse Adam on the table, one {w[4], m[4], v[4]} record per group of four scalars; extra blocks do the
@@ -630,8 +633,9 @@ void train_tile_kernel(TrainTileParams P) {
   __syncthreads(); STAMP(1);
 
   constexpr int LPT = (32 / F) / 8; // levels per thread (8 threads per sample)
-  f32x16v dw[3];
-  for (int q = 0; q < 3; q++) dw[q] = f32x16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int kDw = MODE == 2 ? 6 : 3; // weight-gradient tiles a wave accumulates over all tiles of the block (MODE 2: waves 2 and 3 hold all twelve)
+  f32x16v dw[kDw];
+  for (int q = 0; q < kDw; q++) dw[q] = f32x16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   // what a kept-activation tile reads from memory: this wave's four activation slots, the sample's position and seed
   struct TileIn {
@@ -709,6 +713,7 @@ void train_tile_kernel(TrainTileParams P) {
     const bool live = sid < n_samples;
     uint32_t cidx[LPT][8];
     float cw[LPT][8];
+    float spos[3] = {0.5f, 0.5f, 0.5f}; // kept-activation tiles: the sample's position (TileIn::pos)
     float4 seed = make_float4(0.f, 0.f, 0.f, 0.f);
     // SAVED: backward pass on tiles whose activations the forward pass kept (launch_train_tiles gives this instance
     // exactly those): no table gather, no forward layers -- the corner entries and weights (arithmetic only), the seeds,
@@ -729,9 +734,11 @@ void train_tile_kernel(TrainTileParams P) {
       }
       seed = in.seed;
       const uint4* av = in.av;
-      const float* pos = in.pos;
-#pragma unroll
-      for (int q = 0; q < LPT; q++) train_level_corners<F>(lv[g * LPT + q], pos[0], pos[1], pos[2], cidx[q], cw[q]);
+      // (the corner entries and weights are computed where they are staged for the scatter, behind the chain: three registers of position
+      // across the chain and dW instead of sixteen per level)
+      spos[0] = in.pos[0];
+      spos[1] = in.pos[1];
+      spos[2] = in.pos[2];
       if (g == 1) {
         G[(kGOrr + 0) * TSG + s] = seed.y;
         G[(kGOrr + 1) * TSG + s] = seed.z;
@@ -883,6 +890,32 @@ void train_tile_kernel(TrainTileParams P) {
           split_bf16(v, hi, lo);
         };
         const int ws = cwv;
+        // dW[k][o] += sum_s X[k][s] dOut[o][s] rides in the chain's shadow: waves 2 and 3 (u = 0, 1) had nothing to do between the chain's
+        // barriers, and every gradient block is final a barrier before the chain ends -- dH3 (and the seeds) behind the first, dH2 behind
+        // the second, dOd and dH1 behind the third.  Six 32x32 weight tiles per wave, K = the 32 samples: bf16 matrix cores, 16 samples
+        // per instruction; lane (r, h) supplies 8 consecutive samples of activation row r (one 16-byte LDS read) and of gradient row r
+        // (two); split operands as in the chain (the fp16 activation = hi + lo exactly, the f32 gradient = hi + lo to 16 bits).
+        const int u = wave - 2;
+        const bool dww = wave >= 2 && !(PRV_TRAIN_ABLATE & 2);
+        auto dw_x = [&](int xa, int kk, bf16x8& xh, bf16x8& xl) {
+          const half8 x = *reinterpret_cast<const half8*>(A + (xa + r) * TSA + 16 * kk + 8 * h);
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = (float)x[j];
+          split_bf16(v, xh, xl);
+        };
+        auto dw_mac = [&](f32x16v& acc, const bf16x8& xh, const bf16x8& xl, int ga, int g_rows, int kk) {
+          const float4* gp = reinterpret_cast<const float4*>(G + (ga + r) * TSG + 16 * kk + 8 * h);
+          const float4 g0 = gp[0], g1 = gp[1];
+          const bool valid = r < g_rows;
+          const float gz[8] = {valid ? g0.x : 0.0f, valid ? g0.y : 0.0f, valid ? g0.z : 0.0f, valid ? g0.w : 0.0f,
+                               valid ? g1.x : 0.0f, valid ? g1.y : 0.0f, valid ? g1.z : 0.0f, valid ? g1.w : 0.0f};
+          bf16x8 gh, gl;
+          split_bf16(gz, gh, gl);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, gh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, gh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, gl, acc, 0, 0, 0);
+        };
         const int own = 32 * cwv, other = 32 * (1 - cwv); // first row of this wave's / the other wave's tile of a 64-row layer
         bf16x8 bh[2], bl[2];
         f32x16v d = zero, part = zero; // this wave's rows of the layer in hand | its half-K sum of its own rows, until the other half arrives
@@ -917,6 +950,17 @@ void train_tile_kernel(TrainTileParams P) {
           for (int i = 0; i < 16; i++) G[(kGH2 + other + rho(i, h)) * TSG + r] = give[i];
         }
         __syncthreads();
+        if (dww) { // R2 (rows [32 u, 32 u + 32) of h2 x both halves of dH3) and R3 (the same rows of h3 x the colour seeds)
+#pragma unroll
+          for (int kk = 0; kk < 2; kk++) {
+            bf16x8 xh, xl;
+            dw_x(kAH2 + 32 * u, kk, xh, xl);
+            dw_mac(dw[0], xh, xl, kGH3, 32, kk);
+            dw_mac(dw[1], xh, xl, kGH3 + 32, 32, kk);
+            dw_x(kAH3 + 32 * u, kk, xh, xl);
+            dw_mac(dw[2], xh, xl, kGOrr, 16, kk);
+          }
+        }
         if (chain) {
 #pragma unroll
           for (int i = 0; i < 16; i++) {
@@ -938,6 +982,14 @@ void train_tile_kernel(TrainTileParams P) {
           for (int i = 0; i < 8; i++) G[(kGOd + 16 * (1 - cwv) + rho(i, h)) * TSG + r] = part[i]; // registers 0..7 = rows < 16
         }
         __syncthreads();
+        if (dww) { // R1: the density outputs + SH inputs x half u of dH2
+#pragma unroll
+          for (int kk = 0; kk < 2; kk++) {
+            bf16x8 xh, xl;
+            dw_x(kAIn2, kk, xh, xl);
+            dw_mac(dw[3], xh, xl, kGH2 + 32 * u, 32, kk);
+          }
+        }
         if (chain) {
           f32x16v c = zero;
 #pragma unroll
@@ -973,6 +1025,16 @@ void train_tile_kernel(TrainTileParams P) {
           }
         }
         __syncthreads();
+        if (dww) { // D1 (the features x half u of dH1) and D2 (rows [32 u, 32 u + 32) of h1 x dOd): the one piece outside the chain's shadow
+#pragma unroll
+          for (int kk = 0; kk < 2; kk++) {
+            bf16x8 xh, xl;
+            dw_x(kAFeat, kk, xh, xl);
+            dw_mac(dw[4], xh, xl, kGH1 + 32 * u, 32, kk);
+            dw_x(kAH1 + 32 * u, kk, xh, xl);
+            dw_mac(dw[5], xh, xl, kGOd, 16, kk);
+          }
+        }
         if (chain) {
           if (ws == 0) {
 #pragma unroll
@@ -1030,6 +1092,8 @@ void train_tile_kernel(TrainTileParams P) {
     __syncthreads(); STAMP(12);
     }
     // ---- dW[k][o] += sum_s X[k][s] dOut[o][s]: three 32x32 weight tiles per wave, K = the 32 samples
+    // (MODE 2: on waves 2 and 3, inside the chain above)
+    if constexpr (MODE != 2) {
     if (!(PRV_TRAIN_ABLATE & 2)) {
       // tile q of wave w: {activation row base, gradient row base, valid gradient rows}
       int xa[3], ga[3], gv[3];
@@ -1037,42 +1101,7 @@ void train_tile_kernel(TrainTileParams P) {
       else if (wave == 1) { xa[0] = kAH2 + 32; ga[0] = kGH3; gv[0] = 32; xa[1] = kAH2 + 32; ga[1] = kGH3 + 32; gv[1] = 32; xa[2] = kAH3 + 32; ga[2] = kGOrr; gv[2] = 16; }
       else if (wave == 2) { xa[0] = kAIn2; ga[0] = kGH2; gv[0] = 32; xa[1] = kAIn2; ga[1] = kGH2 + 32; gv[1] = 32; xa[2] = kAH1; ga[2] = kGOd; gv[2] = 16; }
       else { xa[0] = kAFeat; ga[0] = kGH1; gv[0] = 32; xa[1] = kAFeat; ga[1] = kGH1 + 32; gv[1] = 32; xa[2] = kAH1 + 32; ga[2] = kGOd; gv[2] = 16; }
-      if constexpr (MODE == 2 && !(PRV_TRAIN_ABLATE & 128)) {
-        // bf16 matrix cores, 16 samples per instruction (the f32 form below: 2).  Lane (r, h) supplies 8 consecutive samples
-        // of activation row r (one 16-byte LDS read; tiles 0 and 1 of a wave share it) and of gradient row r (two).  Split
-        // operands as in the chain: the fp16 activation = hi + lo exactly, the f32 gradient = hi + lo to 16 bits,
-        // X g ~ X_hi g_hi + X_lo g_hi + X_hi g_lo in the f32 accumulators: 18 instructions per wave and tile for 48.
-        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-        auto split_x = [&](const half8& x, bf16x8& hi, bf16x8& lo) {
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 8; j++) v[j] = (float)x[j];
-          split_bf16(v, hi, lo);
-        };
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-          const int s0 = 16 * kk + 8 * h;
-          bf16x8 xh[2], xl[2];
-          split_x(*reinterpret_cast<const half8*>(A + (xa[0] + r) * TSA + s0), xh[0], xl[0]);
-          split_x(*reinterpret_cast<const half8*>(A + (xa[2] + r) * TSA + s0), xh[1], xl[1]);
-#pragma unroll
-          for (int q = 0; q < 3; q++) {
-            const float4* gp = reinterpret_cast<const float4*>(G + (ga[q] + r) * TSG + s0);
-            const float4 g0 = gp[0], g1 = gp[1];
-            const float gvv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            const bool valid = r < gv[q];
-            bf16x8 gh, gl;
-            float gz[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) gz[j] = valid ? gvv[j] : 0.0f;
-            split_bf16(gz, gh, gl);
-            const int x = q >> 1;
-            dw[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[x], gh, dw[q], 0, 0, 0);
-            dw[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[x], gh, dw[q], 0, 0, 0);
-            dw[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[x], gl, dw[q], 0, 0, 0);
-          }
-        }
-      } else {
+      {
       // the three tiles' MFMAs interleaved (independent accumulators), operands loaded a group ahead
       float a[3][4], b[3][4];
       for (int k0 = h; k0 < 32; k0 += 8) {
@@ -1091,12 +1120,18 @@ void train_tile_kernel(TrainTileParams P) {
       }
       }
     }
+    }
     // ---- scatter the feature gradients into the canonical table gradient.  f32 atomics run at the memory
     // side as 64-byte requests (MI355X_MICROARCH.md, global float atomics): one dword per request is the
     // slow shape.  The (entry, weight) pairs are re-dealt through LDS so that F consecutive lanes add the F
     // features of ONE entry (one request carries the whole entry; x-neighbour corners sit on adjacent lane
     // groups and usually share the line too).
-    __syncthreads(); STAMP(13); // the activation rows are dead: their LDS becomes the staging array
+    if constexpr (MODE != 2) __syncthreads(); // (MODE 2: the chain's last barrier is this one)
+    STAMP(13); // the activation rows are dead: their LDS becomes the staging array
+    // (What the adds of the walk below cost beyond their instructions is back-pressure: a wave stalls at its next vector-memory
+    // instruction while the CU's queue to the memory side is full -- the unpack phase is 13 us without the adds and 40 with them, and it
+    // holds no wait for them: moving every wait for the prefetch in front of the adds changed nothing, r06an / r06ao.  2.6 M requests per
+    // launch are 125 us at the memory side's rate; the launch takes 180.)
     {
       // staging = the (dead) activation region: 256 rows x 33 halfs = 2112 uint2 -> 8 levels of 32 samples at a time.
       // A sample's 64 (entry, weight) pairs sit 65 pairs apart: the writers (lanes = samples) then hit 32 different banks
@@ -1113,6 +1148,7 @@ void train_tile_kernel(TrainTileParams P) {
         for (int q = 0; q < LPT; q++) {
           const int l = g * LPT + q;
           if (l / 8 != pass) continue;
+          if constexpr (SAVED) train_level_corners<F>(lv[l], spos[0], spos[1], spos[2], cidx[q], cw[q]);
 #pragma unroll
           for (int c = 0; c < 8; c++)
             stage[s * kStageStride + (l & 7) * 8 + c] = make_uint2(contributes ? cidx[q][c] : 0xffffffffu, __float_as_uint(cw[q][c]));
@@ -1245,11 +1281,24 @@ void train_tile_kernel(TrainTileParams P) {
     else if (wave == 2) { ly[0] = 2; kb[0] = 0; ob[0] = 0; ov[0] = 32; ly[1] = 2; kb[1] = 0; ob[1] = 32; ov[1] = 32; ly[2] = 1; kb[2] = 0; ob[2] = 0; ov[2] = 16; }
     else { ly[0] = 0; kb[0] = 0; ob[0] = 0; ov[0] = 32; ly[1] = 0; kb[1] = 0; ob[1] = 32; ov[1] = 32; ly[2] = 1; kb[2] = 32; ob[2] = 0; ov[2] = 16; }
     float* part = P.mlp_grad_partial + (size_t)(P.slot_base + (int)blockIdx.x) * PRV_MLP_HALFS;
+    if constexpr (MODE == 2) { // waves 2 and 3 hold the twelve tiles (six each, the order of the chain's three dW stages)
+      if (wave >= 2) {
+        const int u = wave - 2;
+        const int ly6[6] = {3, 3, 4, 2, 0, 1}, kb6[6] = {32 * u, 32 * u, 32 * u, 0, 0, 32 * u}, ob6[6] = {0, 32, 0, 32 * u, 32 * u, 0}, ov6[6] = {32, 32, 16, 32, 32, 16};
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          if (r >= ov6[q]) continue;
+#pragma unroll
+          for (int i = 0; i < 16; i++) part[kLOff[ly6[q]] + (kb6[q] + rho(i, h)) * kLOut[ly6[q]] + ob6[q] + r] = dw[q][i];
+        }
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       if (r >= ov[q]) continue;
 #pragma unroll
       for (int i = 0; i < 16; i++) part[kLOff[ly[q]] + (kb[q] + rho(i, h)) * kLOut[ly[q]] + ob[q] + r] = dw[q][i];
+    }
     }
   }
 }
