@@ -436,8 +436,7 @@ def kernel_figures(m, variant, hbm_bound, scene, layout):
                 "(FETCH_SIZE includes Infinity-Cache hits); fabric-side reads ~= algorithmic bytes, random 64-B requests, against the "
                 "3.8 TB/s the gather calibration (profiles/archive/r01_gather_calib.txt) reaches for this access shape; hbm_algorithmic_frac = the "
                 "same bytes over the 8 TB/s HBM peak, kept for comparison with earlier rounds' `frac`.  A table that really leaves the caches "
-                "needs > 256 MiB; the hashed gather's byte offsets ride 24-bit arithmetic (csrc/prv_api.cpp: a hashed level <= 16 MiB, "
-                "<= 128 MiB in all), so no such workload exists in this build")
+                "needs > 256 MiB: the `field_hbm` side workload of this line (hashed levels beyond 16 MiB ride the generic gather with 32-bit offsets)")
     else:
         # cache-resident table: HBM is not the binding resource (hbm_algorithmic_frac > 1 is a cache effect, not a fraction of
         # anything).  Candidates: SIMD vector issue, the MFMA pipe, L2 bandwidth -- the largest fraction names the bound.
@@ -993,8 +992,9 @@ def run_rank(args):
         training = train_rate("ngp" if api.train_opts().step_mode == api.L.STEP_NGP else "fixed")
         training["note"] = ("fresh field; batch adapts to ~2^18 composited samples per step (upstream's batch); f16-MFMA forward (activations kept), backward dX chain "
                             "and dW on bf16-split MFMAs, merging table scatter, sparse Adam; samples_per_s uses the last batch's count.  Under the engine's "
-                            "marcher the backward launch is bound by its own tile work (0.285 ms of a 0.51 ms step; 2.6 M requests = 0.125 ms at the "
-                            "memory side's rate), under the fixed rule by the request rate (profiles/r06_train_rules.txt, section 4)")
+                            "marcher the backward launch of a trainer alone takes 0.18 ms against 0.125 ms for its 2.6 M requests at the memory side's rate "
+                            "(its blocks' own work is 0.09 ms; five members side by side run it at the request rate), under the fixed rule the request "
+                            "rate binds outright (profiles/r06_train_rules.txt, sections 4 and 10)")
         training["fixed_rule"] = train_rate("fixed")
         tcams.close()
 
