@@ -24,7 +24,7 @@
 //                          thread (level, corner, feature) walks the tile's 32 samples with one (entry, sum) pair (four for patch
 //                          batches) and issues one f32 atomic per run (under PRV_STEP_FIXED_S the memory side's atomic-request rate
 //                          bounds the step; under the engine's marcher the tile work does).  The launch's last blocks also sum the
-//                          step's loss / used-sample slices.  No byte of static LDS to spare: two blocks fill a CU.  MODE 0 / 1 (recomputed
+//                          step's loss / used-sample slices.  Two blocks fill a CU's LDS (80 KB less 960 bytes each).  MODE 0 / 1 (recomputed
 //                          forward, LDS chain on v_mfma_f32_32x32x2_f32) are the fallbacks for tiles beyond the activation buffer and
 //                          the dev switches PRV_TRAIN_FAST_FWD / PRV_TRAIN_REG_CHAIN
 //   adam_table_kernel      sparse Adam on the table, one {w[4], m[4], v[4]} record per group of four scalars; extra blocks do the
@@ -554,7 +554,9 @@ void train_tile_kernel(TrainTileParams P) {
   constexpr int TSA = MODE == 2 ? kTSA2 : kTS, TSG = MODE == 2 ? kTSG2 : kTS;
   // weights and activations are fp16 VALUES (working weights, rounded activations): stored as fp16, widened
   // at the operand read; 21 + 17 KB (+ 36 KB of f32 gradients backward; 21 + 20 + 39 KB with the register-chain instance's strides) -> 2 backward / 4 forward blocks per CU
-  extern __shared__ float lds[];
+  // 16-byte aligned BY DECLARATION: as `float lds[]` the array sits wherever the static __shared__ data ends, and one 4-byte static word
+  // in front of it made every 16- and 8-byte LDS access of this kernel a misaligned one -- 0.335 -> 0.48 ms per step, same results (r06aj, r06au)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
 #if (PRV_TRAIN_ABLATE & 48) == 48
   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -614,8 +616,6 @@ void train_tile_kernel(TrainTileParams P) {
   // level constants: kernel arguments indexed by a per-lane level would be re-fetched from the kernarg
   // segment through the vector memory path before every corner (measured: 37 us per tile) -> LDS copy
   __shared__ LevelCanon lv[16];
-  // (no byte of static LDS to spare here: the block's LDS is 80 KB less 960 bytes, two blocks fill a CU's 160 KB, and one more 4-byte
-  // __shared__ word halved the occupancy -- 0.34 -> 0.50 ms per step, r06aj)
   if (tid < 16 * (int)(sizeof(LevelCanon) / 4))
     reinterpret_cast<uint32_t*>(lv)[tid] = reinterpret_cast<const uint32_t*>(P.levels)[tid];
   if constexpr (MODE == 2) { // fp16 fragments as prepack_frags_kernel left them: 20 KB, 16 bytes per thread and step
