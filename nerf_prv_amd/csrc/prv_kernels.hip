@@ -710,7 +710,9 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 template <int F, int NDENSE, bool NGP, bool CACHE = false>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(CACHE ? 2 : 1))) // the cached instances must keep TWO waves per SIMD (<= 256 registers)
+// the cached instances must keep TWO waves per SIMD (<= 256 registers); the plain ones with dense levels are asked for THREE (<= 168): left alone
+// they took 172 since the octant regions of round 6 -- two waves -- and three are 1.7-2.5 % faster (r06ay); the all-hashed ones would spill 50-80
+__attribute__((amdgpu_waves_per_eu(CACHE ? 2 : NDENSE == 0 ? 1 : 3)))
 void render_queue64_kernel(RenderParams P) {
   __shared__ half8 wl[kNumFrags * 64];
   __shared__ uint32_t mv[4][32][6]; // tail merges: {record, next sample, T, r, g, b} of the rays that change slots, per wave
